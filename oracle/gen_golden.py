@@ -1,0 +1,353 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- generates tests/golden/*.npz from the REAL reference.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/gen_golden.py
+
+It imports the reference's `proteus.dswx_hls` (oracle/_ref_import.py), feeds its
+own per-pixel functions with exhaustive tables, known-answer vectors and seeded
+synthetic tiles, and stores inputs + the reference's outputs as small fixtures.
+The fixtures are data (inputs and expected outputs); no reference source travels.
+The tile cases replay the reference orchestrator's hot segment
+(src/proteus/dswx_hls.py:5088-5112, :5225-5286, :5358-5369) call by call, because
+`generate_dswx_layers` itself needs GDAL, which is not installed here.
+"""
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle._ref_import import import_reference  # noqa: E402
+from proteus_amd.synth import synth_tile          # noqa: E402
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+ALT_THRESHOLDS = {
+    'default': {},
+    'fractional': dict(wigt=0.1, awgt=-12.25, pswt_1_mndwi=-0.3, pswt_1_nir=1499.5,
+                       pswt_1_swir1=900.25, pswt_1_ndvi=0.55, pswt_2_mndwi=-0.25,
+                       pswt_2_blue=999.9, pswt_2_nir=2500.5, pswt_2_swir1=3000.75,
+                       pswt_2_swir2=1000.125, lcmask_nir=1199.5),
+    'zeros': dict(wigt=0.0, awgt=0.3, pswt_1_mndwi=0.0, pswt_1_ndvi=0.0,
+                  pswt_2_mndwi=-1.0),
+    'thirds': dict(wigt=1.0 / 3.0, pswt_1_mndwi=-1.0 / 3.0, pswt_1_ndvi=2.0 / 3.0,
+                   pswt_2_mndwi=-0.2),
+}
+
+
+def make_thresholds(ref, **kw):
+    thr = ref.HlsThresholds()
+    vals = dict(wigt=0.124, awgt=0.0, pswt_1_mndwi=-0.44, pswt_1_nir=1500,
+                pswt_1_swir1=900, pswt_1_ndvi=0.7, pswt_2_mndwi=-0.5,
+                pswt_2_blue=1000, pswt_2_nir=2500, pswt_2_swir1=3000,
+                pswt_2_swir2=1000, lcmask_nir=1200)
+    vals.update(kw)
+    for k, v in vals.items():
+        setattr(thr, k, v)
+    return thr
+
+
+DEFAULT_AEROSOL = ([224, 160, 96], [224, 160, 96],
+                   [224, 192, 160, 128, 96], [224, 192, 160, 128, 96])
+CUSTOM_AEROSOL = ([224, 226, 2, 12, 96], [160, 164], [192, 200, 72], [128, 130, 255, 0])
+
+
+# ---------------------------------------------------------------------------
+def gen_tables(ref):
+    out = {}
+    # A6: the reference's own unit-test vector (tests/test_dswx_hls_units.py:7-28)
+    keys = list(ref.interpreted_dswx_band_dict.keys())
+    unit_in = np.full((1, len(keys) + 1), 111111)
+    for i, k in enumerate(keys):
+        unit_in[0, i] = k
+    out['interp_unit_in'] = unit_in
+    out['interp_unit_out'] = ref.generate_interpreted_layer(unit_in)
+    d = np.arange(64, dtype=np.uint16).reshape(1, -1)
+    out['interp_in'] = d
+    out['interp_out'] = ref.generate_interpreted_layer(d)
+    # A7
+    out['binrepr_in'] = d
+    out['binrepr_out'] = ref._get_binary_representation(d.copy())
+    # A15
+    v = np.arange(256, dtype=np.uint8).reshape(1, -1)
+    out['collapse_in'] = v
+    out['collapse_out'] = ref._collapse_wtr_classes(v)
+    # A13
+    out['bwtr_in'] = v
+    out['bwtr_out'] = ref._get_binary_water_layer(v)
+    # A2
+    for mode in ('mask', 'ignore', 'cover'):
+        out['prelim_' + mode] = ref._compute_preliminary_cloud_layer(v, mode)
+    # A9 on a full grid, default and custom lists
+    fm, cls, nr, cl = np.meshgrid(
+        np.arange(256, dtype=np.uint8),
+        np.array([0, 1, 2, 3, 4, 254, 255], dtype=np.uint8),
+        np.array([1, 1000, 1001, -3], dtype=np.int16),
+        np.array([0, 1, 4, 5, 255], dtype=np.uint8), indexing='ij')
+    out['aer_fmask'], out['aer_cls'], out['aer_nir'], out['aer_cloud'] = \
+        fm, cls, nr, cl
+    for tag, lists in (('default', DEFAULT_AEROSOL), ('custom', CUSTOM_AEROSOL)):
+        w = cls.copy()
+        c = cl.copy()
+        ref._apply_aerosol_class_remapping(w, nr, c, fm, *lists)
+        out[f'aer_{tag}_wtr1'] = w
+        out[f'aer_{tag}_cloud'] = c
+    # A10
+    ld, sh, cls, nr = np.meshgrid(
+        np.arange(256, dtype=np.uint8), np.array([0, 1], dtype=np.uint8),
+        np.array([0, 1, 2, 3, 4, 254, 255], dtype=np.uint8),
+        np.array([1200, 1201, 1], dtype=np.int16), indexing='ij')
+    out['lc_land'], out['lc_shad'], out['lc_cls'], out['lc_nir'] = ld, sh, cls, nr
+    thr = make_thresholds(ref)
+    out['lc_both'] = ref._apply_landcover_and_shadow_masks(cls, nr, ld, sh.astype(bool), thr)
+    out['lc_both_u8shad'] = ref._apply_landcover_and_shadow_masks(cls, nr, ld, sh, thr)
+    out['lc_land_only'] = ref._apply_landcover_and_shadow_masks(cls, nr, ld, None, thr)
+    out['lc_shad_only'] = ref._apply_landcover_and_shadow_masks(cls, nr, None, sh.astype(bool), thr)
+    out['lc_none'] = ref._apply_landcover_and_shadow_masks(cls, nr, None, None, thr)
+    # A11 (non-cover), A12, A14 on grids
+    fm, cl, w2 = np.meshgrid(
+        np.arange(256, dtype=np.uint8),
+        np.array([0, 1, 4, 5, 8, 9, 12, 13], dtype=np.uint8),
+        np.array([0, 1, 2, 3, 4, 254, 255], dtype=np.uint8), indexing='ij')
+    out['snow_fmask'], out['snow_cloud_in'], out['snow_wtr2'] = fm, cl, w2
+    out['snow_cloud_out'] = ref._add_snow_to_cloud_layer(w2, cl.copy(), fm, 'mask')
+    w2, cl = np.meshgrid(np.arange(256, dtype=np.uint8),
+                         np.arange(256, dtype=np.uint8), indexing='ij')
+    out['cm_wtr2'], out['cm_cloud'] = w2, cl
+    out['cm_wtr'] = ref._apply_cloud_masking(w2, cl)
+    out['cm_conf'] = ref._get_confidence_layer(w2, cl)
+    np.savez_compressed(os.path.join(GOLDEN, 'tables.npz'), **out)
+    print('tables.npz', len(out), 'arrays')
+
+
+# ---------------------------------------------------------------------------
+def tie_vectors():
+    """Band 6-tuples that sit exactly on, and one count either side of, every
+    rational value the quotient thresholds can hit, plus the survey's KATs."""
+    rows = [
+        (300, 400, 300, 200, 100, 50), (500, 600, 700, 3000, 2500, 1500),
+        (100, 281, 300, 1700, 219, 50), (100, 282, 300, 1699, 219, 50),
+        (100, 100, 100, 100, 300, 100), (100, 101, 100, 100, 300, 100),
+        (100, 700, 100, 100, 1800, 100), (1, 1, 1, 1, 1, 1),
+        (20000,) * 6, (999, 3000, 2000, 2499, 2999, 999),
+        (1000, 3000, 2000, 2500, 3000, 1000), (400, 1000, 600, 1499, 899, 300),
+        (1, 5000, 1, 1, 1, 32767), (32767,) * 6, (32767, 1, 32767, 1, 32767, 1),
+        (1, 32767, 1, 32767, 1, 32767), (16384, 16384, 16384, 16384, 16384, 16384),
+        (16383, 16384, 16385, 16383, 16384, 16385),
+    ]
+    # mndwi = (g-s1)/(g+s1) == p/q  <=>  g = (q+p)k/2, s1 = (q-p)k/2
+    for p, q in ((31, 250), (-11, 25), (-1, 2), (1, 10), (-3, 10), (-1, 4),
+                 (0, 1), (1, 3), (-1, 3), (-1, 5), (-1, 1)):
+        for k in (2, 4, 10, 22, 50, 64, 100, 130, 200):
+            g2, s2 = (q + p) * k, (q - p) * k
+            if g2 % 2 or s2 % 2:
+                continue
+            g, s1 = g2 // 2, s2 // 2
+            for dg in (-1, 0, 1):
+                for ds in (-1, 0, 1):
+                    gg, ss = g + dg, s1 + ds
+                    if 1 <= gg <= 32767 and 1 <= ss <= 32767:
+                        rows.append((100, gg, 100, 100, ss, 100))
+                        rows.append((900, gg, 300, 1400, ss, 900))
+    # ndvi = (n-r)/(n+r) == p/q
+    for p, q in ((7, 10), (11, 20), (0, 1), (2, 3), (1, 2)):
+        for k in (2, 4, 10, 20, 60, 100, 170, 400):
+            n2, r2 = (q + p) * k, (q - p) * k
+            if n2 % 2 or r2 % 2:
+                continue
+            n, r = n2 // 2, r2 // 2
+            for dn in (-1, 0, 1):
+                for dr in (-1, 0, 1):
+                    nn, rr = n + dn, r + dr
+                    if 1 <= nn <= 32767 and 1 <= rr <= 32767:
+                        rows.append((100, 500, rr, nn, 300, 100))
+                        rows.append((100, 500, rr, nn, 899, 100))
+    return np.asarray(rows, dtype=np.int16)
+
+
+def gen_diag(ref):
+    rng = np.random.default_rng(20251010)
+    parts = [tie_vectors()]
+    # full positive int16 range, uniformly random (lots of int16 wrap)
+    parts.append(rng.integers(1, 32768, size=(60000, 6)).astype(np.int16))
+    # dense cloud around the integer thresholds
+    base = np.array([1000, 1100, 900, 1500, 900, 1000])
+    parts.append((base + rng.integers(-40, 41, size=(60000, 6))).astype(np.int16))
+    # values incl. negatives / zero (clip disabled at this level: the function
+    # sees whatever the caller passes) -> exercises n/0 and 0/0
+    parts.append(rng.integers(-300, 300, size=(30000, 6)).astype(np.int16))
+    special = np.array([(5, 7, 3, 0, -7, 2), (5, -7, 3, 0, 7, 2), (0, 0, 0, 0, 0, 0),
+                        (9, 4, 9, -9, -4, 1), (9, 4, -9, 9, -4, 1),
+                        (1, -32768, 1, 1, -32768, 1), (1, -32768, 1, 1, 32767, 1)],
+                       dtype=np.int16)
+    parts.append(special)
+    vec = np.concatenate(parts, axis=0)
+    out = {'bands': vec}
+    cols = [np.ascontiguousarray(vec[:, i]).reshape(1, -1) for i in range(6)]
+    with np.errstate(all='ignore'):
+        for tag, kw in ALT_THRESHOLDS.items():
+            thr = make_thresholds(ref, **kw)
+            out['diag_' + tag] = ref._compute_diagnostic_tests(*cols, thr)
+            out['thr_' + tag] = np.array(
+                [getattr(thr, k) for k in THR_KEYS], dtype=np.float64)
+        # float indices, for the 1e-6 debug planes
+        g, s1, n, r = cols[1], cols[4], cols[3], cols[2]
+        out['mndwi'] = (g - s1) / (g + s1)
+        out['ndvi'] = (n - r) / (n + r)
+        out['awesh'] = cols[0] + (2.5 * g) - (1.5 * (n + s1)) - (0.25 * cols[5])
+    np.savez_compressed(os.path.join(GOLDEN, 'diag_vectors.npz'), **out)
+    print('diag_vectors.npz', vec.shape[0], 'vectors')
+
+
+THR_KEYS = ('wigt', 'awgt', 'pswt_1_mndwi', 'pswt_1_nir', 'pswt_1_swir1',
+            'pswt_1_ndvi', 'pswt_2_mndwi', 'pswt_2_blue', 'pswt_2_nir',
+            'pswt_2_swir1', 'pswt_2_swir2', 'lcmask_nir')
+
+
+# ---------------------------------------------------------------------------
+def run_reference_chain(ref, bands_raw, fmask, thr, land, shad, ocean, mode,
+                        apply_aerosol, aerosol_lists, band_fills, fmask_fill):
+    """The reference's own functions in the orchestrator's order."""
+    # A0 -- _load_hls_band_from_file :2195-2209, :2298-2299 (GDAL part skipped)
+    invalid = None
+    for img, fill in list(zip(bands_raw, band_fills)) + [(fmask, fmask_fill)]:
+        eq = img == fill
+        invalid = eq if invalid is None else np.logical_or(invalid, eq)
+    assert ref.FLAG_CLIP_NEGATIVE_REFLECTANCE
+    blue, green, red, nir, swir1, swir2 = [np.clip(b, 1, None) for b in bands_raw]
+    invalid_ind = np.where(invalid)
+    valid_array = ~invalid
+    # :5088-5136
+    cloud = ref._compute_preliminary_cloud_layer(fmask, mode)
+    total = fmask.size
+    if ocean is not None:
+        valid_array = np.logical_and(valid_array, ocean)
+        n_not_ocean = np.sum(ocean)
+    else:
+        n_not_ocean = total
+    n_valid = np.sum(valid_array)
+    n_cloud_and_valid = np.sum((cloud != 0) & valid_array)
+    spatial = int(100 * float(n_valid) / total)
+    cloud_cov = 0 if n_valid == 0 else int(100 * float(n_cloud_and_valid) / n_valid)
+    spatial_no = 0 if n_not_ocean == 0 else int(100 * float(n_valid) / n_not_ocean)
+    # :5225-5249
+    with np.errstate(all='ignore'):
+        dd = ref._compute_diagnostic_tests(blue, green, red, nir, swir1, swir2, thr)
+    dd[invalid_ind] = ref.DIAGNOSTIC_LAYER_NO_DATA_DECIMAL
+    wtr_1 = ref.generate_interpreted_layer(dd)
+    diag = ref._get_binary_representation(dd)
+    if ocean is not None:
+        wtr_1[ocean == 0] = ref.WTR_OCEAN_MASKED
+    wtr_1[invalid_ind] = ref.UINT8_FILL_VALUE
+    wtr_1_saved = wtr_1.copy()
+    # :5260-5286
+    if apply_aerosol:
+        ref._apply_aerosol_class_remapping(wtr_1, nir, cloud, fmask, *aerosol_lists)
+    wtr_2 = ref._apply_landcover_and_shadow_masks(wtr_1, nir, land, shad, thr)
+    cloud = ref._add_snow_to_cloud_layer(wtr_2, cloud, fmask, mode)
+    wtr = ref._apply_cloud_masking(wtr_2, cloud)
+    bwtr = ref._get_binary_water_layer(wtr)
+    conf = ref._get_confidence_layer(wtr_2_layer=wtr_2, cloud_layer=cloud)
+    res = {'DIAG': diag, 'WTR-1': wtr_1_saved, 'WTR-1-AEROSOL': wtr_1,
+           'WTR-2': wtr_2, 'WTR': wtr, 'BWTR': bwtr, 'CONF': conf, 'CLOUD': cloud}
+    for name in ('WTR', 'WTR-1', 'WTR-1-AEROSOL', 'WTR-2'):
+        res[name + '.collapsed'] = ref._collapse_wtr_classes(res[name])
+    res['counters'] = np.array([n_valid, n_cloud_and_valid, n_not_ocean,
+                                spatial, cloud_cov, spatial_no], dtype=np.int64)
+    return res
+
+
+TILE_CASES = [
+    # name, tile, H, W, masks(land, shad, ocean), mode, aerosol, lists, thresholds, fills
+    dict(name='t64_plain', tile=0, H=64, W=64),
+    dict(name='t128_all_masks', tile=1, H=128, W=128, land=1, shad=1, ocean=1),
+    dict(name='t100x37_ragged', tile=2, H=100, W=37, land=1, shad=1, ocean=1),
+    dict(name='t96_land_only', tile=3, H=96, W=96, land=1),
+    dict(name='t96_shad_only', tile=4, H=96, W=96, shad=1),
+    dict(name='t96_ocean_only', tile=5, H=96, W=96, ocean=1),
+    dict(name='t128_ignore', tile=6, H=128, W=128, land=1, shad=1, mode='ignore'),
+    dict(name='t128_no_aerosol', tile=7, H=128, W=128, land=1, shad=1, ocean=1,
+         aerosol=False),
+    dict(name='t128_custom_aerosol', tile=8, H=128, W=128, land=1, shad=1,
+         lists='custom'),
+    dict(name='t128_fractional_thr', tile=9, H=128, W=128, land=1, shad=1, ocean=1,
+         thr='fractional'),
+    dict(name='t128_thirds_thr', tile=10, H=128, W=128, thr='thirds'),
+    dict(name='t128_zeros_thr', tile=11, H=128, W=128, thr='zeros'),
+    dict(name='t64_other_fills', tile=12, H=64, W=64, fills='other'),
+    dict(name='t256_all_masks', tile=13, H=256, W=256, land=1, shad=1, ocean=1),
+    dict(name='t1x1', tile=14, H=1, W=1),
+    dict(name='t3x5', tile=15, H=3, W=5, land=1, shad=1, ocean=1),
+    dict(name='t17x16', tile=16, H=17, W=16, land=1, shad=1, ocean=1),
+    dict(name='t160_cover', tile=17, H=160, W=160, land=1, shad=1, ocean=1,
+         mode='cover'),
+]
+
+
+def gen_tiles(ref):
+    rng = np.random.default_rng(7)
+    for case in TILE_CASES:
+        H, W = case['H'], case['W']
+        s = synth_tile(case['tile'], H, W, with_masks=True)
+        bands = [b.copy() for b in s['bands']]
+        fmask = s['fmask'].copy()
+        band_fills = [-9999.0] * 6
+        fmask_fill = 255.0
+        if case.get('fills') == 'other':
+            # fill only present in SOME bands, different value per band
+            band_fills = [-9999.0, -1000.0, 0.0, -9999.0, 32767.0, -9999.5]
+            fmask_fill = 64.0
+            for b, f in zip(bands, band_fills):
+                if float(f).is_integer():
+                    sel = rng.random(b.shape) < 0.02
+                    b[sel] = int(f)
+        if case.get('mode') == 'cover':
+            # make spatially coherent snow / adjacent blobs so the dilation matters
+            yy, xx = np.mgrid[0:H, 0:W]
+            blob = ((yy // 9 + xx // 11) % 5 == 0)
+            fmask = np.where(blob & (fmask != 255), fmask | 4, fmask & ~np.uint8(4)).astype(np.uint8)
+            snowb = ((yy // 7 + 2 * (xx // 5)) % 9 == 0)
+            fmask = np.where(snowb & (fmask != 255), fmask | 16, fmask).astype(np.uint8)
+        land = s['land'] if case.get('land') else None
+        shad = s['shad'].astype(bool) if case.get('shad') else None
+        ocean = s['ocean'] if case.get('ocean') else None
+        mode = case.get('mode', 'mask')
+        thr_tag = case.get('thr', 'default')
+        thr = make_thresholds(ref, **ALT_THRESHOLDS[thr_tag])
+        lists = CUSTOM_AEROSOL if case.get('lists') == 'custom' else DEFAULT_AEROSOL
+        res = run_reference_chain(ref, bands, fmask, thr, land, shad, ocean, mode,
+                                  case.get('aerosol', True), lists,
+                                  band_fills, fmask_fill)
+        store = {'in_bands': np.stack(bands), 'in_fmask': fmask,
+                 'thr': np.array([getattr(thr, k) for k in THR_KEYS], dtype=np.float64),
+                 'band_fills': np.array(band_fills), 'fmask_fill': np.array(fmask_fill),
+                 'mode': np.array(mode), 'apply_aerosol': np.array(case.get('aerosol', True)),
+                 'aerosol_lists': np.array([','.join(map(str, l)) for l in lists])}
+        if land is not None:
+            store['in_land'] = land
+        if shad is not None:
+            store['in_shad'] = shad
+        if ocean is not None:
+            store['in_ocean'] = ocean
+        for k, v in res.items():
+            store['out_' + k] = v
+        np.savez_compressed(os.path.join(GOLDEN, f"tile_{case['name']}.npz"), **store)
+        print('tile', case['name'], H, W)
+
+
+def main():
+    ref = import_reference()
+    if ref is None:
+        raise SystemExit('reference tree not present; goldens can only be '
+                         'regenerated in the build container')
+    os.makedirs(GOLDEN, exist_ok=True)
+    gen_tables(ref)
+    gen_diag(ref)
+    gen_tiles(ref)
+
+
+if __name__ == '__main__':
+    main()

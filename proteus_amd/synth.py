@@ -1,0 +1,109 @@
+"""Deterministic synthetic HLS tiles: host (numpy) generator.
+
+Counter-based: every plane value is a pure function of (seed, tile index,
+pixel index), so any tile of any batch can be regenerated anywhere.  The device
+generator `dswx_synth_fill` (proteus_amd/csrc/dswx_hip.hip) implements the very
+same integer recipe and is tested bit-for-bit against this file.
+
+Recipe (all arithmetic modulo 2**64 / 2**32, no floating point):
+  key = seed*K0 + tile*K1 + pixel ; h0 = mix(key) ; h1 = mix(h0+K0) ; h2 = mix(h1+K0)
+  surface type from h0[0:16]; six reflectance noises from h1 (10 bits each);
+  "value < 1" (clip) and "value > 16384" (int16 wrap) events from h0;
+  Fmask bits, LAND class and SHAD from h2; OCEAN in 32-row bands from a
+  per-band hash.  Fill pixels carry -9999 in every band and 255 in Fmask.
+"""
+import numpy as np
+
+SEED = 20251010
+K0 = 0x9E3779B97F4A7C15
+K1 = 0xD1B54A32D192ED03
+M0 = 0xBF58476D1CE4E5B9
+M1 = 0x94D049BB133111EB
+BAND_FILL = -9999
+FMASK_FILL = 255
+
+# type cut points on a 16-bit draw: water, wet, vegetation, bare, bright, fill
+TYPE_CUTS = (14418, 26214, 42598, 55705, 64225)
+# per type: six band means (blue, green, red, nir, swir1, swir2) and amplitude
+TYPE_MEAN = ((350, 450, 350, 250, 150, 100),
+             (500, 700, 600, 1300, 800, 500),
+             (300, 600, 400, 3500, 1800, 900),
+             (900, 1200, 1500, 2200, 2800, 2300),
+             (6000, 6200, 6400, 6600, 3000, 2500))
+TYPE_AMP = (300, 600, 600, 800, 2500)
+LAND_CLASSES = (200, 201, 21, 121, 50, 150, 99, 100)
+
+_U64 = np.uint64
+
+
+def _mix(x):
+    x = x ^ (x >> _U64(30))
+    x = x * _U64(M0)
+    x = x ^ (x >> _U64(27))
+    x = x * _U64(M1)
+    return x ^ (x >> _U64(31))
+
+
+def _field(h, shift, bits):
+    return ((h >> _U64(shift)) & _U64((1 << bits) - 1)).astype(np.int64)
+
+
+def synth_tile(tile, height, width, seed=SEED, with_masks=False):
+    """Returns dict: 'bands' (6 int16 [H,W], raw, fills in place), 'fmask' u8,
+    and with `with_masks` also 'land', 'shad', 'ocean' (u8)."""
+    n = height * width
+    pix = np.arange(n, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        key = _U64(seed) * _U64(K0) + _U64(tile) * _U64(K1) + pix
+        h0 = _mix(key)
+        h1 = _mix(h0 + _U64(K0))
+        h2 = _mix(h1 + _U64(K0))
+
+    draw = _field(h0, 0, 16)
+    stype = np.searchsorted(np.asarray(TYPE_CUTS), draw, side='right')  # 0..5
+    is_fill = stype == 5
+    st = np.minimum(stype, 4)
+    mean = np.asarray(TYPE_MEAN, dtype=np.int64)[st]          # [n, 6]
+    amp = np.asarray(TYPE_AMP, dtype=np.int64)[st]            # [n]
+
+    clip_evt = _field(h0, 16, 7) == 0
+    clip_band = (_field(h0, 23, 3) * 6) >> 3
+    clip_val = -_field(h0, 26, 8)
+    wrap_evt = _field(h0, 34, 10) == 0
+
+    bands = []
+    for b in range(6):
+        noise = _field(h1, 10 * b, 10)
+        v = mean[:, b] + ((noise * 2 * amp) >> 10) - amp
+        v = np.where(wrap_evt & ((b == 1) | (b == 4)), v + 19000, v)
+        v = np.where(clip_evt & (clip_band == b), clip_val, v)
+        v = np.where(is_fill, BAND_FILL, v)
+        bands.append(v.astype(np.int16).reshape(height, width))
+
+    aerosol = _field(h2, 0, 2)
+    water = (_field(h2, 2, 5) < 10).astype(np.int64)      # p = .31
+    snow = (_field(h2, 7, 5) < 2).astype(np.int64)        # p = .06
+    shadow = (_field(h2, 12, 5) < 3).astype(np.int64)     # p = .09
+    adjacent = (_field(h2, 17, 5) < 3).astype(np.int64)
+    cloud = (_field(h2, 22, 5) < 4).astype(np.int64)      # p = .125
+    cirrus = (_field(h2, 27, 5) < 1).astype(np.int64)
+    fmask = (aerosol << 6) | (water << 5) | (snow << 4) | (shadow << 3) | \
+        (adjacent << 2) | (cloud << 1) | cirrus
+    fmask = np.where(is_fill, FMASK_FILL, fmask).astype(np.uint8)
+    out = {'bands': bands, 'fmask': fmask.reshape(height, width)}
+    if not with_masks:
+        return out
+
+    land_draw = _field(h2, 32, 8)
+    land_cls = np.asarray(LAND_CLASSES, dtype=np.int64)[_field(h2, 40, 3)]
+    land = np.where(land_draw < 179, 255, land_cls).astype(np.uint8)
+    shad = (_field(h2, 43, 5) >= 3).astype(np.uint8)       # 0 (shadow) with p≈.09
+    row_band = (pix // _U64(width)) >> _U64(5)
+    with np.errstate(over='ignore'):
+        hb = _mix(_U64(seed) * _U64(K1) + _U64(tile) * _U64(K0) + row_band +
+                  _U64(0x5851F42D4C957F2D))
+    ocean = (_field(hb, 0, 8) >= 13).astype(np.uint8)      # 0 (ocean) with p≈.05
+    out.update(land=land.reshape(height, width),
+               shad=shad.reshape(height, width),
+               ocean=ocean.reshape(height, width))
+    return out

@@ -1,0 +1,139 @@
+"""The oracle (oracle/dswx_oracle.py) against the reference-generated goldens.
+
+Pins the numpy restatement to outputs of the real PROTEUS functions
+(tests/golden/*.npz, made by oracle/gen_golden.py), including the reference's own
+unit-test vector (reference tests/test_dswx_hls_units.py:7-28)."""
+import numpy as np
+import pytest
+
+from oracle import dswx_oracle as o
+from tests import _golden as G
+
+
+def test_reference_unit_vector():
+    z = G.load('tables.npz')
+    got = o.generate_interpreted_layer(z['interp_unit_in'])
+    assert np.array_equal(got, z['interp_unit_out'])
+    # same assertion the reference's own test makes, restated on the oracle table
+    keys = list(o.DIAG_TO_CLASS)
+    arr = np.full((1, len(keys) + 1), 111111)
+    exp = np.full((1, len(keys) + 1), 255)
+    for i, k in enumerate(keys):
+        arr[0, i] = k
+        exp[0, i] = o.DIAG_TO_CLASS[k]
+    assert np.array_equal(o.generate_interpreted_layer(arr), exp)
+
+
+def test_tables():
+    z = G.load('tables.npz')
+    assert np.array_equal(o.generate_interpreted_layer(z['interp_in']), z['interp_out'])
+    assert np.array_equal(o.get_binary_representation(z['binrepr_in'].copy()),
+                          z['binrepr_out'])
+    assert np.array_equal(o.collapse_wtr_classes(z['collapse_in']), z['collapse_out'])
+    assert np.array_equal(o.get_binary_water_layer(z['bwtr_in']), z['bwtr_out'])
+    for mode in ('mask', 'ignore', 'cover'):
+        assert np.array_equal(
+            o.compute_preliminary_cloud_layer(z['collapse_in'], mode),
+            z['prelim_' + mode])
+    with pytest.raises(Exception):
+        o.compute_preliminary_cloud_layer(z['collapse_in'], 'bogus')
+
+
+def test_aerosol_grid():
+    z = G.load('tables.npz')
+    custom = {0: [224, 226, 2, 12, 96], 2: [160, 164], 3: [192, 200, 72],
+              4: [128, 130, 255, 0]}
+    for tag, lists in (('default', None), ('custom', custom)):
+        w = z['aer_cls'].copy()
+        c = z['aer_cloud'].copy()
+        o.apply_aerosol_class_remapping(w, z['aer_nir'], c, z['aer_fmask'], lists)
+        assert np.array_equal(w, z[f'aer_{tag}_wtr1'])
+        assert np.array_equal(c, z[f'aer_{tag}_cloud'])
+
+
+def test_landcover_shadow_grid():
+    z = G.load('tables.npz')
+    thr = o.Thresholds()
+    cls, nir, land, shad = z['lc_cls'], z['lc_nir'], z['lc_land'], z['lc_shad']
+    f = o.apply_landcover_and_shadow_masks
+    assert np.array_equal(f(cls, nir, land, shad.astype(bool), thr), z['lc_both'])
+    assert np.array_equal(f(cls, nir, land, shad, thr), z['lc_both_u8shad'])
+    assert np.array_equal(f(cls, nir, land, None, thr), z['lc_land_only'])
+    assert np.array_equal(f(cls, nir, None, shad.astype(bool), thr), z['lc_shad_only'])
+    assert np.array_equal(f(cls, nir, None, None, thr), z['lc_none'])
+
+
+def test_cloud_grids():
+    z = G.load('tables.npz')
+    got = o.add_snow_to_cloud_layer(z['snow_wtr2'], z['snow_cloud_in'].copy(),
+                                    z['snow_fmask'], 'mask')
+    assert np.array_equal(got, z['snow_cloud_out'])
+    assert np.array_equal(o.apply_cloud_masking(z['cm_wtr2'], z['cm_cloud']), z['cm_wtr'])
+    assert np.array_equal(o.get_confidence_layer(z['cm_wtr2'], z['cm_cloud']), z['cm_conf'])
+
+
+@pytest.mark.parametrize('tag', ['default', 'fractional', 'zeros', 'thirds'])
+def test_diag_vectors(tag):
+    z = G.load('diag_vectors.npz')
+    cols = [np.ascontiguousarray(z['bands'][:, i]).reshape(1, -1) for i in range(6)]
+    thr = o.Thresholds(**dict(zip(G.THR_KEYS, z['thr_' + tag].tolist())))
+    assert np.array_equal(o.compute_diagnostic_tests(*cols, thr), z['diag_' + tag])
+
+
+def test_survey_known_answers():
+    """(blue..swir2) -> DIAG decimal / saved DIAG / WTR-1."""
+    kats = [((300, 400, 300, 200, 100, 50), 31, 11111, 1),
+            ((500, 600, 700, 3000, 2500, 1500), 0, 0, 0),
+            ((100, 281, 300, 1700, 219, 50), 16, 10000, 4),
+            ((100, 282, 300, 1699, 219, 50), 17, 10001, 4),
+            ((100, 100, 100, 100, 300, 100), 0, 0, 0),
+            ((100, 101, 100, 100, 300, 100), 16, 10000, 4),
+            ((100, 700, 100, 100, 1800, 100), 16, 10000, 4),
+            ((1, 1, 1, 1, 1, 1), 28, 11100, 2),
+            ((20000,) * 6, 4, 100, 0),
+            ((999, 3000, 2000, 2499, 2999, 999), 20, 10100, 4),
+            ((1000, 3000, 2000, 2500, 3000, 1000), 0, 0, 0),
+            ((400, 1000, 600, 1499, 899, 300), 24, 11000, 3),
+            ((1, 5000, 1, 1, 1, 32767), 15, 1111, 1)]
+    thr = o.Thresholds()
+    for vec, dec, saved, cls in kats:
+        cols = [np.array([[v]], dtype=np.int16) for v in vec]
+        d = o.compute_diagnostic_tests(*cols, thr)
+        assert int(d[0, 0]) == dec, vec
+        assert int(o.get_binary_representation(d)[0, 0]) == saved
+        assert int(o.generate_interpreted_layer(d)[0, 0]) == cls
+    fm = np.array([[0, 2, 4, 6, 8, 10, 12, 14, 16, 224]], dtype=np.uint8)
+    assert o.compute_preliminary_cloud_layer(fm, 'mask').tolist() == \
+        [[0, 4, 1, 5, 1, 5, 1, 5, 0, 0]]
+    assert o.compute_preliminary_cloud_layer(fm, 'ignore').tolist() == \
+        [[0, 4, 0, 4, 1, 5, 1, 5, 0, 0]]
+
+
+def test_float_indices():
+    z = G.load('diag_vectors.npz')
+    cols = [np.ascontiguousarray(z['bands'][:, i]).reshape(1, -1) for i in range(6)]
+    mndwi, _, _, awesh, ndvi = o.spectral_indices(*cols)
+    for got, key in ((mndwi, 'mndwi'), (ndvi, 'ndvi'), (awesh, 'awesh')):
+        assert np.array_equal(got, z[key], equal_nan=True)
+
+
+@pytest.mark.parametrize('name', G.tile_case_names())
+def test_tile_chain(name):
+    c = G.tile_case(name)
+    for collapse in (False, True):
+        res = o.classify_tile(
+            c['bands'], c['fmask'], o.Thresholds(**c['thr']),
+            landcover=c['land'], shadow=c['shad'], ocean_mask=c['ocean'],
+            band_fills=c['band_fills'], fmask_fill=c['fmask_fill'],
+            mask_adjacent_to_cloud_mode=c['mode'], apply_aerosol=c['apply_aerosol'],
+            aerosol_fmask_values=c['aerosol_lists'], collapse=collapse)
+        for layer in G.LAYERS:
+            key = layer + '.collapsed' if (collapse and layer in G.COLLAPSABLE) else layer
+            exp = c['expected'][key]
+            assert res[layer].dtype == exp.dtype, layer
+            assert np.array_equal(res[layer], exp), (name, layer, collapse)
+        cnt = res['counters']
+        got = [cnt['n_valid'], cnt['n_cloud_and_valid'], cnt['n_not_ocean'],
+               cnt['SPATIAL_COVERAGE'], cnt['CLOUD_COVERAGE'],
+               cnt['SPATIAL_COVERAGE_EXCLUDING_MASKED_OCEAN']]
+        assert got == c['expected']['counters'].tolist()
