@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the DSWx-HLS per-pixel hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--tiles T] [--masks]
+
+One "step" = one pass of the fused classify kernel over a device-resident batch of
+T synthetic 3660x3660 HLS.L30 tiles (6 int16 bands + Fmask; `--masks` adds
+LAND/SHAD/OCEAN) per GPU.  Inputs are generated in HBM before the timed region.
+For N > 1 launch with torch.distributed.run (one rank per GPU); tiles are sharded
+by rank, there is no data-path collective (weak scaling: T tiles per GPU).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+TILE = 3660
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--tiles', type=int, default=256, help='tiles per GPU per step')
+    ap.add_argument('--masks', action='store_true',
+                    help='also stream LAND/SHAD/OCEAN planes (BASELINE config 5)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline_sample():
+    """The numpy restatement of the reference path (oracle, kind 'port') on ONE
+    synthetic 3660x3660 tile, single thread as the reference runs."""
+    import numpy as np
+    from oracle import dswx_oracle as o
+    from proteus_amd.synth import synth_tile
+    s = synth_tile(0, TILE, TILE)
+    t0 = time.perf_counter()
+    o.classify_tile(s['bands'], s['fmask'])
+    dt = time.perf_counter() - t0
+    return {'value': round(TILE * TILE / dt / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1,
+            'kind': 'port',
+            'sample': f'1 synthetic {TILE}x{TILE} L30 tile, numpy {np.__version__} '
+                      f'oracle/dswx_oracle.py classify_tile, {dt:.2f} s, '
+                      f'host has {os.cpu_count()} logical cores'}
+
+
+def parity_spot_check(ctx, batch, params, tile):
+    """Not timed: one tile of the batch against the scalar C oracle."""
+    import numpy as np
+    from oracle import c_oracle
+    from proteus_amd import _capi
+    bands = [batch.read_tile(b, tile) for b in _capi.BAND_NAMES]
+    kw = {}
+    if batch.masks:
+        kw = {m: batch.read_tile(m, tile) for m in ('land', 'shad', 'ocean')}
+    exp = c_oracle.classify(params, bands, batch.read_tile('fmask', tile), **kw)
+    for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+        if not np.array_equal(batch.read_tile(key, tile), exp[key]):
+            return f'MISMATCH in {key}'
+    if batch.read_counters()[tile].tolist() != exp['counters'].tolist():
+        return 'MISMATCH in counters'
+    return 'bit-exact'
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run '
+                             '--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...')
+        raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
+
+    import torch
+    from proteus_amd import _capi
+    from proteus_amd.synth import SEED
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    ctx = _capi.Context(local_rank)        # raises if the HIP extension / GPU is missing
+    params = _capi.default_params()
+    n_tiles = args.tiles
+    batch = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=args.masks)
+    batch.synth(SEED, tile0=rank * n_tiles)     # rank r owns tiles [r*T, (r+1)*T)
+    ctx.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        batch.classify(params)
+    ctx.synchronize()
+    kernel_info = ctx.last_kernel_info()
+
+    starts = [ctx.event() for _ in range(args.steps)]
+    stops = [ctx.event() for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ctx.record(starts[k])
+        batch.classify(params)
+        ctx.record(stops[k])
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    launch_ms = [ctx.elapsed_ms(a, b) for a, b in zip(starts, stops)]
+    for e in starts + stops:
+        ctx.destroy_event(e)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f'cuda:{local_rank}')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    parity = None
+    if rank == 0 and not args.no_parity:
+        parity = parity_spot_check(ctx, batch, params, n_tiles // 2)
+
+    if rank == 0:
+        px_per_launch = n_tiles * TILE * TILE
+        bytes_per_px = 24 if args.masks else 21      # 13+8 (16+8 with masks)
+        avg_ms = sum(launch_ms) / len(launch_ms)
+        achieved = px_per_launch * bytes_per_px / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        pmc_note = None
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            key = 'masks' if args.masks else 'plain'
+            if key in pmc and pmc[key].get('tiles') == n_tiles:
+                traffic = pmc[key]['hbm_bytes_per_launch']
+                pmc_note = pmc[key].get('source')
+        out = {
+            'metric': 'Mpixels/sec DSWx classify (3660^2 7-band HLS tiles)',
+            'value': round(world * px_per_launch * args.steps / elapsed / 1e6, 1),
+            'unit': 'Mpixels/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'int16+f64', 'data': 'synthetic',
+            'config': {'workload': f'{n_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles per GPU '
+                                   f'per step, device-resident band-planar batch'
+                                   + (', LAND+SHAD+OCEAN planes' if args.masks else ''),
+                       'tiles_per_gpu': n_tiles, 'tile': [TILE, TILE],
+                       'planes_in': 10 if args.masks else 7, 'planes_out': 7,
+                       'sharding': f'tiles by rank x{world}, no collective',
+                       'kernel': kernel_info},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': traffic,
+                         'algorithmic_bytes_per_pixel': bytes_per_px,
+                         'pixels_per_launch': px_per_launch,
+                         'launch_ms_avg': round(avg_ms, 4), 'launch_ms_min': round(min(launch_ms), 4),
+                         'read_frac_of_peak': round(achieved * (bytes_per_px - 8) / bytes_per_px
+                                                    / HBM_PEAK_GBS, 4),
+                         'traffic_source': pmc_note},
+            'parity_check': parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_sample()
+        print(json.dumps(out), flush=True)
+    batch.free()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,168 @@
+/*
+ * dswx_hip.h -- C ABI of the MI355X (gfx950) DSWx-HLS per-pixel classifier.
+ *
+ * This is the drop-in boundary for the per-pixel hot path of NASA PROTEUS
+ * `src/proteus/dswx_hls.py` (reference file:line given per entry point).  The
+ * reference has no FFI: its seam is the run of numpy calls inside
+ * generate_dswx_layers (:5088-5112, :5225-5286, :5358-5369).  A maintainer binds
+ * this library from Python with ctypes (INTEGRATION.md shows the stub) and
+ * replaces that run of calls with ONE call to dswx_classify_host().
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer; no
+ * allocation crosses the ABI except through dswx_device_malloc/free; every
+ * function returns DSWX_OK (0) or a negative status and records a message
+ * retrievable with dswx_last_error() (thread-local).  There is no CPU fallback:
+ * without a HIP device dswx_ctx_create() fails with DSWX_ERR_NO_DEVICE.
+ *
+ * Plane layout ("band-planar batch"): every plane is [n_tiles][n_pixels]
+ * contiguous, n_pixels = H*W row-major, so a batch is one flat array per plane.
+ */
+#ifndef DSWX_HIP_H
+#define DSWX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSWX_ABI_VERSION 1
+
+enum {
+    DSWX_OK = 0,
+    DSWX_ERR_ARG = -1,          /* bad argument (NULL, size, non-finite threshold) */
+    DSWX_ERR_HIP = -2,          /* a HIP runtime call failed                        */
+    DSWX_ERR_NO_DEVICE = -3,    /* no usable gfx950 device                          */
+    DSWX_ERR_UNSUPPORTED = -4,  /* e.g. adjacent-to-cloud mode outside 0..2          */
+    DSWX_ERR_ALIGN = -5         /* device pointer not aligned for its element type  */
+};
+
+/* mask_adjacent_to_cloud_mode, dswx_hls.py:1919-1993 / :1996-2086 */
+enum { DSWX_ADJ_MASK = 0, DSWX_ADJ_IGNORE = 1, DSWX_ADJ_COVER = 2 };
+
+/* index of the counters a tile produces, dswx_hls.py:5104-5112 */
+enum { DSWX_N_VALID = 0, DSWX_N_CLOUD_AND_VALID = 1, DSWX_N_NOT_OCEAN = 2,
+       DSWX_N_COUNTERS = 3 };
+
+/*
+ * Everything that parameterises the chain.
+ *  - the twelve doubles are HlsThresholds (dswx_hls.py:274-318, defaults
+ *    defaults/dswx_hls.yaml:176-212); they must be finite.
+ *  - band_fill / fmask_fill: the `image == fill_value` test of
+ *    _load_hls_band_from_file (:2195-2209); NaN disables the test for a plane.
+ *  - clip_negative_reflectance: FLAG_CLIP_NEGATIVE_REFLECTANCE (:31, :2298).
+ *  - aerosol_fmask_lut[k][v] != 0  <=>  Fmask value v is in the runconfig list
+ *    for WTR-1 class {0,2,3,4}[k] (:1249-1302, defaults yaml :77-89).
+ *  - aerosol_max_nir: AEROSOL_REMAPPING_MAX_NIR (:45-46) = 1000.0.
+ *  - collapse_wtr_classes: FLAG_COLLAPSE_WTR_CLASSES (:26); when set, WTR, WTR-1,
+ *    WTR-1-AEROSOL and WTR-2 leave in the collapsed form the reference SAVES
+ *    (_collapse_wtr_classes :2578-2598, applied at :2688-2689).
+ */
+typedef struct dswx_params {
+    double wigt, awgt, pswt_1_mndwi, pswt_1_nir, pswt_1_swir1, pswt_1_ndvi,
+           pswt_2_mndwi, pswt_2_blue, pswt_2_nir, pswt_2_swir1, pswt_2_swir2,
+           lcmask_nir;
+    double band_fill[6];
+    double fmask_fill;
+    double aerosol_max_nir;
+    int32_t clip_negative_reflectance;
+    int32_t mask_adjacent_to_cloud_mode;
+    int32_t apply_aerosol_class_remapping;
+    int32_t collapse_wtr_classes;
+    uint8_t aerosol_fmask_lut[4][256];
+} dswx_params_t;
+
+/* Inputs.  band[] order: blue, green, red, nir, swir1, swir2 (raw int16 as read
+ * from the HLS files, fill values still in place).  land / shad / ocean are
+ * optional (NULL = layer not given): LAND codes :252-264, SHAD 0 = masked
+ * (:168-169), OCEAN 0 = ocean (:5243-5245). */
+typedef struct dswx_planes_in {
+    const int16_t* band[6];
+    const uint8_t* fmask;
+    const uint8_t* land;
+    const uint8_t* shad;
+    const uint8_t* ocean;
+} dswx_planes_in_t;
+
+/* Outputs; any pointer may be NULL (that layer is then not produced).
+ *   diag          UInt16 decimal-digit rendering, nodata 65535  (:4286-4317, :5227)
+ *   wtr1          WTR-1 as SAVED, i.e. before aerosol remapping (:5229-5258)
+ *   wtr1_aerosol  WTR-1 after _apply_aerosol_class_remapping    (:5260-5266)
+ *   wtr2          _apply_landcover_and_shadow_masks             (:5268)
+ *   wtr           _apply_cloud_masking                          (:5286)
+ *   bwtr          _get_binary_water_layer                       (:5358)
+ *   conf          _get_confidence_layer                         (:5368)
+ *   cloud         _add_snow_to_cloud_layer                      (:5282)
+ *   mndwi/ndvi/awesh  float64 spectral indices (:1872-1887); debug planes, they
+ *                 select a slower kernel variant.                                   */
+typedef struct dswx_planes_out {
+    uint16_t* diag;
+    uint8_t* wtr1;
+    uint8_t* wtr1_aerosol;
+    uint8_t* wtr2;
+    uint8_t* wtr;
+    uint8_t* bwtr;
+    uint8_t* conf;
+    uint8_t* cloud;
+    double* mndwi;
+    double* ndvi;
+    double* awesh;
+} dswx_planes_out_t;
+
+typedef struct dswx_ctx dswx_ctx_t;
+
+/* ---- library / context ------------------------------------------------------ */
+int dswx_abi_version(void);
+const char* dswx_last_error(void);
+int dswx_device_count(void);
+int dswx_ctx_create(int device, dswx_ctx_t** out);
+int dswx_ctx_destroy(dswx_ctx_t* ctx);
+/* fills `p` with defaults/dswx_hls.yaml:73-101,176-212 and the constants above */
+int dswx_params_default(dswx_params_t* p);
+
+/* ---- the hot path ------------------------------------------------------------ */
+/* Host-pointer entry: replaces dswx_hls.py:5089, :5110-5112, :5225-5231,
+ * :5245-5249, :5261, :5268, :5282, :5286, :5358, :5368 for a batch of tiles.
+ * Stages H2D, runs the fused kernel, stages D2H.  counters: [n_tiles][3] or NULL. */
+int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params,
+                       int64_t n_tiles, int64_t height, int64_t width,
+                       const dswx_planes_in_t* in, const dswx_planes_out_t* out,
+                       int64_t* counters);
+
+/* Device-pointer entry (inputs already resident in HBM): asynchronous on
+ * `stream` (a hipStream_t, NULL = the context's stream).  counters: device
+ * int64 [n_tiles][3] or NULL; they are zeroed on the stream first. */
+int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params,
+                         int64_t n_tiles, int64_t n_pixels,
+                         const dswx_planes_in_t* in, const dswx_planes_out_t* out,
+                         int64_t* counters, void* stream);
+
+/* Deterministic synthetic HLS tiles written straight into HBM (SURVEY.md §8d;
+ * same integer recipe as proteus_amd/synth.py).  Fills in->band[0..5], in->fmask
+ * and whichever of land/shad/ocean is non-NULL for tiles tile0..tile0+n_tiles-1. */
+int dswx_synth_fill(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0, int64_t n_tiles,
+                    int64_t height, int64_t width, const dswx_planes_in_t* in,
+                    void* stream);
+
+/* ---- device plumbing for hosts without another HIP binding ------------------- */
+int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);
+int dswx_device_free(dswx_ctx_t* ctx, void* ptr);
+int dswx_memcpy_h2d(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);
+int dswx_memcpy_d2h(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);
+int dswx_memset_d(dswx_ctx_t* ctx, void* dst, int value, size_t bytes);
+int dswx_stream_synchronize(dswx_ctx_t* ctx, void* stream);
+/* HIP events on the stream the kernels run on (timing for bench.py) */
+int dswx_event_create(dswx_ctx_t* ctx, void** out);
+int dswx_event_destroy(dswx_ctx_t* ctx, void* event);
+int dswx_event_record(dswx_ctx_t* ctx, void* event, void* stream);
+int dswx_event_elapsed_ms(dswx_ctx_t* ctx, void* start, void* stop, float* ms);
+
+/* Name and launch geometry of the kernel the last dswx_classify_* call on this
+ * context selected (for profiles / DESIGN.md): writes a NUL-terminated string. */
+int dswx_last_kernel_info(dswx_ctx_t* ctx, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSWX_HIP_H */

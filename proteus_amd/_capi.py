@@ -1,0 +1,421 @@
+"""ctypes binding of include/dswx_hip.h (the C-ABI of the HIP classifier).
+
+There is exactly one compute path: the HIP library.  If it is missing, or no
+MI355X is visible, every entry point here raises -- nothing falls back to numpy.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+DSWX_ABI_VERSION = 1
+OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALIGN = 0, -1, -2, -3, -4, -5
+ADJ_MODES = {'mask': 0, 'ignore': 1, 'cover': 2}
+BAND_NAMES = ('blue', 'green', 'red', 'nir', 'swir1', 'swir2')
+THRESHOLD_NAMES = ('wigt', 'awgt', 'pswt_1_mndwi', 'pswt_1_nir', 'pswt_1_swir1',
+                   'pswt_1_ndvi', 'pswt_2_mndwi', 'pswt_2_blue', 'pswt_2_nir',
+                   'pswt_2_swir1', 'pswt_2_swir2', 'lcmask_nir')
+U8_LAYERS = ('wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud')
+F64_LAYERS = ('mndwi', 'ndvi', 'awesh')
+# every symbol include/dswx_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTED_SYMBOLS = (
+    'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
+    'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
+    'dswx_classify_device', 'dswx_synth_fill', 'dswx_device_malloc',
+    'dswx_device_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
+    'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
+    'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info')
+
+
+class DswxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f'dswx_hip error {code}: {message}')
+        self.code = code
+
+
+class Params(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_double) for n in THRESHOLD_NAMES] +
+                [('band_fill', ctypes.c_double * 6),
+                 ('fmask_fill', ctypes.c_double),
+                 ('aerosol_max_nir', ctypes.c_double),
+                 ('clip_negative_reflectance', ctypes.c_int32),
+                 ('mask_adjacent_to_cloud_mode', ctypes.c_int32),
+                 ('apply_aerosol_class_remapping', ctypes.c_int32),
+                 ('collapse_wtr_classes', ctypes.c_int32),
+                 ('aerosol_fmask_lut', (ctypes.c_uint8 * 256) * 4)])
+
+
+class PlanesIn(ctypes.Structure):
+    _fields_ = [('band', ctypes.c_void_p * 6), ('fmask', ctypes.c_void_p),
+                ('land', ctypes.c_void_p), ('shad', ctypes.c_void_p),
+                ('ocean', ctypes.c_void_p)]
+
+
+class PlanesOut(ctypes.Structure):
+    _fields_ = ([('diag', ctypes.c_void_p)] +
+                [(n, ctypes.c_void_p) for n in U8_LAYERS] +
+                [(n, ctypes.c_void_p) for n in F64_LAYERS])
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f'{path} is missing: the DSWx HIP extension has not been built '
+            '(run `python -m proteus_amd.build`); there is no CPU fallback')
+    lib = ctypes.CDLL(path)
+    vp, i64, cp = ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p
+    pp = ctypes.POINTER(ctypes.c_void_p)
+    sig = {
+        'dswx_abi_version': (ctypes.c_int, []),
+        'dswx_last_error': (cp, []),
+        'dswx_device_count': (ctypes.c_int, []),
+        'dswx_ctx_create': (ctypes.c_int, [ctypes.c_int, pp]),
+        'dswx_ctx_destroy': (ctypes.c_int, [vp]),
+        'dswx_params_default': (ctypes.c_int, [ctypes.POINTER(Params)]),
+        'dswx_classify_host': (ctypes.c_int, [vp, ctypes.POINTER(Params), i64, i64, i64,
+                                              ctypes.POINTER(PlanesIn),
+                                              ctypes.POINTER(PlanesOut), vp]),
+        'dswx_classify_device': (ctypes.c_int, [vp, ctypes.POINTER(Params), i64, i64,
+                                                ctypes.POINTER(PlanesIn),
+                                                ctypes.POINTER(PlanesOut), vp, vp]),
+        'dswx_synth_fill': (ctypes.c_int, [vp, ctypes.c_uint64, i64, i64, i64, i64,
+                                           ctypes.POINTER(PlanesIn), vp]),
+        'dswx_device_malloc': (ctypes.c_int, [vp, ctypes.c_size_t, pp]),
+        'dswx_device_free': (ctypes.c_int, [vp, vp]),
+        'dswx_memcpy_h2d': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t]),
+        'dswx_memcpy_d2h': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t]),
+        'dswx_memset_d': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_size_t]),
+        'dswx_stream_synchronize': (ctypes.c_int, [vp, vp]),
+        'dswx_event_create': (ctypes.c_int, [vp, pp]),
+        'dswx_event_destroy': (ctypes.c_int, [vp, vp]),
+        'dswx_event_record': (ctypes.c_int, [vp, vp, vp]),
+        'dswx_event_elapsed_ms': (ctypes.c_int, [vp, vp, vp,
+                                                 ctypes.POINTER(ctypes.c_float)]),
+        'dswx_last_kernel_info': (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_size_t]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dswx_abi_version() != DSWX_ABI_VERSION:
+        raise RuntimeError('libdswx_hip.so ABI version mismatch; rebuild it')
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise DswxError(rc, load_library().dswx_last_error().decode('utf-8', 'replace'))
+
+
+def device_count():
+    return load_library().dswx_device_count()
+
+
+def default_params():
+    p = Params()
+    _check(load_library().dswx_params_default(ctypes.byref(p)))
+    return p
+
+
+def make_params(thresholds=None, *, band_fills=None, fmask_fill=255.0,
+                clip_negative_reflectance=True, mask_adjacent_to_cloud_mode='mask',
+                apply_aerosol_class_remapping=True, aerosol_fmask_values=None,
+                collapse_wtr_classes=True, aerosol_max_nir=None):
+    """Build a dswx_params_t.
+
+    thresholds: object with the HlsThresholds attributes, or dict, or None
+    (defaults).  aerosol_fmask_values: {class: [fmask values]} for the WTR-1
+    classes 0, 2, 3, 4, or None (defaults).  Unknown modes raise the same
+    Exception text as the reference (dswx_hls.py:1977-1981).
+    """
+    p = default_params()
+    if thresholds is not None:
+        for name in THRESHOLD_NAMES:
+            v = thresholds[name] if isinstance(thresholds, dict) else \
+                getattr(thresholds, name)
+            if v is None:
+                raise ValueError(f'HLS threshold {name} is not set')
+            setattr(p, name, float(v))
+    if band_fills is not None:
+        for i, f in enumerate(band_fills):
+            p.band_fill[i] = float('nan') if f is None else float(f)
+    p.fmask_fill = float('nan') if fmask_fill is None else float(fmask_fill)
+    if mask_adjacent_to_cloud_mode not in ADJ_MODES:
+        raise Exception('ERROR mask adjacent to cloud/cloud-shadow mode:'
+                        f' {mask_adjacent_to_cloud_mode}')
+    p.mask_adjacent_to_cloud_mode = ADJ_MODES[mask_adjacent_to_cloud_mode]
+    p.clip_negative_reflectance = int(bool(clip_negative_reflectance))
+    p.apply_aerosol_class_remapping = int(bool(apply_aerosol_class_remapping))
+    p.collapse_wtr_classes = int(bool(collapse_wtr_classes))
+    if aerosol_max_nir is not None:
+        p.aerosol_max_nir = float(aerosol_max_nir)
+    if aerosol_fmask_values is not None:
+        for row, cls in enumerate((0, 2, 3, 4)):
+            for v in range(256):
+                p.aerosol_fmask_lut[row][v] = 0
+            for v in aerosol_fmask_values[cls]:
+                if 0 <= int(v) <= 255 and int(v) == v:
+                    p.aerosol_fmask_lut[row][int(v)] = 1
+    return p
+
+
+def _host_ptr(arr):
+    return ctypes.c_void_p(arr.ctypes.data)
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed span owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        ptr = ctypes.c_void_p()
+        _check(ctx.lib.dswx_device_malloc(ctx.handle, self.nbytes, ctypes.byref(ptr)))
+        self.ptr = ptr.value
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.dswx_device_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        _check(self.ctx.lib.dswx_memcpy_h2d(self.ctx.handle,
+                                            ctypes.c_void_p(self.ptr + offset),
+                                            _host_ptr(arr), arr.nbytes))
+
+    def download(self, dtype, count, offset=0):
+        out = np.empty(count, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        _check(self.ctx.lib.dswx_memcpy_d2h(self.ctx.handle, _host_ptr(out),
+                                            ctypes.c_void_p(self.ptr + offset),
+                                            out.nbytes))
+        return out
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per process and device (dswx_ctx_t)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib.dswx_ctx_create(int(device), ctypes.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if self.handle:
+            self.lib.dswx_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-pointer path ----------------------------------------------------
+    def classify_host(self, bands, fmask, params, *, land=None, shad=None, ocean=None,
+                      layers=('diag', 'wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr',
+                              'conf', 'cloud'),
+                      counters=True):
+        """bands: six int16 arrays of identical shape [H,W] or [T,H,W].
+
+        Returns {layer: ndarray} (+ 'counters': int64 [T,3]) with the input's shape.
+        """
+        bands = [np.ascontiguousarray(b, dtype=np.int16) for b in bands]
+        if len(bands) != 6:
+            raise ValueError('need six reflectance bands')
+        shape = bands[0].shape
+        if len(shape) == 2:
+            n_tiles, (h, w) = 1, shape
+        elif len(shape) == 3:
+            n_tiles, h, w = shape
+        else:
+            raise ValueError('bands must be [H,W] or [T,H,W]')
+
+        def prep(a, name):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.uint8)   # bool SHAD -> 0/1 u8
+            if a.shape != shape:
+                raise ValueError(f'{name} shape {a.shape} != bands shape {shape}')
+            return a
+
+        for b in bands:
+            if b.shape != shape:
+                raise ValueError('band shapes differ')
+        fmask = prep(fmask, 'fmask')
+        land, shad, ocean = prep(land, 'land'), prep(shad, 'shad'), prep(ocean, 'ocean')
+        pin = PlanesIn()
+        for i, b in enumerate(bands):
+            pin.band[i] = b.ctypes.data
+        pin.fmask = fmask.ctypes.data
+        pin.land = land.ctypes.data if land is not None else None
+        pin.shad = shad.ctypes.data if shad is not None else None
+        pin.ocean = ocean.ctypes.data if ocean is not None else None
+        pout = PlanesOut()
+        res = {}
+        for name in layers:
+            dt = np.uint16 if name == 'diag' else (np.float64 if name in F64_LAYERS
+                                                   else np.uint8)
+            if name != 'diag' and name not in U8_LAYERS and name not in F64_LAYERS:
+                raise KeyError(name)
+            res[name] = np.empty(shape, dtype=dt)
+            setattr(pout, name, res[name].ctypes.data)
+        cnt = np.zeros((n_tiles, 3), dtype=np.int64) if counters else None
+        _check(self.lib.dswx_classify_host(
+            self.handle, ctypes.byref(params), n_tiles, h, w, ctypes.byref(pin),
+            ctypes.byref(pout), _host_ptr(cnt) if counters else None))
+        if counters:
+            res['counters'] = cnt
+        return res
+
+    # ---- device-pointer path --------------------------------------------------
+    def classify_device(self, params, n_tiles, n_pixels, pin, pout, counters_ptr=None,
+                        stream=None):
+        _check(self.lib.dswx_classify_device(
+            self.handle, ctypes.byref(params), int(n_tiles), int(n_pixels),
+            ctypes.byref(pin), ctypes.byref(pout),
+            ctypes.c_void_p(counters_ptr) if counters_ptr else None,
+            ctypes.c_void_p(stream) if stream else None))
+
+    def synth_fill(self, seed, tile0, n_tiles, height, width, pin, stream=None):
+        _check(self.lib.dswx_synth_fill(
+            self.handle, int(seed), int(tile0), int(n_tiles), int(height), int(width),
+            ctypes.byref(pin), ctypes.c_void_p(stream) if stream else None))
+
+    def malloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def synchronize(self, stream=None):
+        _check(self.lib.dswx_stream_synchronize(
+            self.handle, ctypes.c_void_p(stream) if stream else None))
+
+    def event(self):
+        e = ctypes.c_void_p()
+        _check(self.lib.dswx_event_create(self.handle, ctypes.byref(e)))
+        return e
+
+    def record(self, event, stream=None):
+        _check(self.lib.dswx_event_record(
+            self.handle, event, ctypes.c_void_p(stream) if stream else None))
+
+    def elapsed_ms(self, start, stop):
+        ms = ctypes.c_float()
+        _check(self.lib.dswx_event_elapsed_ms(self.handle, start, stop, ctypes.byref(ms)))
+        return ms.value
+
+    def destroy_event(self, event):
+        self.lib.dswx_event_destroy(self.handle, event)
+
+    def last_kernel_info(self):
+        buf = ctypes.create_string_buffer(256)
+        _check(self.lib.dswx_last_kernel_info(self.handle, buf, 256))
+        return buf.value.decode()
+
+
+class DeviceBatch:
+    """Band-planar batch resident in HBM: every plane is [n_tiles][H*W].
+
+    Owns one arena; plane offsets are 256-byte aligned.  Used by bench.py, the
+    multi-GPU driver and the device-path parity tests.
+    """
+
+    def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=()):
+        self.ctx, self.n_tiles, self.height, self.width = ctx, n_tiles, height, width
+        self.n_pixels = height * width
+        total = n_tiles * self.n_pixels
+        self.total = total
+        off = 0
+        self.offsets = {}
+
+        def take(name, nbytes):
+            nonlocal off
+            self.offsets[name] = off
+            off += (nbytes + 255) & ~255
+
+        for b in BAND_NAMES:
+            take(b, total * 2)
+        take('fmask', total)
+        self.masks = masks
+        if masks:
+            for m in ('land', 'shad', 'ocean'):
+                take(m, total)
+        take('diag', total * 2)
+        self.out_layers = ['wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'] + \
+            [x for x in extra_layers if x in U8_LAYERS]
+        for name in self.out_layers:
+            take(name, total)
+        take('counters', n_tiles * 24)
+        self.arena = ctx.malloc(off)
+        self.nbytes = off
+        base = self.arena.ptr
+        self.pin = PlanesIn()
+        for i, b in enumerate(BAND_NAMES):
+            self.pin.band[i] = base + self.offsets[b]
+        self.pin.fmask = base + self.offsets['fmask']
+        if masks:
+            self.pin.land = base + self.offsets['land']
+            self.pin.shad = base + self.offsets['shad']
+            self.pin.ocean = base + self.offsets['ocean']
+        self.pout = PlanesOut()
+        self.pout.diag = base + self.offsets['diag']
+        for name in self.out_layers:
+            setattr(self.pout, name, base + self.offsets[name])
+        self.counters_ptr = base + self.offsets['counters']
+
+    def synth(self, seed, tile0=0, stream=None):
+        self.ctx.synth_fill(seed, tile0, self.n_tiles, self.height, self.width,
+                            self.pin, stream)
+
+    def classify(self, params, stream=None, counters=True):
+        self.ctx.classify_device(params, self.n_tiles, self.n_pixels, self.pin,
+                                 self.pout, self.counters_ptr if counters else None,
+                                 stream)
+
+    def read_tile(self, name, tile):
+        """Download one plane of one tile as [H,W]."""
+        if name in BAND_NAMES:
+            dt, sz = np.int16, 2
+        elif name == 'diag':
+            dt, sz = np.uint16, 2
+        else:
+            dt, sz = np.uint8, 1
+        off = self.offsets[name] + tile * self.n_pixels * sz
+        return self.arena.download(dt, self.n_pixels, off).reshape(self.height, self.width)
+
+    def write_tile(self, name, tile, arr):
+        sz = 2 if name in BAND_NAMES else 1
+        dt = np.int16 if name in BAND_NAMES else np.uint8
+        self.arena.upload(np.ascontiguousarray(arr, dtype=dt).ravel(),
+                          self.offsets[name] + tile * self.n_pixels * sz)
+
+    def read_counters(self):
+        return self.arena.download(np.int64, self.n_tiles * 3,
+                                   self.offsets['counters']).reshape(self.n_tiles, 3)
+
+    def free(self):
+        self.arena.free()

@@ -1,0 +1,876 @@
+// dswx_hip.hip -- MI355X (gfx950 / CDNA4) DSWx-HLS per-pixel classifier.
+//
+// One fused streaming kernel computes, per pixel, everything the reference does
+// in ~100 whole-array numpy passes between src/proteus/dswx_hls.py:5088 and :5369:
+//   A0 fill/clip  A2 preliminary CLOUD  A3 coverage counters  A4 five DIAG tests
+//   A5-A7 DIAG fill + decimal-digit rendering + WTR-1 LUT  A8 ocean/invalid
+//   A9 aerosol remap  A10 land-cover / terrain-shadow  A11 snow -> CLOUD
+//   A12 WTR  A13 BWTR  A14 CONF  A15 collapse      (row ids: SURVEY.md §8a)
+//
+// Roofline: pure HBM streaming, 13 B read + 8 B written per pixel (16 + 8 with
+// LAND/SHAD/OCEAN).  No MFMA: there is no contraction anywhere in this path.
+//
+// Exactness of the float64 threshold tests without a division
+// ------------------------------------------------------------
+// The reference evaluates  fl64(n/d) > t  with n, d int16 (wrapped sums) and t a
+// double (:1872, :1890-1913).  Rounding is monotonic, so
+//     fl64(n/d) > t   <=>   n/d > m,   m = (t + nextup(t))/2   (real midpoint)
+// and n/d == m is impossible (m has a 54-bit odd significand, n/d has |d| < 2^16).
+// With h = (nextup(t) - t)/2 (a power of two, exact in double):
+//     d > 0:  n/d > m  <=>  n - t*d > h*d
+// r = fma(-t, d, n) is the exact value of n - t*d whenever that needs < 2^53 units
+// of the grid both sides live on (always the case near a tie; far from it the sign
+// is all that matters and rounding never changes a sign), and h*d is exact.  So
+//     fl64(n/d) > t   <=>   (fma(-t,d,n) > h*d)  xor  (d < 0)
+// including d == 0 (numpy gives +-inf / nan there and the formula degenerates to
+// n > 0).  (At t == 0 the half gap underflows; a stand-in h = 2^-100 is used, see
+// make_dev_params.)  `<` is the mirror image with the lower midpoint.  tests/ checks this
+// exhaustively over all 2^32 (n, d) pairs against true division.
+//
+// AWESH (:1881) is a multiple of 0.25 and exact in double, so 4*AWESH is compared
+// as an int32.  Integer-vs-double comparisons (:1898-1912, :1361, :1238) become
+// integer comparisons against floor/ceil of the threshold, computed on the host.
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <cstdarg>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "dswx_hip.h"
+
+// ------------------------------------------------------------------------------
+// device-side parameter block (derived on the host from dswx_params_t)
+// ------------------------------------------------------------------------------
+struct DevParams {
+    double qt[4];       // 0 wigt, 1 pswt_1_mndwi, 2 pswt_2_mndwi, 3 pswt_1_ndvi
+    double qh[4];       // half gap to the neighbouring double (sign folded for [3])
+    int32_t awesh4_min;     // 4*AWESH >= this  <=>  awesh > awgt
+    int32_t p1_swir1_max;   // x <= max  <=>  x < threshold
+    int32_t p1_nir_max;
+    int32_t p2_blue_max;
+    int32_t p2_swir1_max;
+    int32_t p2_swir2_max;
+    int32_t p2_nir_max;
+    int32_t lc_nir_min;     // nir >= min  <=>  nir > lcmask_nir
+    int32_t aer_nir_max;    // nir <= max  <=>  nir <= AEROSOL_REMAPPING_MAX_NIR
+    int32_t band_fill[6];   // INT32_MAX = no fill test
+    int32_t fmask_fill;     // -1 = no fill test
+    int32_t clip_min;       // reflectances are max()ed with this: 1, or -32768 (= no clip)
+    int32_t shadow_bits;    // Fmask bits raising CLOUD bit 0: 8, or 8|4 in 'mask' mode
+    int32_t collapse;       // 0 / 1, used as a shift count
+    uint32_t aer_lut[64];   // byte v: bit c set <=> Fmask v remaps WTR-1 class c
+                            // (all zero when aerosol remapping is disabled)
+};
+
+struct KArgs {
+    DevParams P;
+    dswx_planes_in_t in;
+    dswx_planes_out_t out;
+    unsigned long long* counters;   // [n_tiles][3] or nullptr
+    long long n_pixels;             // per tile
+    long long px_begin;             // generic kernel: first pixel of the tile it covers
+};
+
+// DIAG (5 bits) -> WTR-1 class, interpreted_dswx_band_dict :97-143, as three
+// 32-bit masks (bit k of CLS_Bj = bit j of the class of DIAG value k).
+static constexpr uint8_t kClassOfDiag[32] = {
+    /*00000*/ 0, /*00001*/ 0, /*00010*/ 0, /*00011*/ 4, /*00100*/ 0, /*00101*/ 4,
+    /*00110*/ 4, /*00111*/ 2, /*01000*/ 0, /*01001*/ 4, /*01010*/ 4, /*01011*/ 2,
+    /*01100*/ 4, /*01101*/ 2, /*01110*/ 2, /*01111*/ 1, /*10000*/ 4, /*10001*/ 4,
+    /*10010*/ 4, /*10011*/ 2, /*10100*/ 4, /*10101*/ 2, /*10110*/ 2, /*10111*/ 1,
+    /*11000*/ 3, /*11001*/ 2, /*11010*/ 2, /*11011*/ 1, /*11100*/ 2, /*11101*/ 1,
+    /*11110*/ 1, /*11111*/ 1};
+static constexpr uint32_t class_bit_mask(int bit) {
+    uint32_t m = 0;
+    for (int k = 0; k < 32; ++k) m |= (uint32_t)((kClassOfDiag[k] >> bit) & 1) << k;
+    return m;
+}
+static constexpr uint32_t CLS_B0 = class_bit_mask(0);
+static constexpr uint32_t CLS_B1 = class_bit_mask(1);
+static constexpr uint32_t CLS_B2 = class_bit_mask(2);
+
+struct PxOut {
+    uint32_t diag, wtr1, wtr1a, wtr2, wtr, bwtr, conf, cloud;
+};
+
+// fl64(n/d) > t, see the header comment
+__device__ __forceinline__ bool quot_gt(double t, double h, double dn, double dd, bool dneg) {
+    const double r = __builtin_fma(-t, dd, dn);
+    return (r > h * dd) != dneg;
+}
+// fl64(n/d) < t ; hneg = -(t - nextdown(t))/2
+__device__ __forceinline__ bool quot_lt(double t, double hneg, double dn, double dd, bool dneg) {
+    const double r = __builtin_fma(-t, dd, dn);
+    return (r < hneg * dd) != dneg;
+}
+
+__device__ __forceinline__ uint32_t collapse_class(uint32_t v, uint32_t c) {
+    // _collapse_wtr_classes :2578-2598 on the value set {0..4, 252..255};
+    // c = 1 collapses (0,1,1,2,2), c = 0 is the identity
+    return v <= 4u ? (v + c) >> c : v;
+}
+
+// One pixel through the whole chain.  b..s2 are the RAW values (sign-extended),
+// fm the raw Fmask byte; land/shad/ocean carry neutral sentinels (-1 / 1 / 1)
+// when the plane is not given.
+__device__ __forceinline__ void classify_px(const DevParams& P, const uint8_t* __restrict__ lut,
+                                            int b, int g, int r, int n, int s1, int s2, int fm,
+                                            int land, int shad, int ocean, PxOut& o,
+                                            uint32_t& c_valid, uint32_t& c_cloud,
+                                            uint32_t& c_not_ocean) {
+    // A0: cumulative fill test on the raw values, then clip to >= 1
+    const bool invalid = (b == P.band_fill[0]) | (g == P.band_fill[1]) | (r == P.band_fill[2]) |
+                         (n == P.band_fill[3]) | (s1 == P.band_fill[4]) | (s2 == P.band_fill[5]) |
+                         (fm == P.fmask_fill);
+    b = max(b, P.clip_min); g = max(g, P.clip_min); r = max(r, P.clip_min);
+    n = max(n, P.clip_min); s1 = max(s1, P.clip_min); s2 = max(s2, P.clip_min);
+    // A4: int16 wrap-around sums exactly as numpy forms them
+    const int d1 = (short)(g + s1), n1 = (short)(g - s1);
+    const int mbsrv = (short)(g + r), mbsrn = (short)(n + s1);
+    const int n2 = (short)(n - r), d2 = (short)(n + r);
+    const double dn1 = (double)n1, dd1 = (double)d1, dn2 = (double)n2, dd2 = (double)d2;
+    const bool neg1 = d1 < 0, neg2 = d2 < 0;
+    const bool m_wigt = quot_gt(P.qt[0], P.qh[0], dn1, dd1, neg1);
+    const bool m_p1 = quot_gt(P.qt[1], P.qh[1], dn1, dd1, neg1);
+    const bool m_p2 = quot_gt(P.qt[2], P.qh[2], dn1, dd1, neg1);
+    const bool v_p1 = quot_lt(P.qt[3], P.qh[3], dn2, dd2, neg2);
+    const int awesh4 = 4 * b + 10 * g - 6 * mbsrn - s2;
+    const bool t1 = m_wigt;
+    const bool t2 = mbsrv > mbsrn;
+    const bool t3 = awesh4 >= P.awesh4_min;
+    const bool t4 = m_p1 & (s1 <= P.p1_swir1_max) & (n <= P.p1_nir_max) & v_p1;
+    const bool t5 = m_p2 & (b <= P.p2_blue_max) & (s1 <= P.p2_swir1_max) &
+                    (s2 <= P.p2_swir2_max) & (n <= P.p2_nir_max);
+    const uint32_t dd = (uint32_t)t1 | ((uint32_t)t2 << 1) | ((uint32_t)t3 << 2) |
+                        ((uint32_t)t4 << 3) | ((uint32_t)t5 << 4);
+    // A5-A7
+    const uint32_t digits = (t1 ? 1u : 0u) + (t2 ? 10u : 0u) + (t3 ? 100u : 0u) +
+                            (t4 ? 1000u : 0u) + (t5 ? 10000u : 0u);
+    o.diag = invalid ? 65535u : digits;
+    uint32_t cls = ((CLS_B0 >> dd) & 1u) | (((CLS_B1 >> dd) & 1u) << 1) | (((CLS_B2 >> dd) & 1u) << 2);
+    // A8
+    uint32_t w1 = (ocean == 0) ? 254u : cls;
+    w1 = invalid ? 255u : w1;
+    // A2
+    uint32_t pc = (fm & P.shadow_bits) ? 1u : 0u;
+    pc += (fm & 2) ? 4u : 0u;
+    // A3 (the counters see the preliminary CLOUD, before the aerosol bit)
+    const bool valid = (!invalid) & (ocean != 0);
+    c_valid += valid ? 1u : 0u;
+    c_cloud += (valid & (pc != 0u)) ? 1u : 0u;
+    c_not_ocean += (uint32_t)ocean;
+    // A9
+    const uint32_t bits = lut[fm];
+    const bool remap = (w1 <= 4u) & (((bits >> (w1 & 7u)) & 1u) != 0u) & (n <= P.aer_nir_max);
+    const uint32_t w1a = remap ? 1u : w1;
+    pc |= remap ? 8u : 0u;
+    // A10 (every predicate reads the input layer; every hit writes 0)
+    const bool water = (w1a - 1u) <= 3u;
+    const bool psw = (w1a - 3u) <= 1u;
+    const bool bright = n >= P.lc_nir_min;
+    const bool to_zero = ((shad == 0) & (land != 200) & water) |
+                         ((land == 201) & bright & psw) |
+                         (((uint32_t)land < 100u) & bright & psw) |
+                         (((uint32_t)(land - 100) < 100u) & water);
+    const uint32_t w2 = to_zero ? 0u : w1a;
+    // A11
+    uint32_t cl = pc + ((fm & 16) ? 2u : 0u);
+    cl = (w2 == 255u) ? 255u : cl;
+    // A12
+    uint32_t w = w2;
+    w = ((cl != 0u) & (cl != 8u)) ? 253u : w;
+    w = ((cl == 2u) | (cl == 10u)) ? 252u : w;
+    w = (w2 >= 254u) ? w2 : w;
+    // A13
+    const uint32_t bw = ((w - 1u) <= 3u) ? 1u : w;
+    // A14
+    uint32_t cf = w2;
+    const bool cloudy = (cl <= 15u) & ((cl & 5u) != 0u);
+    cf = ((w2 <= 4u) & cloudy) ? w2 + 10u : cf;
+    cf = ((w2 <= 4u) & (cl == 2u)) ? w2 + 20u : cf;
+    // A15
+    const uint32_t cc = (uint32_t)P.collapse;
+    o.wtr1 = collapse_class(w1, cc); o.wtr1a = collapse_class(w1a, cc);
+    o.wtr2 = collapse_class(w2, cc); o.wtr = collapse_class(w, cc);
+    o.bwtr = bw; o.conf = cf; o.cloud = cl;
+}
+
+__device__ __forceinline__ int s16_of(uint32_t dword, int half) {
+    return half ? ((int)dword >> 16) : (int)(short)(dword & 0xffffu);
+}
+__device__ __forceinline__ int u8_of(uint32_t dword, int k) { return (int)((dword >> (8 * k)) & 0xffu); }
+
+// block-wide sum of three per-thread counts -> one atomic per block and counter
+__device__ __forceinline__ void reduce_counters(unsigned long long* __restrict__ dst, uint32_t* red,
+                                                uint32_t c0, uint32_t c1, uint32_t c2) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_xor(c0, off);
+        c1 += __shfl_xor(c1, off);
+        c2 += __shfl_xor(c2, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave * 3 + 0] = c0; red[wave * 3 + 1] = c1; red[wave * 3 + 2] = c2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long s = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w * 3 + threadIdx.x];
+        if (s) atomicAdd(dst + threadIdx.x, s);
+    }
+}
+
+// ------------------------------------------------------------------------------
+// Fused kernel: one 8-pixel group per thread.  16-byte loads from the six int16
+// planes, 8-byte loads from the u8 planes; 16-byte DIAG store, 8-byte u8 stores.
+// grid.y = tile, grid.x covers the tile's whole 8-pixel groups (a ragged
+// remainder of < 8 pixels per tile goes to dswx_classify_v1).
+// ------------------------------------------------------------------------------
+template <bool MASKS>
+__global__ __launch_bounds__(256) void dswx_classify_v8(const KArgs a) {
+    __shared__ uint32_t lut32[64];
+    __shared__ uint32_t red[4 * 3];
+    if (threadIdx.x < 64) lut32[threadIdx.x] = a.P.aer_lut[threadIdx.x];
+    __syncthreads();
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
+    const DevParams& P = a.P;
+
+    const long long n_groups = a.n_pixels >> 3;
+    const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    if (grp < n_groups) {
+        const long long off = (long long)blockIdx.y * a.n_pixels + grp * 8;
+        uint4 v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = *reinterpret_cast<const uint4*>(a.in.band[k] + off);
+        const uint2 vf = *reinterpret_cast<const uint2*>(a.in.fmask + off);
+        uint2 vl = make_uint2(0, 0), vs = make_uint2(0, 0), vo = make_uint2(0, 0);
+        bool has_l = false, has_s = false, has_o = false;
+        if (MASKS) {
+            has_l = a.in.land != nullptr; has_s = a.in.shad != nullptr; has_o = a.in.ocean != nullptr;
+            if (has_l) vl = *reinterpret_cast<const uint2*>(a.in.land + off);
+            if (has_s) vs = *reinterpret_cast<const uint2*>(a.in.shad + off);
+            if (has_o) vo = *reinterpret_cast<const uint2*>(a.in.ocean + off);
+        }
+        uint32_t q_diag[4] = {0, 0, 0, 0};
+        uint32_t q_w1[2] = {0, 0}, q_w1a[2] = {0, 0}, q_w2[2] = {0, 0}, q_w[2] = {0, 0},
+                 q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0};
+        const uint32_t* pb = reinterpret_cast<const uint32_t*>(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int wd = j >> 1, hf = j & 1;
+            const int b = s16_of(pb[0 * 4 + wd], hf), g = s16_of(pb[1 * 4 + wd], hf),
+                      r = s16_of(pb[2 * 4 + wd], hf), n = s16_of(pb[3 * 4 + wd], hf),
+                      s1 = s16_of(pb[4 * 4 + wd], hf), s2 = s16_of(pb[5 * 4 + wd], hf);
+            const int bw = j >> 2, bk = j & 3;
+            const int fm = u8_of(bw ? vf.y : vf.x, bk);
+            int land = -1, shad = 1, ocean = 1;
+            if (MASKS) {
+                if (has_l) land = u8_of(bw ? vl.y : vl.x, bk);
+                if (has_s) shad = u8_of(bw ? vs.y : vs.x, bk);
+                if (has_o) ocean = u8_of(bw ? vo.y : vo.x, bk);
+            }
+            PxOut o;
+            classify_px(P, lut, b, g, r, n, s1, s2, fm, land, shad, ocean, o, c0, c1, c2);
+            q_diag[wd] |= o.diag << (16 * hf);
+            q_w1[bw] |= o.wtr1 << (8 * bk);
+            q_w1a[bw] |= o.wtr1a << (8 * bk);
+            q_w2[bw] |= o.wtr2 << (8 * bk);
+            q_w[bw] |= o.wtr << (8 * bk);
+            q_bw[bw] |= o.bwtr << (8 * bk);
+            q_cf[bw] |= o.conf << (8 * bk);
+            q_cl[bw] |= o.cloud << (8 * bk);
+        }
+        if (a.out.diag) *reinterpret_cast<uint4*>(a.out.diag + off) = make_uint4(q_diag[0], q_diag[1], q_diag[2], q_diag[3]);
+        if (a.out.wtr1) *reinterpret_cast<uint2*>(a.out.wtr1 + off) = make_uint2(q_w1[0], q_w1[1]);
+        if (a.out.wtr1_aerosol) *reinterpret_cast<uint2*>(a.out.wtr1_aerosol + off) = make_uint2(q_w1a[0], q_w1a[1]);
+        if (a.out.wtr2) *reinterpret_cast<uint2*>(a.out.wtr2 + off) = make_uint2(q_w2[0], q_w2[1]);
+        if (a.out.wtr) *reinterpret_cast<uint2*>(a.out.wtr + off) = make_uint2(q_w[0], q_w[1]);
+        if (a.out.bwtr) *reinterpret_cast<uint2*>(a.out.bwtr + off) = make_uint2(q_bw[0], q_bw[1]);
+        if (a.out.conf) *reinterpret_cast<uint2*>(a.out.conf + off) = make_uint2(q_cf[0], q_cf[1]);
+        if (a.out.cloud) *reinterpret_cast<uint2*>(a.out.cloud + off) = make_uint2(q_cl[0], q_cl[1]);
+    }
+    if (a.counters) reduce_counters(a.counters + (long long)blockIdx.y * 3, red, c0, c1, c2);
+}
+
+// ------------------------------------------------------------------------------
+// Generic kernel: one pixel per thread over pixels [px_begin, n_pixels) of every
+// tile, no alignment requirement.  Runs the ragged remainder behind the vector
+// kernel, and whole tiles when a batch of ragged tiles (n_pixels % 8 != 0,
+// n_tiles > 1) or unaligned planes rule the vector kernel out.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
+    __shared__ uint32_t lut32[64];
+    __shared__ uint32_t red[4 * 3];
+    if (threadIdx.x < 64) lut32[threadIdx.x] = a.P.aer_lut[threadIdx.x];
+    __syncthreads();
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    const long long px = a.px_begin + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (px < a.n_pixels) {
+        const long long off = (long long)blockIdx.y * a.n_pixels + px;
+        int land = -1, shad = 1, ocean = 1;
+        if (a.in.land) land = a.in.land[off];
+        if (a.in.shad) shad = a.in.shad[off];
+        if (a.in.ocean) ocean = a.in.ocean[off];
+        PxOut o;
+        classify_px(a.P, lut, a.in.band[0][off], a.in.band[1][off], a.in.band[2][off], a.in.band[3][off],
+                    a.in.band[4][off], a.in.band[5][off], a.in.fmask[off], land, shad, ocean, o, c0, c1, c2);
+        if (a.out.diag) a.out.diag[off] = (uint16_t)o.diag;
+        if (a.out.wtr1) a.out.wtr1[off] = (uint8_t)o.wtr1;
+        if (a.out.wtr1_aerosol) a.out.wtr1_aerosol[off] = (uint8_t)o.wtr1a;
+        if (a.out.wtr2) a.out.wtr2[off] = (uint8_t)o.wtr2;
+        if (a.out.wtr) a.out.wtr[off] = (uint8_t)o.wtr;
+        if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)o.bwtr;
+        if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
+        if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
+    }
+    if (a.counters) reduce_counters(a.counters + (long long)blockIdx.y * 3, red, c0, c1, c2);
+}
+
+// ------------------------------------------------------------------------------
+// Debug planes: float64 MNDWI / NDVI / AWESH exactly as :1872-1887 (true IEEE
+// division; int16 wrap-around sums).  Not on the timed path.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dswx_indices_v1(const KArgs a, long long total) {
+    const long long off = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (off >= total) return;
+    int b = a.in.band[0][off], g = a.in.band[1][off], r = a.in.band[2][off], n = a.in.band[3][off],
+        s1 = a.in.band[4][off], s2 = a.in.band[5][off];
+    const int cm = a.P.clip_min;
+    b = max(b, cm); g = max(g, cm); r = max(r, cm);
+    n = max(n, cm); s1 = max(s1, cm); s2 = max(s2, cm);
+    const int d1 = (short)(g + s1), n1 = (short)(g - s1), mbsrn = (short)(n + s1);
+    const int n2 = (short)(n - r), d2 = (short)(n + r);
+    if (a.out.mndwi) a.out.mndwi[off] = (double)n1 / (double)d1;
+    if (a.out.ndvi) a.out.ndvi[off] = (double)n2 / (double)d2;
+    if (a.out.awesh) a.out.awesh[off] = 0.25 * (double)(4 * b + 10 * g - 6 * mbsrn - s2);
+}
+
+// ------------------------------------------------------------------------------
+// Synthetic tiles (same integer recipe as proteus_amd/synth.py)
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ long long fieldu(unsigned long long h, int shift, int bits) {
+    return (long long)((h >> shift) & ((1ull << bits) - 1ull));
+}
+
+__global__ __launch_bounds__(256) void dswx_synth_v1(dswx_planes_in_t in, unsigned long long seed,
+                                                      long long tile0, long long n_pixels, int width) {
+    const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (px >= n_pixels) return;
+    const long long t = blockIdx.y;
+    const unsigned long long tile = (unsigned long long)(tile0 + t);
+    const long long off = t * n_pixels + px;
+    const unsigned long long K0 = 0x9E3779B97F4A7C15ull, K1 = 0xD1B54A32D192ED03ull;
+    const unsigned long long h0 = mix64(seed * K0 + tile * K1 + (unsigned long long)px);
+    const unsigned long long h1 = mix64(h0 + K0);
+    const unsigned long long h2 = mix64(h1 + K0);
+    const int cuts[5] = {14418, 26214, 42598, 55705, 64225};
+    const int mean[5][6] = {{350, 450, 350, 250, 150, 100},
+                            {500, 700, 600, 1300, 800, 500},
+                            {300, 600, 400, 3500, 1800, 900},
+                            {900, 1200, 1500, 2200, 2800, 2300},
+                            {6000, 6200, 6400, 6600, 3000, 2500}};
+    const int amps[5] = {300, 600, 600, 800, 2500};
+    const int draw = (int)fieldu(h0, 0, 16);
+    int stype = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) stype += draw >= cuts[k] ? 1 : 0;
+    const bool is_fill = stype == 5;
+    const int st = stype < 4 ? stype : 4;
+    const long long amp = amps[st];
+    const bool clip_evt = fieldu(h0, 16, 7) == 0;
+    const int clip_band = (int)((fieldu(h0, 23, 3) * 6) >> 3);
+    const long long clip_val = -fieldu(h0, 26, 8);
+    const bool wrap_evt = fieldu(h0, 34, 10) == 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const long long noise = fieldu(h1, 10 * b, 10);
+        long long v = mean[st][b] + ((noise * 2 * amp) >> 10) - amp;
+        if (wrap_evt && (b == 1 || b == 4)) v += 19000;
+        if (clip_evt && clip_band == b) v = clip_val;
+        if (is_fill) v = -9999;
+        const_cast<int16_t*>(in.band[b])[off] = (int16_t)v;
+    }
+    const long long aerosol = fieldu(h2, 0, 2);
+    const long long water = fieldu(h2, 2, 5) < 10, snow = fieldu(h2, 7, 5) < 2,
+                    shadow = fieldu(h2, 12, 5) < 3, adjacent = fieldu(h2, 17, 5) < 3,
+                    cloud = fieldu(h2, 22, 5) < 4, cirrus = fieldu(h2, 27, 5) < 1;
+    long long fm = (aerosol << 6) | (water << 5) | (snow << 4) | (shadow << 3) | (adjacent << 2) |
+                   (cloud << 1) | cirrus;
+    if (is_fill) fm = 255;
+    const_cast<uint8_t*>(in.fmask)[off] = (uint8_t)fm;
+    if (in.land) {
+        const int classes[8] = {200, 201, 21, 121, 50, 150, 99, 100};
+        const int cls = classes[fieldu(h2, 40, 3)];
+        const_cast<uint8_t*>(in.land)[off] = (uint8_t)(fieldu(h2, 32, 8) < 179 ? 255 : cls);
+    }
+    if (in.shad) const_cast<uint8_t*>(in.shad)[off] = (uint8_t)(fieldu(h2, 43, 5) >= 3 ? 1 : 0);
+    if (in.ocean) {
+        const unsigned long long row_band = (unsigned long long)(px / width) >> 5;
+        const unsigned long long hb = mix64(seed * K1 + tile * K0 + row_band + 0x5851F42D4C957F2Dull);
+        const_cast<uint8_t*>(in.ocean)[off] = (uint8_t)(fieldu(hb, 0, 8) >= 13 ? 1 : 0);
+    }
+}
+
+// ==============================================================================
+// host side
+// ==============================================================================
+struct dswx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    // grow-only staging for dswx_classify_host
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    std::string last_kernel;
+};
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail(DSWX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),  \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// smallest k with (x > t <=> x >= k) for every integer x in the int16-sum range
+static int32_t int_gt_min(double t) {
+    if (std::isnan(t)) return 1 << 30;
+    double k = std::floor(t) + 1.0;
+    if (k > 1e9) return 1 << 30;
+    if (k < -1e9) return -(1 << 30);
+    return (int32_t)k;
+}
+// largest k with (x < t <=> x <= k)
+static int32_t int_lt_max(double t) {
+    if (std::isnan(t)) return -(1 << 30);
+    double k = std::ceil(t) - 1.0;
+    if (k > 1e9) return 1 << 30;
+    if (k < -1e9) return -(1 << 30);
+    return (int32_t)k;
+}
+// largest k with (x <= t <=> x <= k)
+static int32_t int_le_max(double t) {
+    if (std::isnan(t)) return -(1 << 30);
+    double k = std::floor(t);
+    if (k > 1e9) return 1 << 30;
+    if (k < -1e9) return -(1 << 30);
+    return (int32_t)k;
+}
+
+static int make_dev_params(const dswx_params_t* p, DevParams* d) {
+    const double thr[12] = {p->wigt, p->awgt, p->pswt_1_mndwi, p->pswt_1_nir, p->pswt_1_swir1,
+                            p->pswt_1_ndvi, p->pswt_2_mndwi, p->pswt_2_blue, p->pswt_2_nir,
+                            p->pswt_2_swir1, p->pswt_2_swir2, p->lcmask_nir};
+    for (double t : thr)
+        if (!std::isfinite(t) || std::fabs(t) > 1e100 || (t != 0.0 && std::fabs(t) < 1e-290))
+            return fail(DSWX_ERR_ARG, "HLS thresholds must be finite, |t| <= 1e100, and 0 or |t| >= 1e-290");
+    if (!std::isfinite(p->aerosol_max_nir)) return fail(DSWX_ERR_ARG, "aerosol_max_nir must be finite");
+    if (p->mask_adjacent_to_cloud_mode < 0 || p->mask_adjacent_to_cloud_mode > 2)
+        return fail(DSWX_ERR_UNSUPPORTED, "ERROR mask adjacent to cloud/cloud-shadow mode: %d",
+                    p->mask_adjacent_to_cloud_mode);
+    std::memset(d, 0, sizeof *d);
+    const double inf = std::numeric_limits<double>::infinity();
+    // Half gap to the neighbouring double.  At t == 0 the true half gap (2^-1075)
+    // is not representable; any h with 0 < h*|d| < 1 <= |n| separates the same
+    // quotients, so 2^-100 stands in for it.
+    const double h_at_zero = std::ldexp(1.0, -100);
+    const double gt_thr[3] = {p->wigt, p->pswt_1_mndwi, p->pswt_2_mndwi};
+    for (int i = 0; i < 3; ++i) {
+        d->qt[i] = gt_thr[i];
+        d->qh[i] = gt_thr[i] == 0.0 ? h_at_zero : (std::nextafter(gt_thr[i], inf) - gt_thr[i]) * 0.5;
+    }
+    d->qt[3] = p->pswt_1_ndvi;
+    d->qh[3] = p->pswt_1_ndvi == 0.0 ? -h_at_zero
+                                     : -((p->pswt_1_ndvi - std::nextafter(p->pswt_1_ndvi, -inf)) * 0.5);
+    d->awesh4_min = int_gt_min(4.0 * p->awgt);
+    d->p1_swir1_max = int_lt_max(p->pswt_1_swir1);
+    d->p1_nir_max = int_lt_max(p->pswt_1_nir);
+    d->p2_blue_max = int_lt_max(p->pswt_2_blue);
+    d->p2_swir1_max = int_lt_max(p->pswt_2_swir1);
+    d->p2_swir2_max = int_lt_max(p->pswt_2_swir2);
+    d->p2_nir_max = int_lt_max(p->pswt_2_nir);
+    d->lc_nir_min = int_gt_min(p->lcmask_nir);
+    d->aer_nir_max = int_le_max(p->aerosol_max_nir);
+    for (int i = 0; i < 6; ++i) {
+        const double f = p->band_fill[i];
+        d->band_fill[i] = (std::isfinite(f) && f == std::floor(f) && f >= -32768.0 && f <= 32767.0)
+                              ? (int32_t)f : std::numeric_limits<int32_t>::max();
+    }
+    {
+        const double f = p->fmask_fill;
+        d->fmask_fill = (std::isfinite(f) && f == std::floor(f) && f >= 0.0 && f <= 255.0) ? (int32_t)f : -1;
+    }
+    d->clip_min = p->clip_negative_reflectance ? 1 : -32768;
+    d->shadow_bits = p->mask_adjacent_to_cloud_mode == DSWX_ADJ_MASK ? (8 | 4) : 8;
+    d->collapse = p->collapse_wtr_classes ? 1 : 0;
+    const int cls_of_row[4] = {0, 2, 3, 4};
+    for (int v = 0; v < 256 && p->apply_aerosol_class_remapping; ++v) {
+        uint32_t bits = 0;
+        for (int k = 0; k < 4; ++k)
+            if (p->aerosol_fmask_lut[k][v]) bits |= 1u << cls_of_row[k];
+        d->aer_lut[v >> 2] |= bits << (8 * (v & 3));
+    }
+    return DSWX_OK;
+}
+
+extern "C" {
+
+int dswx_abi_version(void) { return DSWX_ABI_VERSION; }
+
+const char* dswx_last_error(void) { return g_err.c_str(); }
+
+int dswx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dswx_params_default(dswx_params_t* p) {
+    if (!p) return fail(DSWX_ERR_ARG, "params is NULL");
+    std::memset(p, 0, sizeof *p);
+    p->wigt = 0.124; p->awgt = 0.0;
+    p->pswt_1_mndwi = -0.44; p->pswt_1_nir = 1500; p->pswt_1_swir1 = 900; p->pswt_1_ndvi = 0.7;
+    p->pswt_2_mndwi = -0.5; p->pswt_2_blue = 1000; p->pswt_2_nir = 2500; p->pswt_2_swir1 = 3000;
+    p->pswt_2_swir2 = 1000; p->lcmask_nir = 1200;
+    for (int i = 0; i < 6; ++i) p->band_fill[i] = -9999.0;
+    p->fmask_fill = 255.0;
+    p->aerosol_max_nir = 0.1 / 0.0001;
+    p->clip_negative_reflectance = 1;
+    p->mask_adjacent_to_cloud_mode = DSWX_ADJ_MASK;
+    p->apply_aerosol_class_remapping = 1;
+    p->collapse_wtr_classes = 1;
+    const int l3[] = {224, 160, 96}, l5[] = {224, 192, 160, 128, 96};
+    for (int v : l3) { p->aerosol_fmask_lut[0][v] = 1; p->aerosol_fmask_lut[1][v] = 1; }
+    for (int v : l5) { p->aerosol_fmask_lut[2][v] = 1; p->aerosol_fmask_lut[3][v] = 1; }
+    return DSWX_OK;
+}
+
+int dswx_ctx_create(int device, dswx_ctx_t** out) {
+    if (!out) return fail(DSWX_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(DSWX_ERR_NO_DEVICE, "no HIP device visible: the DSWx HIP path has no CPU fallback");
+    if (device < 0 || device >= n) return fail(DSWX_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    dswx_ctx* c = new dswx_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(DSWX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return DSWX_OK;
+}
+
+int dswx_ctx_destroy(dswx_ctx_t* ctx) {
+    if (!ctx) return DSWX_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DSWX_OK;
+}
+
+static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t n_pixels,
+                         const dswx_planes_in_t* in, const dswx_planes_out_t* out, int64_t* counters,
+                         void* stream) {
+    if (!ctx || !params || !in || !out) return fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles < 0 || n_pixels < 0) return fail(DSWX_ERR_ARG, "negative size");
+    for (int k = 0; k < 6; ++k)
+        if (!in->band[k]) return fail(DSWX_ERR_ARG, "band[%d] is NULL", k);
+    if (!in->fmask) return fail(DSWX_ERR_ARG, "fmask is NULL");
+    KArgs a;
+    int rc = make_dev_params(params, &a.P);
+    if (rc) return rc;
+    if (params->mask_adjacent_to_cloud_mode == DSWX_ADJ_COVER)
+        return fail(DSWX_ERR_UNSUPPORTED,
+                    "mask_adjacent_to_cloud_mode 'cover' needs the split (dilation) path; "
+                    "the fused kernel implements 'mask' and 'ignore'");
+    for (int k = 0; k < 6; ++k)
+        if (!aligned_to(in->band[k], 2)) return fail(DSWX_ERR_ALIGN, "band[%d] not 2-byte aligned", k);
+    if (out->diag && !aligned_to(out->diag, 2)) return fail(DSWX_ERR_ALIGN, "diag not 2-byte aligned");
+    if (counters && !aligned_to(counters, 8)) return fail(DSWX_ERR_ALIGN, "counters not 8-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (counters && n_tiles > 0)
+        HIP_TRY(hipMemsetAsync(counters, 0, (size_t)n_tiles * 3 * sizeof(int64_t), s));
+    if (n_tiles == 0 || n_pixels == 0) { ctx->last_kernel = "none (empty input)"; return DSWX_OK; }
+    a.in = *in;
+    a.out = *out;
+    a.counters = reinterpret_cast<unsigned long long*>(counters);
+    a.n_pixels = n_pixels;
+
+    const bool any_index = out->mndwi || out->ndvi || out->awesh;
+    const bool masks = in->land || in->shad || in->ocean;
+    bool vec_ok = (n_pixels % 8 == 0) || n_tiles == 1;
+    for (int k = 0; k < 6 && vec_ok; ++k) vec_ok = aligned_to(in->band[k], 16);
+    vec_ok = vec_ok && aligned_to(in->fmask, 8) && (!in->land || aligned_to(in->land, 8)) &&
+             (!in->shad || aligned_to(in->shad, 8)) && (!in->ocean || aligned_to(in->ocean, 8)) &&
+             (!out->diag || aligned_to(out->diag, 16));
+    uint8_t* const u8outs[] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud};
+    for (uint8_t* p : u8outs) vec_ok = vec_ok && (!p || aligned_to(p, 8));
+
+    const int64_t max_y = 65535;
+    char info[256];
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += max_y) {
+        const int64_t nt = (n_tiles - t0 < max_y) ? n_tiles - t0 : max_y;
+        KArgs b = a;
+        const int64_t shift = t0 * n_pixels;
+        for (int k = 0; k < 6; ++k) b.in.band[k] += shift;
+        b.in.fmask += shift;
+        if (b.in.land) b.in.land += shift;
+        if (b.in.shad) b.in.shad += shift;
+        if (b.in.ocean) b.in.ocean += shift;
+        if (b.out.diag) b.out.diag += shift;
+        if (b.out.wtr1) b.out.wtr1 += shift;
+        if (b.out.wtr1_aerosol) b.out.wtr1_aerosol += shift;
+        if (b.out.wtr2) b.out.wtr2 += shift;
+        if (b.out.wtr) b.out.wtr += shift;
+        if (b.out.bwtr) b.out.bwtr += shift;
+        if (b.out.conf) b.out.conf += shift;
+        if (b.out.cloud) b.out.cloud += shift;
+        if (b.out.mndwi) b.out.mndwi += shift;
+        if (b.out.ndvi) b.out.ndvi += shift;
+        if (b.out.awesh) b.out.awesh += shift;
+        if (b.counters) b.counters += t0 * 3;
+        b.px_begin = 0;
+        const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
+        if (groups > 0) {
+            const int64_t gx = (groups + 255) / 256;
+            dim3 grid((unsigned)gx, (unsigned)nt), block(256);
+            if (masks) hipLaunchKernelGGL(dswx_classify_v8<true>, grid, block, 0, s, b);
+            else hipLaunchKernelGGL(dswx_classify_v8<false>, grid, block, 0, s, b);
+            HIP_TRY(hipGetLastError());
+            snprintf(info, sizeof info, "dswx_classify_v8<%s> grid=(%lld,%lld) block=256",
+                     masks ? "true" : "false", (long long)gx, (long long)nt);
+            b.px_begin = groups * 8;
+        }
+        if (b.px_begin < n_pixels) {
+            const int64_t rest = n_pixels - b.px_begin;
+            const int64_t gx = (rest + 255) / 256;
+            dim3 grid((unsigned)gx, (unsigned)nt), block(256);
+            hipLaunchKernelGGL(dswx_classify_v1, grid, block, 0, s, b);
+            if (groups == 0)
+                snprintf(info, sizeof info, "dswx_classify_v1 grid=(%lld,%lld) block=256",
+                         (long long)gx, (long long)nt);
+        }
+        HIP_TRY(hipGetLastError());
+        if (any_index) {
+            const long long total = (long long)nt * n_pixels;
+            dim3 grid((unsigned)((total + 255) / 256)), block(256);
+            hipLaunchKernelGGL(dswx_indices_v1, grid, block, 0, s, b, total);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    ctx->last_kernel = info;
+    return DSWX_OK;
+}
+
+int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t height,
+                       int64_t width, const dswx_planes_in_t* in, const dswx_planes_out_t* out,
+                       int64_t* counters) {
+    if (!ctx || !params || !in || !out) return fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles < 0 || height < 0 || width < 0) return fail(DSWX_ERR_ARG, "negative size");
+    for (int k = 0; k < 6; ++k)
+        if (!in->band[k]) return fail(DSWX_ERR_ARG, "band[%d] is NULL", k);
+    if (!in->fmask) return fail(DSWX_ERR_ARG, "fmask is NULL");
+    {   // validate parameters before touching the device
+        DevParams tmp;
+        int rc = make_dev_params(params, &tmp);
+        if (rc) return rc;
+    }
+    const int64_t P = height * width;
+    if (n_tiles == 0 || P == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // one tile at a time through a grow-only device arena: planes at 256-byte
+    // aligned offsets so the vector kernel is always eligible
+    auto rnd = [](size_t x) { return (x + 255) & ~size_t(255); };
+    size_t off = 0;
+    size_t o_band[6], o_fm, o_land = 0, o_shad = 0, o_ocean = 0;
+    for (int k = 0; k < 6; ++k) { o_band[k] = off; off += rnd((size_t)P * 2); }
+    o_fm = off; off += rnd((size_t)P);
+    if (in->land) { o_land = off; off += rnd((size_t)P); }
+    if (in->shad) { o_shad = off; off += rnd((size_t)P); }
+    if (in->ocean) { o_ocean = off; off += rnd((size_t)P); }
+    size_t o_diag = off; if (out->diag) off += rnd((size_t)P * 2);
+    uint8_t* const h_u8[7] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud};
+    size_t o_u8[7];
+    for (int i = 0; i < 7; ++i) { o_u8[i] = off; if (h_u8[i]) off += rnd((size_t)P); }
+    double* const h_f64[3] = {out->mndwi, out->ndvi, out->awesh};
+    size_t o_f64[3];
+    for (int i = 0; i < 3; ++i) { o_f64[i] = off; if (h_f64[i]) off += rnd((size_t)P * 8); }
+    size_t o_cnt = off; off += 256;
+    if (off > ctx->stage_bytes) {
+        if (ctx->stage) HIP_TRY(hipFree(ctx->stage));
+        ctx->stage = nullptr; ctx->stage_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->stage, off));
+        ctx->stage_bytes = off;
+    }
+    char* base = static_cast<char*>(ctx->stage);
+    hipStream_t s = ctx->stream;
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        const size_t sh = (size_t)t * (size_t)P;
+        dswx_planes_in_t din{};
+        dswx_planes_out_t dout{};
+        for (int k = 0; k < 6; ++k) {
+            HIP_TRY(hipMemcpyAsync(base + o_band[k], in->band[k] + sh, (size_t)P * 2, hipMemcpyHostToDevice, s));
+            din.band[k] = reinterpret_cast<const int16_t*>(base + o_band[k]);
+        }
+        HIP_TRY(hipMemcpyAsync(base + o_fm, in->fmask + sh, (size_t)P, hipMemcpyHostToDevice, s));
+        din.fmask = reinterpret_cast<const uint8_t*>(base + o_fm);
+        if (in->land) { HIP_TRY(hipMemcpyAsync(base + o_land, in->land + sh, (size_t)P, hipMemcpyHostToDevice, s)); din.land = reinterpret_cast<const uint8_t*>(base + o_land); }
+        if (in->shad) { HIP_TRY(hipMemcpyAsync(base + o_shad, in->shad + sh, (size_t)P, hipMemcpyHostToDevice, s)); din.shad = reinterpret_cast<const uint8_t*>(base + o_shad); }
+        if (in->ocean) { HIP_TRY(hipMemcpyAsync(base + o_ocean, in->ocean + sh, (size_t)P, hipMemcpyHostToDevice, s)); din.ocean = reinterpret_cast<const uint8_t*>(base + o_ocean); }
+        if (out->diag) dout.diag = reinterpret_cast<uint16_t*>(base + o_diag);
+        uint8_t** const d_u8[7] = {&dout.wtr1, &dout.wtr1_aerosol, &dout.wtr2, &dout.wtr, &dout.bwtr, &dout.conf, &dout.cloud};
+        for (int i = 0; i < 7; ++i) if (h_u8[i]) *d_u8[i] = reinterpret_cast<uint8_t*>(base + o_u8[i]);
+        double** const d_f64[3] = {&dout.mndwi, &dout.ndvi, &dout.awesh};
+        for (int i = 0; i < 3; ++i) if (h_f64[i]) *d_f64[i] = reinterpret_cast<double*>(base + o_f64[i]);
+        int64_t* dcnt = counters ? reinterpret_cast<int64_t*>(base + o_cnt) : nullptr;
+        int rc = dswx_classify_device(ctx, params, 1, P, &din, &dout, dcnt, s);
+        if (rc) return rc;
+        if (out->diag) HIP_TRY(hipMemcpyAsync(out->diag + sh, dout.diag, (size_t)P * 2, hipMemcpyDeviceToHost, s));
+        for (int i = 0; i < 7; ++i)
+            if (h_u8[i]) HIP_TRY(hipMemcpyAsync(h_u8[i] + sh, *d_u8[i], (size_t)P, hipMemcpyDeviceToHost, s));
+        for (int i = 0; i < 3; ++i)
+            if (h_f64[i]) HIP_TRY(hipMemcpyAsync(h_f64[i] + sh, *d_f64[i], (size_t)P * 8, hipMemcpyDeviceToHost, s));
+        if (counters) HIP_TRY(hipMemcpyAsync(counters + t * 3, dcnt, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return DSWX_OK;
+}
+
+int dswx_synth_fill(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0, int64_t n_tiles, int64_t height,
+                    int64_t width, const dswx_planes_in_t* in, void* stream) {
+    if (!ctx || !in) return fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles < 0 || height < 0 || width < 0 || tile0 < 0) return fail(DSWX_ERR_ARG, "negative size");
+    for (int k = 0; k < 6; ++k)
+        if (!in->band[k]) return fail(DSWX_ERR_ARG, "band[%d] is NULL", k);
+    if (!in->fmask) return fail(DSWX_ERR_ARG, "fmask is NULL");
+    const int64_t P = height * width;
+    if (n_tiles == 0 || P == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int64_t max_y = 65535;
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += max_y) {
+        const int64_t nt = (n_tiles - t0 < max_y) ? n_tiles - t0 : max_y;
+        dswx_planes_in_t b = *in;
+        const int64_t shift = t0 * P;
+        for (int k = 0; k < 6; ++k) b.band[k] += shift;
+        b.fmask += shift;
+        if (b.land) b.land += shift;
+        if (b.shad) b.shad += shift;
+        if (b.ocean) b.ocean += shift;
+        dim3 grid((unsigned)((P + 255) / 256), (unsigned)nt), block(256);
+        hipLaunchKernelGGL(dswx_synth_v1, grid, block, 0, s, b, (unsigned long long)seed,
+                           (long long)(tile0 + t0), (long long)P, (int)width);
+        HIP_TRY(hipGetLastError());
+    }
+    return DSWX_OK;
+}
+
+int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return fail(DSWX_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return DSWX_OK;
+}
+
+int dswx_device_free(dswx_ctx_t* ctx, void* ptr) {
+    if (!ctx) return fail(DSWX_ERR_ARG, "NULL argument");
+    if (!ptr) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipFree(ptr));
+    return DSWX_OK;
+}
+
+int dswx_memcpy_h2d(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return fail(DSWX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return DSWX_OK;
+}
+
+int dswx_memcpy_d2h(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return fail(DSWX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return DSWX_OK;
+}
+
+int dswx_memset_d(dswx_ctx_t* ctx, void* dst, int value, size_t bytes) {
+    if (!ctx) return fail(DSWX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemset(dst, value, bytes));
+    return DSWX_OK;
+}
+
+int dswx_stream_synchronize(dswx_ctx_t* ctx, void* stream) {
+    if (!ctx) return fail(DSWX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    return DSWX_OK;
+}
+
+int dswx_event_create(dswx_ctx_t* ctx, void** out) {
+    if (!ctx || !out) return fail(DSWX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *out = e;
+    return DSWX_OK;
+}
+
+int dswx_event_destroy(dswx_ctx_t* ctx, void* event) {
+    if (!ctx) return fail(DSWX_ERR_ARG, "NULL argument");
+    if (event) HIP_TRY(hipEventDestroy((hipEvent_t)event));
+    return DSWX_OK;
+}
+
+int dswx_event_record(dswx_ctx_t* ctx, void* event, void* stream) {
+    if (!ctx || !event) return fail(DSWX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord((hipEvent_t)event, stream ? (hipStream_t)stream : ctx->stream));
+    return DSWX_OK;
+}
+
+int dswx_event_elapsed_ms(dswx_ctx_t* ctx, void* start, void* stop, float* ms) {
+    if (!ctx || !start || !stop || !ms) return fail(DSWX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return DSWX_OK;
+}
+
+int dswx_last_kernel_info(dswx_ctx_t* ctx, char* buf, size_t buflen) {
+    if (!ctx || !buf || buflen == 0) return fail(DSWX_ERR_ARG, "NULL argument");
+    snprintf(buf, buflen, "%s", ctx->last_kernel.c_str());
+    return DSWX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/dswx_hip.h declares; parameter packing and error paths that need no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from proteus_amd import _capi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'dswx_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(dswx_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_capi.EXPORTED_SYMBOLS) == names
+
+
+def test_abi_version_and_defaults():
+    lib = _capi.load_library()
+    assert lib.dswx_abi_version() == _capi.DSWX_ABI_VERSION
+    p = _capi.default_params()
+    # defaults/dswx_hls.yaml:176-212 and :73-101
+    assert (p.wigt, p.awgt, p.pswt_1_mndwi, p.pswt_1_ndvi, p.pswt_2_mndwi) == \
+        (0.124, 0.0, -0.44, 0.7, -0.5)
+    assert (p.pswt_1_nir, p.pswt_1_swir1, p.pswt_2_blue, p.pswt_2_nir, p.pswt_2_swir1,
+            p.pswt_2_swir2, p.lcmask_nir) == (1500, 900, 1000, 2500, 3000, 1000, 1200)
+    assert list(p.band_fill) == [-9999.0] * 6 and p.fmask_fill == 255.0
+    assert p.aerosol_max_nir == 0.1 / 0.0001
+    assert p.clip_negative_reflectance == 1 and p.collapse_wtr_classes == 1
+    assert p.mask_adjacent_to_cloud_mode == 0 and p.apply_aerosol_class_remapping == 1
+    lut = np.array([list(r) for r in p.aerosol_fmask_lut])
+    assert sorted(np.nonzero(lut[0])[0]) == [96, 160, 224]
+    assert sorted(np.nonzero(lut[1])[0]) == [96, 160, 224]
+    assert sorted(np.nonzero(lut[2])[0]) == [96, 128, 160, 192, 224]
+    assert sorted(np.nonzero(lut[3])[0]) == [96, 128, 160, 192, 224]
+
+
+def test_struct_layout_matches_header():
+    # sizeof(dswx_params_t): 12+6+1+1 doubles, 4 int32, 4*256 bytes
+    assert ctypes.sizeof(_capi.Params) == 20 * 8 + 4 * 4 + 1024
+    assert ctypes.sizeof(_capi.PlanesIn) == 10 * 8
+    assert ctypes.sizeof(_capi.PlanesOut) == 11 * 8
+
+
+def test_bad_mode_raises_like_reference():
+    with pytest.raises(Exception, match='ERROR mask adjacent to cloud/cloud-shadow mode'):
+        _capi.make_params(mask_adjacent_to_cloud_mode='bogus')
+
+
+def test_no_device_fails_loudly():
+    """On a box without a GPU the context cannot be created -- and nothing falls
+    back to a CPU implementation."""
+    if _capi.device_count() > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(_capi.DswxError) as e:
+        _capi.Context(0)
+    assert e.value.code == _capi.ERR_NO_DEVICE
+    assert 'no CPU fallback' in str(e.value)

@@ -1,0 +1,310 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against
+ (1) the reference-generated golden fixtures,
+ (2) the oracle on the same seeded inputs,
+ (3) size-independent properties at BASELINE.json's full tile size.
+Bar: bit-exact for every integer layer; 1e-6 for the float64 debug indices."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import dswx_oracle as o
+from proteus_amd import _capi
+from proteus_amd.synth import synth_tile, SEED
+from tests import _golden as G
+from tests.test_c_oracle import NAME, params_of_case, check_case, binary_repr
+
+pytestmark = pytest.mark.gpu
+
+ALL_LAYERS = ('diag', 'wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud')
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    # fails loudly (DswxError) if the extension or the GPU is missing
+    c = _capi.Context(0)
+    yield c
+    c.close()
+
+
+# ---- (1) golden fixtures ----------------------------------------------------------
+@pytest.mark.parametrize('name', [n for n in G.tile_case_names() if 'cover' not in n])
+def test_golden_tiles(ctx, name):
+    c = G.tile_case(name)
+    for collapse in (False, True):
+        res = ctx.classify_host(c['bands'], c['fmask'], params_of_case(c, collapse),
+                                land=c['land'], shad=c['shad'], ocean=c['ocean'])
+        check_case(res, c, collapse, name)
+
+
+@pytest.mark.parametrize('tag', ['default', 'fractional', 'zeros', 'thirds'])
+def test_golden_diag_vectors(ctx, tag):
+    """152k band vectors incl. every threshold tie, int16 wrap and n/0, 0/0."""
+    z = G.load('diag_vectors.npz')
+    n = z['bands'].shape[0]
+    cols = [np.ascontiguousarray(z['bands'][:, i]).reshape(1, n) for i in range(6)]
+    p = _capi.make_params(dict(zip(G.THR_KEYS, z['thr_' + tag].tolist())),
+                          band_fills=[None] * 6, fmask_fill=None,
+                          clip_negative_reflectance=False)
+    fm = np.zeros((1, n), dtype=np.uint8)
+    res = ctx.classify_host(cols, fm, p, layers=('diag', 'wtr1', 'mndwi', 'ndvi', 'awesh'))
+    assert np.array_equal(res['diag'], binary_repr(z['diag_' + tag]))
+    # float indices: tolerance 1e-6 stated by north_star (they are in fact bit-equal)
+    for k in ('mndwi', 'ndvi', 'awesh'):
+        got, exp = res[k], z[k]
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        fin = np.isfinite(exp)
+        assert np.array_equal(got[~fin & ~np.isnan(exp)], exp[~fin & ~np.isnan(exp)])
+        assert np.max(np.abs(got[fin] - exp[fin]), initial=0.0) <= 1e-6
+
+
+def test_reference_unit_vector_on_gpu(ctx):
+    """The reference's only unit test (tests/test_dswx_hls_units.py:7-28) pins the
+    DIAG -> WTR-1 table; here every one of the 32 DIAG values is forced through the
+    kernel by band vectors found in the golden set, plus the fill value."""
+    z = G.load('diag_vectors.npz')
+    diag = z['diag_default'].ravel()
+    rows = []
+    for d in range(32):
+        idx = np.nonzero(diag == d)[0]
+        assert idx.size, d
+        rows.append(z['bands'][idx[0]])
+    rows = np.asarray(rows, dtype=np.int16)
+    cols = [np.ascontiguousarray(rows[:, i]).reshape(1, -1) for i in range(6)]
+    p = _capi.make_params(band_fills=[None] * 6, fmask_fill=None,
+                          clip_negative_reflectance=False, collapse_wtr_classes=False)
+    res = ctx.classify_host(cols, np.zeros((1, 32), np.uint8), p)
+    exp = np.array([[o.DIAG_TO_CLASS[d] for d in range(32)]], dtype=np.uint8)
+    assert np.array_equal(res['wtr1'], exp)
+
+
+# ---- (2) seeded inputs vs the oracle ----------------------------------------------
+CONFIGS = [
+    dict(),
+    dict(masks=True),
+    dict(masks=True, mode='ignore'),
+    dict(masks=True, aerosol=False),
+    dict(masks=True, lists={0: [224, 226, 2, 12, 96], 2: [160, 164], 3: [192, 200, 72],
+                            4: [128, 130, 255, 0]}),
+    dict(masks=True, thr=dict(wigt=0.1, awgt=-12.25, pswt_1_mndwi=-0.3, pswt_1_nir=1499.5,
+                              pswt_1_swir1=900.25, pswt_1_ndvi=0.55, pswt_2_mndwi=-0.25,
+                              pswt_2_blue=999.9, pswt_2_nir=2500.5, pswt_2_swir1=3000.75,
+                              pswt_2_swir2=1000.125, lcmask_nir=1199.5)),
+    dict(clip=False),
+]
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (1, 7), (5, 3), (64, 64), (100, 37), (333, 517)])
+@pytest.mark.parametrize('cfg', range(len(CONFIGS)))
+def test_seeded_tiles_vs_numpy_oracle(ctx, shape, cfg):
+    cfg = CONFIGS[cfg]
+    h, w = shape
+    s = synth_tile(31 + h, h, w, with_masks=True)
+    masks = cfg.get('masks', False)
+    land, shad, ocean = (s['land'], s['shad'], s['ocean']) if masks else (None, None, None)
+    thr = dict(o.DEFAULT_THRESHOLDS)
+    thr.update(cfg.get('thr', {}))
+    for collapse in (True, False):
+        p = _capi.make_params(thr, mask_adjacent_to_cloud_mode=cfg.get('mode', 'mask'),
+                              apply_aerosol_class_remapping=cfg.get('aerosol', True),
+                              aerosol_fmask_values=cfg.get('lists'),
+                              clip_negative_reflectance=cfg.get('clip', True),
+                              collapse_wtr_classes=collapse)
+        got = ctx.classify_host(s['bands'], s['fmask'], p, land=land, shad=shad, ocean=ocean)
+        with np.errstate(all='ignore'):
+            exp = o.classify_tile(
+                s['bands'], s['fmask'], o.Thresholds(**thr), landcover=land,
+                shadow=shad, ocean_mask=ocean,
+                mask_adjacent_to_cloud_mode=cfg.get('mode', 'mask'),
+                apply_aerosol=cfg.get('aerosol', True),
+                aerosol_fmask_values=cfg.get('lists'),
+                clip_negative_reflectance=cfg.get('clip', True), collapse=collapse)
+        for layer, key in NAME.items():
+            assert np.array_equal(got[key], exp[layer]), (shape, cfg, layer)
+        c = exp['counters']
+        assert got['counters'][0].tolist() == [c['n_valid'], c['n_cloud_and_valid'],
+                                               c['n_not_ocean']]
+
+
+def test_empty_inputs(ctx):
+    p = _capi.default_params()
+    for shape in [(0, 0), (0, 5), (3, 0)]:
+        bands = [np.zeros(shape, np.int16) for _ in range(6)]
+        res = ctx.classify_host(bands, np.zeros(shape, np.uint8), p)
+        assert res['wtr'].shape == shape
+        assert res['counters'].tolist() == [[0, 0, 0]]
+
+
+def test_error_paths(ctx):
+    p = _capi.default_params()
+    bands = [np.ones((4, 4), np.int16) for _ in range(6)]
+    fm = np.zeros((4, 4), np.uint8)
+    p.wigt = float('nan')
+    with pytest.raises(_capi.DswxError) as e:
+        ctx.classify_host(bands, fm, p)
+    assert e.value.code == _capi.ERR_ARG
+    p = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
+    with pytest.raises(_capi.DswxError) as e:
+        ctx.classify_host(bands, fm, p)
+    assert e.value.code == _capi.ERR_UNSUPPORTED
+    with pytest.raises(ValueError):
+        ctx.classify_host(bands[:5], fm, _capi.default_params())
+
+
+# ---- device-resident batches, synthetic generator ----------------------------------
+@pytest.mark.parametrize('geom', [(3, 64, 64, True), (4, 100, 37, True), (2, 5, 3, False),
+                                  (1, 333, 517, True), (5, 128, 96, False)])
+def test_device_batch_and_synth(ctx, geom):
+    n_tiles, h, w, masks = geom
+    batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=masks, extra_layers=('wtr1_aerosol',))
+    batch.synth(SEED, tile0=7)
+    p = _capi.default_params()
+    batch.classify(p)
+    ctx.synchronize()
+    info = ctx.last_kernel_info()
+    # ragged multi-tile batches go to the generic kernel, the rest to the vector one
+    assert ('v8' in info) == ((h * w) % 8 == 0 or n_tiles == 1), info
+    cnt = batch.read_counters()
+    for t in range(n_tiles):
+        s = synth_tile(7 + t, h, w, with_masks=True)
+        for i, name in enumerate(_capi.BAND_NAMES):
+            assert np.array_equal(batch.read_tile(name, t), s['bands'][i]), (name, t)
+        assert np.array_equal(batch.read_tile('fmask', t), s['fmask'])
+        kw = {}
+        if masks:
+            for m in ('land', 'shad', 'ocean'):
+                assert np.array_equal(batch.read_tile(m, t), s[m]), m
+            kw = dict(land=s['land'], shad=s['shad'], ocean=s['ocean'])
+        exp = c_oracle.classify(p, s['bands'], s['fmask'], **kw)
+        for key in ('diag', 'wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+            assert np.array_equal(batch.read_tile(key, t), exp[key]), (key, t)
+        assert cnt[t].tolist() == exp['counters'].tolist()
+    batch.free()
+
+
+def test_unaligned_device_pointers_take_generic_kernel(ctx):
+    """Planes at odd byte offsets: still correct (dswx_classify_v1)."""
+    h, w = 40, 40
+    n = h * w
+    s = synth_tile(3, h, w)
+    arena = ctx.malloc(n * 32)
+    pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
+    off = 2
+    for i, b in enumerate(s['bands']):
+        arena.upload(b.ravel(), off)
+        pin.band[i] = arena.ptr + off
+        off += n * 2 + 2
+    off += 1
+    arena.upload(s['fmask'].ravel(), off)
+    pin.fmask = arena.ptr + off
+    off += n + 1
+    off += off % 2
+    pout.diag = arena.ptr + off
+    diag_off = off
+    off += 2 * n + 3
+    pout.wtr = arena.ptr + off
+    wtr_off = off
+    p = _capi.default_params()
+    ctx.classify_device(p, 1, n, pin, pout)
+    ctx.synchronize()
+    assert 'v1' in ctx.last_kernel_info()
+    exp = c_oracle.classify(p, s['bands'], s['fmask'])
+    assert np.array_equal(arena.download(np.uint16, n, diag_off), exp['diag'].ravel())
+    assert np.array_equal(arena.download(np.uint8, n, wtr_off), exp['wtr'].ravel())
+    arena.free()
+
+
+# ---- (3) full size ------------------------------------------------------------------
+def test_full_size_tile_vs_numpy_oracle(ctx):
+    """BASELINE.json configs[1]: one 3660x3660 L30 tile, bit-exact uint8/uint16 layers
+    vs the numpy restatement of the reference path."""
+    h = w = 3660
+    s = synth_tile(0, h, w)
+    p = _capi.default_params()
+    got = ctx.classify_host(s['bands'], s['fmask'], p)
+    assert 'v8' in ctx.last_kernel_info()
+    exp = o.classify_tile(s['bands'], s['fmask'])
+    for layer, key in NAME.items():
+        assert np.array_equal(got[key], exp[layer]), layer
+    c = exp['counters']
+    assert got['counters'][0].tolist() == [c['n_valid'], c['n_cloud_and_valid'], c['n_not_ocean']]
+
+
+def test_full_size_batch_properties(ctx):
+    """BASELINE.json configs[2]-like batch (8 full tiles with masks, device-resident):
+    C-oracle spot checks on two tiles + size-independent properties on all."""
+    n_tiles, h, w = 8, 3660, 3660
+    batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, extra_layers=('wtr1_aerosol',))
+    batch.synth(SEED, tile0=100)
+    p = _capi.default_params()
+    batch.classify(p)
+    ctx.synchronize()
+    cnt = batch.read_counters()
+    assert 'v8<true>' in ctx.last_kernel_info()
+    for t in (0, n_tiles - 1):
+        s = synth_tile(100 + t, h, w, with_masks=True)
+        exp = c_oracle.classify(p, s['bands'], s['fmask'], land=s['land'], shad=s['shad'],
+                                ocean=s['ocean'])
+        for key in ALL_LAYERS:
+            assert np.array_equal(batch.read_tile(key, t), exp[key]), (key, t)
+        assert cnt[t].tolist() == exp['counters'].tolist()
+    for t in range(n_tiles):
+        wtr, bwtr, conf = (batch.read_tile(k, t) for k in ('wtr', 'bwtr', 'conf'))
+        wtr2, cloud, diag = (batch.read_tile(k, t) for k in ('wtr2', 'cloud', 'diag'))
+        ocean, fmask = batch.read_tile('ocean', t), batch.read_tile('fmask', t)
+        # value sets
+        assert set(np.unique(wtr)) <= {0, 1, 2, 252, 253, 254, 255}
+        assert set(np.unique(bwtr)) <= {0, 1, 252, 253, 254, 255}
+        assert set(np.unique(cloud)) <= set(range(16)) | {255}
+        # fill / ocean propagate identically through every layer
+        fill = diag == 65535
+        for layer in (wtr, bwtr, conf, wtr2, cloud):
+            assert np.array_equal(layer == 255, fill)
+        assert np.array_equal(wtr2 == 254, (ocean == 0) & ~fill)
+        assert np.array_equal(wtr == 254, wtr2 == 254)
+        # BWTR is a function of WTR; WTR is a function of (WTR-2, CLOUD)
+        assert np.array_equal(bwtr, np.where((wtr >= 1) & (wtr <= 2), 1, wtr))
+        clear = (cloud == 0) | (cloud == 8)
+        assert np.array_equal(wtr[clear], wtr2[clear])
+        # counters are sums over the planes
+        valid = ~fill & (ocean != 0)
+        assert cnt[t, 0] == valid.sum()
+        assert cnt[t, 2] == int(ocean.sum(dtype=np.int64))
+        # idempotence: collapse of the collapsed layer is the identity
+        assert np.array_equal(o.collapse_wtr_classes(wtr), wtr)
+    # linearity over tiles: same tile index => same planes wherever it sits in a batch
+    single = _capi.DeviceBatch(ctx, 1, h, w, masks=True)
+    single.synth(SEED, tile0=103)
+    single.classify(p)
+    ctx.synchronize()
+    for key in ('diag', 'wtr', 'conf'):
+        assert np.array_equal(single.read_tile(key, 0), batch.read_tile(key, 3))
+    assert single.read_counters()[0].tolist() == cnt[3].tolist()
+    single.free()
+    batch.free()
+
+
+def test_gpu_quotient_enumeration(ctx):
+    """Every (green, swir1) pair with green in a 1024-value stride set and swir1 over
+    all of int16 (clip off => every reachable (n, d), incl. wrap and d == 0): DIAG bits
+    0/3/4 expose the three MNDWI tests; then the same for NDVI via (nir, red)."""
+    big = 1e9
+    thr = dict(o.DEFAULT_THRESHOLDS, pswt_1_nir=big, pswt_1_swir1=big, pswt_2_blue=big,
+               pswt_2_nir=big, pswt_2_swir1=big, pswt_2_swir2=big)
+    p = _capi.make_params(thr, band_fills=[None] * 6, fmask_fill=None,
+                          clip_negative_reflectance=False)
+    x = np.arange(-32768, 32768, dtype=np.int32)
+    gs = np.concatenate([np.arange(-32768, 32768, 67), [-1, 0, 1, 281, 32767]]).astype(np.int16)
+    a = np.repeat(gs, x.size).astype(np.int16)
+    b = np.tile(x, gs.size).astype(np.int16)
+    const = lambda v: np.full(a.shape, v, np.int16)
+    fm = np.zeros(a.shape, np.uint8).reshape(1, -1)
+    # MNDWI sweep: green=a, swir1=b ; nir/red fixed with ndvi = -1/3 < 0.7
+    bands = [const(5), a, const(200), const(100), b, const(5)]
+    got = ctx.classify_host([v.reshape(1, -1) for v in bands], fm, p, layers=('diag',))
+    exp = c_oracle.classify(p, bands, fm.ravel(), layers=('diag',))
+    assert np.array_equal(got['diag'].ravel(), exp['diag'])
+    # NDVI sweep: nir=a, red=b ; green/swir1 fixed with mndwi = 0.5 > all thresholds
+    bands = [const(5), const(300), b, a, const(100), const(5)]
+    got = ctx.classify_host([v.reshape(1, -1) for v in bands], fm, p, layers=('diag',))
+    exp = c_oracle.classify(p, bands, fm.ravel(), layers=('diag',))
+    assert np.array_equal(got['diag'].ravel(), exp['diag'])
