@@ -23,7 +23,7 @@ F64_LAYERS = ('mndwi', 'ndvi', 'awesh')
 EXPORTED_SYMBOLS = (
     'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
-    'dswx_classify_device', 'dswx_synth_fill', 'dswx_device_malloc',
+    'dswx_classify_device', 'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info')
@@ -92,6 +92,8 @@ def load_library():
         'dswx_classify_device': (ctypes.c_int, [vp, ctypes.POINTER(Params), i64, i64,
                                                 ctypes.POINTER(PlanesIn),
                                                 ctypes.POINTER(PlanesOut), vp, vp]),
+        'dswx_stream_probe': (ctypes.c_int, [vp, i64, i64, ctypes.POINTER(PlanesIn),
+                                             ctypes.POINTER(PlanesOut), ctypes.c_int, vp]),
         'dswx_synth_fill': (ctypes.c_int, [vp, ctypes.c_uint64, i64, i64, i64, i64,
                                            ctypes.POINTER(PlanesIn), vp]),
         'dswx_device_malloc': (ctypes.c_int, [vp, ctypes.c_size_t, pp]),
@@ -302,6 +304,11 @@ class Context:
             ctypes.c_void_p(counters_ptr) if counters_ptr else None,
             ctypes.c_void_p(stream) if stream else None))
 
+    def stream_probe(self, n_tiles, n_pixels, pin, pout, variant=0, stream=None):
+        _check(self.lib.dswx_stream_probe(
+            self.handle, int(n_tiles), int(n_pixels), ctypes.byref(pin),
+            ctypes.byref(pout), int(variant), ctypes.c_void_p(stream) if stream else None))
+
     def synth_fill(self, seed, tile0, n_tiles, height, width, pin, stream=None):
         _check(self.lib.dswx_synth_fill(
             self.handle, int(seed), int(tile0), int(n_tiles), int(height), int(width),
@@ -352,8 +359,15 @@ class DeviceBatch:
         off = 0
         self.offsets = {}
 
+        skew = int(os.environ.get('DSWX_PLANE_SKEW', '0'))
+
         def take(name, nbytes):
+            # optional skew: plane k starts k*skew bytes later than plain packing,
+            # so equal pixel indices of different planes differ in their low
+            # address bits (DRAM channel / bank selection)
             nonlocal off
+            off += skew * len(self.offsets)
+            off = (off + 255) & ~255
             self.offsets[name] = off
             off += (nbytes + 255) & ~255
 

@@ -70,6 +70,7 @@ struct KArgs {
     DevParams P;
     dswx_planes_in_t in;
     dswx_planes_out_t out;
+    uint2* partials;                // vector kernel: per-wave counts, [tile][block][wave]
     unsigned long long* counters;   // [n_tiles][3] or nullptr
     long long n_pixels;             // per tile
     long long px_begin;             // generic kernel: first pixel of the tile it covers
@@ -120,8 +121,7 @@ __device__ __forceinline__ uint32_t collapse_class(uint32_t v, uint32_t c) {
 __device__ __forceinline__ void classify_px(const DevParams& P, const uint8_t* __restrict__ lut,
                                             int b, int g, int r, int n, int s1, int s2, int fm,
                                             int land, int shad, int ocean, PxOut& o,
-                                            uint32_t& c_valid, uint32_t& c_cloud,
-                                            uint32_t& c_not_ocean) {
+                                            bool& is_valid, bool& is_cloud_and_valid) {
     // A0: cumulative fill test on the raw values, then clip to >= 1
     const bool invalid = (b == P.band_fill[0]) | (g == P.band_fill[1]) | (r == P.band_fill[2]) |
                          (n == P.band_fill[3]) | (s1 == P.band_fill[4]) | (s2 == P.band_fill[5]) |
@@ -160,9 +160,8 @@ __device__ __forceinline__ void classify_px(const DevParams& P, const uint8_t* _
     pc += (fm & 2) ? 4u : 0u;
     // A3 (the counters see the preliminary CLOUD, before the aerosol bit)
     const bool valid = (!invalid) & (ocean != 0);
-    c_valid += valid ? 1u : 0u;
-    c_cloud += (valid & (pc != 0u)) ? 1u : 0u;
-    c_not_ocean += (uint32_t)ocean;
+    is_valid = valid;
+    is_cloud_and_valid = valid & (pc != 0u);
     // A9
     const uint32_t bits = lut[fm];
     const bool remap = (w1 <= 4u) & (((bits >> (w1 & 7u)) & 1u) != 0u) & (n <= P.aer_nir_max);
@@ -199,6 +198,17 @@ __device__ __forceinline__ void classify_px(const DevParams& P, const uint8_t* _
     o.bwtr = bw; o.conf = cf; o.cloud = cl;
 }
 
+template <typename T, bool NT> __device__ __forceinline__ T ldg(const void* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
+    return *reinterpret_cast<const T*>(p);
+}
+template <typename T, bool NT> __device__ __forceinline__ void stg(void* p, T v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
+    else *reinterpret_cast<T*>(p) = v;
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int s16_of(uint32_t dword, int half) {
     return half ? ((int)dword >> 16) : (int)(short)(dword & 0xffffu);
 }
@@ -230,9 +240,8 @@ __device__ __forceinline__ void reduce_counters(unsigned long long* __restrict__
 // remainder of < 8 pixels per tile goes to dswx_classify_v1).
 // ------------------------------------------------------------------------------
 template <bool MASKS>
-__global__ __launch_bounds__(256) void dswx_classify_v8(const KArgs a) {
+__global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
     __shared__ uint32_t lut32[64];
-    __shared__ uint32_t red[4 * 3];
     if (threadIdx.x < 64) lut32[threadIdx.x] = a.P.aer_lut[threadIdx.x];
     __syncthreads();
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
@@ -240,41 +249,46 @@ __global__ __launch_bounds__(256) void dswx_classify_v8(const KArgs a) {
 
     const long long n_groups = a.n_pixels >> 3;
     const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
-    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    // A3: per-wave counts from lane-mask popcounts (scalar unit), no atomics
+    uint32_t w_valid = 0, w_cloud = 0, t_ocean = 0;
     if (grp < n_groups) {
         const long long off = (long long)blockIdx.y * a.n_pixels + grp * 8;
-        uint4 v[6];
+        u32x4 v[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = *reinterpret_cast<const uint4*>(a.in.band[k] + off);
-        const uint2 vf = *reinterpret_cast<const uint2*>(a.in.fmask + off);
-        uint2 vl = make_uint2(0, 0), vs = make_uint2(0, 0), vo = make_uint2(0, 0);
+        for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
+        const u32x2 vf = ldg<u32x2, true>(a.in.fmask + off);
+        u32x2 vl = {0u, 0u}, vs = {0u, 0u}, vo = {0u, 0u};
         bool has_l = false, has_s = false, has_o = false;
         if (MASKS) {
             has_l = a.in.land != nullptr; has_s = a.in.shad != nullptr; has_o = a.in.ocean != nullptr;
-            if (has_l) vl = *reinterpret_cast<const uint2*>(a.in.land + off);
-            if (has_s) vs = *reinterpret_cast<const uint2*>(a.in.shad + off);
-            if (has_o) vo = *reinterpret_cast<const uint2*>(a.in.ocean + off);
+            if (has_l) vl = ldg<u32x2, true>(a.in.land + off);
+            if (has_s) vs = ldg<u32x2, true>(a.in.shad + off);
+            if (has_o) {
+                vo = ldg<u32x2, true>(a.in.ocean + off);
+                t_ocean = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
+            }
         }
         uint32_t q_diag[4] = {0, 0, 0, 0};
         uint32_t q_w1[2] = {0, 0}, q_w1a[2] = {0, 0}, q_w2[2] = {0, 0}, q_w[2] = {0, 0},
                  q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0};
-        const uint32_t* pb = reinterpret_cast<const uint32_t*>(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int wd = j >> 1, hf = j & 1;
-            const int b = s16_of(pb[0 * 4 + wd], hf), g = s16_of(pb[1 * 4 + wd], hf),
-                      r = s16_of(pb[2 * 4 + wd], hf), n = s16_of(pb[3 * 4 + wd], hf),
-                      s1 = s16_of(pb[4 * 4 + wd], hf), s2 = s16_of(pb[5 * 4 + wd], hf);
+            const int b = s16_of(v[0][wd], hf), g = s16_of(v[1][wd], hf), r = s16_of(v[2][wd], hf),
+                      n = s16_of(v[3][wd], hf), s1 = s16_of(v[4][wd], hf), s2 = s16_of(v[5][wd], hf);
             const int bw = j >> 2, bk = j & 3;
-            const int fm = u8_of(bw ? vf.y : vf.x, bk);
+            const int fm = u8_of(vf[bw], bk);
             int land = -1, shad = 1, ocean = 1;
             if (MASKS) {
-                if (has_l) land = u8_of(bw ? vl.y : vl.x, bk);
-                if (has_s) shad = u8_of(bw ? vs.y : vs.x, bk);
-                if (has_o) ocean = u8_of(bw ? vo.y : vo.x, bk);
+                if (has_l) land = u8_of(vl[bw], bk);
+                if (has_s) shad = u8_of(vs[bw], bk);
+                if (has_o) ocean = u8_of(vo[bw], bk);
             }
             PxOut o;
-            classify_px(P, lut, b, g, r, n, s1, s2, fm, land, shad, ocean, o, c0, c1, c2);
+            bool ok, cv;
+            classify_px(P, lut, b, g, r, n, s1, s2, fm, land, shad, ocean, o, ok, cv);
+            w_valid += (uint32_t)__popcll(__ballot(ok));
+            w_cloud += (uint32_t)__popcll(__ballot(cv));
             q_diag[wd] |= o.diag << (16 * hf);
             q_w1[bw] |= o.wtr1 << (8 * bk);
             q_w1a[bw] |= o.wtr1a << (8 * bk);
@@ -284,16 +298,52 @@ __global__ __launch_bounds__(256) void dswx_classify_v8(const KArgs a) {
             q_cf[bw] |= o.conf << (8 * bk);
             q_cl[bw] |= o.cloud << (8 * bk);
         }
-        if (a.out.diag) *reinterpret_cast<uint4*>(a.out.diag + off) = make_uint4(q_diag[0], q_diag[1], q_diag[2], q_diag[3]);
-        if (a.out.wtr1) *reinterpret_cast<uint2*>(a.out.wtr1 + off) = make_uint2(q_w1[0], q_w1[1]);
-        if (a.out.wtr1_aerosol) *reinterpret_cast<uint2*>(a.out.wtr1_aerosol + off) = make_uint2(q_w1a[0], q_w1a[1]);
-        if (a.out.wtr2) *reinterpret_cast<uint2*>(a.out.wtr2 + off) = make_uint2(q_w2[0], q_w2[1]);
-        if (a.out.wtr) *reinterpret_cast<uint2*>(a.out.wtr + off) = make_uint2(q_w[0], q_w[1]);
-        if (a.out.bwtr) *reinterpret_cast<uint2*>(a.out.bwtr + off) = make_uint2(q_bw[0], q_bw[1]);
-        if (a.out.conf) *reinterpret_cast<uint2*>(a.out.conf + off) = make_uint2(q_cf[0], q_cf[1]);
-        if (a.out.cloud) *reinterpret_cast<uint2*>(a.out.cloud + off) = make_uint2(q_cl[0], q_cl[1]);
+        if (a.out.diag) stg<u32x4, true>(a.out.diag + off, u32x4{q_diag[0], q_diag[1], q_diag[2], q_diag[3]});
+        if (a.out.wtr1) stg<u32x2, true>(a.out.wtr1 + off, u32x2{q_w1[0], q_w1[1]});
+        if (a.out.wtr1_aerosol) stg<u32x2, true>(a.out.wtr1_aerosol + off, u32x2{q_w1a[0], q_w1a[1]});
+        if (a.out.wtr2) stg<u32x2, true>(a.out.wtr2 + off, u32x2{q_w2[0], q_w2[1]});
+        if (a.out.wtr) stg<u32x2, true>(a.out.wtr + off, u32x2{q_w[0], q_w[1]});
+        if (a.out.bwtr) stg<u32x2, true>(a.out.bwtr + off, u32x2{q_bw[0], q_bw[1]});
+        if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{q_cf[0], q_cf[1]});
+        if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{q_cl[0], q_cl[1]});
     }
-    if (a.counters) reduce_counters(a.counters + (long long)blockIdx.y * 3, red, c0, c1, c2);
+    if (a.partials) {
+        if (MASKS && a.in.ocean != nullptr) {
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) t_ocean += __shfl_xor(t_ocean, sh);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const long long slot = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+            a.partials[slot] = make_uint2(w_valid | (w_cloud << 16), t_ocean);
+        }
+    }
+}
+
+// Sums the vector kernel's per-wave partial counts of one tile (block = tile) and
+// WRITES counters[tile]; the ragged-remainder kernel adds to them afterwards.
+__global__ __launch_bounds__(256) void dswx_counters_finish(const uint2* __restrict__ partials,
+                                                            unsigned long long* __restrict__ counters,
+                                                            long long per_tile, int has_ocean,
+                                                            long long vec_pixels) {
+    __shared__ unsigned long long red[4][3];
+    const uint2* p = partials + (long long)blockIdx.x * per_tile;
+    unsigned long long v = 0, c = 0, o = 0;
+    for (long long i = threadIdx.x; i < per_tile; i += 256) {
+        const uint2 x = p[i];
+        v += x.x & 0xffffu; c += x.x >> 16; o += x.y;
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        v += __shfl_xor(v, sh); c += __shfl_xor(c, sh); o += __shfl_xor(o, sh);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = v; red[threadIdx.x >> 6][1] = c; red[threadIdx.x >> 6][2] = o; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* dst = counters + (long long)blockIdx.x * 3;
+        dst[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        dst[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        dst[2] = has_ocean ? red[0][2] + red[1][2] + red[2][2] + red[3][2] : (unsigned long long)vec_pixels;
+    }
 }
 
 // ------------------------------------------------------------------------------
@@ -317,8 +367,10 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
         if (a.in.shad) shad = a.in.shad[off];
         if (a.in.ocean) ocean = a.in.ocean[off];
         PxOut o;
+        bool ok, cv;
         classify_px(a.P, lut, a.in.band[0][off], a.in.band[1][off], a.in.band[2][off], a.in.band[3][off],
-                    a.in.band[4][off], a.in.band[5][off], a.in.fmask[off], land, shad, ocean, o, c0, c1, c2);
+                    a.in.band[4][off], a.in.band[5][off], a.in.fmask[off], land, shad, ocean, o, ok, cv);
+        c0 = ok ? 1u : 0u; c1 = cv ? 1u : 0u; c2 = (uint32_t)ocean;
         if (a.out.diag) a.out.diag[off] = (uint16_t)o.diag;
         if (a.out.wtr1) a.out.wtr1[off] = (uint8_t)o.wtr1;
         if (a.out.wtr1_aerosol) a.out.wtr1_aerosol[off] = (uint8_t)o.wtr1a;
@@ -329,6 +381,69 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
         if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
     }
     if (a.counters) reduce_counters(a.counters + (long long)blockIdx.y * 3, red, c0, c1, c2);
+}
+
+// ------------------------------------------------------------------------------
+// Roofline probe: the fused kernel's plane traffic (six int16 planes + one u8 plane
+// in, one u16 + six u8 planes out) with trivial math, in several access shapes, to
+// measure the HBM rate each shape can reach at all.  Outputs are meaningless.
+//   PPT   pixels per thread per iteration (8: 16-B int16 / 8-B u8 accesses;
+//         16: 2x16-B int16 / 16-B u8 accesses)
+//   NT    non-temporal loads and stores
+// Each block walks `iters` consecutive chunks of 256*PPT pixels.
+// ------------------------------------------------------------------------------
+template <int PPT, bool NT>
+__global__ __launch_bounds__(256) void dswx_stream_probe_k(const KArgs a, int iters) {
+    const long long n_groups = a.n_pixels / PPT;
+    for (int it = 0; it < iters; ++it) {
+        const long long grp = ((long long)blockIdx.x * iters + it) * 256 + threadIdx.x;
+        if (grp >= n_groups) return;
+        const long long off = (long long)blockIdx.y * a.n_pixels + grp * PPT;
+        if (PPT == 8) {
+            u32x4 x = ldg<u32x4, NT>(a.in.band[0] + off);
+#pragma unroll
+            for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, NT>(a.in.band[k] + off);
+            const u32x2 f = ldg<u32x2, NT>(a.in.fmask + off);
+            u32x2 y; y.x = x.x ^ x.z ^ f.x; y.y = x.y ^ x.w ^ f.y;
+            stg<u32x4, NT>(a.out.diag + off, x);
+            stg<u32x2, NT>(a.out.wtr1 + off, y);
+            stg<u32x2, NT>(a.out.wtr2 + off, y + 1u);
+            stg<u32x2, NT>(a.out.wtr + off, y + 2u);
+            stg<u32x2, NT>(a.out.bwtr + off, y + 3u);
+            stg<u32x2, NT>(a.out.conf + off, ~y);
+            stg<u32x2, NT>(a.out.cloud + off, y + 5u);
+        } else {
+            u32x4 x0 = ldg<u32x4, NT>(a.in.band[0] + off), x1 = ldg<u32x4, NT>(a.in.band[0] + off + 8);
+#pragma unroll
+            for (int k = 1; k < 6; ++k) {
+                x0 ^= ldg<u32x4, NT>(a.in.band[k] + off);
+                x1 ^= ldg<u32x4, NT>(a.in.band[k] + off + 8);
+            }
+            const u32x4 f = ldg<u32x4, NT>(a.in.fmask + off);
+            const u32x4 y = x0 ^ x1 ^ f;
+            stg<u32x4, NT>(a.out.diag + off, x0);
+            stg<u32x4, NT>(a.out.diag + off + 8, x1);
+            stg<u32x4, NT>(a.out.wtr1 + off, y);
+            stg<u32x4, NT>(a.out.wtr2 + off, y + 1u);
+            stg<u32x4, NT>(a.out.wtr + off, y + 2u);
+            stg<u32x4, NT>(a.out.bwtr + off, y + 3u);
+            stg<u32x4, NT>(a.out.conf + off, ~y);
+            stg<u32x4, NT>(a.out.cloud + off, y + 5u);
+        }
+    }
+}
+
+// Calibration: a flat two-stream copy moving the same 13 B in / 8 B out per pixel
+// (reads `n16_in` 16-byte words from src, writes `n16_out` to dst).
+template <bool NT>
+__global__ __launch_bounds__(256) void dswx_flat_copy_k(const u32x4* __restrict__ src, u32x4* __restrict__ dst,
+                                                        long long n16_in, long long n16_out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    u32x4 x = {0u, 0u, 0u, 0u};
+    if (i < n16_in) x = ldg<u32x4, NT>(src + i);
+    // every thread reads one word; the first n16_out threads also write one
+    if (i < n16_out) stg<u32x4, NT>(dst + i, x);
+    else if (x.x == 0x9E3779B9u && x.y == 0x7F4A7C15u) dst[0] = x;   // keep the load alive
 }
 
 // ------------------------------------------------------------------------------
@@ -430,6 +545,9 @@ struct dswx_ctx {
     // grow-only staging for dswx_classify_host
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    // grow-only workspace for the vector kernel's per-wave counter partials
+    void* partials = nullptr;
+    size_t partials_bytes = 0;
     std::string last_kernel;
 };
 
@@ -589,6 +707,7 @@ int dswx_ctx_destroy(dswx_ctx_t* ctx) {
     if (!ctx) return DSWX_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return DSWX_OK;
@@ -659,15 +778,32 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
         if (b.out.awesh) b.out.awesh += shift;
         if (b.counters) b.counters += t0 * 3;
         b.px_begin = 0;
+        b.partials = nullptr;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
         if (groups > 0) {
             const int64_t gx = (groups + 255) / 256;
             dim3 grid((unsigned)gx, (unsigned)nt), block(256);
+            if (b.counters) {
+                const size_t need = (size_t)nt * (size_t)gx * 4 * sizeof(uint2);
+                if (need > ctx->partials_bytes) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    if (ctx->partials) HIP_TRY(hipFree(ctx->partials));
+                    ctx->partials = nullptr; ctx->partials_bytes = 0;
+                    HIP_TRY(hipMalloc(&ctx->partials, need));
+                    ctx->partials_bytes = need;
+                }
+                b.partials = static_cast<uint2*>(ctx->partials);
+            }
             if (masks) hipLaunchKernelGGL(dswx_classify_v8<true>, grid, block, 0, s, b);
             else hipLaunchKernelGGL(dswx_classify_v8<false>, grid, block, 0, s, b);
             HIP_TRY(hipGetLastError());
             snprintf(info, sizeof info, "dswx_classify_v8<%s> grid=(%lld,%lld) block=256",
                      masks ? "true" : "false", (long long)gx, (long long)nt);
+            if (b.counters) {
+                hipLaunchKernelGGL(dswx_counters_finish, dim3((unsigned)nt), dim3(256), 0, s, b.partials,
+                                   b.counters, (long long)gx * 4, in->ocean ? 1 : 0, (long long)groups * 8);
+                HIP_TRY(hipGetLastError());
+            }
             b.px_begin = groups * 8;
         }
         if (b.px_begin < n_pixels) {
@@ -762,6 +898,45 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
         if (counters) HIP_TRY(hipMemcpyAsync(counters + t * 3, dcnt, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    return DSWX_OK;
+}
+
+int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const dswx_planes_in_t* in,
+                      const dswx_planes_out_t* out, int variant, void* stream) {
+    if (!ctx || !in || !out) return fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles <= 0 || n_tiles > 65535 || n_pixels <= 0 || n_pixels % 16)
+        return fail(DSWX_ERR_ARG, "probe needs 1..65535 tiles of a multiple of 16 pixels");
+    if (!out->diag || !out->wtr1 || !out->wtr2 || !out->wtr || !out->bwtr || !out->conf || !out->cloud || !in->fmask)
+        return fail(DSWX_ERR_ARG, "probe needs all seven output planes");
+    for (int k = 0; k < 6; ++k)
+        if (!in->band[k] || !aligned_to(in->band[k], 16)) return fail(DSWX_ERR_ALIGN, "band[%d]", k);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    KArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = *in; a.out = *out; a.n_pixels = n_pixels;
+    // variant = ppt16 | nt << 1 | log2(iters) << 2 ; bit 8: flat two-stream copy of
+    // the same byte counts (needs the planes laid out as DeviceBatch does:
+    // band[0..5], fmask contiguous; diag, wtr1.. contiguous)
+    if (variant & 256) {
+        const long long total = n_tiles * n_pixels;
+        const long long n16_in = total * 13 / 16, n16_out = total * 8 / 16;
+        dim3 grid((unsigned)((n16_in + 255) / 256)), block(256);
+        if (variant & 2) hipLaunchKernelGGL(dswx_flat_copy_k<true>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
+        else hipLaunchKernelGGL(dswx_flat_copy_k<false>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    const bool ppt16 = variant & 1, nt = variant & 2;
+    const int iters = 1 << ((variant >> 2) & 7);
+    const int ppt = ppt16 ? 16 : 8;
+    const int64_t groups = n_pixels / ppt;
+    dim3 grid((unsigned)((groups + 256LL * iters - 1) / (256LL * iters)), (unsigned)n_tiles), block(256);
+    if (!ppt16 && !nt) hipLaunchKernelGGL((dswx_stream_probe_k<8, false>), grid, block, 0, s, a, iters);
+    else if (!ppt16 && nt) hipLaunchKernelGGL((dswx_stream_probe_k<8, true>), grid, block, 0, s, a, iters);
+    else if (ppt16 && !nt) hipLaunchKernelGGL((dswx_stream_probe_k<16, false>), grid, block, 0, s, a, iters);
+    else hipLaunchKernelGGL((dswx_stream_probe_k<16, true>), grid, block, 0, s, a, iters);
+    HIP_TRY(hipGetLastError());
     return DSWX_OK;
 }
 
