@@ -35,6 +35,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <cstdarg>
 #include <limits>
 #include <string>
@@ -70,7 +71,11 @@ struct KArgs {
     DevParams P;
     dswx_planes_in_t in;
     dswx_planes_out_t out;
-    uint2* partials;                // vector kernel: per-wave counts, [tile][block][wave]
+    uint2* partials;                // fused kernel: per-wave counts, [tile][block][wave]
+    uint8_t* u8_out[7];             // fused kernel: the wanted u8 layers, compacted,
+    int u8_region[7];               //   and the LDS staging region each one lives in
+    int n_u8_out;
+    int n_diag_pieces;              // 8 if DIAG is wanted, else 0
     unsigned long long* counters;   // [n_tiles][3] or nullptr
     long long n_pixels;             // per tile
     long long px_begin;             // generic kernel: first pixel of the tile it covers
@@ -116,9 +121,10 @@ __device__ __forceinline__ uint32_t collapse_class(uint32_t v, uint32_t c) {
 }
 
 // One pixel through the whole chain.  b..s2 are the RAW values (sign-extended),
-// fm the raw Fmask byte; land/shad/ocean carry neutral sentinels (-1 / 1 / 1)
-// when the plane is not given.
-__device__ __forceinline__ void classify_px(const DevParams& P, const uint8_t* __restrict__ lut,
+// fm the raw Fmask byte, aer_bits the aerosol table entry of fm (bit c set <=>
+// WTR-1 class c is remapped); land/shad/ocean carry neutral sentinels
+// (-1 / 1 / 1) when the plane is not given.
+__device__ __forceinline__ void classify_px(const DevParams& P, uint32_t aer_bits,
                                             int b, int g, int r, int n, int s1, int s2, int fm,
                                             int land, int shad, int ocean, PxOut& o,
                                             bool& is_valid, bool& is_cloud_and_valid) {
@@ -163,8 +169,7 @@ __device__ __forceinline__ void classify_px(const DevParams& P, const uint8_t* _
     is_valid = valid;
     is_cloud_and_valid = valid & (pc != 0u);
     // A9
-    const uint32_t bits = lut[fm];
-    const bool remap = (w1 <= 4u) & (((bits >> (w1 & 7u)) & 1u) != 0u) & (n <= P.aer_nir_max);
+    const bool remap = (w1 <= 4u) & (((aer_bits >> (w1 & 7u)) & 1u) != 0u) & (n <= P.aer_nir_max);
     const uint32_t w1a = remap ? 1u : w1;
     pc |= remap ? 8u : 0u;
     // A10 (every predicate reads the input layer; every hit writes 0)
@@ -234,25 +239,29 @@ __device__ __forceinline__ void reduce_counters(unsigned long long* __restrict__
 }
 
 // ------------------------------------------------------------------------------
-// Fused kernel: one 8-pixel group per thread.  16-byte loads from the six int16
-// planes, 8-byte loads from the u8 planes; 16-byte DIAG store, 8-byte u8 stores.
-// grid.y = tile, grid.x covers the tile's whole 8-pixel groups (a ragged
-// remainder of < 8 pixels per tile goes to dswx_classify_v1).
+// Fused kernel, direct-store variant (the default): block = 256 threads, one
+// 8-pixel group per thread; 16-byte loads from the six int16 planes, 8-byte loads
+// from the u8 planes; 16-byte DIAG store and 8-byte u8 stores straight from
+// registers, all non-temporal.  grid.y = tile.  Measured 5.1 TB/s (64 tiles); the
+// trivial-math probe of the same access shape reaches 5.3 TB/s.
 // ------------------------------------------------------------------------------
 template <bool MASKS>
 __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
-    __shared__ uint32_t lut32[64];
-    if (threadIdx.x < 64) lut32[threadIdx.x] = a.P.aer_lut[threadIdx.x];
-    __syncthreads();
-    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
     const DevParams& P = a.P;
+    // aerosol table: 256 bytes = one dword per lane of a wave, looked up with
+    // ds_bpermute (no LDS storage, no barrier)
+    const uint32_t lut_reg = a.P.aer_lut[threadIdx.x & 63];
 
     const long long n_groups = a.n_pixels >> 3;
     const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
     // A3: per-wave counts from lane-mask popcounts (scalar unit), no atomics
     uint32_t w_valid = 0, w_cloud = 0, t_ocean = 0;
-    if (grp < n_groups) {
-        const long long off = (long long)blockIdx.y * a.n_pixels + grp * 8;
+    // No divergence: threads past the tile's last group redo that group (their
+    // results are never stored or counted), so every lane stays active for the
+    // cross-lane table lookup below.
+    const bool in_range = grp < n_groups;
+    {
+        const long long off = (long long)blockIdx.y * a.n_pixels + (in_range ? grp : n_groups - 1) * 8;
         u32x4 v[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
@@ -266,6 +275,7 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
             if (has_o) {
                 vo = ldg<u32x2, true>(a.in.ocean + off);
                 t_ocean = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
+                t_ocean = in_range ? t_ocean : 0u;
             }
         }
         uint32_t q_diag[4] = {0, 0, 0, 0};
@@ -284,11 +294,13 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
                 if (has_s) shad = u8_of(vs[bw], bk);
                 if (has_o) ocean = u8_of(vo[bw], bk);
             }
+            const uint32_t aer_bits =
+                ((uint32_t)__builtin_amdgcn_ds_bpermute((fm >> 2) << 2, (int)lut_reg) >> (8 * (fm & 3))) & 0xffu;
             PxOut o;
             bool ok, cv;
-            classify_px(P, lut, b, g, r, n, s1, s2, fm, land, shad, ocean, o, ok, cv);
-            w_valid += (uint32_t)__popcll(__ballot(ok));
-            w_cloud += (uint32_t)__popcll(__ballot(cv));
+            classify_px(P, aer_bits, b, g, r, n, s1, s2, fm, land, shad, ocean, o, ok, cv);
+            w_valid += (uint32_t)__popcll(__ballot(ok & in_range));
+            w_cloud += (uint32_t)__popcll(__ballot(cv & in_range));
             q_diag[wd] |= o.diag << (16 * hf);
             q_w1[bw] |= o.wtr1 << (8 * bk);
             q_w1a[bw] |= o.wtr1a << (8 * bk);
@@ -298,6 +310,7 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
             q_cf[bw] |= o.conf << (8 * bk);
             q_cl[bw] |= o.cloud << (8 * bk);
         }
+        if (in_range) {
         if (a.out.diag) stg<u32x4, true>(a.out.diag + off, u32x4{q_diag[0], q_diag[1], q_diag[2], q_diag[3]});
         if (a.out.wtr1) stg<u32x2, true>(a.out.wtr1 + off, u32x2{q_w1[0], q_w1[1]});
         if (a.out.wtr1_aerosol) stg<u32x2, true>(a.out.wtr1_aerosol + off, u32x2{q_w1a[0], q_w1a[1]});
@@ -306,6 +319,7 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
         if (a.out.bwtr) stg<u32x2, true>(a.out.bwtr + off, u32x2{q_bw[0], q_bw[1]});
         if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{q_cf[0], q_cf[1]});
         if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{q_cl[0], q_cl[1]});
+        }
     }
     if (a.partials) {
         if (MASKS && a.in.ocean != nullptr) {
@@ -319,7 +333,148 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
     }
 }
 
-// Sums the vector kernel's per-wave partial counts of one tile (block = tile) and
+// ------------------------------------------------------------------------------
+// Fused kernel, LDS-staged variant (DSWX_FUSED_VARIANT=1).  Block = 512 threads = 4096 consecutive pixels of one tile
+// (grid.y = tile); each thread classifies one 8-pixel group.
+//
+// Loads: straight to registers, 16 B per lane from each int16 plane and 8 B per
+// lane from each u8 plane, non-temporal.  Seven-plane READS stream at the full
+// HBM rate in this shape (6.3-7.0 TB/s measured), so they are not staged.
+//
+// Stores: transposed through LDS.  Measured on MI355X, a wave that scatters
+// 512 B - 1 KiB to each of the seven output planes gets 3.9-4.5 TB/s of write
+// bandwidth, while a wave that writes one plane in multi-KiB contiguous runs of
+// 16-byte stores gets 6.4 TB/s.  So every thread parks its results in LDS
+// (36 KiB per block), and after one barrier each of the 8 waves streams whole
+// 1 KiB pieces of consecutive plane segments (4 KiB per u8 plane, 8 KiB for DIAG)
+// with 16-byte non-temporal stores.
+// ------------------------------------------------------------------------------
+constexpr int FUSED_THREADS = 512;
+constexpr int FUSED_PX = FUSED_THREADS * 8;            // pixels per block
+constexpr int STAGE_DIAG_BYTES = FUSED_PX * 2;          // 8 KiB
+constexpr int STAGE_U8_BYTES = FUSED_PX;                // 4 KiB per u8 plane
+constexpr int STAGE_BYTES = STAGE_DIAG_BYTES + 7 * STAGE_U8_BYTES;
+
+template <bool MASKS>
+__global__ __launch_bounds__(FUSED_THREADS) void dswx_classify_fused(const KArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE_BYTES];
+    const DevParams& P = a.P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // aerosol table: 256 bytes = one dword per lane of a wave, looked up with
+    // ds_bpermute (no LDS storage, no barrier)
+    const uint32_t lut_reg = a.P.aer_lut[lane];
+
+    const long long n_groups = a.n_pixels >> 3;
+    const long long grp = (long long)blockIdx.x * FUSED_THREADS + threadIdx.x;
+    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    // A3: per-wave counts from lane-mask popcounts (scalar unit), no atomics
+    uint32_t w_valid = 0, w_cloud = 0, t_ocean = 0;
+    // No divergence: threads past the tile's last group redo that group (their
+    // results are never stored or counted), so every lane stays active for the
+    // cross-lane table lookup below.
+    const bool in_range = grp < n_groups;
+    {
+        const long long off = tile_base + (in_range ? grp : n_groups - 1) * 8;
+        u32x4 v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
+        const u32x2 vf = ldg<u32x2, true>(a.in.fmask + off);
+        u32x2 vl = {0u, 0u}, vs = {0u, 0u}, vo = {0u, 0u};
+        bool has_l = false, has_s = false, has_o = false;
+        if (MASKS) {
+            has_l = a.in.land != nullptr; has_s = a.in.shad != nullptr; has_o = a.in.ocean != nullptr;
+            if (has_l) vl = ldg<u32x2, true>(a.in.land + off);
+            if (has_s) vs = ldg<u32x2, true>(a.in.shad + off);
+            if (has_o) {
+                vo = ldg<u32x2, true>(a.in.ocean + off);
+                t_ocean = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
+                t_ocean = in_range ? t_ocean : 0u;
+            }
+        }
+        uint32_t q_diag[4] = {0, 0, 0, 0};
+        uint32_t q_w1[2] = {0, 0}, q_w1a[2] = {0, 0}, q_w2[2] = {0, 0}, q_w[2] = {0, 0},
+                 q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int wd = j >> 1, hf = j & 1;
+            const int b = s16_of(v[0][wd], hf), g = s16_of(v[1][wd], hf), r = s16_of(v[2][wd], hf),
+                      n = s16_of(v[3][wd], hf), s1 = s16_of(v[4][wd], hf), s2 = s16_of(v[5][wd], hf);
+            const int bw = j >> 2, bk = j & 3;
+            const int fm = u8_of(vf[bw], bk);
+            int land = -1, shad = 1, ocean = 1;
+            if (MASKS) {
+                if (has_l) land = u8_of(vl[bw], bk);
+                if (has_s) shad = u8_of(vs[bw], bk);
+                if (has_o) ocean = u8_of(vo[bw], bk);
+            }
+            const uint32_t aer_bits =
+                ((uint32_t)__builtin_amdgcn_ds_bpermute((fm >> 2) << 2, (int)lut_reg) >> (8 * (fm & 3))) & 0xffu;
+            PxOut o;
+            bool ok, cv;
+            classify_px(P, aer_bits, b, g, r, n, s1, s2, fm, land, shad, ocean, o, ok, cv);
+            w_valid += (uint32_t)__popcll(__ballot(ok & in_range));
+            w_cloud += (uint32_t)__popcll(__ballot(cv & in_range));
+            q_diag[wd] |= o.diag << (16 * hf);
+            q_w1[bw] |= o.wtr1 << (8 * bk);
+            q_w1a[bw] |= o.wtr1a << (8 * bk);
+            q_w2[bw] |= o.wtr2 << (8 * bk);
+            q_w[bw] |= o.wtr << (8 * bk);
+            q_bw[bw] |= o.bwtr << (8 * bk);
+            q_cf[bw] |= o.conf << (8 * bk);
+            q_cl[bw] |= o.cloud << (8 * bk);
+        }
+        // park the results: region 0 = DIAG (16 B per thread), regions 1..7 = the u8
+        // layers in dswx_planes_out_t order (8 B per thread)
+        *reinterpret_cast<u32x4*>(stage + threadIdx.x * 16) = u32x4{q_diag[0], q_diag[1], q_diag[2], q_diag[3]};
+        uint8_t* su8 = stage + STAGE_DIAG_BYTES + threadIdx.x * 8;
+        *reinterpret_cast<u32x2*>(su8 + 0 * STAGE_U8_BYTES) = u32x2{q_w1[0], q_w1[1]};
+        if (a.out.wtr1_aerosol) *reinterpret_cast<u32x2*>(su8 + 1 * STAGE_U8_BYTES) = u32x2{q_w1a[0], q_w1a[1]};
+        *reinterpret_cast<u32x2*>(su8 + 2 * STAGE_U8_BYTES) = u32x2{q_w2[0], q_w2[1]};
+        *reinterpret_cast<u32x2*>(su8 + 3 * STAGE_U8_BYTES) = u32x2{q_w[0], q_w[1]};
+        *reinterpret_cast<u32x2*>(su8 + 4 * STAGE_U8_BYTES) = u32x2{q_bw[0], q_bw[1]};
+        *reinterpret_cast<u32x2*>(su8 + 5 * STAGE_U8_BYTES) = u32x2{q_cf[0], q_cf[1]};
+        *reinterpret_cast<u32x2*>(su8 + 6 * STAGE_U8_BYTES) = u32x2{q_cl[0], q_cl[1]};
+    }
+    if (a.partials) {
+        if (MASKS && a.in.ocean != nullptr) {
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) t_ocean += __shfl_xor(t_ocean, sh);
+        }
+        if (lane == 0) {
+            const long long slot = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (FUSED_THREADS / 64) + wave;
+            a.partials[slot] = make_uint2(w_valid | (w_cloud << 16), t_ocean);
+        }
+    }
+    __syncthreads();
+
+    // Store phase.  The block's output is a list of 1 KiB pieces: 8 for DIAG (if
+    // wanted), 4 for each wanted u8 layer, in plane order; wave w takes the w-th
+    // run of consecutive pieces, so it writes 4 KiB runs of a single plane.
+    const long long px0 = (long long)blockIdx.x * FUSED_PX;          // first pixel of the block in its tile
+    const long long n_vec = n_groups * 8;                            // pixels the vector path covers
+    const int n_pieces = a.n_diag_pieces + 4 * a.n_u8_out;
+    const int per_wave = (n_pieces + (FUSED_THREADS / 64) - 1) / (FUSED_THREADS / 64);
+    for (int q = 0; q < per_wave; ++q) {
+        const int piece = wave * per_wave + q;
+        if (piece >= n_pieces) break;
+        if (piece < a.n_diag_pieces) {
+            const long long p = px0 + piece * 512 + lane * 8;        // 8 px = 16 B of DIAG
+            if (p + 8 <= n_vec)
+                stg<u32x4, true>(a.out.diag + tile_base + p,
+                                 *reinterpret_cast<const u32x4*>(stage + piece * 1024 + lane * 16));
+        } else {
+            const int u = (piece - a.n_diag_pieces) >> 2, sub = (piece - a.n_diag_pieces) & 3;
+            const int region = a.u8_region[u];
+            uint8_t* dst = a.u8_out[u] + tile_base;
+            const long long p = px0 + sub * 1024 + lane * 16;        // 16 px = 16 B
+            const uint8_t* src = stage + STAGE_DIAG_BYTES + region * STAGE_U8_BYTES + sub * 1024 + lane * 16;
+            if (p + 16 <= n_vec) stg<u32x4, true>(dst + p, *reinterpret_cast<const u32x4*>(src));
+            else if (p + 8 <= n_vec) stg<u32x2, true>(dst + p, *reinterpret_cast<const u32x2*>(src));
+        }
+    }
+}
+
+// Sums the fused kernel's per-wave partial counts of one tile (block = tile) and
 // WRITES counters[tile]; the ragged-remainder kernel adds to them afterwards.
 __global__ __launch_bounds__(256) void dswx_counters_finish(const uint2* __restrict__ partials,
                                                             unsigned long long* __restrict__ counters,
@@ -368,8 +523,9 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
         if (a.in.ocean) ocean = a.in.ocean[off];
         PxOut o;
         bool ok, cv;
-        classify_px(a.P, lut, a.in.band[0][off], a.in.band[1][off], a.in.band[2][off], a.in.band[3][off],
-                    a.in.band[4][off], a.in.band[5][off], a.in.fmask[off], land, shad, ocean, o, ok, cv);
+        const int fm = a.in.fmask[off];
+        classify_px(a.P, lut[fm], a.in.band[0][off], a.in.band[1][off], a.in.band[2][off], a.in.band[3][off],
+                    a.in.band[4][off], a.in.band[5][off], fm, land, shad, ocean, o, ok, cv);
         c0 = ok ? 1u : 0u; c1 = cv ? 1u : 0u; c2 = (uint32_t)ocean;
         if (a.out.diag) a.out.diag[off] = (uint16_t)o.diag;
         if (a.out.wtr1) a.out.wtr1[off] = (uint8_t)o.wtr1;
@@ -392,19 +548,35 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
 //   NT    non-temporal loads and stores
 // Each block walks `iters` consecutive chunks of 256*PPT pixels.
 // ------------------------------------------------------------------------------
-template <int PPT, bool NT>
-__global__ __launch_bounds__(256) void dswx_stream_probe_k(const KArgs a, int iters) {
+// MODE 0: read + write, 1: reads only, 2: writes only.  XCDMAP: block b works on
+// chunk (b % 8) * ceil(nb / 8) + b / 8, i.e. every XCD walks its own contiguous
+// eighth of the tile (blocks are dealt round-robin over the 8 XCDs).
+template <int PPT, bool NT, int MODE, bool XCDMAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void dswx_stream_probe_k(const KArgs a, int iters) {
     const long long n_groups = a.n_pixels / PPT;
+    long long bx = blockIdx.x;
+    if (XCDMAP) {
+        const long long per = (gridDim.x + 7) / 8;
+        bx = (bx & 7) * per + (bx >> 3);
+    }
     for (int it = 0; it < iters; ++it) {
-        const long long grp = ((long long)blockIdx.x * iters + it) * 256 + threadIdx.x;
+        const long long grp = (bx * iters + it) * BLOCK + threadIdx.x;
         if (grp >= n_groups) return;
         const long long off = (long long)blockIdx.y * a.n_pixels + grp * PPT;
         if (PPT == 8) {
-            u32x4 x = ldg<u32x4, NT>(a.in.band[0] + off);
+            u32x4 x = {1u, 2u, 3u, (uint32_t)grp};
+            u32x2 f = {5u, 6u};
+            if (MODE != 2) {
+                x = ldg<u32x4, NT>(a.in.band[0] + off);
 #pragma unroll
-            for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, NT>(a.in.band[k] + off);
-            const u32x2 f = ldg<u32x2, NT>(a.in.fmask + off);
+                for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, NT>(a.in.band[k] + off);
+                f = ldg<u32x2, NT>(a.in.fmask + off);
+            }
             u32x2 y; y.x = x.x ^ x.z ^ f.x; y.y = x.y ^ x.w ^ f.y;
+            if (MODE == 1) {
+                if (y.x == 0x12345678u && y.y == 0x9abcdef0u) stg<u32x2, NT>(a.out.wtr1 + off, y);
+                continue;
+            }
             stg<u32x4, NT>(a.out.diag + off, x);
             stg<u32x2, NT>(a.out.wtr1 + off, y);
             stg<u32x2, NT>(a.out.wtr2 + off, y + 1u);
@@ -413,14 +585,21 @@ __global__ __launch_bounds__(256) void dswx_stream_probe_k(const KArgs a, int it
             stg<u32x2, NT>(a.out.conf + off, ~y);
             stg<u32x2, NT>(a.out.cloud + off, y + 5u);
         } else {
-            u32x4 x0 = ldg<u32x4, NT>(a.in.band[0] + off), x1 = ldg<u32x4, NT>(a.in.band[0] + off + 8);
+            u32x4 x0 = {1u, 2u, 3u, (uint32_t)grp}, x1 = x0, f = x0;
+            if (MODE != 2) {
+                x0 = ldg<u32x4, NT>(a.in.band[0] + off); x1 = ldg<u32x4, NT>(a.in.band[0] + off + 8);
 #pragma unroll
-            for (int k = 1; k < 6; ++k) {
-                x0 ^= ldg<u32x4, NT>(a.in.band[k] + off);
-                x1 ^= ldg<u32x4, NT>(a.in.band[k] + off + 8);
+                for (int k = 1; k < 6; ++k) {
+                    x0 ^= ldg<u32x4, NT>(a.in.band[k] + off);
+                    x1 ^= ldg<u32x4, NT>(a.in.band[k] + off + 8);
+                }
+                f = ldg<u32x4, NT>(a.in.fmask + off);
             }
-            const u32x4 f = ldg<u32x4, NT>(a.in.fmask + off);
             const u32x4 y = x0 ^ x1 ^ f;
+            if (MODE == 1) {
+                if (y.x == 0x12345678u && y.y == 0x9abcdef0u) stg<u32x4, NT>(a.out.wtr1 + off, y);
+                continue;
+            }
             stg<u32x4, NT>(a.out.diag + off, x0);
             stg<u32x4, NT>(a.out.diag + off + 8, x1);
             stg<u32x4, NT>(a.out.wtr1 + off, y);
@@ -429,6 +608,117 @@ __global__ __launch_bounds__(256) void dswx_stream_probe_k(const KArgs a, int it
             stg<u32x4, NT>(a.out.bwtr + off, y + 3u);
             stg<u32x4, NT>(a.out.conf + off, ~y);
             stg<u32x4, NT>(a.out.cloud + off, y + 5u);
+        }
+    }
+}
+
+// Staged probe: the fused kernel's data movement (register loads, LDS-transposed
+// plane-run stores) with trivial math.  BLOCK threads x 8 px; each wave stores
+// consecutive 1 KiB pieces.
+template <int BLOCK, bool NT>
+__global__ __launch_bounds__(BLOCK) void dswx_staged_probe_k(const KArgs a) {
+    constexpr int PX = BLOCK * 8, WAVES = BLOCK / 64;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[PX * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_groups = a.n_pixels >> 3;
+    const long long grp = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long off = tile_base + (grp < n_groups ? grp : n_groups - 1) * 8;
+    u32x4 x = ldg<u32x4, NT>(a.in.band[0] + off);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, NT>(a.in.band[k] + off);
+    const u32x2 f = ldg<u32x2, NT>(a.in.fmask + off);
+    u32x2 y; y.x = x.x ^ x.z ^ f.x; y.y = x.y ^ x.w ^ f.y;
+    *reinterpret_cast<u32x4*>(stage + threadIdx.x * 16) = x;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) *reinterpret_cast<u32x2*>(stage + PX * 2 + k * PX + threadIdx.x * 8) = y + (uint32_t)k;
+    __syncthreads();
+    uint8_t* const planes[7] = {reinterpret_cast<uint8_t*>(a.out.diag), a.out.wtr1, a.out.wtr2, a.out.wtr,
+                                a.out.bwtr, a.out.conf, a.out.cloud};
+    const long long px0 = (long long)blockIdx.x * PX, n_vec = n_groups * 8;
+    constexpr int DIAG_PIECES = PX * 2 / 1024, U8_PIECES = PX / 1024, PIECES = DIAG_PIECES + 6 * U8_PIECES;
+    constexpr int PER_WAVE = PIECES / WAVES;
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+        const int piece = wave * PER_WAVE + q;
+        if (piece < DIAG_PIECES) {
+            const long long p = px0 + piece * 512 + lane * 8;
+            if (p + 8 <= n_vec) stg<u32x4, NT>(planes[0] + (tile_base + p) * 2, *reinterpret_cast<const u32x4*>(stage + piece * 1024 + lane * 16));
+        } else {
+            const int u = (piece - DIAG_PIECES) / U8_PIECES, sub = (piece - DIAG_PIECES) % U8_PIECES;
+            const long long p = px0 + sub * 1024 + lane * 16;
+            if (p + 16 <= n_vec) stg<u32x4, NT>(planes[1 + u] + tile_base + p, *reinterpret_cast<const u32x4*>(stage + PX * 2 + u * PX + sub * 1024 + lane * 16));
+        }
+    }
+}
+
+// Stream-count calibration: the same 14 planes and bytes, but every block streams
+// 4 KiB of ONE plane (blockIdx.x % 14 selects it): 7 read-only streams and 7
+// write-only streams that never meet inside a block.
+template <bool NT>
+__global__ __launch_bounds__(256) void dswx_plane_per_block_k(const KArgs a, long long total_px) {
+    const int plane = blockIdx.x % 14;
+    const long long chunk = blockIdx.x / 14;                 // 4 KiB chunk index within the plane
+    const long long byte = chunk * 4096 + threadIdx.x * 16;
+    if (plane < 7) {
+        const uint8_t* src = plane < 6 ? reinterpret_cast<const uint8_t*>(a.in.band[plane]) : a.in.fmask;
+        const long long bytes = plane < 6 ? total_px * 2 : total_px;
+        // int16 planes are twice as long: walk two chunks
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (byte < bytes) x = ldg<u32x4, NT>(src + byte);
+        if (plane < 6 && byte + bytes / 2 < bytes && byte < bytes / 2) x ^= ldg<u32x4, NT>(src + bytes / 2 + byte);
+        if (x.x == 0x9E3779B9u && x.y == 0x7F4A7C15u) a.out.wtr1[0] = 1;
+    } else {
+        uint8_t* const planes[7] = {reinterpret_cast<uint8_t*>(a.out.diag), a.out.wtr1, a.out.wtr2, a.out.wtr,
+                                    a.out.bwtr, a.out.conf, a.out.cloud};
+        const int z = plane - 7;
+        const long long bytes = z == 0 ? total_px * 2 : total_px;
+        const u32x4 val = {threadIdx.x, blockIdx.x, 3u, 4u};
+        if (byte < bytes) stg<u32x4, NT>(planes[z] + byte, val);
+        if (z == 0 && byte + bytes / 2 < bytes && byte < bytes / 2) stg<u32x4, NT>(planes[0] + bytes / 2 + byte, val);
+    }
+}
+
+// Role-split calibration, same planes and bytes as the fused kernel, 8 px per lane.
+// SPLIT 0: even blocks read all 7 input planes (two chunks each), odd blocks write
+// all 7 output planes (two chunks each).  SPLIT 1: inside every block waves 0-1
+// only read (two chunks), waves 2-3 only write (two chunks).
+template <int SPLIT, bool NT>
+__global__ __launch_bounds__(256) void dswx_role_split_k(const KArgs a) {
+    const long long n_groups = a.n_pixels >> 3;
+    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    bool reader;
+    long long g0, g1;
+    if (SPLIT == 0) {
+        reader = (blockIdx.x & 1) == 0;
+        const long long pair = blockIdx.x >> 1;                      // covers groups [pair*512, +512)
+        g0 = pair * 512 + threadIdx.x; g1 = g0 + 256;
+    } else {
+        reader = threadIdx.x < 128;
+        const long long t = threadIdx.x & 127;
+        g0 = (long long)blockIdx.x * 256 + t; g1 = g0 + 128;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const long long grp = h ? g1 : g0;
+        if (grp >= n_groups) continue;
+        const long long off = tile_base + grp * 8;
+        if (reader) {
+            u32x4 x = ldg<u32x4, NT>(a.in.band[0] + off);
+#pragma unroll
+            for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, NT>(a.in.band[k] + off);
+            const u32x2 f = ldg<u32x2, NT>(a.in.fmask + off);
+            if ((x.x ^ f.x) == 0x12345678u && (x.y ^ f.y) == 0x9abcdef0u) a.out.wtr1[0] = 1;
+        } else {
+            const u32x4 x = {threadIdx.x, blockIdx.x, 3u, (uint32_t)grp};
+            const u32x2 y = {x.x, x.w};
+            stg<u32x4, NT>(a.out.diag + off, x);
+            stg<u32x2, NT>(a.out.wtr1 + off, y);
+            stg<u32x2, NT>(a.out.wtr2 + off, y + 1u);
+            stg<u32x2, NT>(a.out.wtr + off, y + 2u);
+            stg<u32x2, NT>(a.out.bwtr + off, y + 3u);
+            stg<u32x2, NT>(a.out.conf + off, ~y);
+            stg<u32x2, NT>(a.out.cloud + off, y + 5u);
         }
     }
 }
@@ -444,6 +734,46 @@ __global__ __launch_bounds__(256) void dswx_flat_copy_k(const u32x4* __restrict_
     // every thread reads one word; the first n16_out threads also write one
     if (i < n16_out) stg<u32x4, NT>(dst + i, x);
     else if (x.x == 0x9E3779B9u && x.y == 0x7F4A7C15u) dst[0] = x;   // keep the load alive
+}
+
+// Write-path calibration (outputs meaningless).  WMODE 0: one flat stream of
+// 16-byte stores; 1: seven planes, each BLOCK writes 4 KiB of ONE plane
+// (blockIdx.z = plane); 2: seven planes, each WAVE of a block writes 1 KiB pieces
+// of its own planes (the store shape an LDS-transposed epilogue would have).
+template <int WMODE, bool NT>
+__global__ __launch_bounds__(256) void dswx_write_probe_k(const KArgs a, long long total_px) {
+    const u32x4 val = {threadIdx.x, blockIdx.x, 3u, 4u};
+    if (WMODE == 0) {
+        const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // 16-byte words
+        if (i < total_px * 8 / 16) stg<u32x4, NT>(reinterpret_cast<u32x4*>(a.out.diag) + i, val);
+    } else if (WMODE == 1) {
+        // plane z: 0 = diag (2 B/px, two blocks' worth), 1..6 = u8 planes
+        uint8_t* const planes[7] = {reinterpret_cast<uint8_t*>(a.out.diag), a.out.wtr1, a.out.wtr2, a.out.wtr,
+                                    a.out.bwtr, a.out.conf, a.out.cloud};
+        const int z = blockIdx.z;
+        const long long bytes = z == 0 ? total_px * 2 : total_px;
+        const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 16;
+        if (i < bytes) stg<u32x4, NT>(planes[z] + i, val);
+        if (z == 0 && i + bytes / 2 < bytes && i < bytes / 2) stg<u32x4, NT>(planes[0] + bytes / 2 + i, val);
+    } else {
+        // block covers 4096 px: per u8 plane 4 KiB = 4 wave-stores of 1 KiB, diag 8 KiB = 8.
+        // 32 wave-stores in all, 8 per wave: wave w writes diag quarter w (2) + planes
+        // {w, w+4 (if < 6)} hmm -> keep it simple: wave w writes pieces p = w, w+4, ... of the
+        // 32-piece list [diag x8, wtr1 x4, wtr2 x4, wtr x4, bwtr x4, conf x4, cloud x4]
+        uint8_t* const planes[7] = {reinterpret_cast<uint8_t*>(a.out.diag), a.out.wtr1, a.out.wtr2, a.out.wtr,
+                                    a.out.bwtr, a.out.conf, a.out.cloud};
+        const long long px0 = (long long)blockIdx.x * 4096;
+        if (px0 >= total_px) return;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int piece = wave * 8 + q;             // consecutive pieces: a wave stays in one or two planes
+            int plane, sub;
+            if (piece < 8) { plane = 0; sub = piece; } else { plane = 1 + (piece - 8) / 4; sub = (piece - 8) % 4; }
+            const long long byte0 = plane == 0 ? px0 * 2 : px0;
+            stg<u32x4, NT>(planes[plane] + byte0 + sub * 1024 + lane * 16, val);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------
@@ -549,6 +879,7 @@ struct dswx_ctx {
     void* partials = nullptr;
     size_t partials_bytes = 0;
     std::string last_kernel;
+    int fused_variant = 0;   // 0: direct stores (default); 1: LDS-staged stores (env DSWX_FUSED_VARIANT)
 };
 
 static thread_local std::string g_err;
@@ -694,6 +1025,7 @@ int dswx_ctx_create(int device, dswx_ctx_t** out) {
     HIP_TRY(hipSetDevice(device));
     dswx_ctx* c = new dswx_ctx();
     c->device = device;
+    if (const char* e = std::getenv("DSWX_FUSED_VARIANT")) c->fused_variant = std::atoi(e) == 1 ? 1 : 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -746,13 +1078,14 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
 
     const bool any_index = out->mndwi || out->ndvi || out->awesh;
     const bool masks = in->land || in->shad || in->ocean;
-    bool vec_ok = (n_pixels % 8 == 0) || n_tiles == 1;
+    // the fused kernel needs every plane 16-byte aligned at every tile start
+    bool vec_ok = (n_pixels % 16 == 0) || n_tiles == 1;
     for (int k = 0; k < 6 && vec_ok; ++k) vec_ok = aligned_to(in->band[k], 16);
-    vec_ok = vec_ok && aligned_to(in->fmask, 8) && (!in->land || aligned_to(in->land, 8)) &&
-             (!in->shad || aligned_to(in->shad, 8)) && (!in->ocean || aligned_to(in->ocean, 8)) &&
+    vec_ok = vec_ok && aligned_to(in->fmask, 16) && (!in->land || aligned_to(in->land, 16)) &&
+             (!in->shad || aligned_to(in->shad, 16)) && (!in->ocean || aligned_to(in->ocean, 16)) &&
              (!out->diag || aligned_to(out->diag, 16));
     uint8_t* const u8outs[] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud};
-    for (uint8_t* p : u8outs) vec_ok = vec_ok && (!p || aligned_to(p, 8));
+    for (uint8_t* p : u8outs) vec_ok = vec_ok && (!p || aligned_to(p, 16));
 
     const int64_t max_y = 65535;
     char info[256];
@@ -781,10 +1114,12 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
         b.partials = nullptr;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
         if (groups > 0) {
-            const int64_t gx = (groups + 255) / 256;
-            dim3 grid((unsigned)gx, (unsigned)nt), block(256);
+            const int threads = ctx->fused_variant == 1 ? FUSED_THREADS : 256;
+            const int64_t gx = (groups + threads - 1) / threads;
+            const int waves = threads / 64;
+            dim3 grid((unsigned)gx, (unsigned)nt), block(threads);
             if (b.counters) {
-                const size_t need = (size_t)nt * (size_t)gx * 4 * sizeof(uint2);
+                const size_t need = (size_t)nt * (size_t)gx * waves * sizeof(uint2);
                 if (need > ctx->partials_bytes) {
                     HIP_TRY(hipStreamSynchronize(s));
                     if (ctx->partials) HIP_TRY(hipFree(ctx->partials));
@@ -794,14 +1129,26 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
                 }
                 b.partials = static_cast<uint2*>(ctx->partials);
             }
-            if (masks) hipLaunchKernelGGL(dswx_classify_v8<true>, grid, block, 0, s, b);
-            else hipLaunchKernelGGL(dswx_classify_v8<false>, grid, block, 0, s, b);
+            uint8_t* const u8p[7] = {b.out.wtr1, b.out.wtr1_aerosol, b.out.wtr2, b.out.wtr, b.out.bwtr, b.out.conf, b.out.cloud};
+            b.n_u8_out = 0;
+            for (int i = 0; i < 7; ++i)
+                if (u8p[i]) { b.u8_out[b.n_u8_out] = u8p[i]; b.u8_region[b.n_u8_out] = i; ++b.n_u8_out; }
+            b.n_diag_pieces = b.out.diag ? 8 : 0;
+            if (ctx->fused_variant == 1) {
+                if (masks) hipLaunchKernelGGL(dswx_classify_fused<true>, grid, block, 0, s, b);
+                else hipLaunchKernelGGL(dswx_classify_fused<false>, grid, block, 0, s, b);
+                snprintf(info, sizeof info, "dswx_classify_fused<%s> (LDS-staged) grid=(%lld,%lld) block=%d lds=%d",
+                         masks ? "true" : "false", (long long)gx, (long long)nt, FUSED_THREADS, STAGE_BYTES);
+            } else {
+                if (masks) hipLaunchKernelGGL(dswx_classify_v8<true>, grid, block, 0, s, b);
+                else hipLaunchKernelGGL(dswx_classify_v8<false>, grid, block, 0, s, b);
+                snprintf(info, sizeof info, "dswx_classify_v8<%s> (fused, direct stores) grid=(%lld,%lld) block=256",
+                         masks ? "true" : "false", (long long)gx, (long long)nt);
+            }
             HIP_TRY(hipGetLastError());
-            snprintf(info, sizeof info, "dswx_classify_v8<%s> grid=(%lld,%lld) block=256",
-                     masks ? "true" : "false", (long long)gx, (long long)nt);
             if (b.counters) {
                 hipLaunchKernelGGL(dswx_counters_finish, dim3((unsigned)nt), dim3(256), 0, s, b.partials,
-                                   b.counters, (long long)gx * 4, in->ocean ? 1 : 0, (long long)groups * 8);
+                                   b.counters, (long long)gx * waves, in->ocean ? 1 : 0, (long long)groups * 8);
                 HIP_TRY(hipGetLastError());
             }
             b.px_begin = groups * 8;
@@ -915,7 +1262,8 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const 
     KArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = *in; a.out = *out; a.n_pixels = n_pixels;
-    // variant = ppt16 | nt << 1 | log2(iters) << 2 ; bit 8: flat two-stream copy of
+    // variant = ppt16 | nt << 1 | log2(iters) << 2 | mode << 9 | xcdmap << 11 |
+    // block512 << 12 ; bit 8: flat two-stream copy of
     // the same byte counts (needs the planes laid out as DeviceBatch does:
     // band[0..5], fmask contiguous; diag, wtr1.. contiguous)
     if (variant & 256) {
@@ -927,15 +1275,74 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const 
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }
+    if (variant & 65536) {  // role split: bit 2 = SPLIT, bit 1 = nt
+        const int64_t groups = n_pixels >> 3;
+        const bool wnt = variant & 2;
+        if (variant & 4) {
+            dim3 grid((unsigned)((groups + 255) / 256), (unsigned)n_tiles), block(256);
+            if (wnt) hipLaunchKernelGGL((dswx_role_split_k<1, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((dswx_role_split_k<1, false>), grid, block, 0, s, a);
+        } else {
+            dim3 grid((unsigned)(((groups + 511) / 512) * 2), (unsigned)n_tiles), block(256);
+            if (wnt) hipLaunchKernelGGL((dswx_role_split_k<0, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((dswx_role_split_k<0, false>), grid, block, 0, s, a);
+        }
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & 32768) {  // plane-per-block stream-count calibration, bit 1 = nt
+        const long long total = n_tiles * n_pixels;
+        dim3 grid((unsigned)(((total + 4095) / 4096) * 14)), block(256);
+        if (variant & 2) hipLaunchKernelGGL(dswx_plane_per_block_k<true>, grid, block, 0, s, a, total);
+        else hipLaunchKernelGGL(dswx_plane_per_block_k<false>, grid, block, 0, s, a, total);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & 16384) {  // staged probe: bits 2-3 = log2(BLOCK/256), bit 1 = nt
+        const int lb = (variant >> 2) & 3;
+        const int bs = 256 << lb;
+        const int64_t groups = n_pixels >> 3;
+        dim3 grid((unsigned)((groups + bs - 1) / bs), (unsigned)n_tiles), block(bs);
+        const bool wnt = variant & 2;
+        if (lb == 0) { if (wnt) hipLaunchKernelGGL((dswx_staged_probe_k<256, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((dswx_staged_probe_k<256, false>), grid, block, 0, s, a); }
+        else if (lb == 1) { if (wnt) hipLaunchKernelGGL((dswx_staged_probe_k<512, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((dswx_staged_probe_k<512, false>), grid, block, 0, s, a); }
+        else { if (wnt) hipLaunchKernelGGL((dswx_staged_probe_k<1024, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((dswx_staged_probe_k<1024, false>), grid, block, 0, s, a); }
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & 8192) {   // write-path calibration: bits 2-3 = WMODE, bit 1 = nt
+        const long long total = n_tiles * n_pixels;
+        const int wm = (variant >> 2) & 3;
+        const bool wnt = variant & 2;
+        if (wm == 0) {
+            dim3 grid((unsigned)((total * 8 / 16 + 255) / 256)), block(256);
+            if (wnt) hipLaunchKernelGGL((dswx_write_probe_k<0, true>), grid, block, 0, s, a, total);
+            else hipLaunchKernelGGL((dswx_write_probe_k<0, false>), grid, block, 0, s, a, total);
+        } else if (wm == 1) {
+            dim3 grid((unsigned)((total / 16 + 255) / 256), 1, 7), block(256);
+            if (wnt) hipLaunchKernelGGL((dswx_write_probe_k<1, true>), grid, block, 0, s, a, total);
+            else hipLaunchKernelGGL((dswx_write_probe_k<1, false>), grid, block, 0, s, a, total);
+        } else {
+            dim3 grid((unsigned)((total + 4095) / 4096)), block(256);
+            if (wnt) hipLaunchKernelGGL((dswx_write_probe_k<2, true>), grid, block, 0, s, a, total);
+            else hipLaunchKernelGGL((dswx_write_probe_k<2, false>), grid, block, 0, s, a, total);
+        }
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
     const bool ppt16 = variant & 1, nt = variant & 2;
     const int iters = 1 << ((variant >> 2) & 7);
-    const int ppt = ppt16 ? 16 : 8;
+    const int mode = (variant >> 9) & 3;
+    const bool xcd = variant & 2048, big = variant & 4096;
+    const int ppt = ppt16 ? 16 : 8, bs = big ? 512 : 256;
     const int64_t groups = n_pixels / ppt;
-    dim3 grid((unsigned)((groups + 256LL * iters - 1) / (256LL * iters)), (unsigned)n_tiles), block(256);
-    if (!ppt16 && !nt) hipLaunchKernelGGL((dswx_stream_probe_k<8, false>), grid, block, 0, s, a, iters);
-    else if (!ppt16 && nt) hipLaunchKernelGGL((dswx_stream_probe_k<8, true>), grid, block, 0, s, a, iters);
-    else if (ppt16 && !nt) hipLaunchKernelGGL((dswx_stream_probe_k<16, false>), grid, block, 0, s, a, iters);
-    else hipLaunchKernelGGL((dswx_stream_probe_k<16, true>), grid, block, 0, s, a, iters);
+    dim3 grid((unsigned)((groups + (int64_t)bs * iters - 1) / ((int64_t)bs * iters)), (unsigned)n_tiles), block(bs);
+#define PROBE_LAUNCH(PPT, NT, MODE, XCD, BS) hipLaunchKernelGGL((dswx_stream_probe_k<PPT, NT, MODE, XCD, BS>), grid, block, 0, s, a, iters)
+#define PROBE_SEL5(PPT, NT, MODE, XCD) do { if (big) PROBE_LAUNCH(PPT, NT, MODE, XCD, 512); else PROBE_LAUNCH(PPT, NT, MODE, XCD, 256); } while (0)
+#define PROBE_SEL4(PPT, NT, MODE) do { if (xcd) PROBE_SEL5(PPT, NT, MODE, true); else PROBE_SEL5(PPT, NT, MODE, false); } while (0)
+#define PROBE_SEL3(PPT, NT) do { if (mode == 0) PROBE_SEL4(PPT, NT, 0); else if (mode == 1) PROBE_SEL4(PPT, NT, 1); else PROBE_SEL4(PPT, NT, 2); } while (0)
+#define PROBE_SEL2(PPT) do { if (nt) PROBE_SEL3(PPT, true); else PROBE_SEL3(PPT, false); } while (0)
+    if (ppt16) PROBE_SEL2(16); else PROBE_SEL2(8);
     HIP_TRY(hipGetLastError());
     return DSWX_OK;
 }

@@ -164,7 +164,7 @@ def test_device_batch_and_synth(ctx, geom):
     ctx.synchronize()
     info = ctx.last_kernel_info()
     # ragged multi-tile batches go to the generic kernel, the rest to the vector one
-    assert ('v8' in info) == ((h * w) % 8 == 0 or n_tiles == 1), info
+    assert ('dswx_classify_v8' in info or 'dswx_classify_fused' in info) == ((h * w) % 16 == 0 or n_tiles == 1), info
     cnt = batch.read_counters()
     for t in range(n_tiles):
         s = synth_tile(7 + t, h, w, with_masks=True)
@@ -223,7 +223,7 @@ def test_full_size_tile_vs_numpy_oracle(ctx):
     s = synth_tile(0, h, w)
     p = _capi.default_params()
     got = ctx.classify_host(s['bands'], s['fmask'], p)
-    assert 'v8' in ctx.last_kernel_info()
+    assert 'fused' in ctx.last_kernel_info()
     exp = o.classify_tile(s['bands'], s['fmask'])
     for layer, key in NAME.items():
         assert np.array_equal(got[key], exp[layer]), layer
@@ -241,7 +241,7 @@ def test_full_size_batch_properties(ctx):
     batch.classify(p)
     ctx.synchronize()
     cnt = batch.read_counters()
-    assert 'v8<true>' in ctx.last_kernel_info()
+    assert '<true>' in ctx.last_kernel_info()
     for t in (0, n_tiles - 1):
         s = synth_tile(100 + t, h, w, with_masks=True)
         exp = c_oracle.classify(p, s['bands'], s['fmask'], land=s['land'], shad=s['shad'],
@@ -308,3 +308,22 @@ def test_gpu_quotient_enumeration(ctx):
     got = ctx.classify_host([v.reshape(1, -1) for v in bands], fm, p, layers=('diag',))
     exp = c_oracle.classify(p, bands, fm.ravel(), layers=('diag',))
     assert np.array_equal(got['diag'].ravel(), exp['diag'])
+
+
+def test_staged_variant_parity(monkeypatch):
+    """The LDS-staged store variant (DSWX_FUSED_VARIANT=1) is kept bit-exact too."""
+    monkeypatch.setenv('DSWX_FUSED_VARIANT', '1')
+    c2 = _capi.Context(0)
+    try:
+        for (h, w, masks) in [(64, 64, True), (333, 517, True), (700, 900, False)]:
+            s = synth_tile(77, h, w, with_masks=True)
+            kw = dict(land=s['land'], shad=s['shad'], ocean=s['ocean']) if masks else {}
+            p = _capi.default_params()
+            got = c2.classify_host(s['bands'], s['fmask'], p, **kw)
+            assert 'LDS-staged' in c2.last_kernel_info()
+            exp = c_oracle.classify(p, s['bands'], s['fmask'], **kw)
+            for key in ALL_LAYERS:
+                assert np.array_equal(got[key], exp[key]), (key, h, w)
+            assert got['counters'][0].tolist() == exp['counters'].tolist()
+    finally:
+        c2.close()

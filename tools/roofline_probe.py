@@ -55,11 +55,21 @@ def main():
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
                                                      variant), a.reps)
             out[f'flat 2-stream copy nt={int(bool(variant & 2))}'] = round(px * 21 / (sum(ms) / len(ms)) / 1e6, 1)
-        for variant in range(0, 4):
-            ppt, nt, iters = (16 if variant & 1 else 8), bool(variant & 2), 1 << (variant >> 2)
+        def run(label, variant, nbytes):
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
                                                      variant), a.reps)
-            out[f'probe ppt={ppt} nt={int(nt)} iters={iters}'] = round(px * 21 / (sum(ms) / len(ms)) / 1e6, 1)
+            out[label] = round(px * nbytes / (sum(ms) / len(ms)) / 1e6, 1)
+        for nt in (0, 2):
+            run(f'14 planes, one plane per block nt={nt >> 1}', 32768 | nt, 21)
+            run(f'role split by block (7-plane readers / 7-plane writers) nt={nt >> 1}', 65536 | nt, 21)
+            run(f'role split by wave inside block nt={nt >> 1}', 65536 | 4 | nt, 21)
+        for lb in (0, 1, 2):
+            for nt in (0, 2):
+                run(f'staged probe block={256 << lb} nt={nt >> 1}', 16384 | (lb << 2) | nt, 21)
+        run('probe ppt=8 nt=1 (direct stores)', 2, 21)
+        for wm, name in ((0, 'flat 1 stream'), (1, '7 planes, plane per block'), (2, '7 planes, plane per wave')):
+            for nt in (0, 2):
+                run(f'write-only {name} nt={nt >> 1}', 8192 | (wm << 2) | nt, 8)
     print(json.dumps(out, indent=1))
 
 
