@@ -84,28 +84,20 @@ def main():
         raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
 
     import torch
-    from proteus_amd import _capi
+    from proteus_amd import _capi, shard
     from proteus_amd.synth import SEED
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)
+    cp = shard.ControlPlane(backend='nccl', device=torch.device('cuda', local_rank))
 
     ctx = _capi.Context(local_rank)        # raises if the HIP extension / GPU is missing
     params = _capi.default_params()
     n_tiles = args.tiles
     batch = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=args.masks)
-    batch.synth(SEED, tile0=rank * n_tiles)     # rank r owns tiles [r*T, (r+1)*T)
+    tile0, _ = shard.weak_tile_range(n_tiles, rank)     # rank r owns tiles [r*T, (r+1)*T)
+    batch.synth(SEED, tile0=tile0)
     ctx.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = cp.barrier
 
     for _ in range(args.warmup):
         batch.classify(params)
@@ -130,10 +122,7 @@ def main():
     launch_ms = [ctx.elapsed_ms(a, b) for a, b in zip(starts, stops)]
     for e in starts + stops:
         ctx.destroy_event(e)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f'cuda:{local_rank}')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = cp.max_over_ranks(elapsed)
 
     parity = None
     if rank == 0 and not args.no_parity:
@@ -184,9 +173,7 @@ def main():
         print(json.dumps(out), flush=True)
     batch.free()
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    cp.close()
 
 
 if __name__ == '__main__':

@@ -138,6 +138,13 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params,
                          const dswx_planes_in_t* in, const dswx_planes_out_t* out,
                          int64_t* counters, void* stream);
 
+/* generate_interpreted_layer (dswx_hls.py:1687-1707) alone: `n` DIAG values in
+ * decimal (0..31 -> class 0..4 per interpreted_dswx_band_dict :97-143; 32 and any
+ * other value -> 255), host pointers.  This is the function the reference's unit
+ * test exercises (tests/test_dswx_hls_units.py:7-28). */
+int dswx_interpret_layer_host(dswx_ctx_t* ctx, const int64_t* diag_decimal, int64_t n,
+                              uint8_t* out);
+
 /* Deterministic synthetic HLS tiles written straight into HBM (SURVEY.md §8d;
  * same integer recipe as proteus_amd/synth.py).  Fills in->band[0..5], in->fmask
  * and whichever of land/shad/ocean is non-NULL for tiles tile0..tile0+n_tiles-1. */

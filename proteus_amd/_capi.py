@@ -23,7 +23,7 @@ F64_LAYERS = ('mndwi', 'ndvi', 'awesh')
 EXPORTED_SYMBOLS = (
     'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
-    'dswx_classify_device', 'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
+    'dswx_classify_device', 'dswx_interpret_layer_host', 'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info')
@@ -92,6 +92,7 @@ def load_library():
         'dswx_classify_device': (ctypes.c_int, [vp, ctypes.POINTER(Params), i64, i64,
                                                 ctypes.POINTER(PlanesIn),
                                                 ctypes.POINTER(PlanesOut), vp, vp]),
+        'dswx_interpret_layer_host': (ctypes.c_int, [vp, vp, i64, vp]),
         'dswx_stream_probe': (ctypes.c_int, [vp, i64, i64, ctypes.POINTER(PlanesIn),
                                              ctypes.POINTER(PlanesOut), ctypes.c_int, vp]),
         'dswx_synth_fill': (ctypes.c_int, [vp, ctypes.c_uint64, i64, i64, i64, i64,
@@ -303,6 +304,14 @@ class Context:
             ctypes.byref(pin), ctypes.byref(pout),
             ctypes.c_void_p(counters_ptr) if counters_ptr else None,
             ctypes.c_void_p(stream) if stream else None))
+
+    def interpret_layer(self, diag_decimal):
+        """generate_interpreted_layer on the device; any integer array in, uint8 out."""
+        d = np.ascontiguousarray(diag_decimal, dtype=np.int64)
+        out = np.empty(d.shape, dtype=np.uint8)
+        _check(self.lib.dswx_interpret_layer_host(self.handle, _host_ptr(d), d.size,
+                                                  _host_ptr(out)))
+        return out
 
     def stream_probe(self, n_tiles, n_pixels, pin, pout, variant=0, stream=None):
         _check(self.lib.dswx_stream_probe(

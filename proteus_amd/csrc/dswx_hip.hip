@@ -777,6 +777,24 @@ __global__ __launch_bounds__(256) void dswx_write_probe_k(const KArgs a, long lo
 }
 
 // ------------------------------------------------------------------------------
+// generate_interpreted_layer (:1687-1707) on its own: DIAG in decimal (any integer,
+// as the reference's unit test feeds it) -> WTR-1 class; 32 and anything outside
+// the table -> 255.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dswx_interpret_v1(const long long* __restrict__ diag,
+                                                         uint8_t* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long d = diag[i];
+    uint32_t cls = 255u;
+    if (d >= 0 && d < 32) {
+        const uint32_t k = (uint32_t)d;
+        cls = ((CLS_B0 >> k) & 1u) | (((CLS_B1 >> k) & 1u) << 1) | (((CLS_B2 >> k) & 1u) << 2);
+    }
+    out[i] = (uint8_t)cls;
+}
+
+// ------------------------------------------------------------------------------
 // Debug planes: float64 MNDWI / NDVI / AWESH exactly as :1872-1887 (true IEEE
 // division; int16 wrap-around sums).  Not on the timed path.
 // ------------------------------------------------------------------------------
@@ -1245,6 +1263,31 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
         if (counters) HIP_TRY(hipMemcpyAsync(counters + t * 3, dcnt, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    return DSWX_OK;
+}
+
+int dswx_interpret_layer_host(dswx_ctx_t* ctx, const int64_t* diag_decimal, int64_t n, uint8_t* out) {
+    if (!ctx || (n > 0 && (!diag_decimal || !out))) return fail(DSWX_ERR_ARG, "NULL argument");
+    if (n < 0) return fail(DSWX_ERR_ARG, "negative size");
+    if (n == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, (size_t)n * 8));
+    hipError_t e = hipMalloc(&d_out, (size_t)n);
+    if (e != hipSuccess) { (void)hipFree(d_in); return fail(DSWX_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    hipStream_t s = ctx->stream;
+    e = hipMemcpyAsync(d_in, diag_decimal, (size_t)n * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dswx_interpret_v1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                           static_cast<const long long*>(d_in), static_cast<uint8_t*>(d_out), (long long)n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(DSWX_ERR_HIP, "dswx_interpret_layer_host: %s", hipGetErrorString(e));
     return DSWX_OK;
 }
 

@@ -1,0 +1,1023 @@
+"""Host side of the MI355X DSWx-HLS drop-in: the same public names as PROTEUS
+`src/proteus/dswx_hls.py`, with the per-pixel chain running on the GPU.
+
+Kept from the reference interface (file:line = src/proteus/dswx_hls.py):
+  get_dswx_hls_cli_parser :411      parse_runconfig_file :3601    create_logger :4126
+  generate_dswx_layers :4610        compare_dswx_hls_products :710
+  HlsThresholds :274                RunConfigConstants :321
+  interpreted_dswx_band_dict :97    generate_interpreted_layer :1687
+  band_description_dict :217        layer_names_to_args_dict :229  collapse_wtr_classes_dict :201
+
+What changes: the run of numpy calls inside generate_dswx_layers (:5089, :5110-5112,
+:5225-5231, :5245-5249, :5261, :5268, :5282, :5286, :5358, :5368) is ONE call into the HIP
+library (proteus_amd._capi.Context.classify_host -> dswx_classify_host).  There is no
+numpy implementation of that chain in this package: without the built library or
+without a GPU, generate_dswx_layers raises.
+
+What stays on the host and is NOT re-implemented here (out of scope):
+GDAL reprojection of DEM / land cover / shoreline, the terrain-shadow and land-cover
+builders, COG overviews and validation.  GDAL is not installed in this image, so raster
+I/O goes through proteus_amd.geotiff; ancillary layers can be handed over already on
+the HLS grid with the `landcover_mask=`, `shadow_layer=` and `ocean_mask=` keyword
+extensions (arrays or GeoTIFF paths).  Passing `dem_file`, `landcover_file`,
+`worldcover_file` or `shoreline_shapefile` (which need warping) raises
+NotImplementedError.
+"""
+import argparse
+import glob
+import logging
+import os
+import sys
+from collections import OrderedDict
+from datetime import datetime
+
+import numpy as np
+
+from . import _capi, geotiff, runconfig as _rc
+from .version import VERSION as SOFTWARE_VERSION
+
+FLAG_COLLAPSE_WTR_CLASSES = True          # :26
+FLAG_CLIP_NEGATIVE_REFLECTANCE = True     # :31
+SCALE_FACTOR = 0.0001                     # :44
+AEROSOL_REMAPPING_MAX_NIR = 0.1 / SCALE_FACTOR
+COMPARE_DSWX_HLS_PRODUCTS_ERROR_TOLERANCE = 1e-6
+UINT8_FILL_VALUE = 255
+OCEAN_MASKED_RGBA = (0, 0, 127, 0)
+FILL_VALUE_RGBA = (0, 0, 0, 0)
+DIAGNOSTIC_LAYER_NO_DATA_DECIMAL = 0b100000
+DIAGNOSTIC_LAYER_NO_DATA_BINARY_REPR = 65535
+WTR_SNOW_MASKED, WTR_CLOUD_MASKED, WTR_OCEAN_MASKED = 252, 253, 254
+
+logger = logging.getLogger('dswx_hls')
+
+# HLS v2 per-band file suffixes (:78-92); v1 (HDF4, :62-76) needs GDAL
+l30_v2_band_dict = {'blue': 'B02', 'green': 'B03', 'red': 'B04', 'nir': 'B05',
+                    'swir1': 'B06', 'swir2': 'B07', 'fmask': 'Fmask'}
+s30_v2_band_dict = {'blue': 'B02', 'green': 'B03', 'red': 'B04', 'nir': 'B8A',
+                    'swir1': 'B11', 'swir2': 'B12', 'fmask': 'Fmask'}
+
+# DIAG value -> WTR-1 class (:97-143), grouped by class
+interpreted_dswx_band_dict = {}
+for _cls, _keys in ((0, (0b00000, 0b00001, 0b00010, 0b00100, 0b01000)),
+                    (1, (0b01111, 0b10111, 0b11011, 0b11101, 0b11110, 0b11111)),
+                    (2, (0b00111, 0b01011, 0b01101, 0b01110, 0b10011, 0b10101, 0b10110,
+                         0b11001, 0b11010, 0b11100)),
+                    (3, (0b11000,)),
+                    (4, (0b00011, 0b00101, 0b00110, 0b01001, 0b01010, 0b01100, 0b10000,
+                         0b10001, 0b10010, 0b10100))):
+    for _k in _keys:
+        interpreted_dswx_band_dict[_k] = _cls
+interpreted_dswx_band_dict[DIAGNOSTIC_LAYER_NO_DATA_DECIMAL] = UINT8_FILL_VALUE
+
+collapse_wtr_classes_dict = {0: 0, 1: 1, 2: 1, 3: 2, 4: 2, WTR_OCEAN_MASKED: WTR_OCEAN_MASKED,
+                             WTR_SNOW_MASKED: WTR_SNOW_MASKED,
+                             WTR_CLOUD_MASKED: WTR_CLOUD_MASKED,
+                             UINT8_FILL_VALUE: UINT8_FILL_VALUE}
+collapsable_layers_list = ['WTR', 'WTR-1', 'WTR-2']
+
+band_description_dict = OrderedDict([
+    ('WTR', 'Water classification (WTR)'),
+    ('BWTR', 'Binary Water (BWTR)'),
+    ('CONF', 'Confidence classification (CONF)'),
+    ('DIAG', 'Diagnostic layer (DIAG)'),
+    ('WTR-1', 'Interpretation of diagnostic layer into water classes (WTR-1)'),
+    ('WTR-2', 'Interpreted layer refined using land cover and terrain shadow testing (WTR-2)'),
+    ('LAND', 'Land cover classification (LAND)'),
+    ('SHAD', 'Terrain shadow layer (SHAD)'),
+    ('CLOUD', 'Input HLS Fmask cloud/cloud-shadow classification (CLOUD)'),
+    ('DEM', 'Digital elevation model (DEM)')])
+
+layer_names_to_args_dict = OrderedDict([
+    ('WTR', 'output_interpreted_band'), ('BWTR', 'output_binary_water'),
+    ('CONF', 'output_confidence_layer'), ('DIAG', 'output_diagnostic_layer'),
+    ('WTR-1', 'output_non_masked_dswx'), ('WTR-2', 'output_shadow_masked_dswx'),
+    ('LAND', 'output_landcover'), ('SHAD', 'output_shadow_layer'),
+    ('CLOUD', 'output_cloud_layer'), ('DEM', 'output_dem_layer'),
+    ('RGB', 'output_rgb_file'), ('INFRARED_RGB', 'output_infrared_rgb_file')])
+
+METADATA_FIELDS_TO_COPY_FROM_HLS_LIST = ['MEAN_SUN_AZIMUTH_ANGLE', 'MEAN_SUN_ZENITH_ANGLE',
+                                         'MEAN_VIEW_AZIMUTH_ANGLE', 'MEAN_VIEW_ZENITH_ANGLE',
+                                         'NBAR_SOLAR_ZENITH', 'ACCODE']
+
+_THRESHOLD_NAMES = _capi.THRESHOLD_NAMES
+_AEROSOL_KEYS = (
+    'aerosol_not_water_to_high_conf_water_fmask_values',
+    'aerosol_water_moderate_conf_to_high_conf_water_fmask_values',
+    'aerosol_partial_surface_water_conservative_to_high_conf_water_fmask_values',
+    'aerosol_partial_surface_aggressive_to_high_conf_water_fmask_values')
+
+
+class HlsThresholds:
+    """The twelve reflectance thresholds (:274-318)."""
+
+    def __init__(self):
+        for name in _THRESHOLD_NAMES:
+            setattr(self, name, None)
+
+
+class RunConfigConstants:
+    """Processing / browse constants that come from the runconfig (:321-408)."""
+
+    _FIELDS = ('check_ancillary_inputs_coverage', 'apply_ocean_masking',
+               'apply_aerosol_class_remapping') + _AEROSOL_KEYS + (
+        'shadow_masking_algorithm', 'min_slope_angle', 'max_sun_local_inc_angle',
+        'mask_adjacent_to_cloud_mode', 'forest_mask_landcover_classes',
+        'ocean_masking_shoreline_distance_km', 'browse_image_height', 'browse_image_width',
+        'exclude_psw_aggressive_in_browse', 'not_water_in_browse', 'cloud_in_browse',
+        'snow_in_browse')
+
+    def __init__(self):
+        self.hls_thresholds = HlsThresholds()
+        for name in self._FIELDS:
+            setattr(self, name, None)
+
+
+# -----------------------------------------------------------------------------------
+# command line (:411-702): same flags, same dest names
+# -----------------------------------------------------------------------------------
+def get_dswx_hls_cli_parser():
+    p = argparse.ArgumentParser(
+        description='Generate a DSWx-HLS product from an HLS product',
+        formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument('input_list', type=str, nargs='+',
+                   help='Input YAML run configuration file or HLS product file(s)')
+
+    def files(*flags, dest, help):
+        p.add_argument(*flags, dest=dest, type=str, help=help)
+
+    files('--dem', dest='dem_file', help='Input digital elevation model (DEM)')
+    files('--dem-description', dest='dem_file_description', help='DEM description')
+    files('-c', '--landcover', dest='landcover_file',
+          help='Input Copernicus Land Cover Discrete-Classification-map 100m')
+    files('--landcover-description', dest='landcover_file_description',
+          help='Land cover description')
+    files('-w', '--worldcover', dest='worldcover_file', help='Input ESA WorldCover 10m')
+    files('--worldcover-description', dest='worldcover_file_description',
+          help='WorldCover description')
+    files('-s', '--shoreline', dest='shoreline_shapefile', help='NOAA GSHHS shapefile')
+    files('--shoreline-shape-description', dest='shoreline_shapefile_description',
+          help='NOAA GSHHS shapefile description')
+    # outputs.  The reference concatenates a few alias pairs by accident (missing
+    # commas, e.g. '--bwtr--output-binary-water' at :496-497); both the intended and
+    # the accidental spellings are accepted.
+    files('-o', '--output-file', dest='output_file', help='Output DSWx-HLS product (GeoTIFF)')
+    files('--wtr', '--interpreted-band', dest='output_interpreted_band',
+          help='Output interpreted DSWx layer (GeoTIFF)')
+    files('--output-rgb', '--output-rgb-file', dest='output_rgb_file',
+          help='Output RGB reflectance file (GeoTIFF)')
+    files('--output-infrared-rgb', '--output-infrared-rgb-file',
+          dest='output_infrared_rgb_file', help='Output SWIR-1/NIR/Red composition (GeoTIFF)')
+    files('--bwtr', '--output-binary-water', '--bwtr--output-binary-water',
+          dest='output_binary_water', help='Output binary water mask (GeoTIFF)')
+    files('--conf', '--output-confidence-layer', '--conf--output-confidence-layer',
+          dest='output_confidence_layer', help='Output confidence layer (GeoTIFF)')
+    files('--diag', '--output-diagnostic-layer', dest='output_diagnostic_layer',
+          help='Output diagnostic test layer file (GeoTIFF)')
+    files('--wtr-1', '--output-non-masked-dswx', dest='output_non_masked_dswx',
+          help='Output non-masked DSWx layer file (GeoTIFF)')
+    files('--wtr-2', '--output-shadow-masked-dswx', dest='output_shadow_masked_dswx',
+          help='Output interpreted layer refined with land cover and terrain shadow (GeoTIFF)')
+    files('--land', '--output-land', dest='output_landcover',
+          help='Output landcover classification file (GeoTIFF)')
+    files('--shad', '--output-shadow-layer', dest='output_shadow_layer',
+          help='Output terrain shadow layer file (GeoTIFF)')
+    files('--cloud', '--output-cloud-mask', '--cloud--output-cloud-mask',
+          dest='output_cloud_layer', help='Output cloud/cloud-shadow classification (GeoTIFF)')
+    files('--out-dem', '--output-digital-elevation-model', '--output-elevation-layer',
+          '--out-dem--output-digital-elevation-model', dest='output_dem_layer',
+          help='Output elevation layer file (GeoTIFF)')
+    files('--browse', '--output-browse-image', '--browse--output-browse-image',
+          dest='output_browse_image', help='Output browse image file (png)')
+    p.add_argument('--bheight', '--browse-image-height', '--bheight--browse-image-height',
+                   dest='browse_image_height', type=int, help='Browse PNG height in pixels')
+    p.add_argument('--bwidth', '--browse-image-width', '--bwidth--browse-image-width',
+                   dest='browse_image_width', type=int, help='Browse PNG width in pixels')
+    p.add_argument('--exclude-psw-aggressive-in-browse', dest='exclude_psw_aggressive_in_browse',
+                   action='store_true', default=None,
+                   help='Exclude the Partial Surface Water Aggressive class in the browse image')
+    p.add_argument('--not-water-in-browse', dest='not_water_in_browse', type=str,
+                   choices=['white', 'nodata'], default=None, help='Not Water in the browse image')
+    p.add_argument('--cloud-in-browse', dest='cloud_in_browse', type=str,
+                   choices=['gray', 'nodata'], default=None, help='Cloud in the browse image')
+    p.add_argument('--snow-in-browse', dest='snow_in_browse', type=str,
+                   choices=['cyan', 'gray', 'nodata'], default=None,
+                   help='Snow in the browse image')
+    p.add_argument('--offset-and-scale-inputs', dest='flag_offset_and_scale_inputs',
+                   action='store_true', default=False,
+                   help='Offset and scale HLS inputs before processing')
+    files('--scratch-dir', '--temp-dir', '--temporary-dir', dest='scratch_dir',
+          help='Scratch (temporary) directory')
+    files('--pid', '--product-id', dest='product_id', help='Product ID for the metadata')
+    files('--product-version', dest='product_version', help='Product version for the metadata')
+    for flag, dest, text in (
+            ('--check-ancillary-inputs-coverage', 'check_ancillary_inputs_coverage',
+             'Check if ancillary inputs cover entirely the output product'),
+            ('--apply-ocean-masking', 'apply_ocean_masking', 'Apply ocean masking'),
+            ('--apply-aerosol-masking', 'apply_aerosol_class_remapping', 'Apply aerosol masking')):
+        p.add_argument(flag, dest=dest, action='store_true', default=None, help=text)
+    p.add_argument('--shadow-masking-algorithm', dest='shadow_masking_algorithm', type=str,
+                   choices=['otsu', 'sun_local_inc_angle'], help='Shadow masking algorithm')
+    p.add_argument('--min-slope-angle', dest='min_slope_angle', type=float, help='')
+    p.add_argument('--max-sun-local-inc-angle', dest='max_sun_local_inc_angle', type=float,
+                   help='Maximum local-incidence angle')
+    p.add_argument('--mask-adjacent-to-cloud-mode', dest='mask_adjacent_to_cloud_mode', type=str,
+                   choices=['mask', 'ignore', 'cover'],
+                   help='How areas adjacent to cloud/cloud-shadow are handled')
+    p.add_argument('--copernicus-forest-classes', dest='forest_mask_landcover_classes',
+                   type=list, help='Copernicus CGLS Land Cover 100m forest classes')
+    p.add_argument('--ocean-masking-distance-km', dest='ocean_masking_shoreline_distance_km',
+                   type=float, help='Ocean masking distance from shoreline in km')
+    p.add_argument('--debug', dest='flag_debug', action='store_true', default=False,
+                   help='Activate debug mode')
+    # extensions of this drop-in (not in the reference): ancillary layers that are
+    # already on the HLS grid, and the GPU to run on
+    files('--landcover-mask', dest='landcover_mask', help='LAND layer on the HLS grid (GeoTIFF)')
+    files('--shadow-layer', dest='shadow_layer', help='SHAD layer on the HLS grid (GeoTIFF)')
+    files('--ocean-mask', dest='ocean_mask',
+          help='Ocean mask on the HLS grid, 0 = ocean (GeoTIFF); needs --apply-ocean-masking')
+    p.add_argument('--device', dest='device', type=int, default=None, help='GPU index')
+    files('--log', '--log-file', dest='log_file', help='Log file')
+    p.add_argument('--full-log-format', dest='full_log_formatting', action='store_true',
+                   default=False, help='Enable full formatting of log messages')
+    return p
+
+
+# -----------------------------------------------------------------------------------
+# logging (:4083-4175)
+# -----------------------------------------------------------------------------------
+class Logger:
+    """File-like object feeding complete lines to a logging.Logger (:4083-4123)."""
+
+    def __init__(self, target, level, prefix=''):
+        self.logger, self.level, self.prefix, self.buffer = target, level, prefix, ''
+
+    def write(self, message):
+        self.buffer += message
+        *lines, self.buffer = self.buffer.split('\n')
+        for line in lines:
+            if line:
+                self.logger.log(self.level, self.prefix + line)
+
+    def flush(self):
+        if self.buffer:
+            self.logger.log(self.level, self.buffer)
+        self.buffer = ''
+
+
+def create_logger(log_file, full_log_formatting=None):
+    """Console (+ file) handlers on the 'dswx_hls' logger and stdout/stderr redirected
+    into it, as the reference does (:4126-4175)."""
+    logger.setLevel(logging.DEBUG)
+    if full_log_formatting:
+        fmt = logging.Formatter(
+            '%(asctime)s.%(msecs)03d, %(levelname)s, DSWx-HLS, %(module)s, 999999, '
+            '%(pathname)s:%(lineno)d, "%(message)s"', '%Y-%m-%d %H:%M:%S')
+    else:
+        fmt = logging.Formatter('%(message)s')
+    console = logging.StreamHandler(sys.__stdout__)
+    console.setLevel(logging.DEBUG)
+    console.setFormatter(fmt)
+    logger.addHandler(console)
+    if log_file:
+        fh = logging.FileHandler(log_file)
+        fh.setFormatter(fmt)
+        logger.addHandler(fh)
+    sys.stdout = Logger(logger, logging.INFO)
+    sys.stderr = Logger(logger, logging.ERROR, prefix='[StdErr] ')
+    return logger
+
+
+# -----------------------------------------------------------------------------------
+# runconfig (:3601-3814)
+# -----------------------------------------------------------------------------------
+def parse_runconfig_file(user_runconfig_file=None, args=None):
+    """Load the default runconfig, validate + deep-merge the user's over it, fill a
+    RunConfigConstants and (if given) the argparse namespace `args`.  Precedence:
+    command line > user runconfig > default runconfig."""
+    logger.info(f'Default runconfig file: {_rc.DEFAULT_RUNCONFIG}')
+    config = _rc.load_yaml(_rc.DEFAULT_RUNCONFIG)
+    if user_runconfig_file is not None:
+        if not os.path.isfile(user_runconfig_file):
+            msg = f'ERROR invalid file {user_runconfig_file}'
+            logger.info(msg)
+            raise Exception(msg)
+        logger.info(f'Input runconfig file: {user_runconfig_file}')
+        user = _rc.load_yaml(user_runconfig_file)
+        logger.info(f'Validating runconfig file: {user_runconfig_file}')
+        _rc.validate_runconfig(user, user_runconfig_file)
+        config = _rc.deep_update(config, user)
+    groups = config['runconfig']['groups']
+    processing, browse = groups['processing'], groups['browse_image_group']
+    consts = RunConfigConstants()
+    for group in (processing, browse):
+        for key, val in group.items():
+            if key in RunConfigConstants._FIELDS:
+                setattr(consts, key, val)
+    thresholds = groups.get('hls_thresholds')
+    if thresholds is not None:
+        logger.info('HLS thresholds:')
+        for key, val in thresholds.items():
+            logger.info(f'     {key}: {val}')
+            setattr(consts.hls_thresholds, key, val)
+    if args is None:
+        return consts
+
+    for key in RunConfigConstants._FIELDS:
+        if getattr(args, key, None) is None:
+            setattr(args, key, getattr(consts, key))
+
+    input_file_path = groups['input_file_group']['input_file_path']
+    anc, paths = groups['dynamic_ancillary_file_group'], groups['product_path_group']
+    product_id = paths['product_id'] if paths['product_id'] is not None else 'dswx_hls'
+    pv = paths['product_version']
+    product_version = SOFTWARE_VERSION if pv is None else f'{pv:.1f}'
+    if (input_file_path is not None and len(input_file_path) == 1 and
+            os.path.isdir(input_file_path[0])):
+        logger.info(f'input HLS files directory: {input_file_path[0]}')
+        args.input_list = glob.glob(os.path.join(input_file_path[0], '*.tif'))
+    elif input_file_path is not None:
+        args.input_list = input_file_path
+
+    from_runconfig = {k: anc[k] for k in (
+        'dem_file', 'dem_file_description', 'landcover_file', 'landcover_file_description',
+        'worldcover_file', 'worldcover_file_description', 'shoreline_shapefile',
+        'shoreline_shapefile_description')}
+    from_runconfig.update(scratch_dir=paths['scratch_path'], product_id=product_id,
+                          product_version=product_version)
+    for name, rc_val in from_runconfig.items():
+        cli_val = getattr(args, name, None)
+        if cli_val is not None and rc_val is not None:
+            logger.warning(f'command line {name} "{cli_val}" has precedence over runconfig'
+                           f' {name} "{rc_val}".')
+        elif cli_val is None:
+            setattr(args, name, rc_val)
+    if user_runconfig_file is None:
+        return consts
+
+    out_dir = paths['output_dir']
+    for number, (layer, arg_name) in enumerate(layer_names_to_args_dict.items(), start=1):
+        save = processing['save_' + layer.lower().replace('-', '_')]
+        cli_val = getattr(args, arg_name, None)
+        default_name = os.path.join(
+            out_dir, f'{product_id}_v{product_version}_B{number:02}_{layer}.tif')
+        if cli_val is not None and save:
+            logger.warning(f'command line {arg_name} "{cli_val}" has precedence over runconfig'
+                           f' {arg_name} "{default_name}".')
+        elif cli_val is None and save:
+            setattr(args, arg_name, default_name)
+    if browse['save_browse']:
+        default_name = os.path.join(out_dir, f'{product_id}_v{product_version}_BROWSE.png')
+        cli_val = getattr(args, 'output_browse_image', None)
+        if cli_val is not None:
+            logger.warning(f'command line output_browse_image "{cli_val}" has precedence over'
+                           f' default output_browse_image "{default_name}".')
+        else:
+            args.output_browse_image = default_name
+    return consts
+
+
+# -----------------------------------------------------------------------------------
+# GPU context (one per process and device)
+# -----------------------------------------------------------------------------------
+_contexts = {}
+
+
+def get_context(device=None):
+    """The process-wide HIP context for `device` (default: $DSWX_DEVICE or 0).
+    Raises if the library is not built or no MI355X is visible: no CPU fallback."""
+    if device is None:
+        device = int(os.environ.get('DSWX_DEVICE', '0'))
+    if device not in _contexts:
+        _contexts[device] = _capi.Context(device)
+    return _contexts[device]
+
+
+def generate_interpreted_layer(diagnostic_layer):
+    """DIAG (decimal) -> WTR-1 classes on the GPU (:1687-1707); anything that is not a
+    key of interpreted_dswx_band_dict maps to 255."""
+    logger.info('interpreting diagnostic tests (DIAG -> WTR-1)')
+    return get_context().interpret_layer(np.asarray(diagnostic_layer))
+
+
+# -----------------------------------------------------------------------------------
+# HLS loading (:2136-2425), GDAL-free
+# -----------------------------------------------------------------------------------
+def _harvest_hls_metadata(meta, md):
+    """First reflectance band: copy angles / coverage / ids, derive SPACECRAFT_NAME and
+    SENSOR (:2228-2291).  Returns False (after logging ERROR) for unsupported platforms."""
+    for k, v in meta.items():
+        ku = k.upper()
+        if ku in METADATA_FIELDS_TO_COPY_FROM_HLS_LIST:
+            md[ku] = v
+        elif ku in ('SPATIAL_COVERAGE', 'CLOUD_COVERAGE'):
+            md['INPUT_HLS_PRODUCT_' + ku] = v
+        elif ku in ('LANDSAT_PRODUCT_ID', 'PRODUCT_URI'):
+            md['SENSOR_PRODUCT_ID'] = v
+        elif ku == 'SENSING_TIME':
+            md['SENSING_TIME'] = v
+    sensor = None
+    if 'SPACECRAFT_NAME' in meta:
+        spacecraft = meta['SPACECRAFT_NAME']
+        if 'SENTINEL' not in spacecraft.upper() and 'LANDSAT' not in spacecraft.upper():
+            logger.info(f'ERROR the platform "{spacecraft}" is not supported')
+            return False
+    elif 'SENSOR' in meta:
+        sensor = meta['SENSOR']
+        pid = md.get('SENSOR_PRODUCT_ID', '')
+        if 'OLI' in sensor and 'LC' in pid:
+            i = pid.find('LC')
+            spacecraft = f'Landsat-{int(pid[i + 2:i + 4])}'
+        else:
+            logger.info(f'ERROR the sensor "{sensor}" is not supported')
+            return False
+    else:
+        logger.info('ERROR could not determine the platorm from metadata')
+        return False
+    md['SPACECRAFT_NAME'] = spacecraft
+    if sensor is not None:
+        names = [s.strip() for s in sensor.replace('_TIRS', '').split(';')]
+        md['SENSOR'] = '; '.join(dict.fromkeys(names))
+    elif 'SENTINEL' in spacecraft.upper():
+        md['SENSOR'] = 'MSI'
+    else:
+        md['SENSOR'] = 'OLI'
+    return True
+
+
+def _load_hls_product_v2(file_list, image, md, flag_debug=False):
+    """Reads the seven band files of an HLS v2 product.  Returns False on failure.
+    Fill detection and clipping are NOT done here: the raw planes and the fill values go
+    to the kernel (A0 of the hot path)."""
+    logger.info('loading HLS v.2.0 layers:')
+    image['fills'] = {}
+    for key in l30_v2_band_dict:
+        logger.info(f'    {key}')
+        landsat = 'SPACECRAFT_NAME' not in md or 'LANDSAT' in md['SPACECRAFT_NAME'].upper()
+        suffix = (l30_v2_band_dict if landsat else s30_v2_band_dict)[key]
+        path = next((f for f in file_list if suffix + '.tif' in f), None)
+        if path is None:
+            logger.info(f'ERROR band {key} not found within list of input file(s)')
+            return False
+        try:
+            arr, info = geotiff.read_geotiff(
+                path, window=(0, 0, 1000, 1000) if flag_debug else None)
+        except (OSError, geotiff.GeoTiffError) as e:
+            logger.info(f'ERROR could not open {path}: {e}')
+            return False
+        if flag_debug:
+            logger.info('reading in debug mode')
+        if 'hls_dataset_name' not in image:
+            name = os.path.splitext(os.path.basename(path))[0]
+            image['hls_dataset_name'] = name.replace(f'.{suffix}', '')
+        fill = info.nodata
+        if fill is None and '_FillValue' in info.metadata:
+            fill = float(info.metadata['_FillValue'])
+        elif fill is None:
+            fill = -9999
+        image['fills'][key] = fill
+        image.setdefault('geo_tags', info.geo_tags)
+        image.setdefault('geotransform', info.geotransform)
+        image.setdefault('length', arr.shape[0])
+        image.setdefault('width', arr.shape[1])
+        if key == 'fmask':
+            image[key] = np.ascontiguousarray(arr, dtype=np.uint8)
+            continue
+        if arr.dtype != np.int16:
+            logger.info(f'ERROR band {key} of {path} is {arr.dtype}, expected int16')
+            return False
+        if 'SPACECRAFT_NAME' not in md and not _harvest_hls_metadata(info.metadata, md):
+            return False
+        image[key] = arr
+        image.setdefault('offset', {})[key] = float(info.metadata.get('add_offset', 0.0))
+        image.setdefault('scale', {})[key] = float(info.metadata.get('scale_factor', 1.0))
+    return True
+
+
+# -----------------------------------------------------------------------------------
+# metadata (:3817-4080)
+# -----------------------------------------------------------------------------------
+_LICENSE_TAIL = (' by law or by delegation do not assume any legal responsibility or'
+                 ' liability, whether express or implied, arising from any use of this product.')
+
+
+def _get_dswx_metadata_dict(product_id, product_version):
+    md = OrderedDict()
+    md['PRODUCT_ID'] = product_id
+    md['PRODUCT_VERSION'] = product_version if product_version is not None else SOFTWARE_VERSION
+    md['SOFTWARE_VERSION'] = SOFTWARE_VERSION
+    md['PROJECT'] = 'OPERA'
+    md['PRODUCT_LEVEL'] = '3'
+    md['PRODUCT_TYPE'] = 'DSWx-HLS'
+    md['PRODUCT_SOURCE'] = 'HLS'
+    md['PROCESSING_DATETIME'] = datetime.now().strftime('%Y-%m-%dT%H:%M:%SZ')
+    return md
+
+
+def _source_field(description, path, missing):
+    if description:
+        return description
+    if path:
+        return os.path.basename(path)
+    return missing
+
+
+def _populate_dswx_metadata_datasets(md, hls_dataset, dem_file=None, dem_file_description=None,
+                                     landcover_file=None, landcover_file_description=None,
+                                     worldcover_file=None, worldcover_file_description=None,
+                                     shoreline_shapefile=None,
+                                     shoreline_shapefile_description=None):
+    md['HLS_DATASET'] = hls_dataset
+    md['DEM_SOURCE'] = _source_field(dem_file_description, dem_file, 'NOT_PROVIDED')
+    text, copernicus = '', False
+    if 'SENTINEL' in md['SPACECRAFT_NAME'].upper():
+        copernicus = True
+        text += ('This OPERA DSWx-HLS product contains modified Copernicus Sentinel Earth'
+                 ' Observation (EO) data. Sentinel EO data is provided under COPERNICUS by the'
+                 ' European Union and ESA; all rights reserved. Users, including those who'
+                 ' redistribute, adapt, modify, or combine the contents of this product, must'
+                 ' comply with the terms of the Copernicus Sentinel Data License Agreement. ')
+    if 'COPERNICUS DEM' in md['DEM_SOURCE'].upper():
+        copernicus = True
+        text += ('This OPERA DSWx-HLS product contains modified Copernicus DEM data. The'
+                 ' Copernicus DEM 30-m and Copernicus DEM 90-m were produced using Copernicus'
+                 ' WorldDEM-30 © DLR e.V. 2010-2014 and © Airbus Defence and Space GmbH'
+                 ' 2014-2018, provided under COPERNICUS by the European Union and ESA; all'
+                 ' rights reserved. Users, including those who redistribute, adapt, modify, or'
+                 ' combine the DEM layer (band 10) or derived SHAD layer (band 8), must comply'
+                 ' with the terms of the Copernicus DEM License Agreement. For additional'
+                 ' information, please refer to https://doi.org/10.5270/ESA-c5d3d65. ')
+    who = ' in charge of the OPERA project and the Copernicus programme' if copernicus else \
+        ' in charge of the OPERA project'
+    md['LICENSE'] = text + 'The organizations' + who + _LICENSE_TAIL
+    md['LANDCOVER_SOURCE'] = _source_field(landcover_file_description, landcover_file,
+                                           'NOT_PROVIDED')
+    md['WORLDCOVER_SOURCE'] = _source_field(worldcover_file_description, worldcover_file,
+                                            'NOT_PROVIDED')
+    md['SHORELINE_SOURCE'] = _source_field(shoreline_shapefile_description, shoreline_shapefile,
+                                           'NOT_PROVIDED_OR_NOT_USED')
+
+
+def _populate_dswx_metadata_processing_parameters(md, apply_ocean_masking,
+                                                  apply_aerosol_class_remapping, aerosol_lists,
+                                                  shadow_masking_algorithm, min_slope_angle,
+                                                  max_sun_local_inc_angle,
+                                                  mask_adjacent_to_cloud_mode,
+                                                  forest_mask_landcover_classes,
+                                                  ocean_masking_shoreline_distance_km):
+    md['AEROSOL_CLASS_REMAPPING_ENABLED'] = 'TRUE' if apply_aerosol_class_remapping else 'FALSE'
+    for key, values in zip(_AEROSOL_KEYS, aerosol_lists):
+        # (sic) the reference keys this on forest_mask_landcover_classes, :4040-4045
+        md[key.upper()] = ','.join(str(c) for c in values) \
+            if forest_mask_landcover_classes else 'EMPTY'
+    md['SHADOW_MASKING_ALGORITHM'] = shadow_masking_algorithm.upper()
+    if shadow_masking_algorithm == 'sun_local_inc_angle':
+        md['MIN_SLOPE_ANGLE'] = min_slope_angle
+        md['MAX_SUN_LOCAL_INC_ANGLE'] = max_sun_local_inc_angle
+    else:
+        md['MIN_SLOPE_ANGLE'] = md['MAX_SUN_LOCAL_INC_ANGLE'] = 'NOT_USED'
+    md['MASK_ADJACENT_TO_CLOUD_MODE'] = mask_adjacent_to_cloud_mode
+    md['FOREST_MASK_LANDCOVER_CLASSES'] = \
+        ','.join(str(c) for c in forest_mask_landcover_classes) \
+        if forest_mask_landcover_classes else 'EMPTY'
+    md['OCEAN_MASKING_ENABLED'] = 'TRUE' if apply_ocean_masking else 'FALSE'
+    md['OCEAN_MASKING_SHORELINE_DISTANCE_KM'] = \
+        ocean_masking_shoreline_distance_km if apply_ocean_masking else 'NOT_USED'
+
+
+# -----------------------------------------------------------------------------------
+# colour tables (:1381-1636, :2427-2575), as {value: (r, g, b)}
+# -----------------------------------------------------------------------------------
+def get_transparency_rgb_vals(top_rgb, bottom_rgb, alpha):
+    if alpha < 0 or alpha > 1:
+        raise ValueError('alpha must be in range [0, 1].')
+    return tuple(int(alpha * a + (1 - alpha) * b) for a, b in zip(top_rgb, bottom_rgb))
+
+
+def _get_interpreted_dswx_ctable(flag_collapse_wtr_classes=FLAG_COLLAPSE_WTR_CLASSES,
+                                 layer_name='WTR'):
+    ct = {0: (255, 255, 255)}
+    if flag_collapse_wtr_classes:
+        ct.update({1: (0, 0, 255), 2: (180, 213, 244)})
+    else:
+        ct.update({1: (0, 0, 255), 2: (95, 127, 255), 3: (0, 195, 0), 4: (150, 255, 150)})
+    ct[WTR_OCEAN_MASKED] = OCEAN_MASKED_RGBA[:3]
+    if layer_name == 'WTR':
+        ct[WTR_CLOUD_MASKED] = (175, 175, 175)
+        ct[WTR_SNOW_MASKED] = (0, 255, 255)
+    ct[UINT8_FILL_VALUE] = FILL_VALUE_RGBA[:3]
+    return ct
+
+
+def _get_binary_water_ctable():
+    return {0: (255, 255, 255), 1: (0, 0, 255), WTR_OCEAN_MASKED: OCEAN_MASKED_RGBA[:3],
+            WTR_SNOW_MASKED: (0, 255, 255), WTR_CLOUD_MASKED: (175, 175, 175),
+            UINT8_FILL_VALUE: FILL_VALUE_RGBA[:3]}
+
+
+def _get_binary_mask_ctable():
+    return {0: (64, 64, 64), 1: (255, 255, 255), WTR_OCEAN_MASKED: OCEAN_MASKED_RGBA[:3],
+            UINT8_FILL_VALUE: FILL_VALUE_RGBA[:3]}
+
+
+def _get_cloud_layer_ctable():
+    base = [(255, 255, 255), (64, 64, 64), (0, 255, 255), (0, 127, 127), (192, 192, 192),
+            (127, 127, 127), (255, 0, 255), (127, 127, 255)]
+    ct = {i: c for i, c in enumerate(base)}
+    ct[8] = (228, 205, 167)
+    for i in range(9, 16):
+        ct[i] = base[i - 8]
+    ct[254] = OCEAN_MASKED_RGBA[:3]
+    ct[UINT8_FILL_VALUE] = FILL_VALUE_RGBA[:3]
+    return ct
+
+
+def _get_confidence_layer_ctable():
+    ct = _get_interpreted_dswx_ctable(flag_collapse_wtr_classes=False, layer_name='WTR')
+    cloud_rgb, snow_rgb = ct[WTR_CLOUD_MASKED], ct[WTR_SNOW_MASKED]
+    clear = [ct[c] for c in range(5)]
+    ct[WTR_SNOW_MASKED] = ct[WTR_CLOUD_MASKED] = (0, 0, 0)
+    for c in range(5):
+        ct[10 + c] = get_transparency_rgb_vals(cloud_rgb, clear[c], 0.52)
+        ct[20 + c] = snow_rgb
+    return ct
+
+
+# -----------------------------------------------------------------------------------
+# writers (:2601-2716, :2786-2958): tiled DEFLATE GeoTIFF, no overviews
+# -----------------------------------------------------------------------------------
+def _makedirs(path):
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+
+
+def _save_array(input_array, output_file, dswx_metadata_dict, geo_tags, description=None,
+                output_files_list=None, ctable=None, no_data_value=None):
+    _makedirs(output_file)
+    geotiff.write_geotiff(output_file, input_array, geo_tags=geo_tags,
+                          metadata=dswx_metadata_dict, nodata=no_data_value,
+                          descriptions=[description] if description else None, colormap=ctable)
+    if output_files_list is not None:
+        output_files_list.append(output_file)
+    logger.info(f'file saved: {output_file}')
+
+
+def save_dswx_product(layers, output_file, dswx_metadata_dict, geo_tags,
+                      output_files_list=None):
+    """Multi-band product in band_description_dict order (:2655-2707): every band of the
+    ten that was produced; Byte bands, nodata 255.  DIAG (UInt16) and DEM (Float32) do not
+    fit a Byte file and are skipped here, as gdal.GDT_Byte would truncate them there."""
+    names = [n for n in band_description_dict if layers.get(n) is not None
+             and np.asarray(layers[n]).dtype in (np.uint8, np.bool_)]
+    stack = np.stack([np.asarray(layers[n], dtype=np.uint8) for n in names])
+    _makedirs(output_file)
+    geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict,
+                          nodata=UINT8_FILL_VALUE,
+                          descriptions=[band_description_dict[n] for n in names])
+    if output_files_list is not None:
+        output_files_list.append(output_file)
+    logger.info(f'file saved: {output_file}')
+
+
+def _as_plane(value, shape, name, dtype=np.uint8):
+    """Keyword-extension ancillary layer: ndarray or GeoTIFF path on the HLS grid."""
+    if value is None:
+        return None
+    if isinstance(value, (str, os.PathLike)):
+        value, _ = geotiff.read_geotiff(os.fspath(value))
+    arr = np.asarray(value)
+    if arr.shape != tuple(shape):
+        raise ValueError(f'{name} has shape {arr.shape}, the HLS grid is {tuple(shape)}')
+    return np.ascontiguousarray(arr, dtype=dtype)
+
+
+# -----------------------------------------------------------------------------------
+# the orchestrator (:4610-5417)
+# -----------------------------------------------------------------------------------
+def generate_dswx_layers(input_list,
+                         output_file=None,
+                         hls_thresholds=None,
+                         dem_file=None,
+                         dem_file_description=None,
+                         output_interpreted_band=None,
+                         output_rgb_file=None,
+                         output_infrared_rgb_file=None,
+                         output_binary_water=None,
+                         output_confidence_layer=None,
+                         output_diagnostic_layer=None,
+                         output_non_masked_dswx=None,
+                         output_shadow_masked_dswx=None,
+                         output_landcover=None,
+                         output_shadow_layer=None,
+                         output_cloud_layer=None,
+                         output_dem_layer=None,
+                         output_browse_image=None,
+                         browse_image_height=None,
+                         browse_image_width=None,
+                         exclude_psw_aggressive_in_browse=None,
+                         not_water_in_browse=None,
+                         cloud_in_browse=None,
+                         snow_in_browse=None,
+                         landcover_file=None,
+                         landcover_file_description=None,
+                         worldcover_file=None,
+                         worldcover_file_description=None,
+                         shoreline_shapefile=None,
+                         shoreline_shapefile_description=None,
+                         flag_offset_and_scale_inputs=False,
+                         scratch_dir='.',
+                         product_id=None,
+                         product_version=SOFTWARE_VERSION,
+                         check_ancillary_inputs_coverage=None,
+                         apply_ocean_masking=None,
+                         apply_aerosol_class_remapping=None,
+                         aerosol_not_water_to_high_conf_water_fmask_values=None,
+                         aerosol_water_moderate_conf_to_high_conf_water_fmask_values=None,
+                         aerosol_partial_surface_water_conservative_to_high_conf_water_fmask_values=None,
+                         aerosol_partial_surface_aggressive_to_high_conf_water_fmask_values=None,
+                         shadow_masking_algorithm=None,
+                         min_slope_angle=None,
+                         max_sun_local_inc_angle=None,
+                         mask_adjacent_to_cloud_mode=None,
+                         forest_mask_landcover_classes=None,
+                         ocean_masking_shoreline_distance_km=None,
+                         flag_debug=False,
+                         *,
+                         landcover_mask=None,
+                         shadow_layer=None,
+                         ocean_mask=None,
+                         device=None):
+    """Compute the DSWx-HLS layers of one HLS tile; same signature and return value as the
+    reference (:4610-4657) plus four keyword-only extensions (pre-gridded LAND / SHAD /
+    ocean planes, and the GPU to use).  Returns True, or False after logging 'ERROR ...'
+    when the input cannot be read (:4988-4990)."""
+    local = locals()
+    needs_defaults = [hls_thresholds, check_ancillary_inputs_coverage, apply_ocean_masking,
+                      apply_aerosol_class_remapping, shadow_masking_algorithm, min_slope_angle,
+                      max_sun_local_inc_angle, mask_adjacent_to_cloud_mode,
+                      forest_mask_landcover_classes, ocean_masking_shoreline_distance_km,
+                      browse_image_height, browse_image_width, exclude_psw_aggressive_in_browse,
+                      not_water_in_browse, cloud_in_browse, snow_in_browse] + \
+        [local[k] for k in _AEROSOL_KEYS]
+    consts = parse_runconfig_file() if any(v is None for v in needs_defaults) else None
+
+    def pick(value, name):
+        return getattr(consts, name) if value is None else value
+
+    if hls_thresholds is None:
+        hls_thresholds = consts.hls_thresholds
+    check_ancillary_inputs_coverage = pick(check_ancillary_inputs_coverage,
+                                           'check_ancillary_inputs_coverage')
+    apply_ocean_masking = pick(apply_ocean_masking, 'apply_ocean_masking')
+    apply_aerosol_class_remapping = pick(apply_aerosol_class_remapping,
+                                         'apply_aerosol_class_remapping')
+    aerosol_lists = [pick(local[k], k) for k in _AEROSOL_KEYS]
+    shadow_masking_algorithm = pick(shadow_masking_algorithm, 'shadow_masking_algorithm')
+    min_slope_angle = pick(min_slope_angle, 'min_slope_angle')
+    max_sun_local_inc_angle = pick(max_sun_local_inc_angle, 'max_sun_local_inc_angle')
+    mask_adjacent_to_cloud_mode = pick(mask_adjacent_to_cloud_mode, 'mask_adjacent_to_cloud_mode')
+    forest_mask_landcover_classes = pick(forest_mask_landcover_classes,
+                                         'forest_mask_landcover_classes')
+    ocean_masking_shoreline_distance_km = pick(ocean_masking_shoreline_distance_km,
+                                               'ocean_masking_shoreline_distance_km')
+    if scratch_dir is None:
+        scratch_dir = '.'
+    if product_id is None:
+        product_id = os.path.splitext(os.path.basename(output_file))[0] if output_file \
+            else 'dswx_hls'
+    if isinstance(input_list, (str, os.PathLike)):
+        input_list = [os.fspath(input_list)]
+
+    logger.info(f'PROTEUS software version: {SOFTWARE_VERSION} (MI355X HIP per-pixel path)')
+    logger.info('input files:')
+    logger.info('    HLS product file(s):')
+    for f in input_list:
+        logger.info(f'        {f}')
+    logger.info('product parameters:')
+    logger.info(f'    product ID: {product_id}')
+    logger.info(f'    product version: {product_version}')
+    logger.info('processing parameters:')
+    logger.info(f'    apply ocean masking: {apply_ocean_masking}')
+    logger.info(f'    apply aerosol water class remapping: {apply_aerosol_class_remapping}')
+    logger.info(f'    shadow masking algorithm: {shadow_masking_algorithm}')
+    logger.info(f'    mask adjacent cloud/cloud-shadow mode: {mask_adjacent_to_cloud_mode}')
+    if not apply_ocean_masking:
+        shoreline_shapefile = shoreline_shapefile_description = None
+        ocean_mask = None
+    if shadow_masking_algorithm not in ('otsu', 'sun_local_inc_angle'):
+        msg = f'ERROR Invalid shadow masking algorithm: {shadow_masking_algorithm}'
+        logger.error(msg)
+        raise ValueError(msg)
+    if mask_adjacent_to_cloud_mode not in ('mask', 'ignore', 'cover'):
+        msg = f'ERROR mask adjacent to cloud/cloud-shadow mode: {mask_adjacent_to_cloud_mode}'
+        logger.info(msg)
+        raise Exception(msg)
+    for name, val in (('dem_file', dem_file), ('landcover_file', landcover_file),
+                      ('worldcover_file', worldcover_file),
+                      ('shoreline_shapefile', shoreline_shapefile)):
+        if val is not None:
+            raise NotImplementedError(
+                f'{name}: reprojecting ancillary inputs needs GDAL, which stays on the host and '
+                'is outside this drop-in (SURVEY.md §2); pass the layer already on the HLS grid '
+                'with landcover_mask= / shadow_layer= / ocean_mask=')
+    os.makedirs(scratch_dir, exist_ok=True)
+
+    md = _get_dswx_metadata_dict(product_id, product_version)
+    image = {}
+    # HLS v1 (a single HDF4 file, :4972-4980) needs GDAL's HDF4 driver; every input goes
+    # through the v2 per-band GeoTIFF loader, which reports what is missing
+    ok = _load_hls_product_v2(list(input_list), image, md, flag_debug=flag_debug)
+    if not ok:
+        logger.info(f'ERROR could not read file(s): {input_list}')
+        return False
+    version = '2.0'
+    _populate_dswx_metadata_datasets(md, image['hls_dataset_name'])
+    _populate_dswx_metadata_processing_parameters(
+        md, apply_ocean_masking, apply_aerosol_class_remapping, aerosol_lists,
+        shadow_masking_algorithm, min_slope_angle, max_sun_local_inc_angle,
+        mask_adjacent_to_cloud_mode, forest_mask_landcover_classes,
+        ocean_masking_shoreline_distance_km)
+    logger.info(f'processing HLS {md["SPACECRAFT_NAME"][0]}30 dataset v.{version}')
+    length, width = image['length'], image['width']
+    geo_tags = image['geo_tags']
+
+    # sun angles are required metadata (:5044-5059)
+    def mean_angle(key):
+        parts = md[key].split(', ')
+        vals = [float(p) for p in parts]
+        return sum(vals[:2]) / 2.0 if len(vals) == 2 else vals[0]
+
+    sun_azimuth_angle = mean_angle('MEAN_SUN_AZIMUTH_ANGLE')
+    sun_elevation_angle = 90 - mean_angle('MEAN_SUN_ZENITH_ANGLE')
+    logger.info('Sun parameters (from HLS metadata):')
+    logger.info(f'    mean azimuth angle: {sun_azimuth_angle}')
+    logger.info(f'    mean elevation angle: {sun_elevation_angle}')
+
+    shape = (length, width)
+    landcover_mask = _as_plane(landcover_mask, shape, 'landcover_mask')
+    shadow_layer = _as_plane(shadow_layer, shape, 'shadow_layer')
+    ocean_mask = _as_plane(ocean_mask, shape, 'ocean_mask')
+
+    # ---- the hot path: one call into the HIP library ------------------------------
+    bands = [image[k] for k in _capi.BAND_NAMES]
+    params = _capi.make_params(
+        hls_thresholds,
+        band_fills=[image['fills'][k] for k in _capi.BAND_NAMES],
+        fmask_fill=image['fills']['fmask'],
+        clip_negative_reflectance=FLAG_CLIP_NEGATIVE_REFLECTANCE,
+        mask_adjacent_to_cloud_mode=mask_adjacent_to_cloud_mode,
+        apply_aerosol_class_remapping=apply_aerosol_class_remapping,
+        aerosol_fmask_values=dict(zip((0, 2, 3, 4), aerosol_lists)),
+        collapse_wtr_classes=FLAG_COLLAPSE_WTR_CLASSES,
+        aerosol_max_nir=AEROSOL_REMAPPING_MAX_NIR)
+    if mask_adjacent_to_cloud_mode == 'cover':
+        raise NotImplementedError(
+            "mask_adjacent_to_cloud_mode 'cover' needs the dilation path between WTR-2 and "
+            'CLOUD (SURVEY.md §8 row f2), which is not built yet')
+    ctx = get_context(device)
+    res = ctx.classify_host(bands, image['fmask'], params, land=landcover_mask,
+                            shad=shadow_layer, ocean=ocean_mask)
+    logger.info(f'    per-pixel chain on GPU: {ctx.last_kernel_info()}')
+    n_valid, n_cloud_and_valid, n_not_ocean = (int(v) for v in res['counters'][0])
+
+    # coverage metadata, floor percentages (:5113-5136)
+    total = length * width
+    logger.info('data coverage:')
+    md['SPATIAL_COVERAGE'] = int(100 * float(n_valid) / total)
+    md['SPATIAL_COVERAGE_EXCLUDING_MASKED_OCEAN'] = \
+        0 if n_not_ocean == 0 else int(100 * float(n_valid) / n_not_ocean)
+    md['CLOUD_COVERAGE'] = 0 if n_valid == 0 else int(100 * float(n_cloud_and_valid) / n_valid)
+    logger.info(f'    spatial coverage [%]:  {md["SPATIAL_COVERAGE"]}')
+    logger.info(f'    spatial coverage after ocean masking [%]:'
+                f' {md["SPATIAL_COVERAGE_EXCLUDING_MASKED_OCEAN"]}')
+    logger.info(f'    cloud coverage [%]:  {md["CLOUD_COVERAGE"]}')
+
+    build_list, output_files_list = [], []
+    collapse = FLAG_COLLAPSE_WTR_CLASSES
+    if shadow_layer is not None and output_shadow_layer:
+        _save_array(shadow_layer, output_shadow_layer, md, geo_tags,
+                    description=band_description_dict['SHAD'], output_files_list=build_list,
+                    ctable=_get_binary_mask_ctable())
+    if landcover_mask is not None and output_landcover:
+        _save_array(landcover_mask, output_landcover, md, geo_tags,
+                    description=band_description_dict['LAND'], output_files_list=build_list,
+                    no_data_value=UINT8_FILL_VALUE)
+    if output_diagnostic_layer:
+        _save_array(res['diag'], output_diagnostic_layer, md, geo_tags,
+                    description=band_description_dict['DIAG'], output_files_list=build_list,
+                    no_data_value=DIAGNOSTIC_LAYER_NO_DATA_BINARY_REPR)
+    for key, name, target in (('wtr1', 'WTR-1', output_non_masked_dswx),
+                              ('wtr2', 'WTR-2', output_shadow_masked_dswx),
+                              ('wtr', 'WTR', output_interpreted_band)):
+        if target:
+            _save_array(res[key], target, md, geo_tags, description=band_description_dict[name],
+                        output_files_list=build_list, no_data_value=UINT8_FILL_VALUE,
+                        ctable=_get_interpreted_dswx_ctable(collapse, layer_name=name))
+    if output_cloud_layer:
+        _save_array(res['cloud'], output_cloud_layer, md, geo_tags,
+                    description=band_description_dict['CLOUD'], output_files_list=build_list,
+                    no_data_value=UINT8_FILL_VALUE, ctable=_get_cloud_layer_ctable())
+    if output_binary_water:
+        _save_array(res['bwtr'], output_binary_water, md, geo_tags,
+                    description=band_description_dict['BWTR'], output_files_list=build_list,
+                    no_data_value=UINT8_FILL_VALUE, ctable=_get_binary_water_ctable())
+    if output_confidence_layer:
+        _save_array(res['conf'], output_confidence_layer, md, geo_tags,
+                    description=band_description_dict['CONF'], output_files_list=build_list,
+                    no_data_value=UINT8_FILL_VALUE, ctable=_get_confidence_layer_ctable())
+    for target, what in ((output_rgb_file, 'RGB'), (output_infrared_rgb_file, 'infrared RGB'),
+                         (output_browse_image, 'browse image')):
+        if target:
+            logger.warning(f'{what} output "{target}" skipped: writer not built yet'
+                           ' (SURVEY.md §8 row f4)')
+    if output_file and not output_file.endswith('.vrt'):
+        # the multi-band file carries the post-aerosol WTR-1 (in-place remap, :5260 -> :5389)
+        save_dswx_product({'WTR': res['wtr'], 'BWTR': res['bwtr'], 'CONF': res['conf'],
+                           'WTR-1': res['wtr1_aerosol'], 'WTR-2': res['wtr2'],
+                           'LAND': landcover_mask, 'SHAD': shadow_layer, 'CLOUD': res['cloud']},
+                          output_file, md, geo_tags, output_files_list=output_files_list)
+    elif output_file:
+        logger.warning(f'VRT output "{output_file}" skipped: needs GDAL')
+    logger.info('output files:')
+    for f in build_list + output_files_list:
+        logger.info(f'    {f}')
+    return True
+
+
+# -----------------------------------------------------------------------------------
+# product comparison (:710-871)
+# -----------------------------------------------------------------------------------
+_METADATA_NOT_COMPARED = ('PROCESSING_DATETIME', 'DEM_SOURCE', 'LANDCOVER_SOURCE',
+                          'WORLDCOVER_SOURCE', 'SOFTWARE_VERSION', 'SENSOR')
+
+
+def _compare_dswx_hls_metadata(metadata_1, metadata_2):
+    m1 = {k: v for k, v in metadata_1.items() if k != 'LICENSE'}
+    m2 = {k: v for k, v in metadata_2.items() if k != 'LICENSE'}
+    if len(m1) != len(m2):
+        msg = (f'* input 1 metadata has {len(m1)} entries whereas input 2 metadata has'
+               f' {len(m2)} entries.')
+        if set(m1) - set(m2):
+            msg += f' Input 1 metadata has extra entries with keys: {", ".join(set(m1) - set(m2))}.'
+        if set(m2) - set(m1):
+            msg += f' Input 2 metadata has extra entries with keys: {", ".join(set(m2) - set(m1))}.'
+        return msg, False
+    for k, v in m1.items():
+        if k not in m2:
+            return f'* the metadata key {k} is present in but it is not present in input 2', False
+        if k in _METADATA_NOT_COMPARED:
+            continue
+        if m2[k] != v:
+            return (f'* contents of metadata key {k} from input 1 has value "{v}" whereas the'
+                    f' same key in input 2 metadata has value "{m2[k]}"'), False
+    return None, True
+
+
+def compare_dswx_hls_products(file_1, file_2):
+    """Band-wise np.allclose(atol=1e-6, equal_nan=True), identical geotransform, identical
+    metadata except LICENSE and the keys above (:710-784).  Prints an [OK]/[FAIL] report."""
+    for f in (file_1, file_2):
+        if not os.path.isfile(f):
+            print(f'ERROR file not found: {f}')
+            return False
+    print('Comparing files:')
+    print(f'    file 1: {file_1}')
+    print(f'    file 2: {file_2}')
+    a1, i1 = geotiff.read_geotiff(file_1)
+    a2, i2 = geotiff.read_geotiff(file_2)
+    all_ok = True
+
+    def mark(flag):
+        nonlocal all_ok
+        all_ok = all_ok and flag
+        return '[OK]   ' if flag else '[FAIL] '
+
+    same = i1.bands == i2.bands
+    print(f'{mark(same)}Comparing number of bands')
+    if not same:
+        print(' ' * 7 + f'Input 1 has {i1.bands} bands and input 2 has {i2.bands} bands')
+        return False
+    print('Comparing DSWx bands...')
+    b1 = a1[None] if a1.ndim == 2 else a1
+    b2 = a2[None] if a2.ndim == 2 else a2
+    for b in range(i1.bands):
+        same = b1[b].shape == b2[b].shape and bool(np.allclose(
+            b1[b], b2[b], atol=COMPARE_DSWX_HLS_PRODUCTS_ERROR_TOLERANCE, equal_nan=True))
+        print(f'{mark(same)}     Band {b + 1} - {i1.descriptions[b]}"')
+        if not same and b1[b].shape == b2[b].shape:
+            bad = np.argwhere(np.abs(b1[b].astype(np.float64) - b2[b].astype(np.float64)) >
+                              COMPARE_DSWX_HLS_PRODUCTS_ERROR_TOLERANCE)
+            if bad.size:
+                y, x = bad[0]
+                print(' ' * 7 + f'     * input 1 has value "{b1[b][y, x]}" in position (x: {x},'
+                      f' y: {y}) whereas input 2 has value "{b2[b][y, x]}" in the same position.')
+    same = bool(np.array_equal(i1.geotransform, i2.geotransform))
+    print(f'{mark(same)}Comparing geotransform')
+    if not same:
+        print(' ' * 7 + f'* input 1 geotransform with content "{i1.geotransform}" differs from'
+              f' input 2 geotransform with content "{i2.geotransform}".')
+    msg, same = _compare_dswx_hls_metadata(i1.metadata, i2.metadata)
+    print(f'{mark(same)}Comparing metadata')
+    if not same:
+        print(' ' * 7 + msg)
+    return all_ok

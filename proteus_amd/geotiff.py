@@ -1,0 +1,377 @@
+"""Minimal GeoTIFF reader / writer (no GDAL).
+
+PROTEUS does all raster I/O through GDAL (`_load_hls_band_from_file`
+src/proteus/dswx_hls.py:2136, `_save_array` :2893, `save_dswx_product` :2601,
+`save_as_cog` core.py:7).  GDAL is not installed in this image, so the host side of
+the drop-in carries this small classic-TIFF implementation of exactly what that
+path touches:
+
+ read   little/big-endian classic TIFF, strips or tiles, compression none / DEFLATE
+        (with horizontal predictor), 1..N samples (chunky or planar), u8/i8/u16/i16/
+        u32/i32/f32/f64, GDAL_METADATA (42112), GDAL_NODATA (42113), colour map and
+        the GeoTIFF tags (33550, 33922, 34264, 34735-34737).
+ write  little-endian classic TIFF, 512x512 tiles, DEFLATE + predictor 2 for the
+        integer layers (the reference's COG creation options, core.py:60-75, minus
+        overviews), planar multi-band, nodata, per-band descriptions, colour table,
+        metadata, and the GeoTIFF tags copied from the input HLS file.
+
+The georeferencing is carried opaquely: the projection of the output product is the
+set of GeoKey tags of the input (the reference copies `GetProjection()` the same
+way, :2256-2258 -> :2668).  BigTIFF and LZW are not supported.
+"""
+import struct
+import zlib
+from xml.sax.saxutils import escape, unescape
+
+import numpy as np
+
+TAG_WIDTH, TAG_LENGTH, TAG_BITS, TAG_COMPRESSION, TAG_PHOTOMETRIC = 256, 257, 258, 259, 262
+TAG_STRIP_OFFSETS, TAG_SAMPLES, TAG_ROWS_PER_STRIP, TAG_STRIP_COUNTS = 273, 277, 278, 279
+TAG_PLANAR, TAG_PREDICTOR, TAG_COLORMAP = 284, 317, 320
+TAG_TILE_W, TAG_TILE_L, TAG_TILE_OFFSETS, TAG_TILE_COUNTS = 322, 323, 324, 325
+TAG_EXTRA_SAMPLES, TAG_SAMPLE_FORMAT = 338, 339
+TAG_PIXEL_SCALE, TAG_TIEPOINT, TAG_TRANSFORM = 33550, 33922, 34264
+TAG_GEOKEYS, TAG_GEO_DOUBLES, TAG_GEO_ASCII = 34735, 34736, 34737
+TAG_GDAL_METADATA, TAG_GDAL_NODATA = 42112, 42113
+GEO_TAGS = (TAG_PIXEL_SCALE, TAG_TIEPOINT, TAG_TRANSFORM, TAG_GEOKEYS, TAG_GEO_DOUBLES,
+            TAG_GEO_ASCII)
+
+_TYPE_FMT = {1: 'B', 2: 'c', 3: 'H', 4: 'I', 5: 'II', 6: 'b', 7: 'B', 8: 'h', 9: 'i',
+             10: 'ii', 11: 'f', 12: 'd', 16: 'Q'}
+_TYPE_SIZE = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 6: 1, 7: 1, 8: 2, 9: 4, 10: 8, 11: 4, 12: 8,
+              16: 8}
+
+
+class GeoTiffError(Exception):
+    pass
+
+
+class GeoTiffInfo:
+    """What `gdal.Open` would have told the reference about a file."""
+
+    def __init__(self):
+        self.width = self.height = self.bands = 0
+        self.dtype = None
+        self.nodata = None            # float or None  (GetNoDataValue)
+        self.metadata = {}            # dataset-level GDAL metadata (GetMetadata)
+        self.descriptions = []        # per band
+        self.geo_tags = {}            # raw GeoTIFF tags: tag -> (type, values)
+        self.colormap = None          # [256][3] uint8 or None
+
+    @property
+    def geotransform(self):
+        """GDAL-style 6-tuple (GetGeoTransform); identity-like default if absent."""
+        if TAG_TRANSFORM in self.geo_tags:
+            m = self.geo_tags[TAG_TRANSFORM][1]
+            return (m[3], m[0], m[1], m[7], m[4], m[5])
+        if TAG_PIXEL_SCALE in self.geo_tags and TAG_TIEPOINT in self.geo_tags:
+            sx, sy = self.geo_tags[TAG_PIXEL_SCALE][1][:2]
+            i, j, _, x, y, _ = self.geo_tags[TAG_TIEPOINT][1][:6]
+            return (x - i * sx, sx, 0.0, y + j * sy, 0.0, -sy)
+        return (0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+
+
+def _dtype_of(bits, fmt):
+    table = {(8, 1): np.uint8, (8, 2): np.int8, (16, 1): np.uint16, (16, 2): np.int16,
+             (32, 1): np.uint32, (32, 2): np.int32, (32, 3): np.float32,
+             (64, 3): np.float64}
+    try:
+        return np.dtype(table[(bits, fmt)])
+    except KeyError:
+        raise GeoTiffError(f'unsupported sample: {bits} bits, format {fmt}')
+
+
+def _parse_metadata_xml(text):
+    """GDALMetadata XML -> (dataset dict, {band: description})."""
+    meta, desc = {}, {}
+    pos = 0
+    while True:
+        a = text.find('<Item', pos)
+        if a < 0:
+            break
+        b = text.find('>', a)
+        c = text.find('</Item>', b)
+        if b < 0 or c < 0:
+            break
+        attrs = {}
+        for part in text[a + 5:b].replace("'", '"').split('" '):
+            if '=' in part:
+                k, v = part.split('=', 1)
+                attrs[k.strip()] = v.strip().strip('"')
+        value = unescape(text[b + 1:c], {'&quot;': '"', '&apos;': "'"})
+        name = unescape(attrs.get('name', ''), {'&quot;': '"'})
+        if 'sample' in attrs:
+            if attrs.get('role') == 'description' or name == 'DESCRIPTION':
+                desc[int(attrs['sample'])] = value
+        else:
+            meta[name] = value
+        pos = c + 7
+    return meta, desc
+
+
+def read_geotiff(path, window=None):
+    """Returns (array, GeoTiffInfo).  array is [H,W] for one band, [B,H,W] otherwise.
+    window = (xoff, yoff, xsize, ysize) crops after decoding (the reference's
+    flag_debug read, :2187-2190)."""
+    with open(path, 'rb') as fh:
+        buf = fh.read()
+    if len(buf) < 8:
+        raise GeoTiffError(f'{path}: not a TIFF file')
+    if buf[:2] == b'II':
+        e = '<'
+    elif buf[:2] == b'MM':
+        e = '>'
+    else:
+        raise GeoTiffError(f'{path}: not a TIFF file')
+    magic, ifd = struct.unpack(e + 'HI', buf[2:8])
+    if magic == 43:
+        raise GeoTiffError(f'{path}: BigTIFF is not supported')
+    if magic != 42:
+        raise GeoTiffError(f'{path}: not a TIFF file')
+    (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
+    tags = {}
+    for k in range(n):
+        ent = buf[ifd + 2 + 12 * k: ifd + 14 + 12 * k]
+        tag, typ, count = struct.unpack(e + 'HHI', ent[:8])
+        if typ not in _TYPE_SIZE:
+            continue
+        size = _TYPE_SIZE[typ] * count
+        if size <= 4:
+            raw = ent[8:8 + size]
+        else:
+            (off,) = struct.unpack(e + 'I', ent[8:12])
+            raw = buf[off:off + size]
+        if typ == 2:
+            vals = raw.rstrip(b'\x00').decode('latin-1')
+        elif typ in (5, 10):
+            flat = struct.unpack(e + _TYPE_FMT[typ][0] * (2 * count), raw)
+            vals = [flat[2 * i] / flat[2 * i + 1] if flat[2 * i + 1] else 0.0
+                    for i in range(count)]
+        else:
+            vals = list(struct.unpack(e + _TYPE_FMT[typ] * count, raw))
+        tags[tag] = (typ, vals)
+
+    def one(tag, default=None):
+        if tag not in tags:
+            return default
+        v = tags[tag][1]
+        return v if isinstance(v, str) else v[0]
+
+    info = GeoTiffInfo()
+    info.width, info.height = one(TAG_WIDTH), one(TAG_LENGTH)
+    spp = one(TAG_SAMPLES, 1)
+    info.bands = spp
+    bits = one(TAG_BITS, 1)
+    fmt = one(TAG_SAMPLE_FORMAT, 1)
+    info.dtype = _dtype_of(bits, fmt)
+    comp = one(TAG_COMPRESSION, 1)
+    if comp not in (1, 8, 32946):
+        raise GeoTiffError(f'{path}: compression {comp} is not supported')
+    predictor = one(TAG_PREDICTOR, 1)
+    planar = one(TAG_PLANAR, 1)
+    if predictor not in (1, 2):
+        raise GeoTiffError(f'{path}: predictor {predictor} is not supported')
+    dt = info.dtype.newbyteorder(e)
+    H, W = info.height, info.width
+
+    tiled = TAG_TILE_OFFSETS in tags
+    if tiled:
+        bw, bh = one(TAG_TILE_W), one(TAG_TILE_L)
+        offs, cnts = tags[TAG_TILE_OFFSETS][1], tags[TAG_TILE_COUNTS][1]
+    else:
+        bw, bh = W, min(one(TAG_ROWS_PER_STRIP, H), H)
+        offs, cnts = tags[TAG_STRIP_OFFSETS][1], tags[TAG_STRIP_COUNTS][1]
+    across, down = (W + bw - 1) // bw, (H + bh - 1) // bh
+    planes = spp if planar == 2 else 1
+    chunk_spp = 1 if planar == 2 else spp
+    out = np.zeros((spp, H, W), dtype=info.dtype)
+    if len(offs) < planes * across * down:
+        raise GeoTiffError(f'{path}: truncated block table')
+    idx = 0
+    for p in range(planes):
+        for by in range(down):
+            for bx in range(across):
+                raw = buf[offs[idx]: offs[idx] + cnts[idx]]
+                idx += 1
+                if comp != 1:
+                    raw = zlib.decompress(raw)
+                rows = bh if tiled else min(bh, H - by * bh)
+                need = rows * bw * chunk_spp * dt.itemsize
+                blk = np.frombuffer(raw[:need], dtype=dt).reshape(rows, bw, chunk_spp)
+                if predictor == 2:
+                    blk = np.cumsum(blk.astype(info.dtype), axis=1, dtype=info.dtype)
+                y0, x0 = by * bh, bx * bw
+                hh, ww = min(rows, H - y0), min(bw, W - x0)
+                if planar == 2:
+                    out[p, y0:y0 + hh, x0:x0 + ww] = blk[:hh, :ww, 0]
+                else:
+                    out[:, y0:y0 + hh, x0:x0 + ww] = np.moveaxis(blk[:hh, :ww, :], 2, 0)
+
+    nod = one(TAG_GDAL_NODATA)
+    if nod is not None:
+        try:
+            info.nodata = float(nod.strip())
+        except ValueError:
+            info.nodata = None
+    if TAG_GDAL_METADATA in tags:
+        info.metadata, desc = _parse_metadata_xml(tags[TAG_GDAL_METADATA][1])
+        info.descriptions = [desc.get(i, '') for i in range(spp)]
+    else:
+        info.descriptions = [''] * spp
+    for t in GEO_TAGS:
+        if t in tags:
+            info.geo_tags[t] = tags[t]
+    if TAG_COLORMAP in tags:
+        cm = np.asarray(tags[TAG_COLORMAP][1], dtype=np.uint32).reshape(3, -1)
+        info.colormap = (cm >> 8).astype(np.uint8).T
+    arr = out[0] if spp == 1 else out
+    if window is not None:
+        xo, yo, xs, ys = window
+        arr = arr[..., yo:yo + ys, xo:xo + xs]
+        info.height, info.width = arr.shape[-2:]
+    return np.ascontiguousarray(arr), info
+
+
+def _metadata_xml(metadata, descriptions):
+    items = []
+    for k, v in (metadata or {}).items():
+        items.append(f'  <Item name="{escape(str(k), {chr(34): "&quot;"})}">'
+                     f'{escape(str(v))}</Item>')
+    for i, d in enumerate(descriptions or []):
+        if d:
+            items.append(f'  <Item name="DESCRIPTION" sample="{i}" role="description">'
+                         f'{escape(str(d))}</Item>')
+    return '<GDALMetadata>\n' + '\n'.join(items) + '\n</GDALMetadata>\n'
+
+
+def geo_tags_from_geotransform(geotransform, epsg=None):
+    """GeoTIFF tags for a north-up grid (used by the synthetic HLS writer)."""
+    x0, sx, _, y0, _, sy = geotransform
+    tags = {TAG_PIXEL_SCALE: (12, [float(sx), float(-sy), 0.0]),
+            TAG_TIEPOINT: (12, [0.0, 0.0, 0.0, float(x0), float(y0), 0.0])}
+    if epsg is not None:
+        tags[TAG_GEOKEYS] = (3, [1, 1, 0, 3,
+                                 1024, 0, 1, 1,        # GTModelTypeGeoKey: projected
+                                 1025, 0, 1, 1,        # GTRasterTypeGeoKey: pixel is area
+                                 3072, 0, 1, int(epsg)])
+    return tags
+
+
+def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
+                  descriptions=None, colormap=None, tile=512, compress=True):
+    """array: [H,W] or [B,H,W] (planar multi-band).  colormap: {value: (r,g,b[,a])} or
+    [256][3] (single-band u8 only).  NaN nodata is written as 'nan' like GDAL does."""
+    arr = np.asarray(array)
+    if arr.ndim == 2:
+        arr = arr[None]
+    if arr.ndim != 3:
+        raise GeoTiffError('array must be [H,W] or [B,H,W]')
+    if arr.dtype == np.bool_:
+        arr = arr.astype(np.uint8)
+    B, H, W = arr.shape
+    kind = {'u': 1, 'i': 2, 'f': 3}.get(arr.dtype.kind)
+    if kind is None or arr.dtype.itemsize not in (1, 2, 4, 8):
+        raise GeoTiffError(f'unsupported dtype {arr.dtype}')
+    dt = arr.dtype.newbyteorder('<')
+    predictor = 2 if (compress and kind != 3) else 1
+    blocks, offsets, counts = [], [], []
+    across, down = (W + tile - 1) // tile, (H + tile - 1) // tile
+    for b in range(B):
+        for by in range(down):
+            for bx in range(across):
+                blk = np.zeros((tile, tile), dtype=dt)
+                y0, x0 = by * tile, bx * tile
+                hh, ww = min(tile, H - y0), min(tile, W - x0)
+                blk[:hh, :ww] = arr[b, y0:y0 + hh, x0:x0 + ww]
+                if predictor == 2:
+                    d = blk.copy()
+                    d[:, 1:] = blk[:, 1:] - blk[:, :-1]
+                    blk = d
+                raw = blk.tobytes()
+                blocks.append(zlib.compress(raw, 6) if compress else raw)
+
+    entries = []
+
+    def add(tag, typ, values):
+        entries.append((tag, typ, values))
+
+    add(TAG_WIDTH, 4, [W])
+    add(TAG_LENGTH, 4, [H])
+    add(TAG_BITS, 3, [arr.dtype.itemsize * 8] * B)
+    add(TAG_COMPRESSION, 3, [8 if compress else 1])
+    palette = colormap is not None and B == 1 and arr.dtype == np.uint8
+    add(TAG_PHOTOMETRIC, 3, [3 if palette else 1])
+    add(TAG_SAMPLES, 3, [B])
+    add(TAG_PLANAR, 3, [2 if B > 1 else 1])
+    if predictor == 2:
+        add(TAG_PREDICTOR, 3, [2])
+    if palette:
+        cm = np.zeros((256, 3), dtype=np.uint32)
+        if isinstance(colormap, dict):
+            for v, rgb in colormap.items():
+                cm[int(v)] = rgb[:3]
+        else:
+            cm[:] = np.asarray(colormap)[:, :3]
+        add(TAG_COLORMAP, 3, (cm.T.reshape(-1) * 257).tolist())
+    add(TAG_TILE_W, 3, [tile])
+    add(TAG_TILE_L, 3, [tile])
+    add(TAG_TILE_OFFSETS, 4, None)           # patched below
+    add(TAG_TILE_COUNTS, 4, [len(x) for x in blocks])
+    if B > 1:
+        add(TAG_EXTRA_SAMPLES, 3, [0] * (B - 1))
+    add(TAG_SAMPLE_FORMAT, 3, [kind] * B)
+    for t, (typ, vals) in (geo_tags or {}).items():
+        add(t, typ, vals)
+    add(TAG_GDAL_METADATA, 2, _metadata_xml(metadata, descriptions))
+    if nodata is not None:
+        text = 'nan' if (isinstance(nodata, float) and np.isnan(nodata)) else \
+            (str(int(nodata)) if float(nodata).is_integer() else repr(float(nodata)))
+        add(TAG_GDAL_NODATA, 2, text)
+    entries.sort(key=lambda x: x[0])
+
+    # layout: header | IFD | out-of-line tag data | blocks
+    def pack(typ, values):
+        if typ == 2:
+            return values.encode('latin-1', 'replace') + b'\x00'
+        return struct.pack('<' + _TYPE_FMT[typ] * len(values), *values)
+
+    ifd_off = 8
+    ifd_size = 2 + 12 * len(entries) + 4
+    data_off = ifd_off + ifd_size
+    payloads = {}
+    cursor = data_off
+    for tag, typ, values in entries:
+        if tag == TAG_TILE_OFFSETS:
+            size = 4 * len(blocks)
+        else:
+            size = len(pack(typ, values))
+        if size > 4:
+            payloads[tag] = cursor
+            cursor += size + (size & 1)
+    blk_off = cursor
+    for x in blocks:
+        offsets.append(blk_off)
+        blk_off += len(x) + (len(x) & 1)
+    if blk_off >= 2 ** 32:
+        raise GeoTiffError('file would exceed 4 GiB (BigTIFF not supported)')
+    with open(path, 'wb') as fh:
+        fh.write(struct.pack('<2sHI', b'II', 42, ifd_off))
+        fh.write(struct.pack('<H', len(entries)))
+        tail = []
+        for tag, typ, values in entries:
+            if tag == TAG_TILE_OFFSETS:
+                values = offsets
+            raw = pack(typ, values)
+            count = len(raw) if typ == 2 else len(values)
+            if len(raw) <= 4:
+                fh.write(struct.pack('<HHI', tag, typ, count) + raw.ljust(4, b'\x00'))
+            else:
+                fh.write(struct.pack('<HHII', tag, typ, count, payloads[tag]))
+                tail.append(raw + (b'\x00' if len(raw) & 1 else b''))
+        fh.write(struct.pack('<I', 0))
+        for raw in tail:
+            fh.write(raw)
+        for x in blocks:
+            fh.write(x)
+            if len(x) & 1:
+                fh.write(b'\x00')

@@ -1,0 +1,80 @@
+"""Tile sharding across the GPUs of one node.
+
+Every pixel -- hence every tile -- is independent in the 'mask' / 'ignore' modes, so
+the batch is split statically and contiguously over ranks and no data-path
+collective exists.  torch.distributed (RCCL on the GPU box, gloo in the CPU tests)
+is used only as the control plane: a barrier around the timed region and a MAX
+over ranks of the elapsed time.
+"""
+import os
+
+
+def tile_range(n_tiles, rank, world):
+    """Contiguous static split: rank r owns tiles [lo, hi).  Sizes differ by at
+    most one; the union over ranks is exactly range(n_tiles)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f'bad rank {rank} of {world}')
+    if n_tiles < 0:
+        raise ValueError('n_tiles must be >= 0')
+    lo = (n_tiles * rank) // world
+    hi = (n_tiles * (rank + 1)) // world
+    return lo, hi
+
+
+def weak_tile_range(tiles_per_rank, rank):
+    """Weak scaling (bench.py): every rank owns `tiles_per_rank` tiles."""
+    return rank * tiles_per_rank, (rank + 1) * tiles_per_rank
+
+
+def env_rank():
+    """(rank, local_rank, world) from the torch.distributed.run environment."""
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
+            int(os.environ.get('WORLD_SIZE', '1')))
+
+
+class ControlPlane:
+    """Barrier + max-over-ranks; a no-op object for world == 1."""
+
+    def __init__(self, backend=None, device=None):
+        self.rank, self.local_rank, self.world = env_rank()
+        self.dist = None
+        self.device = device
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            kw = {}
+            if backend == 'nccl' and device is not None:
+                kw['device_id'] = device
+            if not dist.is_initialized():
+                dist.init_process_group(backend, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self.dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64,
+                         device=self.device if self.device is not None else 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_counters(self, local):
+        """All ranks' per-tile counters ([t_r, 3] int64 each) on every rank, in tile order.
+        (Host-side metadata only; 24 bytes per tile.)"""
+        if self.dist is None:
+            return local
+        import torch
+        out = [None] * self.world
+        self.dist.all_gather_object(out, local)
+        import numpy as np
+        return np.concatenate(out, axis=0)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None

@@ -1,0 +1,98 @@
+"""BASELINE.json configs[0]/[1] plumbing on the GPU: synthetic HLS GeoTIFFs + runconfig
+-> bin/dswx_hls.py -> GeoTIFF layers, checked against the oracle; plus the reference's own
+unit test (tests/test_dswx_hls_units.py) restated against this package."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import dswx_oracle as o
+from proteus_amd import dswx_hls as D
+from proteus_amd import geotiff
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import make_synthetic_hls as synth_hls   # noqa: E402
+
+LAYER_FILES = {'WTR': 'B01_WTR', 'BWTR': 'B02_BWTR', 'CONF': 'B03_CONF', 'DIAG': 'B04_DIAG',
+               'WTR-1': 'B05_WTR-1', 'WTR-2': 'B06_WTR-2', 'CLOUD': 'B09_CLOUD'}
+
+
+def test_units():
+    """Same body as the reference's tests/test_dswx_hls_units.py:7-28."""
+    from proteus_amd.dswx_hls import interpreted_dswx_band_dict, generate_interpreted_layer
+    length = 1
+    width = len(interpreted_dswx_band_dict) + 1
+    input_array = np.full((length, width), 111111)
+    expected_output_array = np.full((length, width), 255)
+    for i, (key, value) in enumerate(interpreted_dswx_band_dict.items()):
+        input_array[0, i] = key
+        expected_output_array[0, i] = value
+    output_array = generate_interpreted_layer(input_array)
+    assert np.array_equal(output_array, expected_output_array)
+
+
+@pytest.mark.parametrize('sensor', ['L30', 'S30'])
+def test_runconfig_entry_point(tmp_path, sensor):
+    rcfile, files, _, s = synth_hls.make(str(tmp_path), sensor=sensor, size=512, tile=9)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bin', 'dswx_hls.py'), rcfile,
+                          '--log', str(tmp_path / 'run.log')],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    exp = o.classify_tile(s['bands'], s['fmask'], collapse=True)
+    out_dir = tmp_path / 'output'
+    for layer, stem in LAYER_FILES.items():
+        path = out_dir / f'dswx_hls_synth_v1.0_{stem}.tif'
+        assert path.exists(), (layer, sorted(os.listdir(out_dir)))
+        arr, info = geotiff.read_geotiff(str(path))
+        assert np.array_equal(arr, exp[layer]), layer
+        assert arr.dtype == (np.uint16 if layer == 'DIAG' else np.uint8)
+        assert info.nodata == (65535 if layer == 'DIAG' else 255)
+        assert info.descriptions == [D.band_description_dict[layer]]
+        assert info.geotransform == (600000.0, 30.0, 0.0, 4000020.0, 0.0, -30.0)
+        md = info.metadata
+        c = exp['counters']
+        assert md['SPATIAL_COVERAGE'] == str(c['SPATIAL_COVERAGE'])
+        assert md['CLOUD_COVERAGE'] == str(c['CLOUD_COVERAGE'])
+        assert md['SPATIAL_COVERAGE_EXCLUDING_MASKED_OCEAN'] == \
+            str(c['SPATIAL_COVERAGE_EXCLUDING_MASKED_OCEAN'])
+        assert md['PRODUCT_ID'] == 'dswx_hls_synth' and md['PRODUCT_VERSION'] == '1.0'
+        assert md['SPACECRAFT_NAME'] == ('Landsat-8' if sensor == 'L30' else 'Sentinel-2A')
+        assert md['SENSOR'] == ('OLI' if sensor == 'L30' else 'MSI')
+        assert md['HLS_DATASET'] == f'HLS.{sensor}.T15SYU.2021250T163901.v2.0'
+        assert md['MASK_ADJACENT_TO_CLOUD_MODE'] == 'mask'
+        assert md['INPUT_HLS_PRODUCT_CLOUD_COVERAGE'] == '20'
+    assert not (out_dir / 'dswx_hls_synth_v1.0_B07_LAND.tif').exists()
+    assert 'per-pixel chain on GPU: dswx_classify' in (tmp_path / 'run.log').read_text()
+    wtr = str(out_dir / 'dswx_hls_synth_v1.0_B01_WTR.tif')
+    assert D.compare_dswx_hls_products(wtr, wtr)
+
+
+def test_api_with_masks_and_multiband(tmp_path):
+    rcfile, files, masks, s = synth_hls.make(str(tmp_path), size=300, tile=4, masks=True)
+    out = str(tmp_path / 'product.tif')
+    ok = D.generate_dswx_layers(
+        files, out, apply_ocean_masking=True, mask_adjacent_to_cloud_mode='ignore',
+        landcover_mask=masks['land'], shadow_layer=s['shad'].astype(bool),
+        ocean_mask=masks['ocean'], output_confidence_layer=str(tmp_path / 'conf.tif'),
+        output_shadow_layer=str(tmp_path / 'shad.tif'), output_landcover=str(tmp_path / 'land.tif'))
+    assert ok is True
+    exp = o.classify_tile(s['bands'], s['fmask'], landcover=s['land'], shadow=s['shad'],
+                          ocean_mask=s['ocean'], mask_adjacent_to_cloud_mode='ignore')
+    conf, _ = geotiff.read_geotiff(str(tmp_path / 'conf.tif'))
+    assert np.array_equal(conf, exp['CONF'])
+    stack, info = geotiff.read_geotiff(out)
+    # bands in band_description_dict order, Byte layers only; WTR-1 is the post-aerosol one
+    names = ['WTR', 'BWTR', 'CONF', 'WTR-1', 'WTR-2', 'LAND', 'SHAD', 'CLOUD']
+    assert info.descriptions == [D.band_description_dict[n] for n in names]
+    want = {'WTR': exp['WTR'], 'BWTR': exp['BWTR'], 'CONF': exp['CONF'],
+            'WTR-1': exp['WTR-1-AEROSOL'], 'WTR-2': exp['WTR-2'], 'LAND': s['land'],
+            'SHAD': s['shad'], 'CLOUD': exp['CLOUD']}
+    for i, n in enumerate(names):
+        assert np.array_equal(stack[i], want[n]), n
+    assert info.metadata['OCEAN_MASKING_ENABLED'] == 'TRUE'
+    with pytest.raises(NotImplementedError, match='cover'):
+        D.generate_dswx_layers(files, mask_adjacent_to_cloud_mode='cover')

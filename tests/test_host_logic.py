@@ -1,0 +1,261 @@
+"""Host-side logic that needs no GPU: GeoTIFF I/O, runconfig handling, CLI, metadata,
+product comparison and the error conventions of the reference interface."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+import yaml
+
+from proteus_amd import dswx_hls as D
+from proteus_amd import geotiff, runconfig as rc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import make_synthetic_hls as synth_hls   # noqa: E402
+
+
+# ---- GeoTIFF -------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [np.uint8, np.int16, np.uint16, np.float32, np.float64])
+@pytest.mark.parametrize('compress', [True, False])
+def test_geotiff_roundtrip(tmp_path, dtype, compress):
+    rng = np.random.default_rng(1)
+    a = (rng.integers(0, 200, size=(700, 531)) - 50).astype(dtype)
+    if np.issubdtype(dtype, np.floating):
+        a = a + dtype(0.25)
+        a[3, 4] = np.nan
+    geo = geotiff.geo_tags_from_geotransform((5e5, 30.0, 0, 4e6, 0, -30.0), epsg=32615)
+    path = str(tmp_path / 'x.tif')
+    nod = float('nan') if np.issubdtype(dtype, np.floating) else 255
+    geotiff.write_geotiff(path, a, geo_tags=geo, metadata={'A': 'b & <c>', 'N': 5}, nodata=nod,
+                          descriptions=['Layer "one"'], compress=compress)
+    b, info = geotiff.read_geotiff(path)
+    assert b.dtype == a.dtype and np.array_equal(a, b, equal_nan=True)
+    assert info.geotransform == (5e5, 30.0, 0.0, 4e6, 0.0, -30.0)
+    assert info.metadata == {'A': 'b & <c>', 'N': '5'}
+    assert info.descriptions == ['Layer "one"']
+    assert (np.isnan(info.nodata) if np.issubdtype(dtype, np.floating) else info.nodata == 255.0)
+    assert info.geo_tags[geotiff.TAG_GEOKEYS][1][-1] == 32615
+    sub, _ = geotiff.read_geotiff(path, window=(0, 0, 100, 50))
+    assert np.array_equal(sub, a[:50, :100], equal_nan=True)
+
+
+def test_geotiff_multiband_and_colormap(tmp_path):
+    rng = np.random.default_rng(2)
+    stack = rng.integers(0, 256, size=(3, 100, 90)).astype(np.uint8)
+    p = str(tmp_path / 'm.tif')
+    geotiff.write_geotiff(p, stack, descriptions=['a', 'b', 'c'], nodata=255)
+    back, info = geotiff.read_geotiff(p)
+    assert info.bands == 3 and np.array_equal(back, stack) and info.descriptions == ['a', 'b', 'c']
+    p2 = str(tmp_path / 'c.tif')
+    geotiff.write_geotiff(p2, stack[0], colormap={0: (255, 255, 255), 1: (0, 0, 255), 255: (0, 0, 0)})
+    _, info = geotiff.read_geotiff(p2)
+    assert info.colormap[1].tolist() == [0, 0, 255] and info.colormap[0].tolist() == [255, 255, 255]
+
+
+def test_geotiff_reads_plain_strips(tmp_path):
+    """A hand-made uncompressed, stripped, big-endian TIFF (what other writers produce)."""
+    a = np.arange(6 * 5, dtype='>i2').reshape(6, 5)
+    data = a.tobytes()
+    entries = [(256, 3, 1, 5), (257, 3, 1, 6), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, 1),
+               (273, 4, 1, 8), (277, 3, 1, 1), (278, 3, 1, 6), (279, 4, 1, len(data)), (339, 3, 1, 2)]
+    ifd_off = 8 + len(data)
+    buf = b'MM' + struct.pack('>HI', 42, ifd_off) + data + struct.pack('>H', len(entries))
+    for tag, typ, cnt, val in entries:
+        buf += struct.pack('>HHI', tag, typ, cnt) + (struct.pack('>HH', val, 0) if typ == 3
+                                                      else struct.pack('>I', val))
+    buf += struct.pack('>I', 0)
+    p = tmp_path / 's.tif'
+    p.write_bytes(buf)
+    b, info = geotiff.read_geotiff(str(p))
+    assert b.dtype == np.int16 and np.array_equal(b, a.astype(np.int16)) and info.nodata is None
+
+
+def test_geotiff_rejects_garbage(tmp_path):
+    p = tmp_path / 'bad.tif'
+    p.write_bytes(b'not a tiff at all')
+    with pytest.raises(geotiff.GeoTiffError):
+        geotiff.read_geotiff(str(p))
+
+
+# ---- runconfig ------------------------------------------------------------------------
+def user_runconfig(tmp_path, **processing):
+    doc = {'runconfig': {'name': 'x', 'groups': {
+        'pge_name_group': {'pge_name': 'DSWX_HLS_PGE'},
+        'input_file_group': {'input_file_path': ['a.B02.tif', 'a.B03.tif']},
+        'dynamic_ancillary_file_group': {'dem_file_description': 'some DEM'},
+        'primary_executable': {'product_type': 'DSWX_HLS'},
+        'product_path_group': {'product_path': 'p', 'scratch_path': 'tmp', 'output_dir': 'out',
+                               'product_id': 'PID', 'product_version': 0.5},
+        'processing': processing,
+        'browse_image_group': {'save_browse': True},
+        'hls_thresholds': {'wigt': 0.2}}}}
+    path = tmp_path / 'rc.yaml'
+    path.write_text(yaml.safe_dump(doc))
+    return str(path)
+
+
+def test_default_runconfig_values():
+    c = D.parse_runconfig_file()
+    t = c.hls_thresholds
+    assert (t.wigt, t.awgt, t.pswt_1_mndwi, t.pswt_1_nir, t.pswt_1_swir1, t.pswt_1_ndvi) == \
+        (0.124, 0.0, -0.44, 1500, 900, 0.7)
+    assert (t.pswt_2_mndwi, t.pswt_2_blue, t.pswt_2_nir, t.pswt_2_swir1, t.pswt_2_swir2,
+            t.lcmask_nir) == (-0.5, 1000, 2500, 3000, 1000, 1200)
+    assert c.mask_adjacent_to_cloud_mode == 'mask' and c.apply_aerosol_class_remapping is True
+    assert c.aerosol_not_water_to_high_conf_water_fmask_values == [224, 160, 96]
+    assert c.aerosol_partial_surface_aggressive_to_high_conf_water_fmask_values == \
+        [224, 192, 160, 128, 96]
+    assert c.shadow_masking_algorithm == 'sun_local_inc_angle' and c.apply_ocean_masking is False
+    assert (c.min_slope_angle, c.max_sun_local_inc_angle) == (-5, 40)
+    assert c.forest_mask_landcover_classes == [20, 50, 111, 113, 115, 116, 121, 123, 125, 126]
+    assert (c.browse_image_height, c.not_water_in_browse, c.snow_in_browse) == (1024, 'white', 'cyan')
+
+
+def test_runconfig_precedence_and_layer_names(tmp_path):
+    path = user_runconfig(tmp_path, mask_adjacent_to_cloud_mode='ignore', save_conf=False)
+    args = D.get_dswx_hls_cli_parser().parse_args(
+        [path, '--wtr', 'my_wtr.tif', '--max-sun-local-inc-angle', '33'])
+    c = D.parse_runconfig_file(path, args)
+    assert c.hls_thresholds.wigt == 0.2 and c.hls_thresholds.awgt == 0.0      # user over default
+    assert args.mask_adjacent_to_cloud_mode == 'ignore'                        # user runconfig
+    assert args.max_sun_local_inc_angle == 33.0                                # CLI wins
+    assert args.output_interpreted_band == 'my_wtr.tif'                        # CLI wins
+    assert args.output_binary_water == os.path.join('out', 'PID_v0.5_B02_BWTR.tif')
+    assert args.output_confidence_layer is None                                # save_conf False
+    assert args.output_diagnostic_layer == os.path.join('out', 'PID_v0.5_B04_DIAG.tif')
+    assert args.output_non_masked_dswx == os.path.join('out', 'PID_v0.5_B05_WTR-1.tif')
+    assert args.output_shadow_masked_dswx == os.path.join('out', 'PID_v0.5_B06_WTR-2.tif')
+    assert args.output_cloud_layer == os.path.join('out', 'PID_v0.5_B09_CLOUD.tif')
+    assert args.output_dem_layer == os.path.join('out', 'PID_v0.5_B10_DEM.tif')
+    assert args.output_rgb_file is None                                        # save_rgb default False
+    assert args.output_browse_image == os.path.join('out', 'PID_v0.5_BROWSE.png')
+    assert args.input_list == ['a.B02.tif', 'a.B03.tif']
+    assert (args.product_id, args.product_version, args.scratch_dir) == ('PID', '0.5', 'tmp')
+    assert args.dem_file_description == 'some DEM'
+
+
+def test_runconfig_schema_violations(tmp_path):
+    for bad in (dict(mask_adjacent_to_cloud_mode='bogus'), dict(min_slope_angle=500),
+                dict(save_wtr='yes'), dict(unknown_key=1),
+                dict(aerosol_not_water_to_high_conf_water_fmask_values=[1.5])):
+        with pytest.raises(rc.RunconfigError):
+            D.parse_runconfig_file(user_runconfig(tmp_path, **bad))
+    with pytest.raises(Exception, match='ERROR invalid file'):
+        D.parse_runconfig_file(str(tmp_path / 'missing.yaml'))
+
+
+def test_deep_update_keeps_defaults_on_none():
+    assert rc.deep_update({'a': {'b': 1, 'c': 2}}, {'a': {'b': None, 'c': 3}, 'd': None}) == \
+        {'a': {'b': 1, 'c': 3}}
+
+
+def test_cli_accepts_every_reference_flag():
+    flags = ['--dem', 'd', '--dem-description', 'x', '-c', 'l', '--landcover-description', 'x',
+             '-w', 'w', '--worldcover-description', 'x', '-s', 's', '--shoreline-shape-description',
+             'x', '-o', 'o', '--interpreted-band', 'o', '--output-rgb', 'o', '--output-infrared-rgb',
+             'o', '--bwtr', 'o', '--conf', 'o', '--diag', 'o', '--wtr-1', 'o', '--wtr-2', 'o',
+             '--land', 'o', '--shad', 'o', '--cloud', 'o', '--out-dem', 'o', '--browse', 'o',
+             '--bheight', '10', '--bwidth', '10', '--exclude-psw-aggressive-in-browse',
+             '--not-water-in-browse', 'nodata', '--cloud-in-browse', 'gray', '--snow-in-browse',
+             'cyan', '--offset-and-scale-inputs', '--temp-dir', 't', '--pid', 'p',
+             '--product-version', '1', '--check-ancillary-inputs-coverage', '--apply-ocean-masking',
+             '--apply-aerosol-masking', '--shadow-masking-algorithm', 'otsu', '--min-slope-angle',
+             '-5', '--max-sun-local-inc-angle', '40', '--mask-adjacent-to-cloud-mode', 'cover',
+             '--ocean-masking-distance-km', '1', '--debug', '--log', 'l', '--full-log-format']
+    a = D.get_dswx_hls_cli_parser().parse_args(['in.tif'] + flags)
+    assert a.output_binary_water == 'o' and a.browse_image_height == 10 and a.flag_debug
+    assert a.mask_adjacent_to_cloud_mode == 'cover' and a.apply_ocean_masking is True
+    # the reference's accidental concatenated spellings parse too
+    a = D.get_dswx_hls_cli_parser().parse_args(['in.tif', '--bwtr--output-binary-water', 'q'])
+    assert a.output_binary_water == 'q'
+
+
+# ---- tables / metadata -----------------------------------------------------------------
+def test_tables_match_oracle():
+    from oracle import dswx_oracle as o
+    assert D.interpreted_dswx_band_dict == o.DIAG_TO_CLASS
+    assert D.collapse_wtr_classes_dict == o.COLLAPSE
+    assert list(D.layer_names_to_args_dict)[:10] == list(D.band_description_dict)
+    assert D.AEROSOL_REMAPPING_MAX_NIR == 1000.0
+
+
+def test_hls_metadata_harvest():
+    md = {}
+    ok = D._harvest_hls_metadata({'SENSOR': 'OLI_TIRS; OLI_TIRS', 'MEAN_SUN_AZIMUTH_ANGLE': '1',
+                                  'LANDSAT_PRODUCT_ID': 'LC09_L1TP_x', 'cloud_coverage': '7',
+                                  'SENSING_TIME': 't'}, md)
+    assert ok and md['SPACECRAFT_NAME'] == 'Landsat-9' and md['SENSOR'] == 'OLI'
+    assert md['INPUT_HLS_PRODUCT_CLOUD_COVERAGE'] == '7' and md['SENSOR_PRODUCT_ID'] == 'LC09_L1TP_x'
+    md = {}
+    assert D._harvest_hls_metadata({'SPACECRAFT_NAME': 'Sentinel-2B', 'PRODUCT_URI': 'S2B'}, md)
+    assert md['SENSOR'] == 'MSI' and md['SENSOR_PRODUCT_ID'] == 'S2B'
+    assert not D._harvest_hls_metadata({'SPACECRAFT_NAME': 'Terra'}, {})
+    assert not D._harvest_hls_metadata({'SENSOR': 'MODIS'}, {})
+    assert not D._harvest_hls_metadata({}, {})
+
+
+def test_metadata_dicts():
+    md = D._get_dswx_metadata_dict('PID', None)
+    assert md['PRODUCT_VERSION'] == D.SOFTWARE_VERSION and md['PROJECT'] == 'OPERA'
+    md['SPACECRAFT_NAME'] = 'Sentinel-2A'
+    D._populate_dswx_metadata_datasets(md, 'HLS.S30.x', dem_file='/a/b/dem.tif',
+                                       landcover_file_description='CGLS')
+    assert md['DEM_SOURCE'] == 'dem.tif' and md['LANDCOVER_SOURCE'] == 'CGLS'
+    assert md['WORLDCOVER_SOURCE'] == 'NOT_PROVIDED'
+    assert md['SHORELINE_SOURCE'] == 'NOT_PROVIDED_OR_NOT_USED'
+    assert 'Copernicus Sentinel' in md['LICENSE'] and 'Copernicus programme' in md['LICENSE']
+    D._populate_dswx_metadata_processing_parameters(
+        md, False, True, [[224, 160, 96]] * 2 + [[224, 192]] * 2, 'sun_local_inc_angle', -5, 40,
+        'mask', [20, 50], 1)
+    assert md['AEROSOL_CLASS_REMAPPING_ENABLED'] == 'TRUE'
+    assert md['AEROSOL_NOT_WATER_TO_HIGH_CONF_WATER_FMASK_VALUES'] == '224,160,96'
+    assert md['SHADOW_MASKING_ALGORITHM'] == 'SUN_LOCAL_INC_ANGLE' and md['MIN_SLOPE_ANGLE'] == -5
+    assert md['OCEAN_MASKING_ENABLED'] == 'FALSE'
+    assert md['OCEAN_MASKING_SHORELINE_DISTANCE_KM'] == 'NOT_USED'
+    assert md['FOREST_MASK_LANDCOVER_CLASSES'] == '20,50'
+
+
+def test_confidence_colour_table():
+    ct = D._get_confidence_layer_ctable()
+    assert ct[10] == D.get_transparency_rgb_vals((175, 175, 175), (255, 255, 255), 0.52)
+    assert ct[21] == (0, 255, 255) and ct[252] == (0, 0, 0) and ct[254] == (0, 0, 127)
+    with pytest.raises(ValueError):
+        D.get_transparency_rgb_vals((0, 0, 0), (1, 1, 1), 1.5)
+
+
+# ---- error conventions of generate_dswx_layers (no GPU is reached) ----------------------
+def test_generate_rejects_bad_parameters(tmp_path):
+    rcfile, files, _, _ = synth_hls.make(str(tmp_path), size=64)
+    with pytest.raises(ValueError, match='Invalid shadow masking algorithm'):
+        D.generate_dswx_layers(files, shadow_masking_algorithm='magic')
+    with pytest.raises(Exception, match='ERROR mask adjacent to cloud/cloud-shadow mode'):
+        D.generate_dswx_layers(files, mask_adjacent_to_cloud_mode='bogus')
+    with pytest.raises(NotImplementedError, match='GDAL'):
+        D.generate_dswx_layers(files, dem_file='dem.tif')
+
+
+def test_generate_returns_false_on_unreadable_input(tmp_path):
+    assert D.generate_dswx_layers([str(tmp_path / 'nope.B02.tif'),
+                                   str(tmp_path / 'nope.Fmask.tif')]) is False
+    _, files, _, _ = synth_hls.make(str(tmp_path), size=64)
+    assert D.generate_dswx_layers(files[:3]) is False          # bands missing
+
+
+def test_compare_products(tmp_path, capsys):
+    a = np.arange(100, dtype=np.uint8).reshape(10, 10)
+    geo = geotiff.geo_tags_from_geotransform((0, 30, 0, 0, 0, -30))
+    md = {'PRODUCT_ID': 'x', 'PROCESSING_DATETIME': 't1', 'LICENSE': 'l1'}
+    f1, f2, f3, f4 = (str(tmp_path / n) for n in ('1.tif', '2.tif', '3.tif', '4.tif'))
+    geotiff.write_geotiff(f1, a, geo_tags=geo, metadata=md)
+    geotiff.write_geotiff(f2, a, geo_tags=geo, metadata=dict(md, PROCESSING_DATETIME='t2', LICENSE='z'))
+    b = a.copy()
+    b[3, 4] += 1
+    geotiff.write_geotiff(f3, b, geo_tags=geo, metadata=md)
+    geotiff.write_geotiff(f4, a, geo_tags=geo, metadata=dict(md, PRODUCT_ID='y'))
+    assert D.compare_dswx_hls_products(f1, f2) is True
+    assert D.compare_dswx_hls_products(f1, f3) is False
+    assert '(x: 4, y: 3)' in capsys.readouterr().out
+    assert D.compare_dswx_hls_products(f1, f4) is False
+    assert D.compare_dswx_hls_products(f1, str(tmp_path / 'missing.tif')) is False

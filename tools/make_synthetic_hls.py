@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Writes one synthetic HLS v2 tile as per-band GeoTIFFs plus a runconfig YAML
+(BASELINE.json configs[0]: `dswx_hls.py runconfig.yaml` plumbing case).
+
+    python tools/make_synthetic_hls.py OUT_DIR [--sensor L30|S30] [--size 3660] [--tile 0]
+                                               [--masks]
+
+Files: OUT_DIR/input/HLS.<sensor>.T15SYU.2021250T163901.v2.0.<Bxx|Fmask>.tif with the
+metadata the reference's loader harvests (:2228-2296), OUT_DIR/runconfig.yaml, and with
+--masks OUT_DIR/input_masks/{land,shad,ocean}.tif on the same grid.
+"""
+import argparse
+import os
+import sys
+
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from proteus_amd import geotiff                      # noqa: E402
+from proteus_amd.synth import synth_tile             # noqa: E402
+
+L30 = {'blue': 'B02', 'green': 'B03', 'red': 'B04', 'nir': 'B05', 'swir1': 'B06', 'swir2': 'B07'}
+S30 = {'blue': 'B02', 'green': 'B03', 'red': 'B04', 'nir': 'B8A', 'swir1': 'B11', 'swir2': 'B12'}
+
+
+def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx_hls_synth'):
+    in_dir = os.path.join(out_dir, 'input')
+    os.makedirs(in_dir, exist_ok=True)
+    s = synth_tile(tile, size, size, with_masks=masks)
+    gt = (600000.0, 30.0, 0.0, 4000020.0, 0.0, -30.0)
+    geo = geotiff.geo_tags_from_geotransform(gt, epsg=32615)
+    stem = f'HLS.{sensor}.T15SYU.2021250T163901.v2.0'
+    meta = {'MEAN_SUN_AZIMUTH_ANGLE': '143.2', 'MEAN_SUN_ZENITH_ANGLE': '34.5',
+            'MEAN_VIEW_AZIMUTH_ANGLE': '104.1', 'MEAN_VIEW_ZENITH_ANGLE': '5.2',
+            'NBAR_SOLAR_ZENITH': '34.5', 'ACCODE': 'LaSRC', 'add_offset': '0',
+            'scale_factor': '0.0001', 'SPATIAL_COVERAGE': '98', 'CLOUD_COVERAGE': '20',
+            'SENSING_TIME': '2021-09-07T16:39:01.000000Z', '_FillValue': '-9999'}
+    if sensor == 'L30':
+        meta.update(SENSOR='OLI_TIRS; OLI_TIRS',
+                    LANDSAT_PRODUCT_ID='LC08_L1TP_025035_20210907_20210916_02_T1')
+        names = L30
+    else:
+        meta.update(SPACECRAFT_NAME='Sentinel-2A',
+                    PRODUCT_URI='S2A_MSIL1C_20210907T163901_N0301_R126_T15SYU_20210907T201842.SAFE')
+        names = S30
+    files = []
+    for band, arr in zip(('blue', 'green', 'red', 'nir', 'swir1', 'swir2'), s['bands']):
+        path = os.path.join(in_dir, f'{stem}.{names[band]}.tif')
+        geotiff.write_geotiff(path, arr, geo_tags=geo, metadata=meta, nodata=-9999)
+        files.append(path)
+    path = os.path.join(in_dir, f'{stem}.Fmask.tif')
+    geotiff.write_geotiff(path, s['fmask'], geo_tags=geo, metadata=meta, nodata=255)
+    files.append(path)
+    mask_files = {}
+    if masks:
+        mdir = os.path.join(out_dir, 'input_masks')
+        os.makedirs(mdir, exist_ok=True)
+        for k in ('land', 'shad', 'ocean'):
+            mask_files[k] = os.path.join(mdir, f'{k}.tif')
+            geotiff.write_geotiff(mask_files[k], s[k], geo_tags=geo)
+    rc = {'runconfig': {'name': 'dswx_hls_workflow_synthetic', 'groups': {
+        'pge_name_group': {'pge_name': 'DSWX_HLS_PGE'},
+        'input_file_group': {'input_file_path': [in_dir]},
+        'dynamic_ancillary_file_group': {},
+        'primary_executable': {'product_type': 'DSWX_HLS'},
+        'product_path_group': {'product_path': out_dir,
+                               'scratch_path': os.path.join(out_dir, 'scratch'),
+                               'output_dir': os.path.join(out_dir, 'output'),
+                               'product_id': product_id, 'product_version': 1.0},
+        'processing': {'check_ancillary_inputs_coverage': False, 'save_land': False,
+                       'save_shad': False, 'save_dem': False},
+        'browse_image_group': {'save_browse': False}}}}
+    rc_path = os.path.join(out_dir, 'runconfig.yaml')
+    with open(rc_path, 'w') as fh:
+        yaml.safe_dump(rc, fh, sort_keys=False)
+    return rc_path, files, mask_files, s
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('out_dir')
+    ap.add_argument('--sensor', choices=['L30', 'S30'], default='L30')
+    ap.add_argument('--size', type=int, default=3660)
+    ap.add_argument('--tile', type=int, default=0)
+    ap.add_argument('--masks', action='store_true')
+    a = ap.parse_args()
+    print(make(a.out_dir, a.sensor, a.size, a.tile, a.masks)[0])

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 output of a gpurun call (gpurun_out/prof/...) into the small,
+tracked summaries under profiles/:
+
+  profiles/rNN_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary (as is)
+  profiles/rNN_pmc_counters.csv      per-dispatch FETCH_SIZE / WRITE_SIZE rows of the hot kernel
+  profiles/rNN_summary.json          averages + HBM traffic per launch
+  profiles/pmc_traffic.json          what bench.py reports as roofline.traffic
+
+HBM bytes follow MI355X_MICROARCH.md section HBM: counters are in KiB; on gfx950
+FETCH_SIZE reads exactly half the bytes of a wide coalesced streaming read, so it
+is doubled; WRITE_SIZE is exact for streaming stores.  FETCH and WRITE come from
+SEPARATE --pmc passes.
+
+usage: tools/summarize_profiles.py ROUND TILES [--masks] [--src gpurun_out/prof]
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    if not hits:
+        raise SystemExit(f'no file matches {pattern}')
+    return hits[-1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('round')
+    ap.add_argument('tiles', type=int)
+    ap.add_argument('--masks', action='store_true')
+    ap.add_argument('--src', default=os.path.join(ROOT, 'gpurun_out', 'prof'))
+    ap.add_argument('--kernel', default='dswx_classify')
+    a = ap.parse_args()
+    out = os.path.join(ROOT, 'profiles')
+    os.makedirs(out, exist_ok=True)
+    tag = f'r{int(a.round):02d}' + ('_masks' if a.masks else '')
+    stats = one(os.path.join(a.src, 'trace', '**', '*kernel_stats.csv'))
+    shutil.copy(stats, os.path.join(out, f'{tag}_kernel_stats.csv'))
+    krow = next(r for r in csv.DictReader(open(stats)) if a.kernel in r['Name'])
+    rows = []
+    vals = {}
+    for ctr, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+        f = one(os.path.join(a.src, sub, '**', '*counter_collection.csv'))
+        sel = [r for r in csv.DictReader(open(f))
+               if a.kernel in r['Kernel_Name'] and r['Counter_Name'] == ctr]
+        rows += sel
+        vals[ctr] = [float(r['Counter_Value']) for r in sel]
+    keep = ['Dispatch_Id', 'Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'LDS_Block_Size',
+            'VGPR_Count', 'SGPR_Count', 'Counter_Name', 'Counter_Value', 'Start_Timestamp',
+            'End_Timestamp']
+    with open(os.path.join(out, f'{tag}_pmc_counters.csv'), 'w', newline='') as fh:
+        w = csv.DictWriter(fh, fieldnames=keep)
+        w.writeheader()
+        for r in rows:
+            w.writerow({k: r[k] for k in keep})
+    fetch_kib = sum(vals['FETCH_SIZE']) / len(vals['FETCH_SIZE'])
+    write_kib = sum(vals['WRITE_SIZE']) / len(vals['WRITE_SIZE'])
+    read_bytes = 2.0 * fetch_kib * 1024.0       # gfx950: FETCH_SIZE = half the streamed bytes
+    write_bytes = write_kib * 1024.0
+    px = a.tiles * 3660 * 3660
+    bpp_r, bpp_w = (16 if a.masks else 13), 8
+    summary = {
+        'round': int(a.round), 'tiles': a.tiles, 'masks': a.masks, 'kernel': krow['Name'],
+        'kernel_trace': {'calls': int(krow['Calls']), 'avg_ns': float(krow['AverageNs']),
+                         'min_ns': float(krow['MinNs']), 'max_ns': float(krow['MaxNs'])},
+        'pmc': {'FETCH_SIZE_KiB_avg': fetch_kib, 'WRITE_SIZE_KiB_avg': write_kib,
+                'dispatches': [len(vals['FETCH_SIZE']), len(vals['WRITE_SIZE'])],
+                'read_bytes_corrected': read_bytes, 'write_bytes': write_bytes,
+                'hbm_bytes_per_launch': read_bytes + write_bytes},
+        'algorithmic': {'pixels_per_launch': px, 'read_bytes': px * bpp_r,
+                        'write_bytes': px * bpp_w, 'total': px * (bpp_r + bpp_w)},
+    }
+    summary['traffic_over_algorithmic'] = summary['pmc']['hbm_bytes_per_launch'] / \
+        summary['algorithmic']['total']
+    summary['achieved_GBps_from_trace'] = summary['algorithmic']['total'] / \
+        summary['kernel_trace']['avg_ns']
+    json.dump(summary, open(os.path.join(out, f'{tag}_summary.json'), 'w'), indent=1)
+    tpath = os.path.join(out, 'pmc_traffic.json')
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    traffic['masks' if a.masks else 'plain'] = {
+        'tiles': a.tiles, 'hbm_bytes_per_launch': round(read_bytes + write_bytes),
+        'source': f'profiles/{tag}_pmc_counters.csv: rocprofv3 --pmc FETCH_SIZE and --pmc '
+                  f'WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950), KiB units'}
+    json.dump(traffic, open(tpath, 'w'), indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == '__main__':
+    main()
