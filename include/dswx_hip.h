@@ -132,11 +132,22 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params,
 
 /* Device-pointer entry (inputs already resident in HBM): asynchronous on
  * `stream` (a hipStream_t, NULL = the context's stream).  counters: device
- * int64 [n_tiles][3] or NULL; they are zeroed on the stream first. */
+ * int64 [n_tiles][3] or NULL; they are zeroed on the stream first.  Mode 'cover'
+ * returns DSWX_ERR_UNSUPPORTED here (no geometry): use dswx_classify_device_2d. */
 int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params,
                          int64_t n_tiles, int64_t n_pixels,
                          const dswx_planes_in_t* in, const dswx_planes_out_t* out,
                          int64_t* counters, void* stream);
+
+/* Same, with the tile geometry (n_pixels = height * width).  Required for
+ * mask_adjacent_to_cloud_mode 'cover' (_add_snow_to_cloud_layer :2055-2078), whose
+ * masked dilations are a 2-D neighbourhood operation: the fused kernel then stops
+ * before the snow step and a second, LDS-tiled kernel dilates and finishes CLOUD,
+ * WTR, BWTR and CONF.  For 'mask' / 'ignore' it is identical to dswx_classify_device. */
+int dswx_classify_device_2d(dswx_ctx_t* ctx, const dswx_params_t* params,
+                            int64_t n_tiles, int64_t height, int64_t width,
+                            const dswx_planes_in_t* in, const dswx_planes_out_t* out,
+                            int64_t* counters, void* stream);
 
 /* generate_interpreted_layer (dswx_hls.py:1687-1707) alone: `n` DIAG values in
  * decimal (0..31 -> class 0..4 per interpreted_dswx_band_dict :97-143; 32 and any

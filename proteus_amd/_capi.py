@@ -23,7 +23,7 @@ F64_LAYERS = ('mndwi', 'ndvi', 'awesh')
 EXPORTED_SYMBOLS = (
     'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
-    'dswx_classify_device', 'dswx_interpret_layer_host', 'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
+    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_interpret_layer_host', 'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info')
@@ -92,6 +92,9 @@ def load_library():
         'dswx_classify_device': (ctypes.c_int, [vp, ctypes.POINTER(Params), i64, i64,
                                                 ctypes.POINTER(PlanesIn),
                                                 ctypes.POINTER(PlanesOut), vp, vp]),
+        'dswx_classify_device_2d': (ctypes.c_int, [vp, ctypes.POINTER(Params), i64, i64, i64,
+                                                   ctypes.POINTER(PlanesIn),
+                                                   ctypes.POINTER(PlanesOut), vp, vp]),
         'dswx_interpret_layer_host': (ctypes.c_int, [vp, vp, i64, vp]),
         'dswx_stream_probe': (ctypes.c_int, [vp, i64, i64, ctypes.POINTER(PlanesIn),
                                              ctypes.POINTER(PlanesOut), ctypes.c_int, vp]),
@@ -318,6 +321,14 @@ class Context:
             self.handle, int(n_tiles), int(n_pixels), ctypes.byref(pin),
             ctypes.byref(pout), int(variant), ctypes.c_void_p(stream) if stream else None))
 
+    def classify_device_2d(self, params, n_tiles, height, width, pin, pout, counters_ptr=None,
+                           stream=None):
+        _check(self.lib.dswx_classify_device_2d(
+            self.handle, ctypes.byref(params), int(n_tiles), int(height), int(width),
+            ctypes.byref(pin), ctypes.byref(pout),
+            ctypes.c_void_p(counters_ptr) if counters_ptr else None,
+            ctypes.c_void_p(stream) if stream else None))
+
     def synth_fill(self, seed, tile0, n_tiles, height, width, pin, stream=None):
         _check(self.lib.dswx_synth_fill(
             self.handle, int(seed), int(tile0), int(n_tiles), int(height), int(width),
@@ -415,9 +426,9 @@ class DeviceBatch:
                             self.pin, stream)
 
     def classify(self, params, stream=None, counters=True):
-        self.ctx.classify_device(params, self.n_tiles, self.n_pixels, self.pin,
-                                 self.pout, self.counters_ptr if counters else None,
-                                 stream)
+        self.ctx.classify_device_2d(params, self.n_tiles, self.height, self.width, self.pin,
+                                    self.pout, self.counters_ptr if counters else None,
+                                    stream)
 
     def read_tile(self, name, tile):
         """Download one plane of one tile as [H,W]."""

@@ -76,6 +76,9 @@ struct KArgs {
     int u8_region[7];               //   and the LDS staging region each one lives in
     int n_u8_out;
     int n_diag_pieces;              // 8 if DIAG is wanted, else 0
+    uint8_t* cover_w2;              // 'cover' mode: stage 1 parks the uncollapsed WTR-2 and
+    uint8_t* cover_pc;              //   the pre-snow CLOUD here; stage 2 reads them back
+    int height, width;              // 'cover' stage 2 only
     unsigned long long* counters;   // [n_tiles][3] or nullptr
     long long n_pixels;             // per tile
     long long px_begin;             // generic kernel: first pixel of the tile it covers
@@ -101,6 +104,7 @@ static constexpr uint32_t CLS_B2 = class_bit_mask(2);
 
 struct PxOut {
     uint32_t diag, wtr1, wtr1a, wtr2, wtr, bwtr, conf, cloud;
+    uint32_t w2_raw, pc;   // uncollapsed WTR-2 and pre-snow CLOUD ('cover' stage 1)
 };
 
 // fl64(n/d) > t, see the header comment
@@ -118,6 +122,30 @@ __device__ __forceinline__ uint32_t collapse_class(uint32_t v, uint32_t c) {
     // _collapse_wtr_classes :2578-2598 on the value set {0..4, 252..255};
     // c = 1 collapses (0,1,1,2,2), c = 0 is the identity
     return v <= 4u ? (v + c) >> c : v;
+}
+
+// A11-A15 of one pixel, given the uncollapsed WTR-2 class, the CLOUD value before the
+// snow bit (A2 + A9) and the snow decision (Fmask bit 4, or the dilated snow mask in
+// 'cover' mode).
+__device__ __forceinline__ void finish_px(uint32_t cc, uint32_t w2, uint32_t pc, bool snow, PxOut& o) {
+    // A11
+    uint32_t cl = pc + (snow ? 2u : 0u);
+    cl = (w2 == 255u) ? 255u : cl;
+    // A12
+    uint32_t w = w2;
+    w = ((cl != 0u) & (cl != 8u)) ? 253u : w;
+    w = ((cl == 2u) | (cl == 10u)) ? 252u : w;
+    w = (w2 >= 254u) ? w2 : w;
+    // A13
+    const uint32_t bw = ((w - 1u) <= 3u) ? 1u : w;
+    // A14
+    uint32_t cf = w2;
+    const bool cloudy = (cl <= 15u) & ((cl & 5u) != 0u);
+    cf = ((w2 <= 4u) & cloudy) ? w2 + 10u : cf;
+    cf = ((w2 <= 4u) & (cl == 2u)) ? w2 + 20u : cf;
+    // A15
+    o.wtr2 = collapse_class(w2, cc); o.wtr = collapse_class(w, cc);
+    o.bwtr = bw; o.conf = cf; o.cloud = cl;
 }
 
 // One pixel through the whole chain.  b..s2 are the RAW values (sign-extended),
@@ -181,26 +209,10 @@ __device__ __forceinline__ void classify_px(const DevParams& P, uint32_t aer_bit
                          (((uint32_t)land < 100u) & bright & psw) |
                          (((uint32_t)(land - 100) < 100u) & water);
     const uint32_t w2 = to_zero ? 0u : w1a;
-    // A11
-    uint32_t cl = pc + ((fm & 16) ? 2u : 0u);
-    cl = (w2 == 255u) ? 255u : cl;
-    // A12
-    uint32_t w = w2;
-    w = ((cl != 0u) & (cl != 8u)) ? 253u : w;
-    w = ((cl == 2u) | (cl == 10u)) ? 252u : w;
-    w = (w2 >= 254u) ? w2 : w;
-    // A13
-    const uint32_t bw = ((w - 1u) <= 3u) ? 1u : w;
-    // A14
-    uint32_t cf = w2;
-    const bool cloudy = (cl <= 15u) & ((cl & 5u) != 0u);
-    cf = ((w2 <= 4u) & cloudy) ? w2 + 10u : cf;
-    cf = ((w2 <= 4u) & (cl == 2u)) ? w2 + 20u : cf;
-    // A15
     const uint32_t cc = (uint32_t)P.collapse;
     o.wtr1 = collapse_class(w1, cc); o.wtr1a = collapse_class(w1a, cc);
-    o.wtr2 = collapse_class(w2, cc); o.wtr = collapse_class(w, cc);
-    o.bwtr = bw; o.conf = cf; o.cloud = cl;
+    o.w2_raw = w2; o.pc = pc;
+    finish_px(cc, w2, pc, (fm & 16) != 0, o);
 }
 
 template <typename T, bool NT> __device__ __forceinline__ T ldg(const void* p) {
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
         }
         uint32_t q_diag[4] = {0, 0, 0, 0};
         uint32_t q_w1[2] = {0, 0}, q_w1a[2] = {0, 0}, q_w2[2] = {0, 0}, q_w[2] = {0, 0},
-                 q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0};
+                 q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0}, q_w2r[2] = {0, 0}, q_pc[2] = {0, 0};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int wd = j >> 1, hf = j & 1;
@@ -309,6 +321,8 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
             q_bw[bw] |= o.bwtr << (8 * bk);
             q_cf[bw] |= o.conf << (8 * bk);
             q_cl[bw] |= o.cloud << (8 * bk);
+            q_w2r[bw] |= o.w2_raw << (8 * bk);
+            q_pc[bw] |= o.pc << (8 * bk);
         }
         if (in_range) {
         if (a.out.diag) stg<u32x4, true>(a.out.diag + off, u32x4{q_diag[0], q_diag[1], q_diag[2], q_diag[3]});
@@ -319,6 +333,10 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
         if (a.out.bwtr) stg<u32x2, true>(a.out.bwtr + off, u32x2{q_bw[0], q_bw[1]});
         if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{q_cf[0], q_cf[1]});
         if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{q_cl[0], q_cl[1]});
+        if (a.cover_w2) {   // 'cover' stage 1 (wave-uniform)
+            *reinterpret_cast<u32x2*>(a.cover_w2 + off) = u32x2{q_w2r[0], q_w2r[1]};
+            *reinterpret_cast<u32x2*>(a.cover_pc + off) = u32x2{q_pc[0], q_pc[1]};
+        }
         }
     }
     if (a.partials) {
@@ -474,6 +492,85 @@ __global__ __launch_bounds__(FUSED_THREADS) void dswx_classify_fused(const KArgs
     }
 }
 
+// ------------------------------------------------------------------------------
+// 'cover' mode, stage 2 (_add_snow_to_cloud_layer :2055-2078, then A11-A15).
+//   snow  = dilate^10(Fmask bit 4)            restricted to  area = adjacent & (CLOUD == 0)
+//   clear = dilate^7(~snow & (CLOUD == 0))    restricted to  area & (WTR-2 in 1..4)
+//   snow &= ~clear
+// with scipy.ndimage.binary_dilation semantics: 4-neighbour cross, synchronous
+// iterations, cells outside the mask keep their value, outside the raster = False.
+// k iterations reach k pixels, so a 64 x 64 output tile is exact from a 98 x 98
+// window (halo 10 + 7) held in LDS; the two masked dilations ping-pong between
+// two byte arrays there.  One block = 256 threads; grid = (tiles_x, tiles_y, n_tiles).
+// ------------------------------------------------------------------------------
+constexpr int CV_TILE = 64, CV_HALO = 17, CV_DIM = CV_TILE + 2 * CV_HALO, CV_CELLS = CV_DIM * CV_DIM;
+enum : uint8_t { CV_SNOW = 1, CV_AREA = 2, CV_WATER = 4, CV_CLEAR0 = 8 };
+
+__global__ __launch_bounds__(256) void dswx_cover_stage2(const KArgs a) {
+    __shared__ uint8_t flags[CV_CELLS];      // static per-cell bits (CV_AREA, CV_WATER, CV_CLEAR0)
+    __shared__ uint8_t cur[CV_CELLS];        // the mask being dilated
+    __shared__ uint8_t nxt[CV_CELLS];
+    const int H = a.height, W = a.width;
+    const long long tile_base = (long long)blockIdx.z * a.n_pixels;
+    const int y0 = blockIdx.y * CV_TILE - CV_HALO, x0 = blockIdx.x * CV_TILE - CV_HALO;
+    for (int c = threadIdx.x; c < CV_CELLS; c += 256) {
+        const int y = y0 + c / CV_DIM, x = x0 + c % CV_DIM;
+        uint8_t f = 0, snow = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const long long off = tile_base + (long long)y * W + x;
+            const uint32_t fm = a.in.fmask[off], pc = a.cover_pc[off], w2 = a.cover_w2[off];
+            snow = (fm & 16u) ? 1 : 0;
+            const bool area = (fm & 4u) && pc == 0u;
+            f = (area ? CV_AREA : 0) | ((w2 - 1u) <= 3u ? CV_WATER : 0) | (pc == 0u ? CV_CLEAR0 : 0);
+        }
+        flags[c] = f;
+        cur[c] = snow;
+    }
+    __syncthreads();
+    uint8_t* src = cur;
+    uint8_t* dst = nxt;
+    auto dilate = [&](uint8_t need) {
+        for (int c = threadIdx.x; c < CV_CELLS; c += 256) {
+            uint8_t v = src[c];
+            if (!v && (flags[c] & need) == need) {
+                const int yy = c / CV_DIM, xx = c % CV_DIM;
+                v = (yy > 0 && src[c - CV_DIM]) || (yy < CV_DIM - 1 && src[c + CV_DIM]) ||
+                    (xx > 0 && src[c - 1]) || (xx < CV_DIM - 1 && src[c + 1]);
+            }
+            dst[c] = v;
+        }
+        __syncthreads();
+        uint8_t* t = src; src = dst; dst = t;
+    };
+    for (int it = 0; it < 10; ++it) dilate(CV_AREA);
+    // src = dilated snow.  Keep it in `flags` (bit CV_SNOW) and start the second mask.
+    for (int c = threadIdx.x; c < CV_CELLS; c += 256) {
+        const uint8_t sn = src[c];
+        const uint8_t f = flags[c];
+        flags[c] = f | (sn ? CV_SNOW : 0);
+        dst[c] = (!sn && (f & CV_CLEAR0)) ? 1 : 0;
+    }
+    __syncthreads();
+    { uint8_t* t = src; src = dst; dst = t; }
+    for (int it = 0; it < 7; ++it) dilate(CV_AREA | CV_WATER);
+    // finish the interior 64 x 64
+    const uint32_t cc = (uint32_t)a.P.collapse;
+    for (int i = threadIdx.x; i < CV_TILE * CV_TILE; i += 256) {
+        const int ly = i / CV_TILE, lx = i % CV_TILE;
+        const int y = blockIdx.y * CV_TILE + ly, x = blockIdx.x * CV_TILE + lx;
+        if (y >= H || x >= W) continue;
+        const int c = (ly + CV_HALO) * CV_DIM + lx + CV_HALO;
+        const bool snow = (flags[c] & CV_SNOW) && !src[c];
+        const long long off = tile_base + (long long)y * W + x;
+        PxOut o;
+        finish_px(cc, a.cover_w2[off], a.cover_pc[off], snow, o);
+        if (a.out.wtr) a.out.wtr[off] = (uint8_t)o.wtr;
+        if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)o.bwtr;
+        if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
+        if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
+    }
+}
+
 // Sums the fused kernel's per-wave partial counts of one tile (block = tile) and
 // WRITES counters[tile]; the ragged-remainder kernel adds to them afterwards.
 __global__ __launch_bounds__(256) void dswx_counters_finish(const uint2* __restrict__ partials,
@@ -535,6 +632,7 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
         if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)o.bwtr;
         if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
         if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
+        if (a.cover_w2) { a.cover_w2[off] = (uint8_t)o.w2_raw; a.cover_pc[off] = (uint8_t)o.pc; }
     }
     if (a.counters) reduce_counters(a.counters + (long long)blockIdx.y * 3, red, c0, c1, c2);
 }
@@ -687,11 +785,48 @@ template <int SPLIT, bool NT>
 __global__ __launch_bounds__(256) void dswx_role_split_k(const KArgs a) {
     const long long n_groups = a.n_pixels >> 3;
     const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    if (SPLIT == 2) {
+        // pairs of blocks cover 4096 px: the even one reads all 7 planes (2 groups per
+        // thread), the odd one writes all 7 planes as 1 KiB pieces, 8 consecutive
+        // pieces per wave (the LDS-transposed store shape, without the LDS)
+        // roles alternate every 8 blocks so that every XCD (blocks are dealt round-robin
+        // over the 8 XCDs) hosts readers and writers alike
+        const long long pair = (long long)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+        if (((blockIdx.x >> 3) & 1) == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long long grp = pair * 512 + h * 256 + threadIdx.x;
+                if (grp >= n_groups) continue;
+                const long long off = tile_base + grp * 8;
+                u32x4 x = ldg<u32x4, NT>(a.in.band[0] + off);
+#pragma unroll
+                for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, NT>(a.in.band[k] + off);
+                const u32x2 f = ldg<u32x2, NT>(a.in.fmask + off);
+                if ((x.x ^ f.x) == 0x12345678u && (x.y ^ f.y) == 0x9abcdef0u) a.out.wtr1[0] = 1;
+            }
+        } else {
+            uint8_t* const planes[7] = {reinterpret_cast<uint8_t*>(a.out.diag), a.out.wtr1, a.out.wtr2, a.out.wtr,
+                                        a.out.bwtr, a.out.conf, a.out.cloud};
+            const long long px0 = pair * 4096;
+            if (px0 + 4096 > a.n_pixels) return;
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const u32x4 val = {threadIdx.x, blockIdx.x, 3u, 4u};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int piece = wave * 8 + q;
+                int plane, sub;
+                if (piece < 8) { plane = 0; sub = piece; } else { plane = 1 + (piece - 8) / 4; sub = (piece - 8) % 4; }
+                const long long byte0 = plane == 0 ? (tile_base + px0) * 2 : tile_base + px0;
+                stg<u32x4, NT>(planes[plane] + byte0 + sub * 1024 + lane * 16, val);
+            }
+        }
+        return;
+    }
     bool reader;
     long long g0, g1;
     if (SPLIT == 0) {
-        reader = (blockIdx.x & 1) == 0;
-        const long long pair = blockIdx.x >> 1;                      // covers groups [pair*512, +512)
+        reader = ((blockIdx.x >> 3) & 1) == 0;                       // XCD-balanced roles
+        const long long pair = (long long)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7);   // groups [pair*512, +512)
         g0 = pair * 512 + threadIdx.x; g1 = g0 + 256;
     } else {
         reader = threadIdx.x < 128;
@@ -721,6 +856,27 @@ __global__ __launch_bounds__(256) void dswx_role_split_k(const KArgs a) {
             stg<u32x2, NT>(a.out.cloud + off, y + 5u);
         }
     }
+}
+
+// Layout calibration: the fused kernel's thread mapping and bytes, but the 14 planes
+// interleaved in chunks of CH pixels inside one arena: chunk c holds
+// [6 x int16 | fmask | diag u16 | 6 x u8] for pixels [c*CH, (c+1)*CH), so the 14
+// accesses of a block fall within one 21*CH-byte span instead of 14 distant planes.
+template <int CH, bool NT>
+__global__ __launch_bounds__(256) void dswx_chunked_layout_probe_k(uint8_t* __restrict__ arena, long long total_px) {
+    const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long px = grp * 8;
+    if (px >= total_px) return;
+    const long long c = px / CH, r = px % CH;
+    uint8_t* base = arena + c * (21LL * CH);
+    u32x4 x = ldg<u32x4, NT>(base + r * 2);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, NT>(base + (long long)k * 2 * CH + r * 2);
+    const u32x2 f = ldg<u32x2, NT>(base + 12LL * CH + r);
+    u32x2 y; y.x = x.x ^ x.z ^ f.x; y.y = x.y ^ x.w ^ f.y;
+    stg<u32x4, NT>(base + 13LL * CH + r * 2, x);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) stg<u32x2, NT>(base + (15LL + k) * CH + r, y + (uint32_t)k);
 }
 
 // Calibration: a flat two-stream copy moving the same 13 B in / 8 B out per pixel
@@ -896,6 +1052,9 @@ struct dswx_ctx {
     // grow-only workspace for the vector kernel's per-wave counter partials
     void* partials = nullptr;
     size_t partials_bytes = 0;
+    // grow-only scratch of 'cover' mode: uncollapsed WTR-2 + pre-snow CLOUD planes
+    void* cover = nullptr;
+    size_t cover_bytes = 0;
     std::string last_kernel;
     int fused_variant = 0;   // 0: direct stores (default); 1: LDS-staged stores (env DSWX_FUSED_VARIANT)
 };
@@ -1058,6 +1217,7 @@ int dswx_ctx_destroy(dswx_ctx_t* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->cover) (void)hipFree(ctx->cover);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return DSWX_OK;
@@ -1065,9 +1225,10 @@ int dswx_ctx_destroy(dswx_ctx_t* ctx) {
 
 static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t n_pixels,
-                         const dswx_planes_in_t* in, const dswx_planes_out_t* out, int64_t* counters,
-                         void* stream) {
+// height/width are only needed (and only trusted) in 'cover' mode; 0 = unknown
+static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t n_pixels,
+                                int64_t height, int64_t width, const dswx_planes_in_t* in,
+                                const dswx_planes_out_t* out, int64_t* counters, void* stream) {
     if (!ctx || !params || !in || !out) return fail(DSWX_ERR_ARG, "NULL argument");
     if (n_tiles < 0 || n_pixels < 0) return fail(DSWX_ERR_ARG, "negative size");
     for (int k = 0; k < 6; ++k)
@@ -1076,10 +1237,12 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
     KArgs a;
     int rc = make_dev_params(params, &a.P);
     if (rc) return rc;
-    if (params->mask_adjacent_to_cloud_mode == DSWX_ADJ_COVER)
+    const bool cover = params->mask_adjacent_to_cloud_mode == DSWX_ADJ_COVER;
+    if (cover && (height <= 0 || width <= 0 || height * width != n_pixels))
         return fail(DSWX_ERR_UNSUPPORTED,
-                    "mask_adjacent_to_cloud_mode 'cover' needs the split (dilation) path; "
-                    "the fused kernel implements 'mask' and 'ignore'");
+                    "mask_adjacent_to_cloud_mode 'cover' is a 2-D neighbourhood operation: use "
+                    "dswx_classify_device_2d / dswx_classify_host, which know the tile height and width");
+    if (cover && (height > 2147483647LL || width > 2147483647LL)) return fail(DSWX_ERR_ARG, "tile too large");
     for (int k = 0; k < 6; ++k)
         if (!aligned_to(in->band[k], 2)) return fail(DSWX_ERR_ALIGN, "band[%d] not 2-byte aligned", k);
     if (out->diag && !aligned_to(out->diag, 2)) return fail(DSWX_ERR_ALIGN, "diag not 2-byte aligned");
@@ -1093,6 +1256,23 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
     a.out = *out;
     a.counters = reinterpret_cast<unsigned long long*>(counters);
     a.n_pixels = n_pixels;
+    a.cover_w2 = a.cover_pc = nullptr;
+    a.height = (int)height; a.width = (int)width;
+    dswx_planes_out_t final_out = *out;     // what stage 2 of 'cover' writes
+    if (cover) {
+        const size_t need = 2 * (size_t)n_tiles * (size_t)n_pixels;
+        if (need > ctx->cover_bytes) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (ctx->cover) HIP_TRY(hipFree(ctx->cover));
+            ctx->cover = nullptr; ctx->cover_bytes = 0;
+            HIP_TRY(hipMalloc(&ctx->cover, need));
+            ctx->cover_bytes = need;
+        }
+        a.cover_w2 = static_cast<uint8_t*>(ctx->cover);
+        a.cover_pc = a.cover_w2 + (size_t)n_tiles * (size_t)n_pixels;
+        // stage 1 stops before the snow step: these four layers come from stage 2
+        a.out.wtr = a.out.bwtr = a.out.conf = a.out.cloud = nullptr;
+    }
 
     const bool any_index = out->mndwi || out->ndvi || out->awesh;
     const bool masks = in->land || in->shad || in->ocean;
@@ -1128,11 +1308,13 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
         if (b.out.ndvi) b.out.ndvi += shift;
         if (b.out.awesh) b.out.awesh += shift;
         if (b.counters) b.counters += t0 * 3;
+        if (b.cover_w2) { b.cover_w2 += shift; b.cover_pc += shift; }
         b.px_begin = 0;
         b.partials = nullptr;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
         if (groups > 0) {
-            const int threads = ctx->fused_variant == 1 ? FUSED_THREADS : 256;
+            const bool staged = ctx->fused_variant == 1 && !cover;   // 'cover' stage 1 lives in the direct kernel
+            const int threads = staged ? FUSED_THREADS : 256;
             const int64_t gx = (groups + threads - 1) / threads;
             const int waves = threads / 64;
             dim3 grid((unsigned)gx, (unsigned)nt), block(threads);
@@ -1152,7 +1334,7 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
             for (int i = 0; i < 7; ++i)
                 if (u8p[i]) { b.u8_out[b.n_u8_out] = u8p[i]; b.u8_region[b.n_u8_out] = i; ++b.n_u8_out; }
             b.n_diag_pieces = b.out.diag ? 8 : 0;
-            if (ctx->fused_variant == 1) {
+            if (staged) {
                 if (masks) hipLaunchKernelGGL(dswx_classify_fused<true>, grid, block, 0, s, b);
                 else hipLaunchKernelGGL(dswx_classify_fused<false>, grid, block, 0, s, b);
                 snprintf(info, sizeof info, "dswx_classify_fused<%s> (LDS-staged) grid=(%lld,%lld) block=%d lds=%d",
@@ -1181,6 +1363,24 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
                          (long long)gx, (long long)nt);
         }
         HIP_TRY(hipGetLastError());
+        if (cover) {
+            KArgs c2 = b;
+            c2.out = final_out;
+            if (c2.out.wtr) c2.out.wtr += shift;
+            if (c2.out.bwtr) c2.out.bwtr += shift;
+            if (c2.out.conf) c2.out.conf += shift;
+            if (c2.out.cloud) c2.out.cloud += shift;
+            if (c2.out.wtr || c2.out.bwtr || c2.out.conf || c2.out.cloud) {
+                dim3 grid((unsigned)((width + CV_TILE - 1) / CV_TILE), (unsigned)((height + CV_TILE - 1) / CV_TILE),
+                          (unsigned)nt);
+                hipLaunchKernelGGL(dswx_cover_stage2, grid, dim3(256), 0, s, c2);
+                HIP_TRY(hipGetLastError());
+            }
+            const size_t len = strlen(info);
+            snprintf(info + len, sizeof info - len, " + dswx_cover_stage2 grid=(%lld,%lld,%lld)",
+                     (long long)((width + CV_TILE - 1) / CV_TILE), (long long)((height + CV_TILE - 1) / CV_TILE),
+                     (long long)nt);
+        }
         if (any_index) {
             const long long total = (long long)nt * n_pixels;
             dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -1190,6 +1390,19 @@ int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n
     }
     ctx->last_kernel = info;
     return DSWX_OK;
+}
+
+int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t n_pixels,
+                         const dswx_planes_in_t* in, const dswx_planes_out_t* out, int64_t* counters,
+                         void* stream) {
+    return classify_device_impl(ctx, params, n_tiles, n_pixels, 0, 0, in, out, counters, stream);
+}
+
+int dswx_classify_device_2d(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t height,
+                            int64_t width, const dswx_planes_in_t* in, const dswx_planes_out_t* out,
+                            int64_t* counters, void* stream) {
+    if (height < 0 || width < 0) return fail(DSWX_ERR_ARG, "negative size");
+    return classify_device_impl(ctx, params, n_tiles, height * width, height, width, in, out, counters, stream);
 }
 
 int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t height,
@@ -1253,7 +1466,7 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
         double** const d_f64[3] = {&dout.mndwi, &dout.ndvi, &dout.awesh};
         for (int i = 0; i < 3; ++i) if (h_f64[i]) *d_f64[i] = reinterpret_cast<double*>(base + o_f64[i]);
         int64_t* dcnt = counters ? reinterpret_cast<int64_t*>(base + o_cnt) : nullptr;
-        int rc = dswx_classify_device(ctx, params, 1, P, &din, &dout, dcnt, s);
+        int rc = dswx_classify_device_2d(ctx, params, 1, height, width, &din, &dout, dcnt, s);
         if (rc) return rc;
         if (out->diag) HIP_TRY(hipMemcpyAsync(out->diag + sh, dout.diag, (size_t)P * 2, hipMemcpyDeviceToHost, s));
         for (int i = 0; i < 7; ++i)
@@ -1318,15 +1531,30 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const 
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }
+    if (variant & 131072) {  // chunk-interleaved layout: bits 2-3 select CH = 4096 << (4*sel), bit 1 = nt
+        const long long total = n_tiles * n_pixels;
+        const int sel = (variant >> 2) & 3;
+        dim3 grid((unsigned)((total / 8 + 255) / 256)), block(256);
+        uint8_t* arena = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(in->band[0]));
+        const bool wnt = variant & 2;
+#define CHUNK_LAUNCH(CH) do { if (wnt) hipLaunchKernelGGL((dswx_chunked_layout_probe_k<CH, true>), grid, block, 0, s, arena, total); else hipLaunchKernelGGL((dswx_chunked_layout_probe_k<CH, false>), grid, block, 0, s, arena, total); } while (0)
+        if (sel == 0) CHUNK_LAUNCH(4096); else if (sel == 1) CHUNK_LAUNCH(65536); else if (sel == 2) CHUNK_LAUNCH(1048576); else CHUNK_LAUNCH(16777216);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
     if (variant & 65536) {  // role split: bit 2 = SPLIT, bit 1 = nt
         const int64_t groups = n_pixels >> 3;
         const bool wnt = variant & 2;
-        if (variant & 4) {
+        if (variant & 8) {
+            dim3 grid((unsigned)((((groups + 511) / 512 + 7) / 8) * 16), (unsigned)n_tiles), block(256);
+            if (wnt) hipLaunchKernelGGL((dswx_role_split_k<2, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((dswx_role_split_k<2, false>), grid, block, 0, s, a);
+        } else if (variant & 4) {
             dim3 grid((unsigned)((groups + 255) / 256), (unsigned)n_tiles), block(256);
             if (wnt) hipLaunchKernelGGL((dswx_role_split_k<1, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((dswx_role_split_k<1, false>), grid, block, 0, s, a);
         } else {
-            dim3 grid((unsigned)(((groups + 511) / 512) * 2), (unsigned)n_tiles), block(256);
+            dim3 grid((unsigned)((((groups + 511) / 512 + 7) / 8) * 16), (unsigned)n_tiles), block(256);
             if (wnt) hipLaunchKernelGGL((dswx_role_split_k<0, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((dswx_role_split_k<0, false>), grid, block, 0, s, a);
         }

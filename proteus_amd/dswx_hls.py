@@ -870,10 +870,6 @@ def generate_dswx_layers(input_list,
         aerosol_fmask_values=dict(zip((0, 2, 3, 4), aerosol_lists)),
         collapse_wtr_classes=FLAG_COLLAPSE_WTR_CLASSES,
         aerosol_max_nir=AEROSOL_REMAPPING_MAX_NIR)
-    if mask_adjacent_to_cloud_mode == 'cover':
-        raise NotImplementedError(
-            "mask_adjacent_to_cloud_mode 'cover' needs the dilation path between WTR-2 and "
-            'CLOUD (SURVEY.md §8 row f2), which is not built yet')
     ctx = get_context(device)
     res = ctx.classify_host(bands, image['fmask'], params, land=landcover_mask,
                             shad=shadow_layer, ocean=ocean_mask)

@@ -94,5 +94,13 @@ def test_api_with_masks_and_multiband(tmp_path):
     for i, n in enumerate(names):
         assert np.array_equal(stack[i], want[n]), n
     assert info.metadata['OCEAN_MASKING_ENABLED'] == 'TRUE'
-    with pytest.raises(NotImplementedError, match='cover'):
-        D.generate_dswx_layers(files, mask_adjacent_to_cloud_mode='cover')
+    # 'cover' mode goes through the split (dilation) path
+    ok = D.generate_dswx_layers(files, mask_adjacent_to_cloud_mode='cover',
+                                output_cloud_layer=str(tmp_path / 'cloud_cover.tif'),
+                                output_interpreted_band=str(tmp_path / 'wtr_cover.tif'))
+    assert ok is True
+    exp = o.classify_tile(s['bands'], s['fmask'], mask_adjacent_to_cloud_mode='cover')
+    for name, layer in (('cloud_cover.tif', 'CLOUD'), ('wtr_cover.tif', 'WTR')):
+        arr, info = geotiff.read_geotiff(str(tmp_path / name))
+        assert np.array_equal(arr, exp[layer]), layer
+        assert info.metadata['MASK_ADJACENT_TO_CLOUD_MODE'] == 'cover'

@@ -27,7 +27,7 @@ def ctx():
 
 
 # ---- (1) golden fixtures ----------------------------------------------------------
-@pytest.mark.parametrize('name', [n for n in G.tile_case_names() if 'cover' not in n])
+@pytest.mark.parametrize('name', G.tile_case_names())
 def test_golden_tiles(ctx, name):
     c = G.tile_case(name)
     for collapse in (False, True):
@@ -144,10 +144,18 @@ def test_error_paths(ctx):
     with pytest.raises(_capi.DswxError) as e:
         ctx.classify_host(bands, fm, p)
     assert e.value.code == _capi.ERR_ARG
+    # 'cover' needs the tile geometry: the 1-D device entry refuses it
     p = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
+    arena = ctx.malloc(4096)
+    pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
+    for i in range(6):
+        pin.band[i] = arena.ptr + 256 * i
+    pin.fmask = arena.ptr + 2048
+    pout.wtr = arena.ptr + 3072
     with pytest.raises(_capi.DswxError) as e:
-        ctx.classify_host(bands, fm, p)
+        ctx.classify_device(p, 1, 16, pin, pout)
     assert e.value.code == _capi.ERR_UNSUPPORTED
+    arena.free()
     with pytest.raises(ValueError):
         ctx.classify_host(bands[:5], fm, _capi.default_params())
 
@@ -327,3 +335,76 @@ def test_staged_variant_parity(monkeypatch):
             assert got['counters'][0].tolist() == exp['counters'].tolist()
     finally:
         c2.close()
+
+
+# ---- 'cover' mode: split path with LDS-tiled masked dilations ------
+def blobby_fmask(fmask, seed):
+    """Spatially coherent adjacent-to-cloud and snow patches so that the 10- and 7-step
+    dilations travel (white-noise Fmask alone stops them after a step or two)."""
+    h, w = fmask.shape
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = fmask.copy()
+    valid = out != 255
+    adj = np.zeros((h, w), bool)
+    snow = np.zeros((h, w), bool)
+    for _ in range(max(3, h * w // 1500)):
+        cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(2, 14)
+        adj |= (np.abs(yy - cy) + np.abs(xx - cx) // 2) < r
+        cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(1, 5)
+        snow |= (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+    out = np.where(valid & adj, (out | 4) & ~np.uint8(2 | 8), out & ~np.uint8(4)).astype(np.uint8)
+    out = np.where(valid & snow, out | 16, out).astype(np.uint8)
+    return out
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (7, 9), (64, 64), (65, 63), (100, 37), (160, 160),
+                                   (333, 517)])
+@pytest.mark.parametrize('masks', [False, True])
+def test_cover_mode_vs_numpy_oracle(ctx, shape, masks):
+    h, w = shape
+    s = synth_tile(900 + h, h, w, with_masks=True)
+    fmask = blobby_fmask(s['fmask'], h * 1000 + w)
+    land, shad, ocean = (s['land'], s['shad'], s['ocean']) if masks else (None, None, None)
+    for collapse in (True, False):
+        p = _capi.make_params(mask_adjacent_to_cloud_mode='cover', collapse_wtr_classes=collapse)
+        got = ctx.classify_host(s['bands'], fmask, p, land=land, shad=shad, ocean=ocean)
+        assert 'dswx_cover_stage2' in ctx.last_kernel_info()
+        exp = o.classify_tile(s['bands'], fmask, landcover=land, shadow=shad, ocean_mask=ocean,
+                              mask_adjacent_to_cloud_mode='cover', collapse=collapse)
+        for layer, key in NAME.items():
+            assert np.array_equal(got[key], exp[layer]), (shape, masks, layer, collapse)
+        c = exp['counters']
+        assert got['counters'][0].tolist() == [c['n_valid'], c['n_cloud_and_valid'], c['n_not_ocean']]
+    # the dilation must actually have changed something, or the test is vacuous
+    plain = o.classify_tile(s['bands'], fmask, landcover=land, shadow=shad, ocean_mask=ocean,
+                            mask_adjacent_to_cloud_mode='ignore', collapse=False)
+    if h * w >= 4096:
+        assert not np.array_equal(plain['CLOUD'], exp['CLOUD'])
+
+
+def test_cover_mode_device_batch(ctx):
+    """Multi-tile device-resident batch in 'cover' mode: tiles must not bleed into each
+    other across the tile boundary (the raster edge is False for the dilation)."""
+    n_tiles, h, w = 3, 96, 80
+    batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, extra_layers=('wtr1_aerosol',))
+    batch.synth(SEED, tile0=50)
+    fms = []
+    for t in range(n_tiles):
+        fm = blobby_fmask(batch.read_tile('fmask', t), 77 + t)
+        fm[0, :] |= 16          # snow along the first and last rows: would leak between tiles
+        fm[-1, :] |= 16
+        fm[1, :] = (fm[1, :] | 4) & ~np.uint8(2 | 8)
+        fm[-2, :] = (fm[-2, :] | 4) & ~np.uint8(2 | 8)
+        batch.write_tile('fmask', t, fm)
+        fms.append(fm)
+    p = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
+    batch.classify(p)
+    ctx.synchronize()
+    for t in range(n_tiles):
+        s = synth_tile(50 + t, h, w, with_masks=True)
+        exp = o.classify_tile(s['bands'], fms[t], landcover=s['land'], shadow=s['shad'],
+                              ocean_mask=s['ocean'], mask_adjacent_to_cloud_mode='cover')
+        for layer, key in NAME.items():
+            assert np.array_equal(batch.read_tile(key, t), exp[layer]), (layer, t)
+    batch.free()

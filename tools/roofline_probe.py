@@ -63,6 +63,14 @@ def main():
             run(f'14 planes, one plane per block nt={nt >> 1}', 32768 | nt, 21)
             run(f'role split by block (7-plane readers / 7-plane writers) nt={nt >> 1}', 65536 | nt, 21)
             run(f'role split by wave inside block nt={nt >> 1}', 65536 | 4 | nt, 21)
+            run(f'role split by block, writers use plane-run stores nt={nt >> 1}', 65536 | 8 | nt, 21)
+        # chunk-interleaved layout (needs total px multiple of the chunk: use a prefix)
+        for sel, ch in ((0, 4096), (1, 65536), (2, 1048576), (3, 16777216)):
+            for nt in (0, 2):
+                npx = (px // ch) * ch
+                ms = timed(ctx, lambda: ctx.stream_probe(1, npx, batch.pin, batch.pout,
+                                                         131072 | (sel << 2) | nt), a.reps)
+                out[f'chunk-interleaved planes CH={ch} nt={nt >> 1}'] = round(npx * 21 / (sum(ms) / len(ms)) / 1e6, 1)
         for lb in (0, 1, 2):
             for nt in (0, 2):
                 run(f'staged probe block={256 << lb} nt={nt >> 1}', 16384 | (lb << 2) | nt, 21)
