@@ -156,6 +156,29 @@ int dswx_classify_device_2d(dswx_ctx_t* ctx, const dswx_params_t* params,
 int dswx_interpret_layer_host(dswx_ctx_t* ctx, const int64_t* diag_decimal, int64_t n,
                               uint8_t* out);
 
+/* Terrain shadow layer: _compute_opera_shadow_layer (dswx_hls.py:4215-4283) followed
+ * by the DEM-margin crop (_crop_2d_array_all_sides :4320, used at :5170).
+ *   dem       float32 [height][width] including the margin (DEM_MARGIN_IN_PIXELS = 50, :58)
+ *   shadow    uint8 [height-2*margin][width-2*margin]; 1 = not shadow, 0 = shadow
+ *   sun_vector, sin_azimuth, cos_azimuth: the float64 scalars the reference derives from
+ *             the sun angles (:4246-4253, :4276-4277); the caller computes them (the Python
+ *             host does it with numpy exactly as the reference), so that they are
+ *             bit-identical to the reference's whatever libm is in use
+ *   thresholds in degrees (:4279-4281); pixel spacings as :4217 (default 30, 30).
+ * float32 / float64 split of the arithmetic: see the kernel comment (numpy >= 2 promotion). */
+int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width,
+                           int64_t margin, const double sun_vector[3], double sin_azimuth,
+                           double cos_azimuth, double min_slope_angle,
+                           double max_sun_local_inc_angle, double pixel_spacing_x,
+                           double pixel_spacing_y, uint8_t* shadow);
+/* Device-pointer form for `n_tiles` DEMs of equal size, asynchronous on `stream`. */
+int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles,
+                             int64_t height, int64_t width, int64_t margin,
+                             const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                             double min_slope_angle, double max_sun_local_inc_angle,
+                             double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow,
+                             void* stream);
+
 /* Deterministic synthetic HLS tiles written straight into HBM (SURVEY.md §8d;
  * same integer recipe as proteus_amd/synth.py).  Fills in->band[0..5], in->fmask
  * and whichever of land/shad/ocean is non-NULL for tiles tile0..tile0+n_tiles-1. */

@@ -364,3 +364,33 @@ def classify_tile(bands, fmask, thr=None, *, landcover=None, shadow=None,
                                                     swir1, swir2)
         out.update(MNDWI=mndwi, NDVI=ndvi, AWESH=awesh)
     return out
+
+
+# ---------------------------------------------------------------------------
+# f1  _compute_opera_shadow_layer :4215-4283  and  _crop_2d_array_all_sides :4320
+# ---------------------------------------------------------------------------
+def compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
+                               min_slope_angle, max_sun_local_inc_angle,
+                               pixel_spacing_x=30, pixel_spacing_y=30):
+    """Same expressions, hence the same float32/float64 promotion as the reference gets
+    from whichever numpy runs it (numpy >= 2 here: the products with the float64 sun
+    scalars are float64; numpy 1.23.5, which the reference pins, keeps them float32)."""
+    sun_azimuth = np.radians(sun_azimuth_angle)
+    sun_zenith = np.radians(90 - sun_elevation_angle)
+    to_sun = [np.sin(sun_azimuth) * np.sin(sun_zenith),
+              np.cos(sun_azimuth) * np.sin(sun_zenith),
+              np.cos(sun_zenith)]
+    grad_y, grad_x = np.gradient(dem)
+    normal = [-grad_x / pixel_spacing_x, -grad_y / - abs(pixel_spacing_y), 1]
+    norm = np.sqrt(normal[0] ** 2 + normal[1] ** 2 + 1)
+    sun_inc_angle_degrees = np.degrees(np.arccos(
+        (normal[0] * to_sun[0] + normal[1] * to_sun[1] + normal[2] * to_sun[2]) / norm))
+    directional_slope_angle = np.degrees(np.arctan(
+        normal[0] * np.sin(sun_azimuth) + normal[1] * np.cos(sun_azimuth)))
+    backslope = directional_slope_angle <= min_slope_angle
+    low_inc = sun_inc_angle_degrees <= max_sun_local_inc_angle
+    return low_inc | (~backslope)
+
+
+def crop_2d_array_all_sides(arr, margin):
+    return arr[margin:-margin, margin:-margin]

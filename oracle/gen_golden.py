@@ -338,15 +338,46 @@ def gen_tiles(ref):
         print('tile', case['name'], H, W)
 
 
+SHADOW_CASES = [
+    # name, tile, H, W (with margin), sun azimuth, sun elevation, min slope, max inc
+    dict(name='s_default', tile=0, H=220, W=260, az=143.2, el=55.5, mn=-5, mx=40),
+    dict(name='s_low_sun', tile=1, H=180, W=200, az=231.7, el=18.25, mn=-5, mx=40),
+    dict(name='s_noon_north', tile=2, H=150, W=170, az=0.0, el=89.0, mn=-5, mx=40),
+    dict(name='s_other_thresholds', tile=3, H=160, W=160, az=95.0, el=33.0, mn=2.5, mx=55.5),
+    dict(name='s_thin', tile=4, H=102, W=140, az=310.0, el=40.0, mn=-5, mx=40),
+]
+
+
+def gen_shadow(ref):
+    from proteus_amd.synth import synth_dem
+    margin = ref.DEM_MARGIN_IN_PIXELS
+    for case in SHADOW_CASES:
+        dem = synth_dem(case['tile'], case['H'], case['W'])
+        full = ref._compute_opera_shadow_layer(dem, case['az'], case['el'], case['mn'], case['mx'])
+        cropped = ref._crop_2d_array_all_sides(full, margin)
+        np.savez_compressed(os.path.join(GOLDEN, f"shadow_{case['name']}.npz"), dem=dem,
+                            az=np.array(case['az']), el=np.array(case['el']),
+                            mn=np.array(case['mn']), mx=np.array(case['mx']),
+                            margin=np.array(margin), full=full, cropped=cropped,
+                            numpy_version=np.array(np.__version__))
+        print('shadow', case['name'], full.dtype, float(full.mean()))
+
+
 def main():
     ref = import_reference()
     if ref is None:
         raise SystemExit('reference tree not present; goldens can only be '
                          'regenerated in the build container')
     os.makedirs(GOLDEN, exist_ok=True)
-    gen_tables(ref)
-    gen_diag(ref)
-    gen_tiles(ref)
+    which = sys.argv[1:] or ['tables', 'diag', 'tiles', 'shadow']
+    if 'tables' in which:
+        gen_tables(ref)
+    if 'diag' in which:
+        gen_diag(ref)
+    if 'tiles' in which:
+        gen_tiles(ref)
+    if 'shadow' in which:
+        gen_shadow(ref)
 
 
 if __name__ == '__main__':

@@ -23,7 +23,8 @@ F64_LAYERS = ('mndwi', 'ndvi', 'awesh')
 EXPORTED_SYMBOLS = (
     'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
-    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_interpret_layer_host', 'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
+    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device',
+    'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info')
@@ -96,6 +97,12 @@ def load_library():
                                                    ctypes.POINTER(PlanesIn),
                                                    ctypes.POINTER(PlanesOut), vp, vp]),
         'dswx_interpret_layer_host': (ctypes.c_int, [vp, vp, i64, vp]),
+        'dswx_shadow_layer_host': (ctypes.c_int, [vp, vp, i64, i64, i64,
+                                                  ctypes.POINTER(ctypes.c_double * 3)] +
+                                   [ctypes.c_double] * 6 + [vp]),
+        'dswx_shadow_layer_device': (ctypes.c_int, [vp, vp, i64, i64, i64, i64,
+                                                    ctypes.POINTER(ctypes.c_double * 3)] +
+                                     [ctypes.c_double] * 6 + [vp, vp]),
         'dswx_stream_probe': (ctypes.c_int, [vp, i64, i64, ctypes.POINTER(PlanesIn),
                                              ctypes.POINTER(PlanesOut), ctypes.c_int, vp]),
         'dswx_synth_fill': (ctypes.c_int, [vp, ctypes.c_uint64, i64, i64, i64, i64,
@@ -315,6 +322,22 @@ class Context:
         _check(self.lib.dswx_interpret_layer_host(self.handle, _host_ptr(d), d.size,
                                                   _host_ptr(out)))
         return out
+
+    def shadow_layer(self, dem, sun_vector, sin_azimuth, cos_azimuth, min_slope_angle,
+                     max_sun_local_inc_angle, pixel_spacing_x=30, pixel_spacing_y=30, margin=0):
+        """Terrain shadow layer of one float32 DEM [H,W]; returns bool [H-2m, W-2m]."""
+        dem = np.ascontiguousarray(dem, dtype=np.float32)
+        if dem.ndim != 2:
+            raise ValueError('dem must be 2-D')
+        h, w = dem.shape
+        out = np.empty((max(h - 2 * margin, 0), max(w - 2 * margin, 0)), dtype=np.uint8)
+        vec = (ctypes.c_double * 3)(*[float(v) for v in sun_vector])
+        _check(self.lib.dswx_shadow_layer_host(
+            self.handle, _host_ptr(dem), h, w, int(margin), ctypes.byref(vec),
+            float(sin_azimuth), float(cos_azimuth), float(min_slope_angle),
+            float(max_sun_local_inc_angle), float(pixel_spacing_x), float(pixel_spacing_y),
+            _host_ptr(out)))
+        return out.astype(bool)
 
     def stream_probe(self, n_tiles, n_pixels, pin, pout, variant=0, stream=None):
         _check(self.lib.dswx_stream_probe(

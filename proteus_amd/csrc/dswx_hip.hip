@@ -951,6 +951,56 @@ __global__ __launch_bounds__(256) void dswx_interpret_v1(const long long* __rest
 }
 
 // ------------------------------------------------------------------------------
+// Terrain shadow layer (row f1): _compute_opera_shadow_layer :4215-4283 followed by
+// the margin crop of :4320 / :5170.  One thread per OUTPUT pixel.
+//
+// Arithmetic types follow what numpy >= 2 (NEP 50) gives the reference expressions on a
+// float32 DEM: np.gradient, the division by the pixel spacing, the squares, their sum,
+// `+ 1` and the sqrt stay float32; the products with the float64 sun-vector scalars,
+// the quotient, arccos / arctan / degrees and the comparisons are float64.  (Under the
+// numpy 1.23.5 the reference pins, value-based casting keeps those float32 as well:
+// borderline pixels can differ between the two -- SURVEY.md §7.)  Built without
+// fp contraction; hipcc's float32 division and sqrt are correctly rounded.
+// ------------------------------------------------------------------------------
+struct ShadowArgs {
+    const float* dem;        // [H][W], with margin
+    uint8_t* shadow;         // [H - 2*margin][W - 2*margin]; 1 = not shadow, 0 = shadow
+    long long height, width, margin;
+    float spacing_x, neg_abs_spacing_y;
+    double sun[3];           // target-to-sun unit vector (x, y, z)
+    double sin_az, cos_az;
+    double min_slope_angle, max_sun_local_inc_angle;
+};
+
+__global__ __launch_bounds__(256) void dswx_shadow_v1(const ShadowArgs a) {
+    const long long ow = a.width - 2 * a.margin, oh = a.height - 2 * a.margin;
+    const long long ox = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const long long oy = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= ow || oy >= oh) return;
+    const long long x = ox + a.margin, y = oy + a.margin, W = a.width, H = a.height;
+    const float* d = a.dem + (long long)blockIdx.z * H * W;
+    // np.gradient, edge_order 1, unit spacing: central differences inside,
+    // one-sided at the borders
+    float gx, gy;
+    if (x == 0) gx = d[y * W + 1] - d[y * W];
+    else if (x == W - 1) gx = d[y * W + x] - d[y * W + x - 1];
+    else gx = (d[y * W + x + 1] - d[y * W + x - 1]) / 2.0f;
+    if (y == 0) gy = d[W + x] - d[x];
+    else if (y == H - 1) gy = d[y * W + x] - d[(y - 1) * W + x];
+    else gy = (d[(y + 1) * W + x] - d[(y - 1) * W + x]) / 2.0f;
+    const float n0 = -gx / a.spacing_x;
+    const float n1 = -gy / a.neg_abs_spacing_y;
+    const float norm = sqrtf(n0 * n0 + n1 * n1 + 1.0f);
+    const double dot = (double)n0 * a.sun[0] + (double)n1 * a.sun[1] + a.sun[2];
+    const double RAD2DEG = 180.0 / 3.141592653589793238462643383279502884;
+    const double inc_deg = acos(dot / (double)norm) * RAD2DEG;
+    const double slope_deg = atan((double)n0 * a.sin_az + (double)n1 * a.cos_az) * RAD2DEG;
+    const bool backslope = slope_deg <= a.min_slope_angle;
+    const bool low_inc = inc_deg <= a.max_sun_local_inc_angle;
+    a.shadow[(long long)blockIdx.z * oh * ow + oy * ow + ox] = (low_inc | !backslope) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------
 // Debug planes: float64 MNDWI / NDVI / AWESH exactly as :1872-1887 (true IEEE
 // division; int16 wrap-around sums).  Not on the timed path.
 // ------------------------------------------------------------------------------
@@ -1501,6 +1551,77 @@ int dswx_interpret_layer_host(dswx_ctx_t* ctx, const int64_t* diag_decimal, int6
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(DSWX_ERR_HIP, "dswx_interpret_layer_host: %s", hipGetErrorString(e));
+    return DSWX_OK;
+}
+
+static int shadow_args(ShadowArgs* a, int64_t height, int64_t width, int64_t margin, const double sun_vector[3],
+                       double sin_azimuth, double cos_azimuth, double min_slope_angle,
+                       double max_sun_local_inc_angle, double pixel_spacing_x, double pixel_spacing_y) {
+    if (!sun_vector) return fail(DSWX_ERR_ARG, "sun_vector is NULL");
+    if (height < 2 || width < 2)
+        return fail(DSWX_ERR_ARG, "Shape of array too small to calculate a numerical gradient, "
+                                  "at least 2 elements are required.");
+    if (margin < 0 || 2 * margin >= height || 2 * margin >= width) return fail(DSWX_ERR_ARG, "bad margin");
+    a->height = height; a->width = width; a->margin = margin;
+    a->spacing_x = (float)pixel_spacing_x;
+    a->neg_abs_spacing_y = (float)(-std::fabs(pixel_spacing_y));
+    for (int i = 0; i < 3; ++i) a->sun[i] = sun_vector[i];
+    a->sin_az = sin_azimuth; a->cos_az = cos_azimuth;
+    a->min_slope_angle = min_slope_angle; a->max_sun_local_inc_angle = max_sun_local_inc_angle;
+    return DSWX_OK;
+}
+
+int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
+                             int64_t margin, const double sun_vector[3], double sin_azimuth,
+                             double cos_azimuth, double min_slope_angle, double max_sun_local_inc_angle,
+                             double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream) {
+    if (!ctx || !dem || !shadow) return fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles < 0 || n_tiles > 65535) return fail(DSWX_ERR_ARG, "n_tiles out of range");
+    ShadowArgs a;
+    int rc = shadow_args(&a, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, min_slope_angle,
+                         max_sun_local_inc_angle, pixel_spacing_x, pixel_spacing_y);
+    if (rc) return rc;
+    if (n_tiles == 0) return DSWX_OK;
+    a.dem = dem; a.shadow = shadow;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const long long ow = width - 2 * margin, oh = height - 2 * margin;
+    dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
+    if (grid.y > 65535) return fail(DSWX_ERR_ARG, "raster too tall for one launch");
+    hipLaunchKernelGGL(dswx_shadow_v1, grid, block, 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
+                           const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                           double min_slope_angle, double max_sun_local_inc_angle, double pixel_spacing_x,
+                           double pixel_spacing_y, uint8_t* shadow) {
+    if (!ctx || !dem || !shadow) return fail(DSWX_ERR_ARG, "NULL argument");
+    ShadowArgs chk;
+    int rc = shadow_args(&chk, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, min_slope_angle,
+                         max_sun_local_inc_angle, pixel_spacing_x, pixel_spacing_y);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t in_bytes = (size_t)height * (size_t)width * 4;
+    const size_t out_px = (size_t)(height - 2 * margin) * (size_t)(width - 2 * margin);
+    void* d_dem = nullptr;
+    void* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_dem, in_bytes));
+    hipError_t e = hipMalloc(&d_out, out_px);
+    hipStream_t s = ctx->stream;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dem, dem, in_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        rc = dswx_shadow_layer_device(ctx, static_cast<const float*>(d_dem), 1, height, width, margin, sun_vector,
+                                      sin_azimuth, cos_azimuth, min_slope_angle, max_sun_local_inc_angle,
+                                      pixel_spacing_x, pixel_spacing_y, static_cast<uint8_t*>(d_out), s);
+        if (rc == DSWX_OK) e = hipMemcpyAsync(shadow, d_out, out_px, hipMemcpyDeviceToHost, s);
+        if (rc == DSWX_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(d_dem);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(DSWX_ERR_HIP, "dswx_shadow_layer_host: %s", hipGetErrorString(e));
     return DSWX_OK;
 }
 

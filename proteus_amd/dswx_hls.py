@@ -399,6 +399,36 @@ def generate_interpreted_layer(diagnostic_layer):
     return get_context().interpret_layer(np.asarray(diagnostic_layer))
 
 
+DEM_MARGIN_IN_PIXELS = 50                 # :58
+
+
+def _compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
+                                min_slope_angle, max_sun_local_inc_angle,
+                                pixel_spacing_x=30, pixel_spacing_y=30, margin=0):
+    """Terrain shadow mask from sun local-incidence and back-slope angles on the GPU
+    (:4215-4283); True = not shadow, False = shadow, same shape as `dem` (or cropped by
+    `margin` on all sides, fusing _crop_2d_array_all_sides :4320).  The five float64 sun
+    scalars are formed here with numpy exactly as the reference forms them (:4246-4253,
+    :4276-4277) and handed to the kernel."""
+    sun_azimuth = np.radians(sun_azimuth_angle)
+    sun_zenith = np.radians(90 - sun_elevation_angle)
+    target_to_sun_unit_vector = [np.sin(sun_azimuth) * np.sin(sun_zenith),
+                                 np.cos(sun_azimuth) * np.sin(sun_zenith),
+                                 np.cos(sun_zenith)]
+    dem = np.asarray(dem)
+    if dem.ndim != 2 or min(dem.shape) < 2:
+        raise ValueError('Shape of array too small to calculate a numerical gradient, '
+                         'at least 2 elements are required.')
+    return get_context().shadow_layer(
+        dem, target_to_sun_unit_vector, np.sin(sun_azimuth), np.cos(sun_azimuth),
+        min_slope_angle, max_sun_local_inc_angle, pixel_spacing_x, pixel_spacing_y,
+        margin=margin)
+
+
+def _crop_2d_array_all_sides(input_2d_array, margin):
+    return input_2d_array[margin:-margin, margin:-margin]
+
+
 # -----------------------------------------------------------------------------------
 # HLS loading (:2136-2425), GDAL-free
 # -----------------------------------------------------------------------------------

@@ -107,3 +107,20 @@ def synth_tile(tile, height, width, seed=SEED, with_masks=False):
                shad=shad.reshape(height, width),
                ocean=ocean.reshape(height, width))
     return out
+
+
+def synth_dem(tile, height, width, seed=SEED):
+    """Deterministic float32 DEM [height, width] in metres: a few sinusoidal ridges
+    (slopes up to ~35 degrees at 30 m spacing), a flat lake and +-1.5 m of hash noise,
+    so that both shadow tests and their thresholds are exercised."""
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    rng_phase = [((seed * 7919 + tile * 104729 + k * 1299709) % 6283) / 1000.0 for k in range(4)]
+    z = (420.0 * np.sin(xx / 37.0 + rng_phase[0]) * np.cos(yy / 53.0 + rng_phase[1]) +
+         180.0 * np.sin((xx + 2.0 * yy) / 19.0 + rng_phase[2]) +
+         60.0 * np.cos((3.0 * xx - yy) / 11.0 + rng_phase[3]) + 900.0)
+    z = np.where(z < 650.0, 650.0, z)                       # a flat "lake"
+    pix = (yy * width + xx).astype(np.uint64)
+    with np.errstate(over='ignore'):
+        h = _mix(_U64(seed) * _U64(K1) + _U64(tile) * _U64(K0) + pix)
+    noise = (_field(h, 0, 12).astype(np.float64) / 4096.0 - 0.5) * 3.0
+    return (z + noise).astype(np.float32)

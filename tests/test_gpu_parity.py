@@ -408,3 +408,35 @@ def test_cover_mode_device_batch(ctx):
         for layer, key in NAME.items():
             assert np.array_equal(batch.read_tile(key, t), exp[layer]), (layer, t)
     batch.free()
+
+
+# ---- terrain shadow layer --------------------------------------------
+@pytest.mark.parametrize('name', ['s_default', 's_low_sun', 's_noon_north',
+                                  's_other_thresholds', 's_thin'])
+def test_shadow_layer_golden(ctx, name):
+    """Against the reference's own output (numpy 2.x promotion).  The float32 part is
+    bit-exact by construction; arccos/arctan are float64 on both sides and only a pixel
+    whose angle sits within an ulp or two of the threshold could differ: none does."""
+    from proteus_amd import dswx_hls as D
+    z = G.load(f'shadow_{name}.npz')
+    args = (float(z['az']), float(z['el']), float(z['mn']), float(z['mx']))
+    full = D._compute_opera_shadow_layer(z['dem'], *args)
+    assert full.dtype == np.bool_ and full.shape == z['dem'].shape
+    assert np.array_equal(full, z['full'])
+    m = int(z['margin'])
+    assert np.array_equal(D._compute_opera_shadow_layer(z['dem'], *args, margin=m), z['cropped'])
+    assert np.array_equal(D._crop_2d_array_all_sides(full, m), z['cropped'])
+
+
+def test_shadow_layer_full_size(ctx):
+    """2100 x 2100 DEM (50 px margin each side) vs the numpy oracle;
+    mismatch budget 1e-6 of the pixels for the float64 transcendental last-ulp cases."""
+    from proteus_amd import dswx_hls as D
+    from proteus_amd.synth import synth_dem
+    dem = synth_dem(7, 2100, 2100)
+    got = D._compute_opera_shadow_layer(dem, 143.2, 55.5, -5, 40, margin=50)
+    exp = o.crop_2d_array_all_sides(o.compute_opera_shadow_layer(dem, 143.2, 55.5, -5, 40), 50)
+    assert got.shape == (2000, 2000)
+    assert np.count_nonzero(got != exp) <= 1e-6 * got.size
+    with pytest.raises(ValueError, match='too small'):
+        D._compute_opera_shadow_layer(np.zeros((1, 5), np.float32), 10, 10, -5, 40)

@@ -137,3 +137,18 @@ def test_tile_chain(name):
                cnt['SPATIAL_COVERAGE'], cnt['CLOUD_COVERAGE'],
                cnt['SPATIAL_COVERAGE_EXCLUDING_MASKED_OCEAN']]
         assert got == c['expected']['counters'].tolist()
+
+
+SHADOW_CASES = ['s_default', 's_low_sun', 's_noon_north', 's_other_thresholds', 's_thin']
+
+
+@pytest.mark.parametrize('name', SHADOW_CASES)
+def test_shadow_layer(name):
+    z = G.load(f'shadow_{name}.npz')
+    if str(z['numpy_version']).split('.')[0] != np.__version__.split('.')[0]:
+        pytest.skip('golden made with a numpy of another promotion regime')
+    full = o.compute_opera_shadow_layer(z['dem'], float(z['az']), float(z['el']),
+                                        float(z['mn']), float(z['mx']))
+    assert full.dtype == np.bool_ and np.array_equal(full, z['full'])
+    assert np.array_equal(o.crop_2d_array_all_sides(full, int(z['margin'])), z['cropped'])
+    assert 0.05 < z['cropped'].mean() < 0.95        # both classes present
