@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DSWX_ABI_VERSION 1
+#define DSWX_ABI_VERSION 2
 
 enum {
     DSWX_OK = 0,
@@ -58,6 +58,9 @@ enum { DSWX_N_VALID = 0, DSWX_N_CLOUD_AND_VALID = 1, DSWX_N_NOT_OCEAN = 2,
  *  - collapse_wtr_classes: FLAG_COLLAPSE_WTR_CLASSES (:26); when set, WTR, WTR-1,
  *    WTR-1-AEROSOL and WTR-2 leave in the collapsed form the reference SAVES
  *    (_collapse_wtr_classes :2578-2598, applied at :2688-2689).
+ *  - browse_*: the keyword arguments of _compute_browse_array (:3057-3064); the browse
+ *    layer is derived from the UNCOLLAPSED WTR (PSW-aggressive is dropped before the
+ *    collapse, :3112-3119), which only exists inside the kernel.
  */
 typedef struct dswx_params {
     double wigt, awgt, pswt_1_mndwi, pswt_1_nir, pswt_1_swir1, pswt_1_ndvi,
@@ -70,6 +73,13 @@ typedef struct dswx_params {
     int32_t mask_adjacent_to_cloud_mode;
     int32_t apply_aerosol_class_remapping;
     int32_t collapse_wtr_classes;
+    /* browse layer, _compute_browse_array :3057-3129 (only read when out->browse != NULL) */
+    int32_t browse_exclude_psw_aggressive;
+    int32_t browse_not_water_to_nodata;
+    int32_t browse_cloud_to_nodata;
+    int32_t browse_snow_to_nodata;
+    int32_t browse_ocean_masked_to_nodata;
+    int32_t reserved_;
     uint8_t aerosol_fmask_lut[4][256];
 } dswx_params_t;
 
@@ -94,6 +104,7 @@ typedef struct dswx_planes_in {
  *   bwtr          _get_binary_water_layer                       (:5358)
  *   conf          _get_confidence_layer                         (:5368)
  *   cloud         _add_snow_to_cloud_layer                      (:5282)
+ *   browse        _compute_browse_array on WTR                  (:5309-5316)
  *   mndwi/ndvi/awesh  float64 spectral indices (:1872-1887); debug planes, they
  *                 select a slower kernel variant.                                   */
 typedef struct dswx_planes_out {
@@ -105,6 +116,7 @@ typedef struct dswx_planes_out {
     uint8_t* bwtr;
     uint8_t* conf;
     uint8_t* cloud;
+    uint8_t* browse;
     double* mndwi;
     double* ndvi;
     double* awesh;
@@ -178,6 +190,19 @@ int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles,
                              double min_slope_angle, double max_sun_local_inc_angle,
                              double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow,
                              void* stream);
+
+/* LAND layer, the per-pixel part of create_landcover_mask (dswx_hls.py:994-1115) after
+ * the two GDAL warps: `worldcover_up3` is the ESA WorldCover map on the 3x finer grid
+ * (uint8 [3*height][3*width]), `copernicus` the CGLS-100m map on the HLS grid (uint8
+ * [height][width]).  3x3 sums of WorldCover {80,90,95} (water), 50 (urban), 10 (tree,
+ * only where the CGLS class is one of `forest_classes`) -- decimate_by_summation
+ * :874-904 -- then the hierarchy of :1058-1103 with `thresholds` = [evergreen,
+ * low-intensity developed, high-intensity developed, water] (landcover_threshold_dict
+ * :270-271) and year_offset = WorldCover year - 2000.  land: uint8 [height][width]. */
+int dswx_landcover_mask_host(dswx_ctx_t* ctx, const uint8_t* worldcover_up3,
+                             const uint8_t* copernicus, int64_t height, int64_t width,
+                             const int32_t* forest_classes, int32_t n_forest_classes,
+                             const int32_t thresholds[4], int32_t year_offset, uint8_t* land);
 
 /* Deterministic synthetic HLS tiles written straight into HBM (SURVEY.md §8d;
  * same integer recipe as proteus_amd/synth.py).  Fills in->band[0..5], in->fmask

@@ -145,6 +145,14 @@ int oracle_classify(const dswx_params_t* p, int64_t n, const dswx_planes_in_t* i
                            cl == 11 || cl == 12 || cl == 13 || cl == 14 || cl == 15;
         if (cf <= 4 && cloudy) cf = (uint8_t)(cf + 10);
         if (cf <= 4 && cl == 2) cf = (uint8_t)(cf + 20);
+        /* _compute_browse_array :3110-3128 on the uncollapsed WTR */
+        uint8_t br = w;
+        if (p->browse_exclude_psw_aggressive && br == 4) br = 0;
+        if (p->collapse_wtr_classes) br = collapse(br);
+        if (p->browse_not_water_to_nodata && br == 0) br = 255;
+        if (p->browse_cloud_to_nodata && br == 253) br = 255;
+        if (p->browse_snow_to_nodata && br == 252) br = 255;
+        if (p->browse_ocean_masked_to_nodata && br == 254) br = 255;
         if (p->collapse_wtr_classes) {
             w1 = collapse(w1); w1a = collapse(w1a); w2 = collapse(w2); w = collapse(w);
         }
@@ -156,6 +164,7 @@ int oracle_classify(const dswx_params_t* p, int64_t n, const dswx_planes_in_t* i
         if (out->bwtr) out->bwtr[i] = bw;
         if (out->conf) out->conf[i] = cf;
         if (out->cloud) out->cloud[i] = cl;
+        if (out->browse) out->browse[i] = br;
         if (out->mndwi) out->mndwi[i] = mndwi;
         if (out->ndvi) out->ndvi[i] = ndvi;
         if (out->awesh) out->awesh[i] = awesh;

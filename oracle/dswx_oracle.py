@@ -394,3 +394,66 @@ def compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
 
 def crop_2d_array_all_sides(arr, margin):
     return arr[margin:-margin, margin:-margin]
+
+
+# ---------------------------------------------------------------------------
+# f4  _compute_browse_array :3057-3129 (input: the UNCOLLAPSED WTR layer)
+# ---------------------------------------------------------------------------
+def compute_browse_array(wtr_uncollapsed, flag_collapse_wtr_classes=True,
+                         exclude_psw_aggressive=False, set_not_water_to_nodata=False,
+                         set_cloud_to_nodata=False, set_snow_to_nodata=False,
+                         set_ocean_masked_to_nodata=True):
+    out = wtr_uncollapsed.copy()
+    if exclude_psw_aggressive:
+        out[out == 4] = 0
+    if flag_collapse_wtr_classes:
+        out = collapse_wtr_classes(out)
+    if set_not_water_to_nodata:
+        out[out == 0] = FILL_U8
+    if set_cloud_to_nodata:
+        out[out == WTR_CLOUD] = FILL_U8
+    if set_snow_to_nodata:
+        out[out == WTR_SNOW] = FILL_U8
+    if set_ocean_masked_to_nodata:
+        out[out == WTR_OCEAN] = FILL_U8
+    return out
+
+
+# ---------------------------------------------------------------------------
+# f3  create_landcover_mask :994-1115 after the GDAL warps; decimate_by_summation :874-904
+# ---------------------------------------------------------------------------
+LANDCOVER_THRESHOLDS = {'standard': [6, 3, 7, 3], 'water heavy': [6, 3, 7, 1]}   # :270-271
+
+
+def decimate_by_summation(image, size_y, size_x):
+    out = None
+    for i in range(size_y):
+        for j in range(size_x):
+            part = image[i::size_y, j::size_x]
+            if out is None:
+                cur = np.copy(part)
+                out = np.zeros_like(cur)
+            else:
+                cur[0:part.shape[0], 0:part.shape[1]] = part
+            out += cur
+    return out
+
+
+def landcover_mask_from_warped(worldcover_up3, copernicus, forest_classes, mask_type='standard',
+                               year=2000):
+    water = decimate_by_summation(np.isin(worldcover_up3, [80, 90, 95]).astype(np.uint8), 3, 3)
+    urban = decimate_by_summation((worldcover_up3 == 50).astype(np.uint8), 3, 3)
+    tree = decimate_by_summation((worldcover_up3 == 10).astype(np.uint8), 3, 3)
+    forest = np.zeros_like(tree, dtype=np.uint8)
+    if forest_classes is not None:
+        for c in forest_classes:
+            forest |= (copernicus == c)
+    tree = np.where(forest, tree, 0)
+    land = np.full(water.shape, FILL_U8, dtype=np.uint8)
+    thr = LANDCOVER_THRESHOLDS[mask_type.lower()]
+    off = year - 2000
+    land[tree >= thr[0]] = LAND_EVERGREEN
+    land[urban >= thr[1]] = LAND_LOW_DEV0 + off
+    land[urban >= thr[2]] = LAND_HIGH_DEV0 + off
+    land[water >= thr[3]] = LAND_WATER
+    return land

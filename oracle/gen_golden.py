@@ -363,13 +363,69 @@ def gen_shadow(ref):
         print('shadow', case['name'], full.dtype, float(full.mean()))
 
 
+def gen_browse(ref):
+    codes = np.arange(256, dtype=np.uint8).reshape(1, -1)
+    out = {'codes': codes}
+    for mask in range(32):
+        collapse, excl, nw, cl, sn = [(mask >> k) & 1 == 1 for k in range(5)]
+        for ocean in (True, False):
+            key = f'b_{int(collapse)}{int(excl)}{int(nw)}{int(cl)}{int(sn)}{int(ocean)}'
+            out[key] = ref._compute_browse_array(
+                codes, flag_collapse_wtr_classes=collapse, exclude_psw_aggressive=excl,
+                set_not_water_to_nodata=nw, set_cloud_to_nodata=cl, set_snow_to_nodata=sn,
+                set_ocean_masked_to_nodata=ocean)
+    np.savez_compressed(os.path.join(GOLDEN, 'browse_tables.npz'), **out)
+    print('browse_tables.npz', len(out) - 1, 'option sets')
+
+
+LAND_CASES = [dict(name='l_standard', tile=0, H=90, W=120, year=2021, kind='standard'),
+              dict(name='l_water_heavy', tile=1, H=64, W=64, year=2020, kind='water heavy'),
+              dict(name='l_no_forest', tile=2, H=50, W=70, year=2000, kind='standard', forest=[]),
+              dict(name='l_odd', tile=3, H=33, W=41, year=2099, kind='standard')]
+DEFAULT_FOREST = [20, 50, 111, 113, 115, 116, 121, 123, 125, 126]
+
+
+def gen_landcover(ref):
+    """Replays create_landcover_mask :994-1115 on already-warped arrays with the
+    reference's own helpers (the two gdal.Warp calls are the part that cannot run here)."""
+    from proteus_amd.synth import synth_landcover_inputs
+    cls = ref.dswx_hls_landcover_classes_dict
+    for case in LAND_CASES:
+        wc, cg = synth_landcover_inputs(case['tile'], case['H'], case['W'])
+        forest_classes = case.get('forest', DEFAULT_FOREST)
+        water = ref.decimate_by_summation(np.isin(wc, [80, 90, 95]).astype(np.uint8), 3, 3)
+        urban = ref.decimate_by_summation((wc == 50).astype(np.uint8), 3, 3)
+        tree = ref.decimate_by_summation((wc == 10).astype(np.uint8), 3, 3)
+        forest = np.zeros_like(tree, dtype=np.uint8)
+        for c in forest_classes:
+            forest |= (cg == c)
+        tree = np.where(forest, tree, 0)
+        land = np.full(water.shape, cls['fill_value'], dtype=np.uint8)
+        thr = ref.landcover_threshold_dict[case['kind']]
+        off = case['year'] - 2000
+        ref._update_landcover_array(land, tree, thr[0], cls['evergreen_forest'])
+        ref._update_landcover_array(land, urban, thr[1], cls['low_intensity_developed_offset'] + off)
+        ref._update_landcover_array(land, urban, thr[2], cls['high_intensity_developed_offset'] + off)
+        ref._update_landcover_array(land, water, thr[3], cls['water'])
+        np.savez_compressed(os.path.join(GOLDEN, f"land_{case['name']}.npz"), worldcover_up3=wc,
+                            copernicus=cg, forest_classes=np.array(forest_classes, dtype=np.int32),
+                            thresholds=np.array(thr, dtype=np.int32), year=np.array(case['year']),
+                            kind=np.array(case['kind']), land=land)
+        u, c = np.unique(land, return_counts=True)
+        print('land', case['name'], dict(zip(u.tolist(), c.tolist())))
+
+
 def main():
     ref = import_reference()
     if ref is None:
         raise SystemExit('reference tree not present; goldens can only be '
                          'regenerated in the build container')
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ['tables', 'diag', 'tiles', 'shadow']
+    which = sys.argv[1:] or ['tables', 'diag', 'tiles', 'shadow', 'browse', 'land']
+    if 'browse' in which:
+        gen_browse(ref)
+    if 'land' in which:
+        gen_landcover(ref)
     if 'tables' in which:
         gen_tables(ref)
     if 'diag' in which:

@@ -10,20 +10,20 @@ import numpy as np
 
 from . import build as _build
 
-DSWX_ABI_VERSION = 1
+DSWX_ABI_VERSION = 2
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALIGN = 0, -1, -2, -3, -4, -5
 ADJ_MODES = {'mask': 0, 'ignore': 1, 'cover': 2}
 BAND_NAMES = ('blue', 'green', 'red', 'nir', 'swir1', 'swir2')
 THRESHOLD_NAMES = ('wigt', 'awgt', 'pswt_1_mndwi', 'pswt_1_nir', 'pswt_1_swir1',
                    'pswt_1_ndvi', 'pswt_2_mndwi', 'pswt_2_blue', 'pswt_2_nir',
                    'pswt_2_swir1', 'pswt_2_swir2', 'lcmask_nir')
-U8_LAYERS = ('wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud')
+U8_LAYERS = ('wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud', 'browse')
 F64_LAYERS = ('mndwi', 'ndvi', 'awesh')
 # every symbol include/dswx_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = (
     'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
-    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device',
+    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device', 'dswx_landcover_mask_host',
     'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
@@ -45,6 +45,12 @@ class Params(ctypes.Structure):
                  ('mask_adjacent_to_cloud_mode', ctypes.c_int32),
                  ('apply_aerosol_class_remapping', ctypes.c_int32),
                  ('collapse_wtr_classes', ctypes.c_int32),
+                 ('browse_exclude_psw_aggressive', ctypes.c_int32),
+                 ('browse_not_water_to_nodata', ctypes.c_int32),
+                 ('browse_cloud_to_nodata', ctypes.c_int32),
+                 ('browse_snow_to_nodata', ctypes.c_int32),
+                 ('browse_ocean_masked_to_nodata', ctypes.c_int32),
+                 ('reserved_', ctypes.c_int32),
                  ('aerosol_fmask_lut', (ctypes.c_uint8 * 256) * 4)])
 
 
@@ -103,6 +109,8 @@ def load_library():
         'dswx_shadow_layer_device': (ctypes.c_int, [vp, vp, i64, i64, i64, i64,
                                                     ctypes.POINTER(ctypes.c_double * 3)] +
                                      [ctypes.c_double] * 6 + [vp, vp]),
+        'dswx_landcover_mask_host': (ctypes.c_int, [vp, vp, vp, i64, i64, vp, ctypes.c_int32, vp,
+                                                    ctypes.c_int32, vp]),
         'dswx_stream_probe': (ctypes.c_int, [vp, i64, i64, ctypes.POINTER(PlanesIn),
                                              ctypes.POINTER(PlanesOut), ctypes.c_int, vp]),
         'dswx_synth_fill': (ctypes.c_int, [vp, ctypes.c_uint64, i64, i64, i64, i64,
@@ -148,7 +156,10 @@ def default_params():
 def make_params(thresholds=None, *, band_fills=None, fmask_fill=255.0,
                 clip_negative_reflectance=True, mask_adjacent_to_cloud_mode='mask',
                 apply_aerosol_class_remapping=True, aerosol_fmask_values=None,
-                collapse_wtr_classes=True, aerosol_max_nir=None):
+                collapse_wtr_classes=True, aerosol_max_nir=None,
+                exclude_psw_aggressive_in_browse=True, not_water_in_browse='white',
+                cloud_in_browse='gray', snow_in_browse='cyan',
+                set_ocean_masked_to_nodata=True):
     """Build a dswx_params_t.
 
     thresholds: object with the HlsThresholds attributes, or dict, or None
@@ -177,6 +188,12 @@ def make_params(thresholds=None, *, band_fills=None, fmask_fill=255.0,
     p.collapse_wtr_classes = int(bool(collapse_wtr_classes))
     if aerosol_max_nir is not None:
         p.aerosol_max_nir = float(aerosol_max_nir)
+    # browse options as generate_dswx_layers maps them (dswx_hls.py:5309-5316)
+    p.browse_exclude_psw_aggressive = int(bool(exclude_psw_aggressive_in_browse))
+    p.browse_not_water_to_nodata = int(not_water_in_browse == 'nodata')
+    p.browse_cloud_to_nodata = int(cloud_in_browse == 'nodata')
+    p.browse_snow_to_nodata = int(snow_in_browse == 'nodata')
+    p.browse_ocean_masked_to_nodata = int(bool(set_ocean_masked_to_nodata))
     if aerosol_fmask_values is not None:
         for row, cls in enumerate((0, 2, 3, 4)):
             for v in range(256):
@@ -338,6 +355,23 @@ class Context:
             float(max_sun_local_inc_angle), float(pixel_spacing_x), float(pixel_spacing_y),
             _host_ptr(out)))
         return out.astype(bool)
+
+    def landcover_mask(self, worldcover_up3, copernicus, forest_classes, thresholds=(6, 3, 7, 3),
+                       year_offset=0):
+        """LAND layer from the warped WorldCover (3x grid) and CGLS (HLS grid) maps."""
+        wc = np.ascontiguousarray(worldcover_up3, dtype=np.uint8)
+        cg = np.ascontiguousarray(copernicus, dtype=np.uint8)
+        h, w = cg.shape
+        if wc.shape != (3 * h, 3 * w):
+            raise ValueError(f'worldcover_up3 shape {wc.shape} != {(3 * h, 3 * w)}')
+        fc = np.ascontiguousarray(list(forest_classes or []), dtype=np.int32)
+        thr = np.ascontiguousarray(thresholds, dtype=np.int32)
+        out = np.empty((h, w), dtype=np.uint8)
+        _check(self.lib.dswx_landcover_mask_host(
+            self.handle, _host_ptr(wc), _host_ptr(cg), h, w,
+            _host_ptr(fc) if fc.size else None, int(fc.size), _host_ptr(thr), int(year_offset),
+            _host_ptr(out)))
+        return out
 
     def stream_probe(self, n_tiles, n_pixels, pin, pout, variant=0, stream=None):
         _check(self.lib.dswx_stream_probe(

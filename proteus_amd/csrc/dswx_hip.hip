@@ -63,6 +63,8 @@ struct DevParams {
     int32_t clip_min;       // reflectances are max()ed with this: 1, or -32768 (= no clip)
     int32_t shadow_bits;    // Fmask bits raising CLOUD bit 0: 8, or 8|4 in 'mask' mode
     int32_t collapse;       // 0 / 1, used as a shift count
+    uint32_t browse_lut[3]; // byte k: browse value of the k-th uncollapsed WTR code
+                            // (0,1,2,3,4,252,253,254,255), _compute_browse_array :3057-3129
     uint32_t aer_lut[64];   // byte v: bit c set <=> Fmask v remaps WTR-1 class c
                             // (all zero when aerosol remapping is disabled)
 };
@@ -105,6 +107,7 @@ static constexpr uint32_t CLS_B2 = class_bit_mask(2);
 struct PxOut {
     uint32_t diag, wtr1, wtr1a, wtr2, wtr, bwtr, conf, cloud;
     uint32_t w2_raw, pc;   // uncollapsed WTR-2 and pre-snow CLOUD ('cover' stage 1)
+    uint32_t browse;       // _compute_browse_array of the uncollapsed WTR
 };
 
 // fl64(n/d) > t, see the header comment
@@ -127,7 +130,8 @@ __device__ __forceinline__ uint32_t collapse_class(uint32_t v, uint32_t c) {
 // A11-A15 of one pixel, given the uncollapsed WTR-2 class, the CLOUD value before the
 // snow bit (A2 + A9) and the snow decision (Fmask bit 4, or the dilated snow mask in
 // 'cover' mode).
-__device__ __forceinline__ void finish_px(uint32_t cc, uint32_t w2, uint32_t pc, bool snow, PxOut& o) {
+__device__ __forceinline__ void finish_px(const DevParams& P, uint32_t w2, uint32_t pc, bool snow, PxOut& o) {
+    const uint32_t cc = (uint32_t)P.collapse;
     // A11
     uint32_t cl = pc + (snow ? 2u : 0u);
     cl = (w2 == 255u) ? 255u : cl;
@@ -146,6 +150,10 @@ __device__ __forceinline__ void finish_px(uint32_t cc, uint32_t w2, uint32_t pc,
     // A15
     o.wtr2 = collapse_class(w2, cc); o.wtr = collapse_class(w, cc);
     o.bwtr = bw; o.conf = cf; o.cloud = cl;
+    // browse layer: nine-entry byte table indexed by the rank of the WTR code
+    const uint32_t bi = w <= 4u ? w : 5u + (w & 3u);            // 252..255 -> 5..8
+    const uint32_t word = bi < 4u ? P.browse_lut[0] : (bi < 8u ? P.browse_lut[1] : P.browse_lut[2]);
+    o.browse = (word >> (8u * (bi & 3u))) & 0xffu;
 }
 
 // One pixel through the whole chain.  b..s2 are the RAW values (sign-extended),
@@ -212,7 +220,7 @@ __device__ __forceinline__ void classify_px(const DevParams& P, uint32_t aer_bit
     const uint32_t cc = (uint32_t)P.collapse;
     o.wtr1 = collapse_class(w1, cc); o.wtr1a = collapse_class(w1a, cc);
     o.w2_raw = w2; o.pc = pc;
-    finish_px(cc, w2, pc, (fm & 16) != 0, o);
+    finish_px(P, w2, pc, (fm & 16) != 0, o);
 }
 
 template <typename T, bool NT> __device__ __forceinline__ T ldg(const void* p) {
@@ -257,8 +265,11 @@ __device__ __forceinline__ void reduce_counters(unsigned long long* __restrict__
 // registers, all non-temporal.  grid.y = tile.  Measured 5.1 TB/s (64 tiles); the
 // trivial-math probe of the same access shape reaches 5.3 TB/s.
 // ------------------------------------------------------------------------------
-template <bool MASKS>
-__global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
+// EXTRAS: also produce the browse plane and the two scratch planes of 'cover' stage 1
+// (kept out of the default instantiation so that its register and instruction budget
+// is untouched)
+template <bool MASKS, bool EXTRAS, int WPS = 4>
+__global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
     const DevParams& P = a.P;
     // aerosol table: 256 bytes = one dword per lane of a wave, looked up with
     // ds_bpermute (no LDS storage, no barrier)
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
         }
         uint32_t q_diag[4] = {0, 0, 0, 0};
         uint32_t q_w1[2] = {0, 0}, q_w1a[2] = {0, 0}, q_w2[2] = {0, 0}, q_w[2] = {0, 0},
-                 q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0}, q_w2r[2] = {0, 0}, q_pc[2] = {0, 0};
+                 q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0}, q_w2r[2] = {0, 0}, q_pc[2] = {0, 0}, q_br[2] = {0, 0};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int wd = j >> 1, hf = j & 1;
@@ -321,8 +332,11 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
             q_bw[bw] |= o.bwtr << (8 * bk);
             q_cf[bw] |= o.conf << (8 * bk);
             q_cl[bw] |= o.cloud << (8 * bk);
-            q_w2r[bw] |= o.w2_raw << (8 * bk);
-            q_pc[bw] |= o.pc << (8 * bk);
+            if (EXTRAS) {
+                q_w2r[bw] |= o.w2_raw << (8 * bk);
+                q_pc[bw] |= o.pc << (8 * bk);
+                q_br[bw] |= o.browse << (8 * bk);
+            }
         }
         if (in_range) {
         if (a.out.diag) stg<u32x4, true>(a.out.diag + off, u32x4{q_diag[0], q_diag[1], q_diag[2], q_diag[3]});
@@ -333,7 +347,8 @@ __global__ __launch_bounds__(256, 4) void dswx_classify_v8(const KArgs a) {
         if (a.out.bwtr) stg<u32x2, true>(a.out.bwtr + off, u32x2{q_bw[0], q_bw[1]});
         if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{q_cf[0], q_cf[1]});
         if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{q_cl[0], q_cl[1]});
-        if (a.cover_w2) {   // 'cover' stage 1 (wave-uniform)
+        if (EXTRAS && a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{q_br[0], q_br[1]});
+        if (EXTRAS && a.cover_w2) {   // 'cover' stage 1 (wave-uniform)
             *reinterpret_cast<u32x2*>(a.cover_w2 + off) = u32x2{q_w2r[0], q_w2r[1]};
             *reinterpret_cast<u32x2*>(a.cover_pc + off) = u32x2{q_pc[0], q_pc[1]};
         }
@@ -554,7 +569,6 @@ __global__ __launch_bounds__(256) void dswx_cover_stage2(const KArgs a) {
     { uint8_t* t = src; src = dst; dst = t; }
     for (int it = 0; it < 7; ++it) dilate(CV_AREA | CV_WATER);
     // finish the interior 64 x 64
-    const uint32_t cc = (uint32_t)a.P.collapse;
     for (int i = threadIdx.x; i < CV_TILE * CV_TILE; i += 256) {
         const int ly = i / CV_TILE, lx = i % CV_TILE;
         const int y = blockIdx.y * CV_TILE + ly, x = blockIdx.x * CV_TILE + lx;
@@ -563,11 +577,12 @@ __global__ __launch_bounds__(256) void dswx_cover_stage2(const KArgs a) {
         const bool snow = (flags[c] & CV_SNOW) && !src[c];
         const long long off = tile_base + (long long)y * W + x;
         PxOut o;
-        finish_px(cc, a.cover_w2[off], a.cover_pc[off], snow, o);
+        finish_px(a.P, a.cover_w2[off], a.cover_pc[off], snow, o);
         if (a.out.wtr) a.out.wtr[off] = (uint8_t)o.wtr;
         if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)o.bwtr;
         if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
         if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
+        if (a.out.browse) a.out.browse[off] = (uint8_t)o.browse;
     }
 }
 
@@ -632,6 +647,7 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
         if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)o.bwtr;
         if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
         if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
+        if (a.out.browse) a.out.browse[off] = (uint8_t)o.browse;
         if (a.cover_w2) { a.cover_w2[off] = (uint8_t)o.w2_raw; a.cover_pc[off] = (uint8_t)o.pc; }
     }
     if (a.counters) reduce_counters(a.counters + (long long)blockIdx.y * 3, red, c0, c1, c2);
@@ -1001,6 +1017,47 @@ __global__ __launch_bounds__(256) void dswx_shadow_v1(const ShadowArgs a) {
 }
 
 // ------------------------------------------------------------------------------
+// LAND layer (row f3): the per-pixel part of create_landcover_mask :994-1115.
+// One thread per HLS pixel: 3x3 WorldCover block -> three counts -> class hierarchy.
+// ------------------------------------------------------------------------------
+struct LandArgs {
+    const uint8_t* wc3;      // [3H][3W]
+    const uint8_t* cgls;     // [H][W]
+    uint8_t* land;           // [H][W]
+    long long height, width;
+    uint32_t forest_bits[8]; // 256-bit set of CGLS forest classes
+    int thr_tree, thr_low, thr_high, thr_water;
+    int low_class, high_class;   // year_offset, 100 + year_offset (as uint8)
+};
+
+__global__ __launch_bounds__(256) void dswx_landcover_v1(const LandArgs a) {
+    const long long x = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const long long y = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.width || y >= a.height) return;
+    int water = 0, urban = 0, tree = 0;
+    const long long W3 = 3 * a.width;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint8_t* row = a.wc3 + (3 * y + i) * W3 + 3 * x;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int v = row[j];
+            water += (v == 80) | (v == 90) | (v == 95);
+            urban += v == 50;
+            tree += v == 10;
+        }
+    }
+    const int c = a.cgls[y * a.width + x];
+    if (!((a.forest_bits[c >> 5] >> (c & 31)) & 1u)) tree = 0;
+    int v = 255;
+    if (tree >= a.thr_tree) v = 201;
+    if (urban >= a.thr_low) v = a.low_class;
+    if (urban >= a.thr_high) v = a.high_class;
+    if (water >= a.thr_water) v = 200;
+    a.land[y * a.width + x] = (uint8_t)v;
+}
+
+// ------------------------------------------------------------------------------
 // Debug planes: float64 MNDWI / NDVI / AWESH exactly as :1872-1887 (true IEEE
 // division; int16 wrap-around sums).  Not on the timed path.
 // ------------------------------------------------------------------------------
@@ -1107,6 +1164,7 @@ struct dswx_ctx {
     size_t cover_bytes = 0;
     std::string last_kernel;
     int fused_variant = 0;   // 0: direct stores (default); 1: LDS-staged stores (env DSWX_FUSED_VARIANT)
+    int tune_wps = 6;        // launch-bound variant of the plain kernel (env DSWX_TUNE_WPS: 4, 6, 8)
 };
 
 static thread_local std::string g_err;
@@ -1200,6 +1258,19 @@ static int make_dev_params(const dswx_params_t* p, DevParams* d) {
     d->clip_min = p->clip_negative_reflectance ? 1 : -32768;
     d->shadow_bits = p->mask_adjacent_to_cloud_mode == DSWX_ADJ_MASK ? (8 | 4) : 8;
     d->collapse = p->collapse_wtr_classes ? 1 : 0;
+    {   // _compute_browse_array :3110-3128 applied to each possible uncollapsed WTR code
+        const int codes[9] = {0, 1, 2, 3, 4, 252, 253, 254, 255};
+        for (int k = 0; k < 9; ++k) {
+            int v = codes[k];
+            if (p->browse_exclude_psw_aggressive && v == 4) v = 0;
+            if (p->collapse_wtr_classes && v <= 4) v = (v + 1) >> 1;
+            if (p->browse_not_water_to_nodata && v == 0) v = 255;
+            if (p->browse_cloud_to_nodata && v == 253) v = 255;
+            if (p->browse_snow_to_nodata && v == 252) v = 255;
+            if (p->browse_ocean_masked_to_nodata && v == 254) v = 255;
+            d->browse_lut[k >> 2] |= (uint32_t)v << (8 * (k & 3));
+        }
+    }
     const int cls_of_row[4] = {0, 2, 3, 4};
     for (int v = 0; v < 256 && p->apply_aerosol_class_remapping; ++v) {
         uint32_t bits = 0;
@@ -1236,6 +1307,9 @@ int dswx_params_default(dswx_params_t* p) {
     p->mask_adjacent_to_cloud_mode = DSWX_ADJ_MASK;
     p->apply_aerosol_class_remapping = 1;
     p->collapse_wtr_classes = 1;
+    // defaults/dswx_hls.yaml:128-169 (browse_image_group) and :5316
+    p->browse_exclude_psw_aggressive = 1;
+    p->browse_ocean_masked_to_nodata = 1;
     const int l3[] = {224, 160, 96}, l5[] = {224, 192, 160, 128, 96};
     for (int v : l3) { p->aerosol_fmask_lut[0][v] = 1; p->aerosol_fmask_lut[1][v] = 1; }
     for (int v : l5) { p->aerosol_fmask_lut[2][v] = 1; p->aerosol_fmask_lut[3][v] = 1; }
@@ -1253,6 +1327,7 @@ int dswx_ctx_create(int device, dswx_ctx_t** out) {
     dswx_ctx* c = new dswx_ctx();
     c->device = device;
     if (const char* e = std::getenv("DSWX_FUSED_VARIANT")) c->fused_variant = std::atoi(e) == 1 ? 1 : 0;
+    if (const char* e = std::getenv("DSWX_TUNE_WPS")) c->tune_wps = std::atoi(e);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -1321,7 +1396,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         a.cover_w2 = static_cast<uint8_t*>(ctx->cover);
         a.cover_pc = a.cover_w2 + (size_t)n_tiles * (size_t)n_pixels;
         // stage 1 stops before the snow step: these four layers come from stage 2
-        a.out.wtr = a.out.bwtr = a.out.conf = a.out.cloud = nullptr;
+        a.out.wtr = a.out.bwtr = a.out.conf = a.out.cloud = a.out.browse = nullptr;
     }
 
     const bool any_index = out->mndwi || out->ndvi || out->awesh;
@@ -1332,7 +1407,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     vec_ok = vec_ok && aligned_to(in->fmask, 16) && (!in->land || aligned_to(in->land, 16)) &&
              (!in->shad || aligned_to(in->shad, 16)) && (!in->ocean || aligned_to(in->ocean, 16)) &&
              (!out->diag || aligned_to(out->diag, 16));
-    uint8_t* const u8outs[] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud};
+    uint8_t* const u8outs[] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud,
+                               out->browse};
     for (uint8_t* p : u8outs) vec_ok = vec_ok && (!p || aligned_to(p, 16));
 
     const int64_t max_y = 65535;
@@ -1354,6 +1430,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         if (b.out.bwtr) b.out.bwtr += shift;
         if (b.out.conf) b.out.conf += shift;
         if (b.out.cloud) b.out.cloud += shift;
+        if (b.out.browse) b.out.browse += shift;
         if (b.out.mndwi) b.out.mndwi += shift;
         if (b.out.ndvi) b.out.ndvi += shift;
         if (b.out.awesh) b.out.awesh += shift;
@@ -1363,7 +1440,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         b.partials = nullptr;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
         if (groups > 0) {
-            const bool staged = ctx->fused_variant == 1 && !cover;   // 'cover' stage 1 lives in the direct kernel
+            // 'cover' stage 1 and the browse plane live in the direct kernel only
+            const bool staged = ctx->fused_variant == 1 && !cover && !b.out.browse;
             const int threads = staged ? FUSED_THREADS : 256;
             const int64_t gx = (groups + threads - 1) / threads;
             const int waves = threads / 64;
@@ -1390,10 +1468,15 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
                 snprintf(info, sizeof info, "dswx_classify_fused<%s> (LDS-staged) grid=(%lld,%lld) block=%d lds=%d",
                          masks ? "true" : "false", (long long)gx, (long long)nt, FUSED_THREADS, STAGE_BYTES);
             } else {
-                if (masks) hipLaunchKernelGGL(dswx_classify_v8<true>, grid, block, 0, s, b);
-                else hipLaunchKernelGGL(dswx_classify_v8<false>, grid, block, 0, s, b);
-                snprintf(info, sizeof info, "dswx_classify_v8<%s> (fused, direct stores) grid=(%lld,%lld) block=256",
-                         masks ? "true" : "false", (long long)gx, (long long)nt);
+                const bool extras = b.out.browse || b.cover_w2;
+                if (masks && extras) hipLaunchKernelGGL((dswx_classify_v8<true, true>), grid, block, 0, s, b);
+                else if (masks) hipLaunchKernelGGL((dswx_classify_v8<true, false>), grid, block, 0, s, b);
+                else if (extras) hipLaunchKernelGGL((dswx_classify_v8<false, true>), grid, block, 0, s, b);
+                else if (ctx->tune_wps == 6) hipLaunchKernelGGL((dswx_classify_v8<false, false, 6>), grid, block, 0, s, b);
+                else if (ctx->tune_wps == 8) hipLaunchKernelGGL((dswx_classify_v8<false, false, 8>), grid, block, 0, s, b);
+                else hipLaunchKernelGGL((dswx_classify_v8<false, false, 4>), grid, block, 0, s, b);
+                snprintf(info, sizeof info, "dswx_classify_v8<%s,%s> (fused, direct stores) grid=(%lld,%lld) block=256",
+                         masks ? "true" : "false", extras ? "true" : "false", (long long)gx, (long long)nt);
             }
             HIP_TRY(hipGetLastError());
             if (b.counters) {
@@ -1420,7 +1503,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             if (c2.out.bwtr) c2.out.bwtr += shift;
             if (c2.out.conf) c2.out.conf += shift;
             if (c2.out.cloud) c2.out.cloud += shift;
-            if (c2.out.wtr || c2.out.bwtr || c2.out.conf || c2.out.cloud) {
+            if (c2.out.browse) c2.out.browse += shift;
+            if (c2.out.wtr || c2.out.bwtr || c2.out.conf || c2.out.cloud || c2.out.browse) {
                 dim3 grid((unsigned)((width + CV_TILE - 1) / CV_TILE), (unsigned)((height + CV_TILE - 1) / CV_TILE),
                           (unsigned)nt);
                 hipLaunchKernelGGL(dswx_cover_stage2, grid, dim3(256), 0, s, c2);
@@ -1482,9 +1566,10 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
     if (in->shad) { o_shad = off; off += rnd((size_t)P); }
     if (in->ocean) { o_ocean = off; off += rnd((size_t)P); }
     size_t o_diag = off; if (out->diag) off += rnd((size_t)P * 2);
-    uint8_t* const h_u8[7] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud};
-    size_t o_u8[7];
-    for (int i = 0; i < 7; ++i) { o_u8[i] = off; if (h_u8[i]) off += rnd((size_t)P); }
+    uint8_t* const h_u8[8] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud,
+                              out->browse};
+    size_t o_u8[8];
+    for (int i = 0; i < 8; ++i) { o_u8[i] = off; if (h_u8[i]) off += rnd((size_t)P); }
     double* const h_f64[3] = {out->mndwi, out->ndvi, out->awesh};
     size_t o_f64[3];
     for (int i = 0; i < 3; ++i) { o_f64[i] = off; if (h_f64[i]) off += rnd((size_t)P * 8); }
@@ -1511,15 +1596,16 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
         if (in->shad) { HIP_TRY(hipMemcpyAsync(base + o_shad, in->shad + sh, (size_t)P, hipMemcpyHostToDevice, s)); din.shad = reinterpret_cast<const uint8_t*>(base + o_shad); }
         if (in->ocean) { HIP_TRY(hipMemcpyAsync(base + o_ocean, in->ocean + sh, (size_t)P, hipMemcpyHostToDevice, s)); din.ocean = reinterpret_cast<const uint8_t*>(base + o_ocean); }
         if (out->diag) dout.diag = reinterpret_cast<uint16_t*>(base + o_diag);
-        uint8_t** const d_u8[7] = {&dout.wtr1, &dout.wtr1_aerosol, &dout.wtr2, &dout.wtr, &dout.bwtr, &dout.conf, &dout.cloud};
-        for (int i = 0; i < 7; ++i) if (h_u8[i]) *d_u8[i] = reinterpret_cast<uint8_t*>(base + o_u8[i]);
+        uint8_t** const d_u8[8] = {&dout.wtr1, &dout.wtr1_aerosol, &dout.wtr2, &dout.wtr, &dout.bwtr, &dout.conf, &dout.cloud,
+                                   &dout.browse};
+        for (int i = 0; i < 8; ++i) if (h_u8[i]) *d_u8[i] = reinterpret_cast<uint8_t*>(base + o_u8[i]);
         double** const d_f64[3] = {&dout.mndwi, &dout.ndvi, &dout.awesh};
         for (int i = 0; i < 3; ++i) if (h_f64[i]) *d_f64[i] = reinterpret_cast<double*>(base + o_f64[i]);
         int64_t* dcnt = counters ? reinterpret_cast<int64_t*>(base + o_cnt) : nullptr;
         int rc = dswx_classify_device_2d(ctx, params, 1, height, width, &din, &dout, dcnt, s);
         if (rc) return rc;
         if (out->diag) HIP_TRY(hipMemcpyAsync(out->diag + sh, dout.diag, (size_t)P * 2, hipMemcpyDeviceToHost, s));
-        for (int i = 0; i < 7; ++i)
+        for (int i = 0; i < 8; ++i)
             if (h_u8[i]) HIP_TRY(hipMemcpyAsync(h_u8[i] + sh, *d_u8[i], (size_t)P, hipMemcpyDeviceToHost, s));
         for (int i = 0; i < 3; ++i)
             if (h_f64[i]) HIP_TRY(hipMemcpyAsync(h_f64[i] + sh, *d_f64[i], (size_t)P * 8, hipMemcpyDeviceToHost, s));
@@ -1622,6 +1708,50 @@ int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, in
     if (d_out) (void)hipFree(d_out);
     if (rc) return rc;
     if (e != hipSuccess) return fail(DSWX_ERR_HIP, "dswx_shadow_layer_host: %s", hipGetErrorString(e));
+    return DSWX_OK;
+}
+
+int dswx_landcover_mask_host(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
+                             int64_t height, int64_t width, const int32_t* forest_classes,
+                             int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset,
+                             uint8_t* land) {
+    if (!ctx || !worldcover_up3 || !copernicus || !thresholds || !land) return fail(DSWX_ERR_ARG, "NULL argument");
+    if (height < 0 || width < 0 || n_forest_classes < 0 || (n_forest_classes > 0 && !forest_classes))
+        return fail(DSWX_ERR_ARG, "bad size");
+    if (height == 0 || width == 0) return DSWX_OK;
+    LandArgs a;
+    std::memset(&a, 0, sizeof a);
+    for (int i = 0; i < n_forest_classes; ++i) {
+        const int c = forest_classes[i];
+        if (c >= 0 && c <= 255) a.forest_bits[c >> 5] |= 1u << (c & 31);
+    }
+    a.thr_tree = thresholds[0]; a.thr_low = thresholds[1]; a.thr_high = thresholds[2]; a.thr_water = thresholds[3];
+    // numpy stores the class through a uint8 array: values wrap modulo 256
+    a.low_class = (int)(uint8_t)(0 + year_offset);
+    a.high_class = (int)(uint8_t)(100 + year_offset);
+    a.height = height; a.width = width;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)height * (size_t)width;
+    void* d_wc = nullptr; void* d_cg = nullptr; void* d_out = nullptr;
+    hipError_t e = hipMalloc(&d_wc, 9 * n);
+    if (e == hipSuccess) e = hipMalloc(&d_cg, n);
+    if (e == hipSuccess) e = hipMalloc(&d_out, n);
+    hipStream_t s = ctx->stream;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_wc, worldcover_up3, 9 * n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cg, copernicus, n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        a.wc3 = static_cast<const uint8_t*>(d_wc); a.cgls = static_cast<const uint8_t*>(d_cg);
+        a.land = static_cast<uint8_t*>(d_out);
+        dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4)), block(256);
+        hipLaunchKernelGGL(dswx_landcover_v1, grid, block, 0, s, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(land, d_out, n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d_wc) (void)hipFree(d_wc);
+    if (d_cg) (void)hipFree(d_cg);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(DSWX_ERR_HIP, "dswx_landcover_mask_host: %s", hipGetErrorString(e));
     return DSWX_OK;
 }
 

@@ -124,3 +124,28 @@ def synth_dem(tile, height, width, seed=SEED):
         h = _mix(_U64(seed) * _U64(K1) + _U64(tile) * _U64(K0) + pix)
     noise = (_field(h, 0, 12).astype(np.float64) / 4096.0 - 0.5) * 3.0
     return (z + noise).astype(np.float32)
+
+
+def synth_landcover_inputs(tile, height, width, seed=SEED):
+    """(worldcover_up3 [3H,3W] u8, copernicus [H,W] u8): patchy class maps so that the
+    3x3 counts cross every threshold of the LAND hierarchy."""
+    wc_classes = np.array([10, 10, 10, 20, 30, 40, 50, 50, 60, 80, 90, 95, 100, 10, 50, 80], np.uint8)
+    cg_classes = np.array([111, 113, 115, 116, 121, 123, 125, 126, 20, 50, 30, 40, 60, 80, 112, 200],
+                          np.uint8)
+
+    def hashed(h, w, cell, salt):
+        yy, xx = np.mgrid[0:h, 0:w]
+        key = ((yy // cell).astype(np.uint64) * _U64(40503) + (xx // cell).astype(np.uint64))
+        with np.errstate(over='ignore'):
+            hv = _mix(_U64(seed) * _U64(K0) + _U64(tile) * _U64(K1) + key + _U64(salt))
+            fine = _mix(hv + (yy.astype(np.uint64) * _U64(w) + xx.astype(np.uint64)) * _U64(K0))
+        return hv, fine
+
+    hv, fine = hashed(3 * height, 3 * width, 7, 11)
+    coarse_cls = wc_classes[_field(hv, 0, 4)]
+    noisy_cls = wc_classes[_field(fine, 8, 4)]
+    wc = np.where(_field(fine, 0, 3) < 3, noisy_cls, coarse_cls).astype(np.uint8)
+    hv, fine = hashed(height, width, 9, 23)
+    cg = np.where(_field(fine, 0, 3) < 1, cg_classes[_field(fine, 8, 4)],
+                  cg_classes[_field(hv, 0, 4)]).astype(np.uint8)
+    return wc, cg

@@ -49,10 +49,10 @@ def test_abi_version_and_defaults():
 
 
 def test_struct_layout_matches_header():
-    # sizeof(dswx_params_t): 12+6+1+1 doubles, 4 int32, 4*256 bytes
-    assert ctypes.sizeof(_capi.Params) == 20 * 8 + 4 * 4 + 1024
+    # sizeof(dswx_params_t): 12+6+1+1 doubles, 10 int32, 4*256 bytes
+    assert ctypes.sizeof(_capi.Params) == 20 * 8 + 10 * 4 + 1024
     assert ctypes.sizeof(_capi.PlanesIn) == 10 * 8
-    assert ctypes.sizeof(_capi.PlanesOut) == 11 * 8
+    assert ctypes.sizeof(_capi.PlanesOut) == 12 * 8
 
 
 def test_bad_mode_raises_like_reference():

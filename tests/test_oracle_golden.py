@@ -152,3 +152,22 @@ def test_shadow_layer(name):
     assert full.dtype == np.bool_ and np.array_equal(full, z['full'])
     assert np.array_equal(o.crop_2d_array_all_sides(full, int(z['margin'])), z['cropped'])
     assert 0.05 < z['cropped'].mean() < 0.95        # both classes present
+
+
+def test_browse_tables():
+    z = G.load('browse_tables.npz')
+    for key in z.files:
+        if not key.startswith('b_'):
+            continue
+        collapse, excl, nw, cl, sn, ocean = [c == '1' for c in key[2:]]
+        got = o.compute_browse_array(z['codes'], collapse, excl, nw, cl, sn, ocean)
+        assert np.array_equal(got, z[key]), key
+
+
+@pytest.mark.parametrize('name', ['l_standard', 'l_water_heavy', 'l_no_forest', 'l_odd'])
+def test_landcover_mask(name):
+    z = G.load(f'land_{name}.npz')
+    got = o.landcover_mask_from_warped(z['worldcover_up3'], z['copernicus'],
+                                       z['forest_classes'].tolist(), str(z['kind']), int(z['year']))
+    assert np.array_equal(got, z['land'])
+    assert o.LANDCOVER_THRESHOLDS[str(z['kind'])] == z['thresholds'].tolist()
