@@ -895,6 +895,36 @@ __global__ __launch_bounds__(256) void dswx_chunked_layout_probe_k(uint8_t* __re
     for (int k = 0; k < 6; ++k) stg<u32x2, NT>(base + (15LL + k) * CH + r, y + (uint32_t)k);
 }
 
+// Plane-specialised waves: block = 7 waves over a 4096-px chunk; wave k reads only input
+// plane k (8 KiB of an int16 plane, 4 KiB of Fmask) and then writes only output plane k
+// (8 KiB of DIAG, 4 KiB of a u8 layer).  Same bytes as the fused kernel; this is what a
+// warp-specialised loader / storer design would present to the memory system.
+template <bool NT>
+__global__ __launch_bounds__(448) void dswx_plane_per_wave_k(const KArgs a, long long total_px) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long px0 = (long long)blockIdx.x * 4096;
+    if (px0 + 4096 > total_px) return;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    if (wave < 6) {
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(a.in.band[wave]) + px0 * 2;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc ^= ldg<u32x4, NT>(src + q * 1024 + lane * 16);
+    } else {
+        const uint8_t* src = a.in.fmask + px0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc ^= ldg<u32x4, NT>(src + q * 1024 + lane * 16);
+    }
+    uint8_t* const planes[7] = {reinterpret_cast<uint8_t*>(a.out.diag), a.out.wtr1, a.out.wtr2, a.out.wtr,
+                                a.out.bwtr, a.out.conf, a.out.cloud};
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) stg<u32x4, NT>(planes[0] + px0 * 2 + q * 1024 + lane * 16, acc + (uint32_t)q);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stg<u32x4, NT>(planes[wave] + px0 + q * 1024 + lane * 16, acc + (uint32_t)q);
+    }
+}
+
 // Calibration: a flat two-stream copy moving the same 13 B in / 8 B out per pixel
 // (reads `n16_in` 16-byte words from src, writes `n16_out` to dst).
 template <bool NT>
@@ -1779,6 +1809,14 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const 
         dim3 grid((unsigned)((n16_in + 255) / 256)), block(256);
         if (variant & 2) hipLaunchKernelGGL(dswx_flat_copy_k<true>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
         else hipLaunchKernelGGL(dswx_flat_copy_k<false>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & 262144) {  // plane-specialised waves, bit 1 = nt
+        const long long total = n_tiles * n_pixels;
+        dim3 grid((unsigned)(total / 4096)), block(448);
+        if (variant & 2) hipLaunchKernelGGL(dswx_plane_per_wave_k<true>, grid, block, 0, s, a, total);
+        else hipLaunchKernelGGL(dswx_plane_per_wave_k<false>, grid, block, 0, s, a, total);
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }

@@ -638,6 +638,65 @@ def _get_interpreted_dswx_ctable(flag_collapse_wtr_classes=FLAG_COLLAPSE_WTR_CLA
     return ct
 
 
+def _get_browse_ctable(flag_collapse_wtr_classes=FLAG_COLLAPSE_WTR_CLASSES, not_water_color='white',
+                       cloud_color='gray', snow_color='cyan'):
+    """Browse colour table (:1449-1526): WTR colours with the three display options."""
+    if not_water_color not in ('white', 'nodata'):
+        raise ValueError(f"not_water_color is {not_water_color}, but must be one of 'white' or 'nodata'")
+    if cloud_color not in ('gray', 'nodata'):
+        raise ValueError(f"cloud_color is {cloud_color}, but must be one of 'gray' or 'nodata'")
+    if snow_color not in ('cyan', 'gray', 'nodata'):
+        raise ValueError(f"snow_color is {snow_color}, but must be one of 'cyan', 'gray', or 'nodata'")
+    ct = _get_interpreted_dswx_ctable(flag_collapse_wtr_classes=flag_collapse_wtr_classes)
+    if snow_color == 'gray':
+        ct[WTR_SNOW_MASKED] = ct[WTR_CLOUD_MASKED]
+    elif snow_color == 'nodata':
+        ct[WTR_SNOW_MASKED] = FILL_VALUE_RGBA[:3]
+    ct[WTR_CLOUD_MASKED] = FILL_VALUE_RGBA[:3] if cloud_color == 'nodata' else (175, 175, 175)
+    if not_water_color == 'nodata':
+        ct[0] = FILL_VALUE_RGBA[:3]
+    return ct
+
+
+def geotiff2png(src_geotiff_filename, dest_png_filename, output_height=None, output_width=None,
+                logger=None):
+    """Paletted Byte GeoTIFF -> resized PNG, nearest neighbour (:2719-2783; integer layers
+    only, which is all the workflow feeds it); the nodata index is transparent."""
+    arr, info = geotiff.read_geotiff(src_geotiff_filename)
+    if arr.ndim != 2 or arr.dtype != np.uint8:
+        raise ValueError('geotiff2png handles single-band Byte rasters')
+    h = arr.shape[0] if output_height is None else output_height
+    w = arr.shape[1] if output_width is None else output_width
+    small = geotiff.resample_nearest(arr, h, w)
+    _makedirs(dest_png_filename)
+    geotiff.write_png_palette(dest_png_filename, small, info.colormap,
+                              transparent_index=None if info.nodata is None else int(info.nodata))
+    (logger or logging.getLogger('proteus')).info(f'Browse Image PNG created: {dest_png_filename}')
+
+
+def _save_output_rgb_file(red, green, blue, output_file, offset_dict, scale_dict,
+                          flag_offset_and_scale_inputs, dswx_metadata_dict, geo_tags,
+                          invalid_mask=None, output_files_list=None, flag_infrared=False):
+    """Three-band Float32 reflectance composite (:2961-3054): scale * (float32(band) - offset),
+    NaN on invalid pixels."""
+    keys = ('swir1', 'nir', 'red') if flag_infrared else ('red', 'green', 'blue')
+    planes = []
+    for arr, key in zip((red, green, blue), keys):
+        if not flag_offset_and_scale_inputs:
+            arr = scale_dict[key] * (np.asarray(arr, dtype=np.float32) - offset_dict[key])
+        else:
+            arr = np.array(arr, dtype=np.float32)
+        if invalid_mask is not None:
+            arr[invalid_mask] = np.nan
+        planes.append(np.asarray(arr, dtype=np.float32))
+    _makedirs(output_file)
+    geotiff.write_geotiff(output_file, np.stack(planes), geo_tags=geo_tags,
+                          metadata=dswx_metadata_dict)
+    if output_files_list is not None:
+        output_files_list.append(output_file)
+    logger.info(f'file saved: {output_file}')
+
+
 def _get_binary_water_ctable():
     return {0: (255, 255, 255), 1: (0, 0, 255), WTR_OCEAN_MASKED: OCEAN_MASKED_RGBA[:3],
             WTR_SNOW_MASKED: (0, 255, 255), WTR_CLOUD_MASKED: (175, 175, 175),
@@ -794,6 +853,7 @@ def generate_dswx_layers(input_list,
     def pick(value, name):
         return getattr(consts, name) if value is None else value
 
+
     if hls_thresholds is None:
         hls_thresholds = consts.hls_thresholds
     check_ancillary_inputs_coverage = pick(check_ancillary_inputs_coverage,
@@ -899,10 +959,19 @@ def generate_dswx_layers(input_list,
         apply_aerosol_class_remapping=apply_aerosol_class_remapping,
         aerosol_fmask_values=dict(zip((0, 2, 3, 4), aerosol_lists)),
         collapse_wtr_classes=FLAG_COLLAPSE_WTR_CLASSES,
-        aerosol_max_nir=AEROSOL_REMAPPING_MAX_NIR)
+        aerosol_max_nir=AEROSOL_REMAPPING_MAX_NIR,
+        exclude_psw_aggressive_in_browse=pick(exclude_psw_aggressive_in_browse,
+                                              'exclude_psw_aggressive_in_browse'),
+        not_water_in_browse=pick(not_water_in_browse, 'not_water_in_browse'),
+        cloud_in_browse=pick(cloud_in_browse, 'cloud_in_browse'),
+        snow_in_browse=pick(snow_in_browse, 'snow_in_browse'),
+        set_ocean_masked_to_nodata=True)
     ctx = get_context(device)
+    wanted = ['diag', 'wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud']
+    if output_browse_image:
+        wanted.append('browse')
     res = ctx.classify_host(bands, image['fmask'], params, land=landcover_mask,
-                            shad=shadow_layer, ocean=ocean_mask)
+                            shad=shadow_layer, ocean=ocean_mask, layers=tuple(wanted))
     logger.info(f'    per-pixel chain on GPU: {ctx.last_kernel_info()}')
     n_valid, n_cloud_and_valid, n_not_ocean = (int(v) for v in res['counters'][0])
 
@@ -951,11 +1020,33 @@ def generate_dswx_layers(input_list,
         _save_array(res['conf'], output_confidence_layer, md, geo_tags,
                     description=band_description_dict['CONF'], output_files_list=build_list,
                     no_data_value=UINT8_FILL_VALUE, ctable=_get_confidence_layer_ctable())
-    for target, what in ((output_rgb_file, 'RGB'), (output_infrared_rgb_file, 'infrared RGB'),
-                         (output_browse_image, 'browse image')):
-        if target:
-            logger.warning(f'{what} output "{target}" skipped: writer not built yet'
-                           ' (SURVEY.md §8 row f4)')
+    if output_rgb_file or output_infrared_rgb_file:
+        # writer-side packaging (:5204-5223): the composites use the clipped reflectances
+        invalid_mask = res['diag'] == DIAGNOSTIC_LAYER_NO_DATA_BINARY_REPR
+        clipped = {k: (np.clip(image[k], 1, None) if FLAG_CLIP_NEGATIVE_REFLECTANCE else image[k])
+                   for k in ('blue', 'green', 'red', 'nir', 'swir1')}
+        if output_rgb_file:
+            _save_output_rgb_file(clipped['red'], clipped['green'], clipped['blue'], output_rgb_file,
+                                  image['offset'], image['scale'], flag_offset_and_scale_inputs, md,
+                                  geo_tags, invalid_mask, output_files_list)
+        if output_infrared_rgb_file:
+            _save_output_rgb_file(clipped['swir1'], clipped['nir'], clipped['red'],
+                                  output_infrared_rgb_file, image['offset'], image['scale'],
+                                  flag_offset_and_scale_inputs, md, geo_tags, invalid_mask,
+                                  output_files_list, flag_infrared=True)
+    if output_browse_image:
+        # browse = _compute_browse_array(WTR) from the kernel; full-res GeoTIFF + resized PNG
+        # (:5301-5349)
+        browse_tif = output_browse_image.replace('.png', '.tif')
+        _save_array(res['browse'], browse_tif, md, geo_tags, output_files_list=output_files_list,
+                    no_data_value=UINT8_FILL_VALUE,
+                    ctable=_get_browse_ctable(collapse, pick(not_water_in_browse, 'not_water_in_browse'),
+                                              pick(cloud_in_browse, 'cloud_in_browse'),
+                                              pick(snow_in_browse, 'snow_in_browse')))
+        geotiff2png(browse_tif, output_browse_image,
+                    output_height=pick(browse_image_height, 'browse_image_height'),
+                    output_width=pick(browse_image_width, 'browse_image_width'), logger=logger)
+        output_files_list.append(output_browse_image)
     if output_file and not output_file.endswith('.vrt'):
         # the multi-band file carries the post-aerosol WTR-1 (in-place remap, :5260 -> :5389)
         save_dswx_product({'WTR': res['wtr'], 'BWTR': res['bwtr'], 'CONF': res['conf'],

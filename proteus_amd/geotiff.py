@@ -375,3 +375,45 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
             fh.write(x)
             if len(x) & 1:
                 fh.write(b'\x00')
+
+
+def write_png_palette(path, indices, colormap, transparent_index=None):
+    """8-bit palette PNG (what `gdal.Translate(format='PNG')` produces from a paletted
+    Byte GeoTIFF): `indices` uint8 [H,W], `colormap` {value: (r,g,b)} or [256][3]."""
+    idx = np.ascontiguousarray(indices, dtype=np.uint8)
+    if idx.ndim != 2:
+        raise GeoTiffError('PNG writer needs a 2-D uint8 array')
+    h, w = idx.shape
+    pal = np.zeros((256, 3), dtype=np.uint8)
+    if isinstance(colormap, dict):
+        for v, rgb in colormap.items():
+            pal[int(v)] = rgb[:3]
+    elif colormap is not None:
+        pal[:] = np.asarray(colormap)[:, :3]
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack('>I', len(data)) + body + struct.pack('>I', zlib.crc32(body) & 0xffffffff)
+
+    raw = np.empty((h, w + 1), dtype=np.uint8)
+    raw[:, 0] = 0                      # filter type 0 on every scanline
+    raw[:, 1:] = idx
+    out = [b'\x89PNG\r\n\x1a\n', chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 3, 0, 0, 0)),
+           chunk(b'PLTE', pal.tobytes())]
+    if transparent_index is not None:
+        alpha = bytearray([255] * 256)
+        alpha[int(transparent_index)] = 0
+        out.append(chunk(b'tRNS', bytes(alpha)))
+    out.append(chunk(b'IDAT', zlib.compress(raw.tobytes(), 6)))
+    out.append(chunk(b'IEND', b''))
+    with open(path, 'wb') as fh:
+        fh.write(b''.join(out))
+
+
+def resample_nearest(arr, out_height, out_width):
+    """Nearest-neighbour decimation the way GDAL RasterIO picks source pixels:
+    src = floor((dst + 0.5) * src_size / dst_size)."""
+    h, w = arr.shape[-2:]
+    ys = np.minimum(((np.arange(out_height) + 0.5) * h / out_height).astype(np.int64), h - 1)
+    xs = np.minimum(((np.arange(out_width) + 0.5) * w / out_width).astype(np.int64), w - 1)
+    return arr[..., ys[:, None], xs[None, :]]

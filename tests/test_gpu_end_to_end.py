@@ -104,3 +104,63 @@ def test_api_with_masks_and_multiband(tmp_path):
         arr, info = geotiff.read_geotiff(str(tmp_path / name))
         assert np.array_equal(arr, exp[layer]), layer
         assert info.metadata['MASK_ADJACENT_TO_CLOUD_MODE'] == 'cover'
+
+
+def test_browse_png_and_rgb_outputs(tmp_path):
+    import struct
+    import zlib
+    _, files, _, s = synth_hls.make(str(tmp_path), size=256, tile=2)
+    ok = D.generate_dswx_layers(
+        files, output_browse_image=str(tmp_path / 'b.png'), browse_image_height=64,
+        browse_image_width=32, output_rgb_file=str(tmp_path / 'rgb.tif'),
+        output_infrared_rgb_file=str(tmp_path / 'irgb.tif'), not_water_in_browse='nodata')
+    assert ok is True
+    raw = o.classify_tile(s['bands'], s['fmask'], collapse=False)
+    exp_browse = o.compute_browse_array(raw['WTR'], True, True, set_not_water_to_nodata=True)
+    btif, info = geotiff.read_geotiff(str(tmp_path / 'b.tif'))
+    assert np.array_equal(btif, exp_browse) and info.nodata == 255
+    assert info.colormap[1].tolist() == [0, 0, 255] and info.colormap[253].tolist() == [175, 175, 175]
+    png = (tmp_path / 'b.png').read_bytes()
+    assert png[:8] == b'\x89PNG\r\n\x1a\n'
+    w, h, depth, ctype = struct.unpack('>IIBB', png[16:26])
+    assert (w, h, depth, ctype) == (32, 64, 8, 3)
+    pos, idat = 8, b''
+    while pos < len(png):
+        n, tag = struct.unpack('>I4s', png[pos:pos + 8])
+        if tag == b'IDAT':
+            idat += png[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(64, 33)
+    assert np.array_equal(rows[:, 1:], geotiff.resample_nearest(exp_browse, 64, 32))
+    # composites: scale * (float32(clipped band) - offset), NaN where invalid
+    rgb, info = geotiff.read_geotiff(str(tmp_path / 'rgb.tif'))
+    invalid = raw['DIAG'] == 65535
+    for i, k in enumerate((2, 1, 0)):        # red, green, blue
+        exp = 0.0001 * (np.clip(s['bands'][k], 1, None).astype(np.float32) - 0.0)
+        exp = exp.astype(np.float32)
+        exp[invalid] = np.nan
+        assert rgb.dtype == np.float32 and np.array_equal(rgb[i], exp, equal_nan=True)
+    irgb, _ = geotiff.read_geotiff(str(tmp_path / 'irgb.tif'))
+    exp = (0.0001 * (np.clip(s['bands'][4], 1, None).astype(np.float32) - 0.0)).astype(np.float32)
+    exp[invalid] = np.nan
+    assert np.array_equal(irgb[0], exp, equal_nan=True)
+
+
+def test_batch_driver_single_gpu(tmp_path):
+    """Node-level driver with one GPU: three tiles through one worker process."""
+    from proteus_amd import batch
+    rcs = []
+    for t in range(3):
+        d = tmp_path / f'tile{t}'
+        rcfile, _, _, _ = synth_hls.make(str(d), size=128, tile=20 + t, product_id=f'T{t}')
+        rcs.append(rcfile)
+    ok, results = batch.run_batch(rcs, 1)
+    assert ok, results
+    assert [r['runconfig'] for r in results] == rcs and all(r['device'] == 0 for r in results)
+    for t in range(3):
+        arr, _ = geotiff.read_geotiff(str(tmp_path / f'tile{t}' / 'output' / f'T{t}_v1.0_B01_WTR.tif'))
+        s = synth_hls.synth_tile(20 + t, 128, 128)
+        assert np.array_equal(arr, o.classify_tile(s['bands'], s['fmask'])['WTR'])
+    # a broken runconfig is reported, the others still run
+    ok, results = batch.run_batch([rcs[0], str(tmp_path / 'missing.yaml')], 1)
+    assert not ok and results[0]['ok'] and not results[1]['ok']

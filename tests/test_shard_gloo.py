@@ -88,3 +88,14 @@ def test_two_rank_gloo_control_plane(tmp_path):
         c = o.classify_tile(s['bands'], s['fmask'])['counters']
         exp.append([c['n_valid'], c['n_cloud_and_valid'], c['n_not_ocean']])
     assert out['counters'] == exp
+
+
+def test_batch_plan():
+    from proteus_amd import batch
+    rcs = [f'rc{i}.yaml' for i in range(10)]
+    p = batch.plan(rcs, 4)
+    assert [g for g, _ in p] == [0, 1, 2, 3]
+    assert sum((c for _, c in p), []) == rcs
+    assert {len(c) for _, c in p} <= {2, 3}
+    few = batch.plan(rcs[:2], 8)
+    assert sum((c for _, c in few), []) == rcs[:2] and max(len(c) for _, c in few) == 1

@@ -61,6 +61,7 @@ def main():
             out[label] = round(px * nbytes / (sum(ms) / len(ms)) / 1e6, 1)
         for nt in (0, 2):
             run(f'14 planes, one plane per block nt={nt >> 1}', 32768 | nt, 21)
+            run(f'one plane per wave (7-wave blocks over 4096 px) nt={nt >> 1}', 262144 | nt, 21)
             run(f'role split by block (7-plane readers / 7-plane writers) nt={nt >> 1}', 65536 | nt, 21)
             run(f'role split by wave inside block nt={nt >> 1}', 65536 | 4 | nt, 21)
             run(f'role split by block, writers use plane-run stores nt={nt >> 1}', 65536 | 8 | nt, 21)
