@@ -233,6 +233,8 @@ template <typename T, bool NT> __device__ __forceinline__ void stg(void* p, T v)
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) void* gptr_t;     // LDS-DMA source
+typedef __attribute__((address_space(3))) void* lptr_t;           // LDS-DMA destination
 
 __device__ __forceinline__ int s16_of(uint32_t dword, int half) {
     return half ? ((int)dword >> 16) : (int)(short)(dword & 0xffffu);
@@ -501,6 +503,167 @@ __global__ __launch_bounds__(FUSED_THREADS) void dswx_classify_fused(const KArgs
             uint8_t* dst = a.u8_out[u] + tile_base;
             const long long p = px0 + sub * 1024 + lane * 16;        // 16 px = 16 B
             const uint8_t* src = stage + STAGE_DIAG_BYTES + region * STAGE_U8_BYTES + sub * 1024 + lane * 16;
+            if (p + 16 <= n_vec) stg<u32x4, true>(dst + p, *reinterpret_cast<const u32x4*>(src));
+            else if (p + 8 <= n_vec) stg<u32x2, true>(dst + p, *reinterpret_cast<const u32x2*>(src));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// Fused kernel, warp-specialised variant (DSWX_FUSED_VARIANT=2).  Block = 256 threads =
+// one 2048-pixel chunk of a tile (grid.y = tile).
+//
+//  phase A  the chunk's input planes are pulled into LDS with LDS-DMA
+//           (global_load_lds, 16 B per lane, 1 KiB per wave-instruction, no VGPRs).
+//           The 1 KiB pieces are dealt to the waves in plane order, 8 consecutive
+//           pieces each: waves 0-2 read two whole 4 KiB band segments, wave 3 the u8
+//           planes -- every wave streams whole contiguous plane segments;
+//  phase B  each thread reads its 8 pixels from the LDS images (ds_read_b128 / b64),
+//           barrier, classifies them exactly as the direct kernel does, and parks the
+//           results in LDS *over* the input images (they are dead by then);
+//  phase C  each wave writes 4 consecutive 1 KiB pieces of the output planes with
+//           16-byte non-temporal stores (4 KiB DIAG runs, 2 KiB u8 runs).
+// LDS per block: 26 KiB (32 KiB with LAND/SHAD/OCEAN) -> 5-6 blocks per CU.
+// The trivial-math probe of this data movement (dswx_ws_probe_k) runs ~15 % above the
+// direct-store probe on the same device.
+// ------------------------------------------------------------------------------
+constexpr int WS_PX = 2048;
+constexpr int WS_BAND_BYTES = WS_PX * 2, WS_U8_BYTES = WS_PX;
+constexpr int WS_IN_FMASK = 6 * WS_BAND_BYTES;                    // 24 KiB
+constexpr int WS_IN_MASKS = WS_IN_FMASK + WS_U8_BYTES;            // land, shad, ocean follow
+constexpr int WS_OUT_U8 = WS_BAND_BYTES;                          // after the 4 KiB DIAG image
+
+template <bool MASKS>
+__global__ __launch_bounds__(256, MASKS ? 4 : 5) void dswx_classify_ws(const KArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WS_IN_MASKS + (MASKS ? 3 * WS_U8_BYTES : 0)];
+    const DevParams& P = a.P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lut_reg = a.P.aer_lut[lane];
+    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long px0 = (long long)blockIdx.x * WS_PX;
+    const long long n_vec = (a.n_pixels >> 3) << 3;       // pixels the vector path covers
+    // last byte offsets a 16-byte access may start at without leaving the covered range
+    // (n_vec >= 8; a shorter final access re-reads in-range bytes, never stored or counted)
+    const long long last16_i16 = (n_vec - 8) * 2, last16_u8 = n_vec >= 16 ? n_vec - 16 : 0;
+
+    // ---- phase A: LDS-DMA, pieces of 1 KiB in plane order
+    const bool has_l = MASKS && a.in.land, has_s = MASKS && a.in.shad, has_o = MASKS && a.in.ocean;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int piece = wave * 8 + q;
+        if (piece < 24) {
+            const int plane = piece >> 2, sub = piece & 3;
+            long long byte = (px0 * 2) + sub * 1024 + lane * 16;
+            byte = byte <= last16_i16 ? byte : last16_i16;
+            __builtin_amdgcn_global_load_lds(
+                (gptr_t)(reinterpret_cast<const uint8_t*>(a.in.band[plane]) + tile_base * 2 + byte),
+                (lptr_t)(lds + plane * WS_BAND_BYTES + sub * 1024), 16, 0, 2);
+        } else {
+            const int u = (piece - 24) >> 1, sub = (piece - 24) & 1;      // 0 fmask, 1 land, 2 shad, 3 ocean
+            const uint8_t* src = u == 0 ? a.in.fmask : (u == 1 ? a.in.land : (u == 2 ? a.in.shad : a.in.ocean));
+            const bool present = u == 0 || (MASKS && ((u == 1 && has_l) || (u == 2 && has_s) || (u == 3 && has_o)));
+            if (present) {
+                long long byte = px0 + sub * 1024 + lane * 16;
+                byte = byte <= last16_u8 ? byte : last16_u8;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + tile_base + byte),
+                                                 (lptr_t)(lds + WS_IN_FMASK + u * WS_U8_BYTES + sub * 1024), 16, 0, 2);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- phase B: registers <- LDS images
+    const long long grp = (px0 >> 3) + threadIdx.x;
+    const bool in_range = grp < (a.n_pixels >> 3);
+    u32x4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = *reinterpret_cast<const u32x4*>(lds + k * WS_BAND_BYTES + threadIdx.x * 16);
+    const u32x2 vf = *reinterpret_cast<const u32x2*>(lds + WS_IN_FMASK + threadIdx.x * 8);
+    u32x2 vl = {0u, 0u}, vs = {0u, 0u}, vo = {0u, 0u};
+    uint32_t w_valid = 0, w_cloud = 0, t_ocean = 0;
+    if (MASKS) {
+        if (has_l) vl = *reinterpret_cast<const u32x2*>(lds + WS_IN_MASKS + threadIdx.x * 8);
+        if (has_s) vs = *reinterpret_cast<const u32x2*>(lds + WS_IN_MASKS + WS_U8_BYTES + threadIdx.x * 8);
+        if (has_o) {
+            vo = *reinterpret_cast<const u32x2*>(lds + WS_IN_MASKS + 2 * WS_U8_BYTES + threadIdx.x * 8);
+            t_ocean = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
+            t_ocean = in_range ? t_ocean : 0u;
+        }
+    }
+    __syncthreads();                                     // the input images are dead from here on
+
+    uint32_t q_diag[4] = {0, 0, 0, 0};
+    uint32_t q_w1[2] = {0, 0}, q_w1a[2] = {0, 0}, q_w2[2] = {0, 0}, q_w[2] = {0, 0},
+             q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int wd = j >> 1, hf = j & 1;
+        const int b = s16_of(v[0][wd], hf), g = s16_of(v[1][wd], hf), r = s16_of(v[2][wd], hf),
+                  n = s16_of(v[3][wd], hf), s1 = s16_of(v[4][wd], hf), s2 = s16_of(v[5][wd], hf);
+        const int bw = j >> 2, bk = j & 3;
+        const int fm = u8_of(vf[bw], bk);
+        int land = -1, shad = 1, ocean = 1;
+        if (MASKS) {
+            if (has_l) land = u8_of(vl[bw], bk);
+            if (has_s) shad = u8_of(vs[bw], bk);
+            if (has_o) ocean = u8_of(vo[bw], bk);
+        }
+        const uint32_t aer_bits =
+            ((uint32_t)__builtin_amdgcn_ds_bpermute((fm >> 2) << 2, (int)lut_reg) >> (8 * (fm & 3))) & 0xffu;
+        PxOut o;
+        bool ok, cv;
+        classify_px(P, aer_bits, b, g, r, n, s1, s2, fm, land, shad, ocean, o, ok, cv);
+        w_valid += (uint32_t)__popcll(__ballot(ok & in_range));
+        w_cloud += (uint32_t)__popcll(__ballot(cv & in_range));
+        q_diag[wd] |= o.diag << (16 * hf);
+        q_w1[bw] |= o.wtr1 << (8 * bk);
+        q_w1a[bw] |= o.wtr1a << (8 * bk);
+        q_w2[bw] |= o.wtr2 << (8 * bk);
+        q_w[bw] |= o.wtr << (8 * bk);
+        q_bw[bw] |= o.bwtr << (8 * bk);
+        q_cf[bw] |= o.conf << (8 * bk);
+        q_cl[bw] |= o.cloud << (8 * bk);
+    }
+    // park the results over the dead input images: DIAG 4 KiB, then 7 u8 regions of 2 KiB
+    *reinterpret_cast<u32x4*>(lds + threadIdx.x * 16) = u32x4{q_diag[0], q_diag[1], q_diag[2], q_diag[3]};
+    uint8_t* su8 = lds + WS_OUT_U8 + threadIdx.x * 8;
+    *reinterpret_cast<u32x2*>(su8 + 0 * WS_U8_BYTES) = u32x2{q_w1[0], q_w1[1]};
+    if (a.out.wtr1_aerosol) *reinterpret_cast<u32x2*>(su8 + 1 * WS_U8_BYTES) = u32x2{q_w1a[0], q_w1a[1]};
+    *reinterpret_cast<u32x2*>(su8 + 2 * WS_U8_BYTES) = u32x2{q_w2[0], q_w2[1]};
+    *reinterpret_cast<u32x2*>(su8 + 3 * WS_U8_BYTES) = u32x2{q_w[0], q_w[1]};
+    *reinterpret_cast<u32x2*>(su8 + 4 * WS_U8_BYTES) = u32x2{q_bw[0], q_bw[1]};
+    *reinterpret_cast<u32x2*>(su8 + 5 * WS_U8_BYTES) = u32x2{q_cf[0], q_cf[1]};
+    *reinterpret_cast<u32x2*>(su8 + 6 * WS_U8_BYTES) = u32x2{q_cl[0], q_cl[1]};
+    if (a.partials) {
+        if (MASKS && has_o) {
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) t_ocean += __shfl_xor(t_ocean, sh);
+        }
+        if (lane == 0) {
+            const long long slot = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+            a.partials[slot] = make_uint2(w_valid | (w_cloud << 16), t_ocean);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: 1 KiB pieces in plane order (DIAG 4, each wanted u8 layer 2), consecutive per wave
+    const int n_pieces = (a.n_diag_pieces ? 4 : 0) + 2 * a.n_u8_out;
+    const int per_wave = (n_pieces + 3) / 4;
+    const int diag_pieces = a.n_diag_pieces ? 4 : 0;
+    for (int q = 0; q < per_wave; ++q) {
+        const int piece = wave * per_wave + q;
+        if (piece >= n_pieces) break;
+        if (piece < diag_pieces) {
+            const long long p = px0 + piece * 512 + lane * 8;
+            if (p + 8 <= n_vec)
+                stg<u32x4, true>(a.out.diag + tile_base + p, *reinterpret_cast<const u32x4*>(lds + piece * 1024 + lane * 16));
+        } else {
+            const int u = (piece - diag_pieces) >> 1, sub = (piece - diag_pieces) & 1;
+            const int region = a.u8_region[u];
+            uint8_t* dst = a.u8_out[u] + tile_base;
+            const long long p = px0 + sub * 1024 + lane * 16;
+            const uint8_t* src = lds + WS_OUT_U8 + region * WS_U8_BYTES + sub * 1024 + lane * 16;
             if (p + 16 <= n_vec) stg<u32x4, true>(dst + p, *reinterpret_cast<const u32x4*>(src));
             else if (p + 8 <= n_vec) stg<u32x2, true>(dst + p, *reinterpret_cast<const u32x2*>(src));
         }
@@ -925,6 +1088,70 @@ __global__ __launch_bounds__(448) void dswx_plane_per_wave_k(const KArgs a, long
     }
 }
 
+// Warp-specialised data movement: block = 256 threads over a 2048-px chunk.
+//  phase A  wave w pulls planes {w, w+4} of the chunk into LDS with LDS-DMA
+//           (global_load_lds, 1 KiB per wave-instruction, no VGPR staging): each wave
+//           reads 4 KiB (2 KiB for Fmask) of ONE plane contiguously;
+//  phase B  every thread folds its 8 pixels out of the seven LDS images and parks
+//           results in the output staging regions;
+//  phase C  wave w writes whole plane runs (as the LDS-staged kernel does).
+// LDS: 26 KiB in + 18 KiB out = 44 KiB per block (3 blocks per CU).
+template <bool NT>
+__global__ __launch_bounds__(256) void dswx_ws_probe_k(const KArgs a) {
+    constexpr int PX = 2048;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_in[6 * PX * 2 + PX];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_out[PX * 2 + 6 * PX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long px0 = (long long)blockIdx.x * PX;
+    if (px0 + PX > a.n_pixels) return;       // probe only: whole chunks
+    // phase A
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int plane = wave + 4 * h;
+        if (plane < 6) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(a.in.band[plane]) + (tile_base + px0) * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + q * 1024 + lane * 16),
+                                                 (lptr_t)(lds_in + plane * (PX * 2) + q * 1024), 16, 0, NT ? 2 : 0);
+        } else if (plane == 6) {
+            const uint8_t* src = a.in.fmask + tile_base + px0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + q * 1024 + lane * 16),
+                                                 (lptr_t)(lds_in + 6 * (PX * 2) + q * 1024), 16, 0, NT ? 2 : 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // phase B
+    u32x4 x = *reinterpret_cast<const u32x4*>(lds_in + threadIdx.x * 16);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) x ^= *reinterpret_cast<const u32x4*>(lds_in + k * (PX * 2) + threadIdx.x * 16);
+    const u32x2 f = *reinterpret_cast<const u32x2*>(lds_in + 6 * (PX * 2) + threadIdx.x * 8);
+    u32x2 y; y.x = x.x ^ x.z ^ f.x; y.y = x.y ^ x.w ^ f.y;
+    *reinterpret_cast<u32x4*>(lds_out + threadIdx.x * 16) = x;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) *reinterpret_cast<u32x2*>(lds_out + PX * 2 + k * PX + threadIdx.x * 8) = y + (uint32_t)k;
+    __syncthreads();
+    // phase C: 16 pieces of 1 KiB (diag 4, six u8 planes 2 each), 4 consecutive per wave
+    uint8_t* const planes[7] = {reinterpret_cast<uint8_t*>(a.out.diag), a.out.wtr1, a.out.wtr2, a.out.wtr,
+                                a.out.bwtr, a.out.conf, a.out.cloud};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave * 4 + q;
+        if (piece < 4) {
+            stg<u32x4, NT>(planes[0] + (tile_base + px0) * 2 + piece * 1024 + lane * 16,
+                           *reinterpret_cast<const u32x4*>(lds_out + piece * 1024 + lane * 16));
+        } else {
+            const int u = (piece - 4) >> 1, sub = (piece - 4) & 1;
+            stg<u32x4, NT>(planes[1 + u] + tile_base + px0 + sub * 1024 + lane * 16,
+                           *reinterpret_cast<const u32x4*>(lds_out + PX * 2 + u * PX + sub * 1024 + lane * 16));
+        }
+    }
+}
+
 // Calibration: a flat two-stream copy moving the same 13 B in / 8 B out per pixel
 // (reads `n16_in` 16-byte words from src, writes `n16_out` to dst).
 template <bool NT>
@@ -1193,7 +1420,8 @@ struct dswx_ctx {
     void* cover = nullptr;
     size_t cover_bytes = 0;
     std::string last_kernel;
-    int fused_variant = 0;   // 0: direct stores (default); 1: LDS-staged stores (env DSWX_FUSED_VARIANT)
+    int fused_variant = 0;   // env DSWX_FUSED_VARIANT -- 0: direct stores (default); 1: LDS-staged
+                             // stores; 2: warp-specialised (LDS-DMA in, plane-run stores out)
     int tune_wps = 6;        // launch-bound variant of the plain kernel (env DSWX_TUNE_WPS: 4, 6, 8)
 };
 
@@ -1356,7 +1584,10 @@ int dswx_ctx_create(int device, dswx_ctx_t** out) {
     HIP_TRY(hipSetDevice(device));
     dswx_ctx* c = new dswx_ctx();
     c->device = device;
-    if (const char* e = std::getenv("DSWX_FUSED_VARIANT")) c->fused_variant = std::atoi(e) == 1 ? 1 : 0;
+    if (const char* e = std::getenv("DSWX_FUSED_VARIANT")) {
+        const int v = std::atoi(e);
+        c->fused_variant = (v == 1 || v == 2) ? v : 0;
+    }
     if (const char* e = std::getenv("DSWX_TUNE_WPS")) c->tune_wps = std::atoi(e);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -1471,9 +1702,11 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
         if (groups > 0) {
             // 'cover' stage 1 and the browse plane live in the direct kernel only
-            const bool staged = ctx->fused_variant == 1 && !cover && !b.out.browse;
+            const bool plain_outputs = !cover && !b.out.browse;
+            const bool staged = ctx->fused_variant == 1 && plain_outputs;
+            const bool wspec = ctx->fused_variant == 2 && plain_outputs;
             const int threads = staged ? FUSED_THREADS : 256;
-            const int64_t gx = (groups + threads - 1) / threads;
+            const int64_t gx = (groups + threads - 1) / threads;     // 2048 px per 256-thread block
             const int waves = threads / 64;
             dim3 grid((unsigned)gx, (unsigned)nt), block(threads);
             if (b.counters) {
@@ -1492,7 +1725,12 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             for (int i = 0; i < 7; ++i)
                 if (u8p[i]) { b.u8_out[b.n_u8_out] = u8p[i]; b.u8_region[b.n_u8_out] = i; ++b.n_u8_out; }
             b.n_diag_pieces = b.out.diag ? 8 : 0;
-            if (staged) {
+            if (wspec) {
+                if (masks) hipLaunchKernelGGL(dswx_classify_ws<true>, grid, block, 0, s, b);
+                else hipLaunchKernelGGL(dswx_classify_ws<false>, grid, block, 0, s, b);
+                snprintf(info, sizeof info, "dswx_classify_ws<%s> (warp-specialised, LDS-DMA) grid=(%lld,%lld) block=256",
+                         masks ? "true" : "false", (long long)gx, (long long)nt);
+            } else if (staged) {
                 if (masks) hipLaunchKernelGGL(dswx_classify_fused<true>, grid, block, 0, s, b);
                 else hipLaunchKernelGGL(dswx_classify_fused<false>, grid, block, 0, s, b);
                 snprintf(info, sizeof info, "dswx_classify_fused<%s> (LDS-staged) grid=(%lld,%lld) block=%d lds=%d",
@@ -1809,6 +2047,13 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const 
         dim3 grid((unsigned)((n16_in + 255) / 256)), block(256);
         if (variant & 2) hipLaunchKernelGGL(dswx_flat_copy_k<true>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
         else hipLaunchKernelGGL(dswx_flat_copy_k<false>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & 524288) {  // warp-specialised LDS-DMA data movement, bit 1 = nt
+        dim3 grid((unsigned)(n_pixels / 2048), (unsigned)n_tiles), block(256);
+        if (variant & 2) hipLaunchKernelGGL(dswx_ws_probe_k<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(dswx_ws_probe_k<false>, grid, block, 0, s, a);
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }

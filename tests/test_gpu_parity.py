@@ -318,21 +318,40 @@ def test_gpu_quotient_enumeration(ctx):
     assert np.array_equal(got['diag'].ravel(), exp['diag'])
 
 
-def test_staged_variant_parity(monkeypatch):
-    """The LDS-staged store variant (DSWX_FUSED_VARIANT=1) is kept bit-exact too."""
-    monkeypatch.setenv('DSWX_FUSED_VARIANT', '1')
+@pytest.mark.parametrize('variant,tag', [('1', 'LDS-staged'), ('2', 'warp-specialised')])
+def test_kernel_variants_parity(monkeypatch, variant, tag):
+    """The alternative fused kernels (DSWX_FUSED_VARIANT=1: LDS-staged stores, =2:
+    warp-specialised LDS-DMA pipeline) are kept bit-exact too."""
+    monkeypatch.setenv('DSWX_FUSED_VARIANT', variant)
     c2 = _capi.Context(0)
     try:
-        for (h, w, masks) in [(64, 64, True), (333, 517, True), (700, 900, False)]:
+        for (h, w, masks) in [(64, 64, True), (333, 517, True), (700, 900, False), (45, 46, False),
+                              (3, 5, True), (1024, 1030, True)]:
             s = synth_tile(77, h, w, with_masks=True)
             kw = dict(land=s['land'], shad=s['shad'], ocean=s['ocean']) if masks else {}
             p = _capi.default_params()
             got = c2.classify_host(s['bands'], s['fmask'], p, **kw)
-            assert 'LDS-staged' in c2.last_kernel_info()
+            if h * w >= 8:
+                assert tag in c2.last_kernel_info()
             exp = c_oracle.classify(p, s['bands'], s['fmask'], **kw)
             for key in ALL_LAYERS:
                 assert np.array_equal(got[key], exp[key]), (key, h, w)
             assert got['counters'][0].tolist() == exp['counters'].tolist()
+        # a device-resident multi-tile batch, masks partly present
+        batch = _capi.DeviceBatch(c2, 3, 128, 144, masks=True, extra_layers=('wtr1_aerosol',))
+        batch.synth(SEED, tile0=11)
+        batch.pin.shad = None
+        p = _capi.default_params()
+        batch.classify(p)
+        c2.synchronize()
+        cnt = batch.read_counters()
+        for t in range(3):
+            s = synth_tile(11 + t, 128, 144, with_masks=True)
+            exp = c_oracle.classify(p, s['bands'], s['fmask'], land=s['land'], ocean=s['ocean'])
+            for key in ALL_LAYERS:
+                assert np.array_equal(batch.read_tile(key, t), exp[key]), (key, t)
+            assert cnt[t].tolist() == exp['counters'].tolist()
+        batch.free()
     finally:
         c2.close()
 

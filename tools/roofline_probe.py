@@ -62,6 +62,7 @@ def main():
         for nt in (0, 2):
             run(f'14 planes, one plane per block nt={nt >> 1}', 32768 | nt, 21)
             run(f'one plane per wave (7-wave blocks over 4096 px) nt={nt >> 1}', 262144 | nt, 21)
+            run(f'warp-specialised LDS-DMA in, plane-run stores out nt={nt >> 1}', 524288 | nt, 21)
             run(f'role split by block (7-plane readers / 7-plane writers) nt={nt >> 1}', 65536 | nt, 21)
             run(f'role split by wave inside block nt={nt >> 1}', 65536 | 4 | nt, 21)
             run(f'role split by block, writers use plane-run stores nt={nt >> 1}', 65536 | 8 | nt, 21)
