@@ -11,7 +11,9 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRC = os.path.join(PKG, 'csrc', 'dswx_hip.hip')
+CSRC = os.path.join(PKG, 'csrc')
+SOURCES = [os.path.join(CSRC, n) for n in ('dswx_hip.hip', 'dswx_variants.hip', 'dswx_probes.hip')]
+HEADERS = [os.path.join(CSRC, n) for n in ('dswx_device.h', 'dswx_host.h')]
 INCLUDE = os.path.join(ROOT, 'include')
 LIB_DIR = os.path.join(PKG, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libdswx_hip.so')
@@ -31,7 +33,7 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [SRC, os.path.join(INCLUDE, 'dswx_hip.h')]
+    deps = SOURCES + HEADERS + [os.path.join(INCLUDE, 'dswx_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -40,7 +42,7 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ['-I', INCLUDE, SRC, '-o', LIB_PATH + '.tmp']
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ['-I', INCLUDE, '-I', CSRC] + SOURCES + ['-o', LIB_PATH + '.tmp']
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)

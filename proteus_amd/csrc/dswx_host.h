@@ -1,0 +1,56 @@
+// dswx_host.h -- host-side internals shared by the translation units of libdswx_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "dswx_device.h"
+
+struct dswx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    // grow-only staging for dswx_classify_host
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    // grow-only workspace for the vector kernel's per-wave counter partials
+    void* partials = nullptr;
+    size_t partials_bytes = 0;
+    // device copy of the lookup tables of the table-driven kernel (rebuilt per call)
+    void* tables = nullptr;
+    // grow-only scratch of 'cover' mode: uncollapsed WTR-2 + pre-snow CLOUD planes
+    void* cover = nullptr;
+    size_t cover_bytes = 0;
+    std::string last_kernel;
+    int fused_variant = 0;   // env DSWX_FUSED_VARIANT -- 0: direct stores (default); 1: LDS-staged
+                             // stores; 2: warp-specialised (LDS-DMA in, plane-run stores out);
+                             // 3: table-driven (packed int16 + LDS tables + v_perm packing);
+                             // 4: warp-specialised data movement + table-driven compute;
+                             // 5: persistent double-buffered pipeline of 4
+    int tune_pipe_blocks = 512;   // persistent pipeline: total blocks (env DSWX_TUNE_PIPE_BLOCKS)
+    int tune_ablate = 0;     // diagnostic ablation level of variant 4 (env DSWX_TUNE_ABLATE; outputs invalid)
+    int tune_chunks = 1;     // table-driven kernel: chunks per block (env DSWX_TUNE_CHUNKS: 1, 4)
+    int tune_lut_wps = 5;    // table-driven kernel: launch bound (env DSWX_TUNE_LUT_WPS: 4, 5, 6)
+    int tune_wps = 6;        // launch-bound variant of the plain kernel (env DSWX_TUNE_WPS: 4, 6, 8)
+};
+
+// records a printf-style message for dswx_last_error() and returns `code`
+int dswx_fail(int code, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return dswx_fail(DSWX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                             __FILE__, __LINE__);                                                  \
+    } while (0)
+
+static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// ---- experimental fused-kernel variants (dswx_variants.hip), selected by DSWX_FUSED_VARIANT
+// block size and grid.x the selected variant wants for `groups` 8-pixel groups per tile
+void dswx_variant_geometry(const dswx_ctx* ctx, long long groups, long long n_tiles, int* threads, long long* gx);
+// launches the selected variant; `info` receives its description
+int dswx_variant_launch(dswx_ctx* ctx, const KArgs& args, bool masks, dim3 grid, dim3 block, hipStream_t stream,
+                        char* info, size_t info_len);

@@ -319,7 +319,8 @@ def test_gpu_quotient_enumeration(ctx):
 
 
 @pytest.mark.parametrize('variant,tag', [('1', 'LDS-staged'), ('2', 'warp-specialised'),
-                                         ('3', 'table-driven'), ('4', 'warp-specialised + table-driven')])
+                                         ('3', 'table-driven'), ('4', 'warp-specialised + table-driven'),
+                                         ('5', 'pipeline')])
 def test_kernel_variants_parity(monkeypatch, variant, tag):
     """The alternative fused kernels (DSWX_FUSED_VARIANT=1: LDS-staged stores, =2:
     warp-specialised LDS-DMA pipeline) are kept bit-exact too."""
