@@ -778,7 +778,9 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         if (groups > 0) {
             // 'cover' stage 1 and the browse plane live in the direct kernel only
             const bool plain_outputs = !cover && !b.out.browse;
-            const bool variant = ctx->fused_variant != 0 && plain_outputs;
+            // the LDS-DMA variants (2, 4, 5) move 16 pixels per lane of the u8 planes
+            const bool dma16_ok = (n_pixels & 15) == 0 || ctx->fused_variant == 1 || ctx->fused_variant == 3;
+            const bool variant = ctx->fused_variant != 0 && plain_outputs && dma16_ok;
             int threads = 256;
             long long gx_ll = (groups + 255) / 256;
             if (variant) dswx_variant_geometry(ctx, groups, nt, &threads, &gx_ll);
