@@ -151,9 +151,10 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'int16+f64', 'data': 'synthetic',
             'config': {'workload': f'{n_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles per GPU '
-                                   f'per step, device-resident band-planar batch'
+                                   f'per step, device-resident band-planar batch '
+                                   f'(tile stride {batch.tile_stride} px = 256-byte aligned tile starts)'
                                    + (', LAND+SHAD+OCEAN planes' if args.masks else ''),
-                       'tiles_per_gpu': n_tiles, 'tile': [TILE, TILE],
+                       'tiles_per_gpu': n_tiles, 'tile': [TILE, TILE], 'tile_stride_px': batch.tile_stride,
                        'planes_in': 10 if args.masks else 7, 'planes_out': 7,
                        'sharding': f'tiles by rank x{world}, no collective',
                        'kernel': kernel_info},

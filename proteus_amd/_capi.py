@@ -10,7 +10,7 @@ import numpy as np
 
 from . import build as _build
 
-DSWX_ABI_VERSION = 2
+DSWX_ABI_VERSION = 3
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALIGN = 0, -1, -2, -3, -4, -5
 ADJ_MODES = {'mask': 0, 'ignore': 1, 'cover': 2}
 BAND_NAMES = ('blue', 'green', 'red', 'nir', 'swir1', 'swir2')
@@ -23,7 +23,7 @@ F64_LAYERS = ('mndwi', 'ndvi', 'awesh')
 EXPORTED_SYMBOLS = (
     'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
-    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device', 'dswx_landcover_mask_host',
+    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_classify_batch', 'dswx_synth_batch', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device', 'dswx_landcover_mask_host',
     'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
@@ -52,6 +52,11 @@ class Params(ctypes.Structure):
                  ('browse_ocean_masked_to_nodata', ctypes.c_int32),
                  ('reserved_', ctypes.c_int32),
                  ('aerosol_fmask_lut', (ctypes.c_uint8 * 256) * 4)])
+
+
+class BatchGeom(ctypes.Structure):
+    _fields_ = [('n_tiles', ctypes.c_int64), ('height', ctypes.c_int64), ('width', ctypes.c_int64),
+                ('tile_stride', ctypes.c_int64)]
 
 
 class PlanesIn(ctypes.Structure):
@@ -102,6 +107,11 @@ def load_library():
         'dswx_classify_device_2d': (ctypes.c_int, [vp, ctypes.POINTER(Params), i64, i64, i64,
                                                    ctypes.POINTER(PlanesIn),
                                                    ctypes.POINTER(PlanesOut), vp, vp]),
+        'dswx_classify_batch': (ctypes.c_int, [vp, ctypes.POINTER(Params), ctypes.POINTER(BatchGeom),
+                                               ctypes.POINTER(PlanesIn), ctypes.POINTER(PlanesOut),
+                                               vp, vp]),
+        'dswx_synth_batch': (ctypes.c_int, [vp, ctypes.c_uint64, i64, ctypes.POINTER(BatchGeom),
+                                            ctypes.POINTER(PlanesIn), vp]),
         'dswx_interpret_layer_host': (ctypes.c_int, [vp, vp, i64, vp]),
         'dswx_shadow_layer_host': (ctypes.c_int, [vp, vp, i64, i64, i64,
                                                   ctypes.POINTER(ctypes.c_double * 3)] +
@@ -111,7 +121,7 @@ def load_library():
                                      [ctypes.c_double] * 6 + [vp, vp]),
         'dswx_landcover_mask_host': (ctypes.c_int, [vp, vp, vp, i64, i64, vp, ctypes.c_int32, vp,
                                                     ctypes.c_int32, vp]),
-        'dswx_stream_probe': (ctypes.c_int, [vp, i64, i64, ctypes.POINTER(PlanesIn),
+        'dswx_stream_probe': (ctypes.c_int, [vp, i64, i64, i64, ctypes.POINTER(PlanesIn),
                                              ctypes.POINTER(PlanesOut), ctypes.c_int, vp]),
         'dswx_synth_fill': (ctypes.c_int, [vp, ctypes.c_uint64, i64, i64, i64, i64,
                                            ctypes.POINTER(PlanesIn), vp]),
@@ -373,10 +383,21 @@ class Context:
             _host_ptr(out)))
         return out
 
-    def stream_probe(self, n_tiles, n_pixels, pin, pout, variant=0, stream=None):
+    def stream_probe(self, n_tiles, n_pixels, pin, pout, variant=0, stream=None, tile_stride=0):
         _check(self.lib.dswx_stream_probe(
-            self.handle, int(n_tiles), int(n_pixels), ctypes.byref(pin),
+            self.handle, int(n_tiles), int(n_pixels), int(tile_stride), ctypes.byref(pin),
             ctypes.byref(pout), int(variant), ctypes.c_void_p(stream) if stream else None))
+
+    def classify_batch(self, params, geom, pin, pout, counters_ptr=None, stream=None):
+        _check(self.lib.dswx_classify_batch(
+            self.handle, ctypes.byref(params), ctypes.byref(geom), ctypes.byref(pin),
+            ctypes.byref(pout), ctypes.c_void_p(counters_ptr) if counters_ptr else None,
+            ctypes.c_void_p(stream) if stream else None))
+
+    def synth_batch(self, seed, tile0, geom, pin, stream=None):
+        _check(self.lib.dswx_synth_batch(
+            self.handle, int(seed), int(tile0), ctypes.byref(geom), ctypes.byref(pin),
+            ctypes.c_void_p(stream) if stream else None))
 
     def classify_device_2d(self, params, n_tiles, height, width, pin, pout, counters_ptr=None,
                            stream=None):
@@ -422,16 +443,21 @@ class Context:
 
 
 class DeviceBatch:
-    """Band-planar batch resident in HBM: every plane is [n_tiles][H*W].
+    """Band-planar batch resident in HBM: every plane is [n_tiles][tile_stride].
 
-    Owns one arena; plane offsets are 256-byte aligned.  Used by bench.py, the
-    multi-GPU driver and the device-path parity tests.
+    Owns one arena; plane offsets are 256-byte aligned and, by default, the tile stride is
+    H*W rounded up to a multiple of 256 pixels, so every tile starts on a 256-byte boundary
+    in every plane (contiguous tiles of 3660 x 3660 do not: 13,395,600 = 144 mod 256, which
+    costs ~20 % of the HBM rate).  `tile_align=1` gives contiguous tiles.
+    Used by bench.py, the multi-GPU driver and the device-path parity tests.
     """
 
-    def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=()):
+    def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=(), tile_align=256):
         self.ctx, self.n_tiles, self.height, self.width = ctx, n_tiles, height, width
         self.n_pixels = height * width
-        total = n_tiles * self.n_pixels
+        self.tile_stride = -(-self.n_pixels // tile_align) * tile_align
+        self.geom = BatchGeom(n_tiles, height, width, self.tile_stride)
+        total = n_tiles * self.tile_stride
         self.total = total
         off = 0
         self.offsets = {}
@@ -479,13 +505,11 @@ class DeviceBatch:
         self.counters_ptr = base + self.offsets['counters']
 
     def synth(self, seed, tile0=0, stream=None):
-        self.ctx.synth_fill(seed, tile0, self.n_tiles, self.height, self.width,
-                            self.pin, stream)
+        self.ctx.synth_batch(seed, tile0, self.geom, self.pin, stream)
 
     def classify(self, params, stream=None, counters=True):
-        self.ctx.classify_device_2d(params, self.n_tiles, self.height, self.width, self.pin,
-                                    self.pout, self.counters_ptr if counters else None,
-                                    stream)
+        self.ctx.classify_batch(params, self.geom, self.pin, self.pout,
+                                self.counters_ptr if counters else None, stream)
 
     def read_tile(self, name, tile):
         """Download one plane of one tile as [H,W]."""
@@ -495,14 +519,14 @@ class DeviceBatch:
             dt, sz = np.uint16, 2
         else:
             dt, sz = np.uint8, 1
-        off = self.offsets[name] + tile * self.n_pixels * sz
+        off = self.offsets[name] + tile * self.tile_stride * sz
         return self.arena.download(dt, self.n_pixels, off).reshape(self.height, self.width)
 
     def write_tile(self, name, tile, arr):
         sz = 2 if name in BAND_NAMES else 1
         dt = np.int16 if name in BAND_NAMES else np.uint8
         self.arena.upload(np.ascontiguousarray(arr, dtype=dt).ravel(),
-                          self.offsets[name] + tile * self.n_pixels * sz)
+                          self.offsets[name] + tile * self.tile_stride * sz)
 
     def read_counters(self):
         return self.arena.download(np.int64, self.n_tiles * 3,

@@ -48,6 +48,7 @@ struct KArgs {
     int height, width;              // 'cover' stage 2 only
     unsigned long long* counters;   // [n_tiles][3] or nullptr
     long long n_pixels;             // per tile
+    long long tile_stride;          // pixels between the starts of consecutive tiles in every plane
     long long px_begin;             // generic kernel: first pixel of the tile it covers
 };
 

@@ -23,7 +23,8 @@ struct dswx_ctx {
     void* cover = nullptr;
     size_t cover_bytes = 0;
     std::string last_kernel;
-    int fused_variant = 0;   // env DSWX_FUSED_VARIANT -- 0: direct stores (default); 1: LDS-staged
+    int fused_variant = -1;  // env DSWX_FUSED_VARIANT -- unset (-1): automatic = 3 when every tile starts on a
+                             // 256-byte boundary in every plane, else 0;  0: direct stores; 1: LDS-staged
                              // stores; 2: warp-specialised (LDS-DMA in, plane-run stores out);
                              // 3: table-driven (packed int16 + LDS tables + v_perm packing);
                              // 4: warp-specialised data movement + table-driven compute;
@@ -31,7 +32,7 @@ struct dswx_ctx {
     int tune_pipe_blocks = 512;   // persistent pipeline: total blocks (env DSWX_TUNE_PIPE_BLOCKS)
     int tune_ablate = 0;     // diagnostic ablation level of variant 4 (env DSWX_TUNE_ABLATE; outputs invalid)
     int tune_chunks = 1;     // table-driven kernel: chunks per block (env DSWX_TUNE_CHUNKS: 1, 4)
-    int tune_lut_wps = 5;    // table-driven kernel: launch bound (env DSWX_TUNE_LUT_WPS: 4, 5, 6)
+    int tune_lut_wps = 4;    // table-driven kernel: launch bound (env DSWX_TUNE_LUT_WPS: 4, 5, 6)
     int tune_wps = 6;        // launch-bound variant of the plain kernel (env DSWX_TUNE_WPS: 4, 6, 8)
 };
 
@@ -50,7 +51,8 @@ static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cas
 
 // ---- experimental fused-kernel variants (dswx_variants.hip), selected by DSWX_FUSED_VARIANT
 // block size and grid.x the selected variant wants for `groups` 8-pixel groups per tile
-void dswx_variant_geometry(const dswx_ctx* ctx, long long groups, long long n_tiles, int* threads, long long* gx);
+void dswx_variant_geometry(const dswx_ctx* ctx, int variant, long long groups, long long n_tiles, int* threads,
+                           long long* gx);
 // launches the selected variant; `info` receives its description
-int dswx_variant_launch(dswx_ctx* ctx, const KArgs& args, bool masks, dim3 grid, dim3 block, hipStream_t stream,
-                        char* info, size_t info_len);
+int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& args, bool masks, dim3 grid, dim3 block,
+                        hipStream_t stream, char* info, size_t info_len);

@@ -28,11 +28,11 @@ __global__ __launch_bounds__(BLOCK) void dswx_stream_probe_k(const KArgs a, int 
     for (int it = 0; it < iters; ++it) {
         const long long grp = (bx * iters + it) * BLOCK + threadIdx.x;
         if (grp >= n_groups) return;
-        const long long off = (long long)blockIdx.y * a.n_pixels + grp * PPT;
+        const long long off = (long long)blockIdx.y * a.tile_stride + grp * PPT;
         if (PPT == 8) {
             u32x4 x = {1u, 2u, 3u, (uint32_t)grp};
             u32x2 f = {5u, 6u};
-            if (MODE != 2) {
+            if (MODE != 2 && MODE != 4) {
                 x = ldg<u32x4, NT>(a.in.band[0] + off);
 #pragma unroll
                 for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, NT>(a.in.band[k] + off);
@@ -44,6 +44,19 @@ __global__ __launch_bounds__(BLOCK) void dswx_stream_probe_k(const KArgs a, int 
                 continue;
             }
             stg<u32x4, NT>(a.out.diag + off, x);
+            if (MODE >= 3) {
+                // 16 B per lane from the even lanes: lane 2k covers its own 8 px and lane 2k+1's
+                if ((threadIdx.x & 1) == 0) {
+                    const u32x4 z = {y.x, y.y, y.x + 7u, y.y + 9u};
+                    stg<u32x4, NT>(a.out.wtr1 + off, z);
+                    stg<u32x4, NT>(a.out.wtr2 + off, z + 1u);
+                    stg<u32x4, NT>(a.out.wtr + off, z + 2u);
+                    stg<u32x4, NT>(a.out.bwtr + off, z + 3u);
+                    stg<u32x4, NT>(a.out.conf + off, ~z);
+                    stg<u32x4, NT>(a.out.cloud + off, z + 5u);
+                }
+                continue;
+            }
             stg<u32x2, NT>(a.out.wtr1 + off, y);
             stg<u32x2, NT>(a.out.wtr2 + off, y + 1u);
             stg<u32x2, NT>(a.out.wtr + off, y + 2u);
@@ -52,7 +65,7 @@ __global__ __launch_bounds__(BLOCK) void dswx_stream_probe_k(const KArgs a, int 
             stg<u32x2, NT>(a.out.cloud + off, y + 5u);
         } else {
             u32x4 x0 = {1u, 2u, 3u, (uint32_t)grp}, x1 = x0, f = x0;
-            if (MODE != 2) {
+            if (MODE != 2 && MODE != 4) {
                 x0 = ldg<u32x4, NT>(a.in.band[0] + off); x1 = ldg<u32x4, NT>(a.in.band[0] + off + 8);
 #pragma unroll
                 for (int k = 1; k < 6; ++k) {
@@ -66,8 +79,16 @@ __global__ __launch_bounds__(BLOCK) void dswx_stream_probe_k(const KArgs a, int 
                 if (y.x == 0x12345678u && y.y == 0x9abcdef0u) stg<u32x4, NT>(a.out.wtr1 + off, y);
                 continue;
             }
-            stg<u32x4, NT>(a.out.diag + off, x0);
-            stg<u32x4, NT>(a.out.diag + off + 8, x1);
+            if (MODE >= 3) {
+                // the wave's 2 KiB of DIAG as two lane-contiguous 1 KiB stores (a real kernel
+                // moves the data between lanes first)
+                const long long wbase = off - (long long)(threadIdx.x & 63) * 16;       // first pixel of the wave
+                stg<u32x4, NT>(a.out.diag + wbase + (threadIdx.x & 63) * 8, x0);
+                stg<u32x4, NT>(a.out.diag + wbase + 512 + (threadIdx.x & 63) * 8, x1);
+            } else {
+                stg<u32x4, NT>(a.out.diag + off, x0);
+                stg<u32x4, NT>(a.out.diag + off + 8, x1);
+            }
             stg<u32x4, NT>(a.out.wtr1 + off, y);
             stg<u32x4, NT>(a.out.wtr2 + off, y + 1u);
             stg<u32x4, NT>(a.out.wtr + off, y + 2u);
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(BLOCK) void dswx_staged_probe_k(const KArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_groups = a.n_pixels >> 3;
     const long long grp = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
     const long long off = tile_base + (grp < n_groups ? grp : n_groups - 1) * 8;
     u32x4 x = ldg<u32x4, NT>(a.in.band[0] + off);
 #pragma unroll
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(256) void dswx_plane_per_block_k(const KArgs a, lon
 template <int SPLIT, bool NT>
 __global__ __launch_bounds__(256) void dswx_role_split_k(const KArgs a) {
     const long long n_groups = a.n_pixels >> 3;
-    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
     if (SPLIT == 2) {
         // pairs of blocks cover 4096 px: the even one reads all 7 planes (2 groups per
         // thread), the odd one writes all 7 planes as 1 KiB pieces, 8 consecutive
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(256) void dswx_ws_probe_k(const KArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_in[6 * PX * 2 + PX];
     __shared__ __attribute__((aligned(16))) uint8_t lds_out[PX * 2 + 6 * PX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
     const long long px0 = (long long)blockIdx.x * PX;
     if (px0 + PX > a.n_pixels) return;       // probe only: whole chunks
     // phase A
@@ -339,6 +360,27 @@ __global__ __launch_bounds__(256) void dswx_ws_probe_k(const KArgs a) {
                            *reinterpret_cast<const u32x4*>(lds_out + PX * 2 + u * PX + sub * 1024 + lane * 16));
         }
     }
+}
+
+// Write-shape grid: every wave writes R consecutive 1 KiB pieces (16 B per lane) to each of P
+// of the six u8 output planes, plane after plane; the grid covers all six planes.  Tells
+// run length per plane (R KiB) from planes-per-wave (P) in the store efficiency.
+template <int P, int R, bool NT>
+__global__ __launch_bounds__(256) void dswx_write_grid_k(const KArgs a, long long total_px) {
+    uint8_t* const planes[6] = {a.out.wtr1, a.out.wtr2, a.out.wtr, a.out.bwtr, a.out.conf, a.out.cloud};
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;     // global wave id
+    // a "super-chunk" of R KiB per plane is covered by 6 / P waves (one per group of P planes)
+    constexpr int GROUPS = 6 / P;
+    const long long chunk = wave / GROUPS;
+    const int g = (int)(wave % GROUPS);
+    const long long byte0 = chunk * (R * 1024LL);
+    if (byte0 + R * 1024LL > total_px) return;
+    const u32x4 val = {threadIdx.x, blockIdx.x, 3u, 4u};
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r) stg<u32x4, NT>(planes[g * P + p] + byte0 + r * 1024 + lane * 16, val);
 }
 
 // Calibration: a flat two-stream copy moving the same 13 B in / 8 B out per pixel
@@ -396,8 +438,8 @@ __global__ __launch_bounds__(256) void dswx_write_probe_k(const KArgs a, long lo
 
 extern "C" {
 
-int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const dswx_planes_in_t* in,
-                      const dswx_planes_out_t* out, int variant, void* stream) {
+int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, int64_t tile_stride,
+                      const dswx_planes_in_t* in, const dswx_planes_out_t* out, int variant, void* stream) {
     if (!ctx || !in || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     if (n_tiles <= 0 || n_tiles > 65535 || n_pixels <= 0 || n_pixels % 16)
         return dswx_fail(DSWX_ERR_ARG, "probe needs 1..65535 tiles of a multiple of 16 pixels");
@@ -410,6 +452,7 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const 
     KArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = *in; a.out = *out; a.n_pixels = n_pixels;
+    a.tile_stride = tile_stride ? tile_stride : n_pixels;
     // variant = ppt16 | nt << 1 | log2(iters) << 2 | mode << 9 | xcdmap << 11 |
     // block512 << 12 ; bit 8: flat two-stream copy of
     // the same byte counts (needs the planes laid out as DeviceBatch does:
@@ -420,6 +463,19 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const 
         dim3 grid((unsigned)((n16_in + 255) / 256)), block(256);
         if (variant & 2) hipLaunchKernelGGL(dswx_flat_copy_k<true>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
         else hipLaunchKernelGGL(dswx_flat_copy_k<false>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & 1048576) {  // write-shape grid: bits 2-3 = log2-ish P index {1,2,3,6}, bits 4-5 = log2 R, bit 1 = nt
+        const long long total = n_tiles * n_pixels;
+        const int pi = (variant >> 2) & 3, ri = (variant >> 4) & 3;
+        const bool wnt = variant & 2;
+        const int Pv[4] = {1, 2, 3, 6}, Rv[4] = {1, 2, 4, 8};
+        const long long waves = (total / (Rv[ri] * 1024LL)) * (6 / Pv[pi]);
+        dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define WG(PP, RR) do { if (wnt) hipLaunchKernelGGL((dswx_write_grid_k<PP, RR, true>), grid, block, 0, s, a, total); else hipLaunchKernelGGL((dswx_write_grid_k<PP, RR, false>), grid, block, 0, s, a, total); } while (0)
+#define WG_R(PP) do { if (ri == 0) WG(PP, 1); else if (ri == 1) WG(PP, 2); else if (ri == 2) WG(PP, 4); else WG(PP, 8); } while (0)
+        if (pi == 0) WG_R(1); else if (pi == 1) WG_R(2); else if (pi == 2) WG_R(3); else WG_R(6);
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }
@@ -510,7 +566,7 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const 
     }
     const bool ppt16 = variant & 1, nt = variant & 2;
     const int iters = 1 << ((variant >> 2) & 7);
-    const int mode = (variant >> 9) & 3;
+    const int mode = ((variant >> 9) & 3) + ((variant & (1 << 21)) ? 3 : 0);   // bit 21: +3 (fixed store shapes)
     const bool xcd = variant & 2048, big = variant & 4096;
     const int ppt = ppt16 ? 16 : 8, bs = big ? 512 : 256;
     const int64_t groups = n_pixels / ppt;
@@ -518,7 +574,7 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, const 
 #define PROBE_LAUNCH(PPT, NT, MODE, XCD, BS) hipLaunchKernelGGL((dswx_stream_probe_k<PPT, NT, MODE, XCD, BS>), grid, block, 0, s, a, iters)
 #define PROBE_SEL5(PPT, NT, MODE, XCD) do { if (big) PROBE_LAUNCH(PPT, NT, MODE, XCD, 512); else PROBE_LAUNCH(PPT, NT, MODE, XCD, 256); } while (0)
 #define PROBE_SEL4(PPT, NT, MODE) do { if (xcd) PROBE_SEL5(PPT, NT, MODE, true); else PROBE_SEL5(PPT, NT, MODE, false); } while (0)
-#define PROBE_SEL3(PPT, NT) do { if (mode == 0) PROBE_SEL4(PPT, NT, 0); else if (mode == 1) PROBE_SEL4(PPT, NT, 1); else PROBE_SEL4(PPT, NT, 2); } while (0)
+#define PROBE_SEL3(PPT, NT) do { if (mode == 0) PROBE_SEL4(PPT, NT, 0); else if (mode == 1) PROBE_SEL4(PPT, NT, 1); else if (mode == 2) PROBE_SEL4(PPT, NT, 2); else if (mode == 3) PROBE_SEL4(PPT, NT, 3); else PROBE_SEL4(PPT, NT, 4); } while (0)
 #define PROBE_SEL2(PPT) do { if (nt) PROBE_SEL3(PPT, true); else PROBE_SEL3(PPT, false); } while (0)
     if (ppt16) PROBE_SEL2(16); else PROBE_SEL2(8);
     HIP_TRY(hipGetLastError());

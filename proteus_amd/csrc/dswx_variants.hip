@@ -41,7 +41,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void dswx_classify_fused(const KArgs
 
     const long long n_groups = a.n_pixels >> 3;
     const long long grp = (long long)blockIdx.x * FUSED_THREADS + threadIdx.x;
-    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
     // A3: per-wave counts from lane-mask popcounts (scalar unit), no atomics
     uint32_t w_valid = 0, w_cloud = 0, t_ocean = 0;
     // No divergence: threads past the tile's last group redo that group (their
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, MASKS ? 4 : 5) void dswx_classify_ws(const KAr
     const DevParams& P = a.P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t lut_reg = a.P.aer_lut[lane];
-    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
     const long long px0 = (long long)blockIdx.x * WS_PX;
     const long long n_vec = (a.n_pixels >> 3) << 3;       // pixels the vector path covers
     // last byte offsets a 16-byte access may start at without leaving the covered range
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_wslut(const KArgs a, c
     __shared__ uint2 s_chain[N_CHAIN];
     const DevParams& P = a.P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
     const long long px0 = (long long)blockIdx.x * WS_PX;
     const long long n_vec = (a.n_pixels >> 3) << 3;
     const long long last16_i16 = (n_vec - 8) * 2, last16_u8 = n_vec >= 16 ? n_vec - 16 : 0;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_pipe(const KArgs a, co
     __shared__ uint2 s_chain[N_CHAIN];
     const DevParams& P = a.P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
     const long long n_groups = a.n_pixels >> 3, n_vec = n_groups << 3;
     const long long n_chunks = (n_vec + WS_PX - 1) / WS_PX;
     const long long last16_i16 = (n_vec - 8) * 2, last16_u8 = n_vec >= 16 ? n_vec - 16 : 0;
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
 
     const DevParams& P = a.P;
     const long long n_groups = a.n_pixels >> 3;
-    const long long tile_base = (long long)blockIdx.y * a.n_pixels;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
     const bool has_l = MASKS && a.in.land, has_s = MASKS && a.in.shad, has_o = MASKS && a.in.ocean;
     uint32_t cnt = 0, t_ocean = 0;       // cnt: valid in the low half, cloud-and-valid in the high half
 
@@ -859,8 +859,9 @@ static void make_lut_consts(const DevParams& d, LutConsts* c) {
     c->awesh_init = -d.awesh4_min;
 }
 
-void dswx_variant_geometry(const dswx_ctx* ctx, long long groups, long long n_tiles, int* threads, long long* gx) {
-    const int v = ctx->fused_variant;
+void dswx_variant_geometry(const dswx_ctx* ctx, int variant, long long groups, long long n_tiles, int* threads,
+                           long long* gx) {
+    const int v = variant;
     *threads = v == 1 ? FUSED_THREADS : 256;
     const int lut_chunks = (ctx->tune_chunks == 1 || ctx->tune_chunks == 4) ? ctx->tune_chunks : 1;
     const long long per_block = (long long)*threads * (v == 3 ? lut_chunks : 1);
@@ -872,11 +873,11 @@ void dswx_variant_geometry(const dswx_ctx* ctx, long long groups, long long n_ti
     }
 }
 
-int dswx_variant_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 block, hipStream_t s, char* info,
-                        size_t info_len) {
+int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& b, bool masks, dim3 grid, dim3 block, hipStream_t s,
+                        char* info, size_t info_len) {
     const long long gx = grid.x, nt = grid.y;
-    const bool staged = ctx->fused_variant == 1, wspec = ctx->fused_variant == 2, tabled = ctx->fused_variant == 3,
-               wslut = ctx->fused_variant == 4, piped = ctx->fused_variant == 5;
+    const bool staged = variant == 1, wspec = variant == 2, tabled = variant == 3, wslut = variant == 4,
+               piped = variant == 5;
     const int lut_chunks = (ctx->tune_chunks == 1 || ctx->tune_chunks == 4) ? ctx->tune_chunks : 1;
             if (piped) {
                 if (!ctx->tables) HIP_TRY(hipMalloc(&ctx->tables, sizeof(Tables)));

@@ -53,6 +53,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.Params) == 20 * 8 + 10 * 4 + 1024
     assert ctypes.sizeof(_capi.PlanesIn) == 10 * 8
     assert ctypes.sizeof(_capi.PlanesOut) == 12 * 8
+    assert ctypes.sizeof(_capi.BatchGeom) == 4 * 8
 
 
 def test_bad_mode_raises_like_reference():

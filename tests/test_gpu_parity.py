@@ -161,18 +161,24 @@ def test_error_paths(ctx):
 
 
 # ---- device-resident batches, synthetic generator ----------------------------------
+@pytest.mark.parametrize('tile_align', [256, 1])
 @pytest.mark.parametrize('geom', [(3, 64, 64, True), (4, 100, 37, True), (2, 5, 3, False),
                                   (1, 333, 517, True), (5, 128, 96, False)])
-def test_device_batch_and_synth(ctx, geom):
+def test_device_batch_and_synth(ctx, geom, tile_align):
+    """tile_align=256: every tile starts on a 256-byte boundary (the default batch layout);
+    tile_align=1: contiguous tiles, as a caller with one flat [n_tiles][H*W] array has."""
     n_tiles, h, w, masks = geom
-    batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=masks, extra_layers=('wtr1_aerosol',))
+    batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=masks, extra_layers=('wtr1_aerosol',),
+                              tile_align=tile_align)
+    assert batch.tile_stride % tile_align == 0 and batch.tile_stride >= h * w
     batch.synth(SEED, tile0=7)
     p = _capi.default_params()
     batch.classify(p)
     ctx.synchronize()
     info = ctx.last_kernel_info()
-    # ragged multi-tile batches go to the generic kernel, the rest to the vector one
-    assert ('dswx_classify_v8' in info or 'dswx_classify_fused' in info) == ((h * w) % 16 == 0 or n_tiles == 1), info
+    # contiguous ragged multi-tile batches go to the generic kernel, the rest to the vector one
+    vector = 'dswx_classify_v8' in info or 'dswx_classify_lut' in info
+    assert vector == (h * w >= 8 and (batch.tile_stride % 16 == 0 or n_tiles == 1)), info
     cnt = batch.read_counters()
     for t in range(n_tiles):
         s = synth_tile(7 + t, h, w, with_masks=True)
@@ -231,7 +237,7 @@ def test_full_size_tile_vs_numpy_oracle(ctx):
     s = synth_tile(0, h, w)
     p = _capi.default_params()
     got = ctx.classify_host(s['bands'], s['fmask'], p)
-    assert 'fused' in ctx.last_kernel_info()
+    assert 'dswx_classify_lut' in ctx.last_kernel_info()      # aligned single tile -> table-driven
     exp = o.classify_tile(s['bands'], s['fmask'])
     for layer, key in NAME.items():
         assert np.array_equal(got[key], exp[layer]), layer
@@ -249,7 +255,7 @@ def test_full_size_batch_properties(ctx):
     batch.classify(p)
     ctx.synchronize()
     cnt = batch.read_counters()
-    assert '<true,' in ctx.last_kernel_info()
+    assert 'dswx_classify_lut<true>' in ctx.last_kernel_info()
     for t in (0, n_tiles - 1):
         s = synth_tile(100 + t, h, w, with_masks=True)
         exp = c_oracle.classify(p, s['bands'], s['fmask'], land=s['land'], shad=s['shad'],
@@ -318,7 +324,7 @@ def test_gpu_quotient_enumeration(ctx):
     assert np.array_equal(got['diag'].ravel(), exp['diag'])
 
 
-@pytest.mark.parametrize('variant,tag', [('1', 'LDS-staged'), ('2', 'warp-specialised'),
+@pytest.mark.parametrize('variant,tag', [('0', 'direct stores'), ('1', 'LDS-staged'), ('2', 'warp-specialised'),
                                          ('3', 'table-driven'), ('4', 'warp-specialised + table-driven'),
                                          ('5', 'pipeline')])
 def test_kernel_variants_parity(monkeypatch, variant, tag):

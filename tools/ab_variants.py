@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--masks', action='store_true')
+    ap.add_argument('--tile-align', type=int, default=256)
     a = ap.parse_args()
     ctxs = []
     for v in a.variants:
@@ -37,7 +38,7 @@ def main():
             else:
                 os.environ[k] = old
     base = ctxs[0]
-    batch = _capi.DeviceBatch(base, a.tiles, 3660, 3660, masks=a.masks)
+    batch = _capi.DeviceBatch(base, a.tiles, 3660, 3660, masks=a.masks, tile_align=a.tile_align)
     batch.synth(SEED)
     base.synchronize()
     p = _capi.default_params()
@@ -47,12 +48,12 @@ def main():
     info = {}
     for r in range(a.rounds):
         for v, ctx in zip(a.variants, ctxs):
-            ctx.classify_device(p, a.tiles, batch.n_pixels, batch.pin, batch.pout, batch.counters_ptr)
+            ctx.classify_batch(p, batch.geom, batch.pin, batch.pout, batch.counters_ptr)
             ctx.synchronize()
             e0, e1 = ctx.event(), ctx.event()
             ctx.record(e0)
             for _ in range(a.reps):
-                ctx.classify_device(p, a.tiles, batch.n_pixels, batch.pin, batch.pout, batch.counters_ptr)
+                ctx.classify_batch(p, batch.geom, batch.pin, batch.pout, batch.counters_ptr)
             ctx.record(e1)
             ms = ctx.elapsed_ms(e0, e1) / a.reps
             res[v].append(px * bpp / ms / 1e6)

@@ -35,9 +35,10 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--masks', action='store_true')
     ap.add_argument('--size', type=int, default=3660)
+    ap.add_argument('--tile-align', type=int, default=256, help='1 = contiguous tiles')
     a = ap.parse_args()
     ctx = _capi.Context(0)
-    batch = _capi.DeviceBatch(ctx, a.tiles, a.size, a.size, masks=a.masks)
+    batch = _capi.DeviceBatch(ctx, a.tiles, a.size, a.size, masks=a.masks, tile_align=a.tile_align)
     batch.synth(SEED)
     ctx.synchronize()
     p = _capi.default_params()
@@ -53,11 +54,11 @@ def main():
     if not a.masks:
         for variant in (256, 258):
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
-                                                     variant), a.reps)
+                                                     variant, tile_stride=batch.tile_stride), a.reps)
             out[f'flat 2-stream copy nt={int(bool(variant & 2))}'] = round(px * 21 / (sum(ms) / len(ms)) / 1e6, 1)
         def run(label, variant, nbytes):
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
-                                                     variant), a.reps)
+                                                     variant, tile_stride=batch.tile_stride), a.reps)
             out[label] = round(px * nbytes / (sum(ms) / len(ms)) / 1e6, 1)
         for nt in (0, 2):
             run(f'14 planes, one plane per block nt={nt >> 1}', 32768 | nt, 21)
@@ -77,6 +78,18 @@ def main():
             for nt in (0, 2):
                 run(f'staged probe block={256 << lb} nt={nt >> 1}', 16384 | (lb << 2) | nt, 21)
         run('probe ppt=8 nt=1 (direct stores)', 2, 21)
+        for ppt16 in (0, 1):
+            for nt in (0, 2):
+                tag = f'ppt={16 if ppt16 else 8} nt={nt >> 1}'
+                run(f'fused shape {tag} (as is)', ppt16 | nt, 21)
+                run(f'fused shape {tag}, all stores lane-contiguous 16 B', ppt16 | nt | (1 << 21), 21)
+                run(f'fused shape {tag} write-only (as is)', ppt16 | nt | (2 << 9), 8)
+                run(f'fused shape {tag} write-only, all stores lane-contiguous 16 B', ppt16 | nt | (1 << 9) | (1 << 21), 8)
+        for pi, P in enumerate((1, 2, 3, 6)):
+            for ri, R in enumerate((1, 2, 4, 8)):
+                for nt in (0, 2):
+                    run(f'write grid: {P} planes per wave x {R} KiB runs nt={nt >> 1}',
+                        1048576 | (pi << 2) | (ri << 4) | nt, 6)
         for wm, name in ((0, 'flat 1 stream'), (1, '7 planes, plane per block'), (2, '7 planes, plane per wave')):
             for nt in (0, 2):
                 run(f'write-only {name} nt={nt >> 1}', 8192 | (wm << 2) | nt, 8)
