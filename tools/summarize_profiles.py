@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def one(pattern):
-    hits = sorted(glob.glob(pattern, recursive=True))
+    hits = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)   # newest run wins
     if not hits:
         raise SystemExit(f'no file matches {pattern}')
     return hits[-1]
