@@ -1,0 +1,105 @@
+// dswx_classify_lut.hip -- the production fused kernel on 256-byte aligned batch layouts:
+// table-driven compute (dswx_tables.h) with direct register loads and stores.
+//
+// Block = 256 threads = 2048 consecutive pixels of one tile (grid.y = tile); each thread owns one
+// 8-pixel group: 6 x 16-B + 1 x 8-B non-temporal loads (+ 3 x 8 B with LAND / SHAD / OCEAN),
+// 1 x 16-B + 6 x 8-B non-temporal stores.  The tables (2.3 KiB; 9.5 KiB with masks) are
+// rebuilt on the device for every call by dswx_build_tables from the same px_w1 / px_chain
+// the scalar kernel uses and copied into LDS by every block.
+#include <cstdio>
+
+#include "dswx_host.h"
+#include "dswx_tables.h"
+
+// LUT_CHUNKS: 2048-px chunks per block (amortises the table load); WPS: launch bound
+template <bool MASKS, int LUT_CHUNKS, int WPS>
+__global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
+                                                             const Tables* __restrict__ tabs) {
+    constexpr int N_CHAIN = MASKS ? 1024 : 128;
+    __shared__ uint32_t s_lut1[128];
+    __shared__ uint16_t s_fm16[256];
+    __shared__ uint8_t s_land8[MASKS ? 256 : 4];
+    __shared__ uint2 s_chain[N_CHAIN];
+    for (int i = threadIdx.x; i < 128; i += 256) s_lut1[i] = tabs->lut1[i];
+    for (int i = threadIdx.x; i < 128; i += 256) reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
+    if (MASKS) for (int i = threadIdx.x; i < 64; i += 256) reinterpret_cast<uint32_t*>(s_land8)[i] = reinterpret_cast<const uint32_t*>(tabs->land8)[i];
+    for (int i = threadIdx.x; i < N_CHAIN; i += 256) s_chain[i] = tabs->chain[i];
+    __syncthreads();
+
+    const DevParams& P = a.P;
+    const long long n_groups = a.n_pixels >> 3;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
+    const bool has_l = MASKS && a.in.land, has_s = MASKS && a.in.shad, has_o = MASKS && a.in.ocean;
+    uint32_t cnt = 0, t_ocean = 0;       // cnt: valid in the low half, cloud-and-valid in the high half
+
+    for (int c = 0; c < LUT_CHUNKS; ++c) {
+        const long long grp = ((long long)blockIdx.x * LUT_CHUNKS + c) * 256 + threadIdx.x;
+        if ((grp - threadIdx.x) >= n_groups) break;                       // block-uniform
+        const bool in_range = grp < n_groups;
+        const long long off = tile_base + (in_range ? grp : n_groups - 1) * 8;
+        u32x4 v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
+        const u32x2 vf = ldg<u32x2, true>(a.in.fmask + off);
+        u32x2 vl = {0u, 0u}, vs = {0x01010101u, 0x01010101u}, vo = {0x01010101u, 0x01010101u};
+        if (MASKS) {
+            if (has_l) vl = ldg<u32x2, true>(a.in.land + off);
+            if (has_s) vs = ldg<u32x2, true>(a.in.shad + off);
+            if (has_o) {
+                vo = ldg<u32x2, true>(a.in.ocean + off);
+                const uint32_t so = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
+                t_ocean += in_range ? so : 0u;
+            }
+        }
+        uint32_t w1w[8], chx[8], chy[8];      // per-pixel table words
+        lut_group<MASKS>(P, C, s_lut1, s_fm16, s_land8, s_chain, v, vf, vl, vs, vo, has_l, in_range, w1w, chx, chy, cnt);
+        if (in_range) {
+            GroupPlanes gp;
+            lut_pack(w1w, chx, chy, gp);
+            if (a.out.diag) stg<u32x4, true>(a.out.diag + off, u32x4{gp.diag[0], gp.diag[1], gp.diag[2], gp.diag[3]});
+            if (a.out.wtr1) stg<u32x2, true>(a.out.wtr1 + off, u32x2{gp.w1[0], gp.w1[1]});
+            if (a.out.wtr1_aerosol) stg<u32x2, true>(a.out.wtr1_aerosol + off, u32x2{gp.w1a[0], gp.w1a[1]});
+            if (a.out.wtr2) stg<u32x2, true>(a.out.wtr2 + off, u32x2{gp.w2[0], gp.w2[1]});
+            if (a.out.wtr) stg<u32x2, true>(a.out.wtr + off, u32x2{gp.w[0], gp.w[1]});
+            if (a.out.bwtr) stg<u32x2, true>(a.out.bwtr + off, u32x2{gp.bw[0], gp.bw[1]});
+            if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{gp.cf[0], gp.cf[1]});
+            if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{gp.cl[0], gp.cl[1]});
+        }
+    }
+    if (a.partials) {
+        uint32_t c0 = cnt, c2 = t_ocean;
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) { c0 += __shfl_xor(c0, sh); c2 += __shfl_xor(c2, sh); }
+        if ((threadIdx.x & 63) == 0) {
+            const long long slot = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+            a.partials[slot] = make_uint2(c0, c2);
+        }
+    }
+}
+
+void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, int* threads, long long* gx) {
+    const int lut_chunks = (ctx->tune_chunks == 1 || ctx->tune_chunks == 4) ? ctx->tune_chunks : 1;
+    *threads = 256;
+    const long long per_block = 256LL * lut_chunks;
+    *gx = (groups + per_block - 1) / per_block;
+}
+
+int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 block, hipStream_t s, char* info,
+                    size_t info_len) {
+    const int lut_chunks = (ctx->tune_chunks == 1 || ctx->tune_chunks == 4) ? ctx->tune_chunks : 1;
+    if (!ctx->tables) HIP_TRY(hipMalloc(&ctx->tables, sizeof(Tables)));
+    Tables* tabs = static_cast<Tables*>(ctx->tables);
+    LutConsts lc;
+    make_lut_consts(b.P, &lc);
+    hipLaunchKernelGGL(dswx_build_tables, dim3(4), dim3(256), 0, s, b.P, tabs);
+    // launch bound: 4 waves per SIMD everywhere by default (5 spills with masks; 5 / 6 are within
+    // 1 % without), env DSWX_TUNE_LUT_WPS
+    const int wps = ctx->tune_lut_wps;
+#define LUT_LAUNCH(M, CH, W) hipLaunchKernelGGL((dswx_classify_lut<M, CH, W>), grid, block, 0, s, b, lc, tabs)
+#define LUT_SEL_W(M, CH) do { if (wps >= 6) LUT_LAUNCH(M, CH, 6); else if (wps == 5) LUT_LAUNCH(M, CH, 5); else LUT_LAUNCH(M, CH, 4); } while (0)
+#define LUT_SEL_C(M) do { if (lut_chunks == 4) LUT_SEL_W(M, 4); else LUT_SEL_W(M, 1); } while (0)
+    if (masks) LUT_SEL_C(true); else LUT_SEL_C(false);
+    snprintf(info, info_len, "dswx_classify_lut<%s> (table-driven) grid=(%lld,%lld) block=256 chunks=%d wps=%d",
+             masks ? "true" : "false", (long long)grid.x, (long long)grid.y, lut_chunks, wps);
+    return DSWX_OK;
+}

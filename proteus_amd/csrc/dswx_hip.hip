@@ -799,7 +799,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             const bool variant = vsel != 0 && plain_outputs && dma16_ok;
             int threads = 256;
             long long gx_ll = (groups + 255) / 256;
-            if (variant) dswx_variant_geometry(ctx, vsel, groups, nt, &threads, &gx_ll);
+            if (variant && vsel == 3) dswx_lut_geometry(ctx, groups, &threads, &gx_ll);
+            else if (variant) dswx_variant_geometry(ctx, vsel, groups, nt, &threads, &gx_ll);
             const int64_t gx = gx_ll;
             const int waves = threads / 64;
             dim3 grid((unsigned)gx, (unsigned)nt), block(threads);
@@ -820,7 +821,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
                 if (u8p[i]) { b.u8_out[b.n_u8_out] = u8p[i]; b.u8_region[b.n_u8_out] = i; ++b.n_u8_out; }
             b.n_diag_pieces = b.out.diag ? 8 : 0;
             if (variant) {
-                const int vrc = dswx_variant_launch(ctx, vsel, b, masks, grid, block, s, info, sizeof info);
+                const int vrc = vsel == 3 ? dswx_lut_launch(ctx, b, masks, grid, block, s, info, sizeof info)
+                                          : dswx_variant_launch(ctx, vsel, b, masks, grid, block, s, info, sizeof info);
                 if (vrc) return vrc;
             } else {
                 const bool extras = b.out.browse || b.cover_w2;

@@ -49,7 +49,12 @@ int dswx_fail(int code, const char* fmt, ...);
 
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-// ---- experimental fused-kernel variants (dswx_variants.hip), selected by DSWX_FUSED_VARIANT
+// ---- table-driven production kernel (dswx_classify_lut.hip)
+void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, int* threads, long long* gx);
+int dswx_lut_launch(dswx_ctx* ctx, const KArgs& args, bool masks, dim3 grid, dim3 block, hipStream_t stream,
+                    char* info, size_t info_len);
+
+// ---- experimental fused-kernel variants (dswx_variants.hip), DSWX_FUSED_VARIANT = 1, 2, 4, 5
 // block size and grid.x the selected variant wants for `groups` 8-pixel groups per tile
 void dswx_variant_geometry(const dswx_ctx* ctx, int variant, long long groups, long long n_tiles, int* threads,
                            long long* gx);

@@ -268,6 +268,32 @@ __global__ __launch_bounds__(256) void dswx_chunked_layout_probe_k(uint8_t* __re
     for (int k = 0; k < 6; ++k) stg<u32x2, NT>(base + (15LL + k) * CH + r, y + (uint32_t)k);
 }
 
+// Record layout probe: pixels are grouped in records of CHPX pixels; an input record is
+// [6 x int16 plane pieces | fmask piece] = 13*CHPX contiguous bytes and an output
+// record [diag | 6 x u8 pieces] = 8*CHPX contiguous bytes.  A block handles 2048 px of
+// one record with exactly the fused kernel's per-lane access widths, so all 14 accesses
+// of a block fall in two short contiguous spans (record sizes are NOT powers of two).
+template <int CHPX, bool NT>
+__global__ __launch_bounds__(256) void dswx_record_probe_k(const uint8_t* __restrict__ in_arena,
+                                                           uint8_t* __restrict__ out_arena, long long n_blocks) {
+    constexpr int SUB = CHPX / 2048;
+    const long long b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const long long rec = b / SUB;
+    const int j = (int)(b % SUB);
+    const uint8_t* irec = in_arena + rec * (13LL * CHPX);
+    uint8_t* orec = out_arena + rec * (8LL * CHPX);
+    const int t = threadIdx.x;
+    u32x4 x = ldg<u32x4, NT>(irec + j * 4096 + t * 16);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, NT>(irec + (long long)k * 2 * CHPX + j * 4096 + t * 16);
+    const u32x2 f = ldg<u32x2, NT>(irec + 12LL * CHPX + j * 2048 + t * 8);
+    u32x2 y; y.x = x.x ^ x.z ^ f.x; y.y = x.y ^ x.w ^ f.y;
+    stg<u32x4, NT>(orec + j * 4096 + t * 16, x);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) stg<u32x2, NT>(orec + (2LL + k) * CHPX + j * 2048 + t * 8, y + (uint32_t)k);
+}
+
 // Plane-specialised waves: block = 7 waves over a 4096-px chunk; wave k reads only input
 // plane k (8 KiB of an int16 plane, 4 KiB of Fmask) and then writes only output plane k
 // (8 KiB of DIAG, 4 KiB of a u8 layer).  Same bytes as the fused kernel; this is what a
@@ -491,6 +517,19 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, int64_
         dim3 grid((unsigned)(total / 4096)), block(448);
         if (variant & 2) hipLaunchKernelGGL(dswx_plane_per_wave_k<true>, grid, block, 0, s, a, total);
         else hipLaunchKernelGGL(dswx_plane_per_wave_k<false>, grid, block, 0, s, a, total);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & (1 << 22)) {  // record layout: bits 2-3 select CHPX = 2048 << (2*sel), bit 1 = nt
+        const long long total = n_tiles * a.tile_stride;
+        const int sel = (variant >> 2) & 3;
+        const long long n_blocks = total / 2048 / 64 * 64;
+        dim3 grid((unsigned)n_blocks), block(256);
+        const uint8_t* ia = reinterpret_cast<const uint8_t*>(in->band[0]);
+        uint8_t* oa = reinterpret_cast<uint8_t*>(out->diag);
+        const bool wnt = variant & 2;
+#define REC_LAUNCH(CH) do { if (wnt) hipLaunchKernelGGL((dswx_record_probe_k<CH, true>), grid, block, 0, s, ia, oa, n_blocks); else hipLaunchKernelGGL((dswx_record_probe_k<CH, false>), grid, block, 0, s, ia, oa, n_blocks); } while (0)
+        if (sel == 0) REC_LAUNCH(2048); else if (sel == 1) REC_LAUNCH(8192); else if (sel == 2) REC_LAUNCH(32768); else REC_LAUNCH(131072);
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }

@@ -1,12 +1,14 @@
-// dswx_variants.hip -- experimental variants of the fused kernel, selected per context with
-// DSWX_FUSED_VARIANT = 1..5.  All are bit-exact (tests/test_gpu_parity.py::
-// test_kernel_variants_parity) and all are slower than the default direct-store kernel today;
-// they are kept because each isolates one structural idea measured in DESIGN.md section 5.
+// dswx_variants.hip -- experimental data-movement structures of the fused kernel, selected per
+// context with DSWX_FUSED_VARIANT = 1, 2, 4, 5.  All are bit-exact (tests/test_gpu_parity.py::
+// test_kernel_variants_parity) and all are slower than the production kernels (0: dswx_classify_v8
+// in dswx_hip.hip, 3: dswx_classify_lut in dswx_classify_lut.hip); they are kept because each
+// isolates one structural idea measured in DESIGN.md section 5.
 #include <cstdio>
 #include <cstring>
 #include <limits>
 
 #include "dswx_host.h"
+#include "dswx_tables.h"
 
 // ------------------------------------------------------------------------------
 // Fused kernel, LDS-staged variant (DSWX_FUSED_VARIANT=1).  Block = 512 threads = 4096 consecutive pixels of one tile
@@ -310,186 +312,6 @@ __global__ __launch_bounds__(256, MASKS ? 4 : 5) void dswx_classify_ws(const KAr
     }
 }
 
-// ==============================================================================
-// Table-driven fused kernel (DSWX_FUSED_VARIANT=3)
-// ==============================================================================
-// The per-pixel chain after the five tests is a pure function of a few bits, so it is
-// tabulated ON THE DEVICE by dswx_build_tables -- which calls the very same px_w1 /
-// px_chain the scalar path uses (one source of truth) -- and the hot kernel only
-//   * does the arithmetic part in packed int16 (v_pk_*: two pixels per instruction) and
-//     in sign-bit form (no compare -> lane-mask -> select chains, hence almost no SALU),
-//   * looks three small LDS tables up per pixel,
-//   * transposes the table words into plane order with v_perm_b32.
-struct Tables {
-    uint32_t lut1[128];    // [T1 | T2<<1 | !T3<<2 | T4<<3 | T5<<4 | invalid<<5 | ocean0<<6]
-                           //   -> DIAG(16) | WTR-1 code(8) << 16 | WTR-1 as saved(8) << 24
-    uint16_t fm16[256];    // Fmask byte -> aerosol class bits(5) | shadow<<5 | cloud<<6 | snow<<7
-                           //   | is_fill<<8 | prelim_cloud_nonzero<<9
-    uint8_t land8[256];    // LAND byte -> is_water(200) | psw_rule_class(201 or <100)<<1 | high_dev<<2
-    uint2 chain[1024];     // [code | remap<<3 | shadow<<4 | cloud<<5 | snow<<6 | shadrule<<7 |
-                           //  lcpsw<<8 | lchigh<<9] -> x = WTR-1-AEROSOL | WTR-2<<8 | WTR<<16 | BWTR<<24,
-                           //                           y = CONF | CLOUD<<8
-};
-// WTR-1 "code": 0..4 = class, 5 = ocean masked (254), 6 = fill (255)
-
-__global__ __launch_bounds__(256) void dswx_build_tables(const DevParams P, Tables* __restrict__ t) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t cc = (uint32_t)P.collapse;
-    if (i < 128) {
-        const uint32_t dd = (uint32_t)(i & 3) | ((((uint32_t)i >> 2) & 1u) ^ 1u) << 2 | (((uint32_t)i >> 3) & 3u) << 3;
-        uint32_t diag, w1;
-        px_w1(dd, (i >> 5) & 1, (i >> 6) & 1, diag, w1);
-        const uint32_t code = w1 <= 4u ? w1 : (w1 == 254u ? 5u : 6u);
-        t->lut1[i] = diag | (code << 16) | (collapse_class(w1, cc) << 24);
-    }
-    if (i < 256) {
-        const uint32_t aer = (P.aer_lut[i >> 2] >> (8 * (i & 3))) & 0x1fu;
-        const uint32_t shadow = (i & P.shadow_bits) ? 1u : 0u, cloud = (i >> 1) & 1u, snow = (i >> 4) & 1u;
-        t->fm16[i] = (uint16_t)(aer | shadow << 5 | cloud << 6 | snow << 7 | (i == P.fmask_fill ? 1u : 0u) << 8 |
-                                (shadow | cloud) << 9);
-        t->land8[i] = (uint8_t)((i == 200 ? 1 : 0) | ((i == 201 || i < 100) ? 2 : 0) | ((i >= 100 && i < 200) ? 4 : 0));
-    }
-    if (i < 1024) {
-        const uint32_t code = i & 7;
-        const uint32_t w1 = code <= 4u ? code : (code == 5u ? 254u : 255u);
-        const uint32_t pc = ((i >> 4) & 1u) + 4u * ((i >> 5) & 1u);
-        PxOut o;
-        px_chain(P, w1, (i >> 3) & 1, pc, (i >> 6) & 1, (i >> 7) & 1, (i >> 8) & 1, (i >> 9) & 1, o);
-        t->chain[i] = make_uint2(o.wtr1a | o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24, o.conf | o.cloud << 8);
-    }
-}
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
-}
-__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
-}
-__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {   // signed, saturating
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_max_i(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ uint32_t hi32(double x) { return (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32); }
-__device__ __forceinline__ uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
-
-// packed / derived constants of one launch (kernel argument)
-struct LutConsts {
-    uint32_t fill_pk[6], fill_off[6];   // x ^ fill_pk, | fill_off (0x00010001 disables a band's test)
-    uint32_t clip_pk;                   // packed clip minimum
-    uint32_t k_p1_swir1, k_p1_nir, k_p2_blue, k_p2_swir1, k_p2_swir2, k_p2_nir, k_lc_nir, k_aer_nir;   // packed
-    uint32_t force4, force5, force_dark, force_noaer;   // 0x80008000 when a threshold lies outside int16
-    int32_t awesh_init;                 // -awesh4_min
-};
-
-// 4 pixels' table words -> 4 plane dwords (byte k of every word -> plane k)
-__device__ __forceinline__ void transpose4(const uint32_t a[4], uint32_t out[4]) {
-    const uint32_t t01l = perm_b32(a[1], a[0], 0x05010400u), t01h = perm_b32(a[1], a[0], 0x07030602u);
-    const uint32_t t23l = perm_b32(a[3], a[2], 0x05010400u), t23h = perm_b32(a[3], a[2], 0x07030602u);
-    out[0] = perm_b32(t23l, t01l, 0x05040100u); out[1] = perm_b32(t23l, t01l, 0x07060302u);
-    out[2] = perm_b32(t23h, t01h, 0x05040100u); out[3] = perm_b32(t23h, t01h, 0x07060302u);
-}
-
-// The table-driven classification of one 8-pixel group held in registers.  Leaves, per
-// pixel j, the three table words (w1w: DIAG | code | WTR-1; chx: WTR-1-AEROSOL, WTR-2, WTR,
-// BWTR; chy: CONF, CLOUD) and adds the group's coverage counts to `cnt`.
-template <bool MASKS>
-__device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C, const uint32_t* __restrict__ s_lut1,
-                                          const uint16_t* __restrict__ s_fm16, const uint8_t* __restrict__ s_land8,
-                                          const uint2* __restrict__ s_chain, const u32x4 (&v)[6], const u32x2 vf,
-                                          const u32x2 vl, const u32x2 vs, const u32x2 vo, bool has_l, bool in_range,
-                                          uint32_t (&w1w)[8], uint32_t (&chx)[8], uint32_t (&chy)[8], uint32_t& cnt) {
-#pragma unroll
-        for (int wd = 0; wd < 4; ++wd) {
-            // ---- two pixels at a time, packed int16
-            uint32_t x[6], e[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { x[k] = v[k][wd]; e[k] = (x[k] ^ C.fill_pk[k]) | C.fill_off[k]; }
-            const uint32_t emin = pk_min_u(pk_min_u(pk_min_u(e[0], e[1]), pk_min_u(e[2], e[3])), pk_min_u(e[4], e[5]));
-            const uint32_t bandvalid = pk_min_u(emin, 0x00010001u);         // 1 per half: no band equals its fill
-#pragma unroll
-            for (int k = 0; k < 6; ++k) x[k] = pk_max_i(x[k], C.clip_pk);   // A0 clip
-            const uint32_t b = x[0], g = x[1], r = x[2], n = x[3], s1 = x[4], s2 = x[5];
-            const uint32_t d1 = pk_add(g, s1), n1 = pk_sub(g, s1), mv = pk_add(g, r), mn = pk_add(n, s1);
-            const uint32_t n2 = pk_sub(n, r), d2 = pk_add(n, r);
-            // sign bit (15 / 31) set  <=>  ...
-            const uint32_t t2s = pk_sub_sat(mn, mv);                                            // T2 true
-            const uint32_t viol4 = pk_sub_sat(C.k_p1_swir1, s1) | pk_sub_sat(C.k_p1_nir, n) | C.force4;   // T4 ints fail
-            const uint32_t viol5 = pk_sub_sat(C.k_p2_blue, b) | pk_sub_sat(C.k_p2_swir1, s1) |
-                                   pk_sub_sat(C.k_p2_swir2, s2) | pk_sub_sat(C.k_p2_nir, n) | C.force5;   // T5 ints fail
-            const uint32_t dark = pk_sub_sat(n, C.k_lc_nir) | C.force_dark;                     // nir NOT > lcmask_nir
-            const uint32_t noaer = pk_sub_sat(C.k_aer_nir, n) | C.force_noaer;                  // nir NOT <= 1000
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int j = wd * 2 + hf, sh = 16 * hf;
-                const int bw = j >> 2, bk = j & 3;
-                // ---- A4 quotient tests, sign-bit form (see the header comment)
-                const int in1 = s16_of(n1, hf), id1 = s16_of(d1, hf), in2 = s16_of(n2, hf), id2 = s16_of(d2, hf);
-                const double dn1 = (double)in1, dd1 = (double)id1, dn2 = (double)in2, dd2 = (double)id2;
-                const double r0 = __builtin_fma(-P.qt[0], dd1, dn1), r1 = __builtin_fma(-P.qt[1], dd1, dn1),
-                             r2 = __builtin_fma(-P.qt[2], dd1, dn1), r3 = __builtin_fma(-P.qt[3], dd2, dn2);
-                // sign(h*d - r) = 1  <=>  r > h*d ;  sign(r - hneg*d) = 1  <=>  r < hneg*d ; exact zero -> +0
-                const uint32_t g0 = hi32(__builtin_fma(P.qh[0], dd1, -r0)) >> 31, g1 = hi32(__builtin_fma(P.qh[1], dd1, -r1)) >> 31,
-                               g2 = hi32(__builtin_fma(P.qh[2], dd1, -r2)) >> 31, l3 = hi32(__builtin_fma(-P.qh[3], dd2, r3)) >> 31;
-                const uint32_t neg1 = (uint32_t)id1 >> 31, neg2 = (uint32_t)id2 >> 31;
-                const uint32_t t1 = g0 ^ neg1, m_p1 = g1 ^ neg1, m_p2 = g2 ^ neg1, v_p1 = l3 ^ neg2;
-                // ---- AWESH as int32: sign set <=> 4*awesh < awesh4_min  (T3 false)
-                const int aw = C.awesh_init + 4 * s16_of(b, hf) + 10 * s16_of(g, hf) - 6 * s16_of(mn, hf) - s16_of(s2, hf);
-                const uint32_t t3n = (uint32_t)aw >> 31;
-                const uint32_t t2 = (t2s >> (15 + sh)) & 1u;
-                const uint32_t t4 = m_p1 & v_p1 & ~(viol4 >> (15 + sh)) & 1u;
-                const uint32_t t5 = m_p2 & ~(viol5 >> (15 + sh)) & 1u;
-                const uint32_t fm = (vf[bw] >> (8 * bk)) & 0xffu;
-                const uint32_t F = s_fm16[fm];
-                const uint32_t band_ok = (bandvalid >> sh) & 1u;
-                const uint32_t invalid = (band_ok ^ 1u) | ((F >> 8) & 1u);
-                uint32_t ocean_nz = 1u, shad_nz = 1u, lbits = 0u;
-                if (MASKS) {
-                    ocean_nz = min((vo[bw] >> (8 * bk)) & 0xffu, 1u);
-                    shad_nz = min((vs[bw] >> (8 * bk)) & 0xffu, 1u);
-                    if (has_l) lbits = s_land8[(vl[bw] >> (8 * bk)) & 0xffu];
-                }
-                const uint32_t idx1 = t1 | t2 << 1 | t3n << 2 | t4 << 3 | t5 << 4 | invalid << 5 | (ocean_nz ^ 1u) << 6;
-                const uint32_t word1 = s_lut1[idx1];
-                const uint32_t code = (word1 >> 16) & 7u;
-                const uint32_t remap = (F >> code) & ~(noaer >> (15 + sh)) & 1u;
-                uint32_t idx2 = code | remap << 3 | ((F >> 5) & 7u) << 4;
-                if (MASKS) {
-                    const uint32_t shadrule = (shad_nz ^ 1u) & ~lbits & 1u;
-                    const uint32_t lcpsw = (lbits >> 1) & ~(dark >> (15 + sh)) & 1u;
-                    idx2 |= shadrule << 7 | lcpsw << 8 | ((lbits >> 2) & 1u) << 9;
-                }
-                const uint2 ch = s_chain[idx2];
-                w1w[j] = word1; chx[j] = ch.x; chy[j] = ch.y;
-                // ---- A3
-                const uint32_t valid = (invalid ^ 1u) & ocean_nz & (in_range ? 1u : 0u);
-                cnt += valid + ((valid & (F >> 9)) << 16);
-            }
-        }
-}
-
-// table words of 8 pixels -> plane dwords, in the order DIAG[4], WTR-1[2], then (lo, hi)
-// pairs of WTR-1-AEROSOL, WTR-2, WTR, BWTR, CONF, CLOUD
-struct GroupPlanes { uint32_t diag[4], w1[2], w1a[2], w2[2], w[2], bw[2], cf[2], cl[2]; };
-__device__ __forceinline__ void lut_pack(const uint32_t (&w1w)[8], const uint32_t (&chx)[8], const uint32_t (&chy)[8],
-                                         GroupPlanes& g) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) g.diag[k] = perm_b32(w1w[2 * k + 1], w1w[2 * k], 0x05040100u);
-    g.w1[0] = perm_b32(perm_b32(w1w[3], w1w[2], 0x0c0c0703u), perm_b32(w1w[1], w1w[0], 0x0c0c0703u), 0x05040100u);
-    g.w1[1] = perm_b32(perm_b32(w1w[7], w1w[6], 0x0c0c0703u), perm_b32(w1w[5], w1w[4], 0x0c0c0703u), 0x05040100u);
-    uint32_t pa[4], pb[4], qa[4], qb[4];
-    transpose4(chx, pa); transpose4(chx + 4, pb);
-    transpose4(chy, qa); transpose4(chy + 4, qb);
-    g.w1a[0] = pa[0]; g.w1a[1] = pb[0]; g.w2[0] = pa[1]; g.w2[1] = pb[1];
-    g.w[0] = pa[2]; g.w[1] = pb[2]; g.bw[0] = pa[3]; g.bw[1] = pb[3];
-    g.cf[0] = qa[0]; g.cf[1] = qb[0]; g.cl[0] = qa[1]; g.cl[1] = qb[1];
-}
 
 // ------------------------------------------------------------------------------
 // Warp-specialised data movement + table-driven compute (DSWX_FUSED_VARIANT=4): phases A
@@ -766,107 +588,14 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_pipe(const KArgs a, co
     }
 }
 
-// LUT_CHUNKS: 2048-px chunks per block (amortises the table load); WPS: launch bound
-template <bool MASKS, int LUT_CHUNKS, int WPS>
-__global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
-                                                             const Tables* __restrict__ tabs) {
-    constexpr int N_CHAIN = MASKS ? 1024 : 128;
-    __shared__ uint32_t s_lut1[128];
-    __shared__ uint16_t s_fm16[256];
-    __shared__ uint8_t s_land8[MASKS ? 256 : 4];
-    __shared__ uint2 s_chain[N_CHAIN];
-    for (int i = threadIdx.x; i < 128; i += 256) s_lut1[i] = tabs->lut1[i];
-    for (int i = threadIdx.x; i < 128; i += 256) reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
-    if (MASKS) for (int i = threadIdx.x; i < 64; i += 256) reinterpret_cast<uint32_t*>(s_land8)[i] = reinterpret_cast<const uint32_t*>(tabs->land8)[i];
-    for (int i = threadIdx.x; i < N_CHAIN; i += 256) s_chain[i] = tabs->chain[i];
-    __syncthreads();
-
-    const DevParams& P = a.P;
-    const long long n_groups = a.n_pixels >> 3;
-    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
-    const bool has_l = MASKS && a.in.land, has_s = MASKS && a.in.shad, has_o = MASKS && a.in.ocean;
-    uint32_t cnt = 0, t_ocean = 0;       // cnt: valid in the low half, cloud-and-valid in the high half
-
-    for (int c = 0; c < LUT_CHUNKS; ++c) {
-        const long long grp = ((long long)blockIdx.x * LUT_CHUNKS + c) * 256 + threadIdx.x;
-        if ((grp - threadIdx.x) >= n_groups) break;                       // block-uniform
-        const bool in_range = grp < n_groups;
-        const long long off = tile_base + (in_range ? grp : n_groups - 1) * 8;
-        u32x4 v[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
-        const u32x2 vf = ldg<u32x2, true>(a.in.fmask + off);
-        u32x2 vl = {0u, 0u}, vs = {0x01010101u, 0x01010101u}, vo = {0x01010101u, 0x01010101u};
-        if (MASKS) {
-            if (has_l) vl = ldg<u32x2, true>(a.in.land + off);
-            if (has_s) vs = ldg<u32x2, true>(a.in.shad + off);
-            if (has_o) {
-                vo = ldg<u32x2, true>(a.in.ocean + off);
-                const uint32_t so = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
-                t_ocean += in_range ? so : 0u;
-            }
-        }
-        uint32_t w1w[8], chx[8], chy[8];      // per-pixel table words
-        lut_group<MASKS>(P, C, s_lut1, s_fm16, s_land8, s_chain, v, vf, vl, vs, vo, has_l, in_range, w1w, chx, chy, cnt);
-        if (in_range) {
-            GroupPlanes gp;
-            lut_pack(w1w, chx, chy, gp);
-            if (a.out.diag) stg<u32x4, true>(a.out.diag + off, u32x4{gp.diag[0], gp.diag[1], gp.diag[2], gp.diag[3]});
-            if (a.out.wtr1) stg<u32x2, true>(a.out.wtr1 + off, u32x2{gp.w1[0], gp.w1[1]});
-            if (a.out.wtr1_aerosol) stg<u32x2, true>(a.out.wtr1_aerosol + off, u32x2{gp.w1a[0], gp.w1a[1]});
-            if (a.out.wtr2) stg<u32x2, true>(a.out.wtr2 + off, u32x2{gp.w2[0], gp.w2[1]});
-            if (a.out.wtr) stg<u32x2, true>(a.out.wtr + off, u32x2{gp.w[0], gp.w[1]});
-            if (a.out.bwtr) stg<u32x2, true>(a.out.bwtr + off, u32x2{gp.bw[0], gp.bw[1]});
-            if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{gp.cf[0], gp.cf[1]});
-            if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{gp.cl[0], gp.cl[1]});
-        }
-    }
-    if (a.partials) {
-        uint32_t c0 = cnt, c2 = t_ocean;
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) { c0 += __shfl_xor(c0, sh); c2 += __shfl_xor(c2, sh); }
-        if ((threadIdx.x & 63) == 0) {
-            const long long slot = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
-            a.partials[slot] = make_uint2(c0, c2);
-        }
-    }
-}
 
 
-static uint32_t pack16(int v) { return ((uint32_t)v & 0xffffu) * 0x10001u; }
-
-static void make_lut_consts(const DevParams& d, LutConsts* c) {
-    std::memset(c, 0, sizeof *c);
-    for (int k = 0; k < 6; ++k) {
-        if (d.band_fill[k] == std::numeric_limits<int32_t>::max()) c->fill_off[k] = 0x00010001u;
-        else c->fill_pk[k] = pack16(d.band_fill[k]);
-    }
-    c->clip_pk = pack16(d.clip_min);
-    // "x <= k": pack k clamped to int16; below the int16 range the test can never hold
-    auto le = [](int32_t k, uint32_t* force) {
-        if (k < -32768) { *force = 0x80008000u; return pack16(-32768); }
-        return pack16(k > 32767 ? 32767 : k);
-    };
-    uint32_t f4a = 0, f4b = 0, f5a = 0, f5b = 0, f5c = 0, f5d = 0;
-    c->k_p1_swir1 = le(d.p1_swir1_max, &f4a); c->k_p1_nir = le(d.p1_nir_max, &f4b);
-    c->k_p2_blue = le(d.p2_blue_max, &f5a); c->k_p2_swir1 = le(d.p2_swir1_max, &f5b);
-    c->k_p2_swir2 = le(d.p2_swir2_max, &f5c); c->k_p2_nir = le(d.p2_nir_max, &f5d);
-    c->force4 = f4a | f4b; c->force5 = f5a | f5b | f5c | f5d;
-    c->k_aer_nir = le(d.aer_nir_max, &c->force_noaer);
-    // "nir >= k": above the int16 range never bright, below it always
-    if (d.lc_nir_min > 32767) { c->force_dark = 0x80008000u; c->k_lc_nir = pack16(32767); }
-    else c->k_lc_nir = pack16(d.lc_nir_min < -32768 ? -32768 : d.lc_nir_min);
-    c->awesh_init = -d.awesh4_min;
-}
 
 void dswx_variant_geometry(const dswx_ctx* ctx, int variant, long long groups, long long n_tiles, int* threads,
                            long long* gx) {
-    const int v = variant;
-    *threads = v == 1 ? FUSED_THREADS : 256;
-    const int lut_chunks = (ctx->tune_chunks == 1 || ctx->tune_chunks == 4) ? ctx->tune_chunks : 1;
-    const long long per_block = (long long)*threads * (v == 3 ? lut_chunks : 1);
-    *gx = (groups + per_block - 1) / per_block;
-    if (v == 5) {
+    *threads = variant == 1 ? FUSED_THREADS : 256;
+    *gx = (groups + *threads - 1) / *threads;
+    if (variant == 5) {
         // persistent grid: ~tune_pipe_blocks blocks in all, spread evenly over the tiles
         const long long want = (ctx->tune_pipe_blocks + n_tiles - 1) / n_tiles;
         if (want < *gx) *gx = want < 1 ? 1 : want;
@@ -876,57 +605,47 @@ void dswx_variant_geometry(const dswx_ctx* ctx, int variant, long long groups, l
 int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& b, bool masks, dim3 grid, dim3 block, hipStream_t s,
                         char* info, size_t info_len) {
     const long long gx = grid.x, nt = grid.y;
-    const bool staged = variant == 1, wspec = variant == 2, tabled = variant == 3, wslut = variant == 4,
-               piped = variant == 5;
-    const int lut_chunks = (ctx->tune_chunks == 1 || ctx->tune_chunks == 4) ? ctx->tune_chunks : 1;
-            if (piped) {
-                if (!ctx->tables) HIP_TRY(hipMalloc(&ctx->tables, sizeof(Tables)));
-                Tables* tabs = static_cast<Tables*>(ctx->tables);
-                LutConsts lc;
-                make_lut_consts(b.P, &lc);
-                hipLaunchKernelGGL(dswx_build_tables, dim3(4), dim3(256), 0, s, b.P, tabs);
-                if (masks) hipLaunchKernelGGL((dswx_classify_pipe<true, 2>), grid, block, 0, s, b, lc, tabs);
-                else hipLaunchKernelGGL((dswx_classify_pipe<false, 2>), grid, block, 0, s, b, lc, tabs);
-                snprintf(info, info_len, "dswx_classify_pipe<%s> (persistent double-buffered LDS-DMA pipeline) grid=(%lld,%lld) block=256",
-                         masks ? "true" : "false", (long long)gx, (long long)nt);
-            } else if (wslut) {
-                if (!ctx->tables) HIP_TRY(hipMalloc(&ctx->tables, sizeof(Tables)));
-                Tables* tabs = static_cast<Tables*>(ctx->tables);
-                LutConsts lc;
-                make_lut_consts(b.P, &lc);
-                hipLaunchKernelGGL(dswx_build_tables, dim3(4), dim3(256), 0, s, b.P, tabs);
-                const int wps = ctx->tune_lut_wps;
+    const char* m = masks ? "true" : "false";
+    Tables* tabs = nullptr;
+    LutConsts lc;
+    if (variant == 4 || variant == 5) {
+        if (!ctx->tables) HIP_TRY(hipMalloc(&ctx->tables, sizeof(Tables)));
+        tabs = static_cast<Tables*>(ctx->tables);
+        make_lut_consts(b.P, &lc);
+        hipLaunchKernelGGL(dswx_build_tables, dim3(4), dim3(256), 0, s, b.P, tabs);
+    }
+    switch (variant) {
+    case 1:
+        if (masks) hipLaunchKernelGGL(dswx_classify_fused<true>, grid, block, 0, s, b);
+        else hipLaunchKernelGGL(dswx_classify_fused<false>, grid, block, 0, s, b);
+        snprintf(info, info_len, "dswx_classify_fused<%s> (LDS-staged) grid=(%lld,%lld) block=%d lds=%d", m, gx, nt,
+                 FUSED_THREADS, STAGE_BYTES);
+        break;
+    case 2:
+        if (masks) hipLaunchKernelGGL(dswx_classify_ws<true>, grid, block, 0, s, b);
+        else hipLaunchKernelGGL(dswx_classify_ws<false>, grid, block, 0, s, b);
+        snprintf(info, info_len, "dswx_classify_ws<%s> (warp-specialised, LDS-DMA) grid=(%lld,%lld) block=256", m, gx, nt);
+        break;
+    case 4: {
+        const int wps = ctx->tune_lut_wps;
 #define WSLUT_LAUNCH(M, W) hipLaunchKernelGGL((dswx_classify_wslut<M, W>), grid, block, 0, s, b, lc, tabs)
-                if (masks) { if (wps >= 5) WSLUT_LAUNCH(true, 5); else if (wps == 4) WSLUT_LAUNCH(true, 4); else WSLUT_LAUNCH(true, 3); }
-                else if (ctx->tune_ablate == 1) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 1>), grid, block, 0, s, b, lc, tabs);
-                else if (ctx->tune_ablate == 2) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 2>), grid, block, 0, s, b, lc, tabs);
-                else if (ctx->tune_ablate == 3) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 3>), grid, block, 0, s, b, lc, tabs);
-                else { if (wps >= 5) WSLUT_LAUNCH(false, 5); else if (wps == 4) WSLUT_LAUNCH(false, 4); else WSLUT_LAUNCH(false, 3); }
-                snprintf(info, info_len, "dswx_classify_wslut<%s> (warp-specialised + table-driven) grid=(%lld,%lld) block=256 wps=%d",
-                         masks ? "true" : "false", (long long)gx, (long long)nt, wps);
-            } else if (tabled) {
-                if (!ctx->tables) HIP_TRY(hipMalloc(&ctx->tables, sizeof(Tables)));
-                Tables* tabs = static_cast<Tables*>(ctx->tables);
-                LutConsts lc;
-                make_lut_consts(b.P, &lc);
-                hipLaunchKernelGGL(dswx_build_tables, dim3(4), dim3(256), 0, s, b.P, tabs);
-                const int wps = ctx->tune_lut_wps;
-#define LUT_LAUNCH(M, CH, W) hipLaunchKernelGGL((dswx_classify_lut<M, CH, W>), grid, block, 0, s, b, lc, tabs)
-#define LUT_SEL_W(M, CH) do { if (wps >= 6) LUT_LAUNCH(M, CH, 6); else if (wps == 5) LUT_LAUNCH(M, CH, 5); else LUT_LAUNCH(M, CH, 4); } while (0)
-#define LUT_SEL_C(M) do { if (lut_chunks == 4) LUT_SEL_W(M, 4); else LUT_SEL_W(M, 1); } while (0)
-                if (masks) LUT_SEL_C(true); else LUT_SEL_C(false);
-                snprintf(info, info_len, "dswx_classify_lut<%s> (table-driven) grid=(%lld,%lld) block=256 chunks=%d wps=%d",
-                         masks ? "true" : "false", (long long)gx, (long long)nt, lut_chunks, wps);
-            } else if (wspec) {
-                if (masks) hipLaunchKernelGGL(dswx_classify_ws<true>, grid, block, 0, s, b);
-                else hipLaunchKernelGGL(dswx_classify_ws<false>, grid, block, 0, s, b);
-                snprintf(info, info_len, "dswx_classify_ws<%s> (warp-specialised, LDS-DMA) grid=(%lld,%lld) block=256",
-                         masks ? "true" : "false", (long long)gx, (long long)nt);
-            } else if (staged) {
-                if (masks) hipLaunchKernelGGL(dswx_classify_fused<true>, grid, block, 0, s, b);
-                else hipLaunchKernelGGL(dswx_classify_fused<false>, grid, block, 0, s, b);
-                snprintf(info, info_len, "dswx_classify_fused<%s> (LDS-staged) grid=(%lld,%lld) block=%d lds=%d",
-                         masks ? "true" : "false", (long long)gx, (long long)nt, FUSED_THREADS, STAGE_BYTES);
-            }
+        if (masks) { if (wps >= 5) WSLUT_LAUNCH(true, 5); else if (wps == 4) WSLUT_LAUNCH(true, 4); else WSLUT_LAUNCH(true, 3); }
+        else if (ctx->tune_ablate == 1) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 1>), grid, block, 0, s, b, lc, tabs);
+        else if (ctx->tune_ablate == 2) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 2>), grid, block, 0, s, b, lc, tabs);
+        else if (ctx->tune_ablate == 3) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 3>), grid, block, 0, s, b, lc, tabs);
+        else { if (wps >= 5) WSLUT_LAUNCH(false, 5); else if (wps == 4) WSLUT_LAUNCH(false, 4); else WSLUT_LAUNCH(false, 3); }
+        snprintf(info, info_len, "dswx_classify_wslut<%s> (warp-specialised + table-driven) grid=(%lld,%lld) block=256 wps=%d",
+                 m, gx, nt, wps);
+        break;
+    }
+    case 5:
+        if (masks) hipLaunchKernelGGL((dswx_classify_pipe<true, 2>), grid, block, 0, s, b, lc, tabs);
+        else hipLaunchKernelGGL((dswx_classify_pipe<false, 2>), grid, block, 0, s, b, lc, tabs);
+        snprintf(info, info_len, "dswx_classify_pipe<%s> (persistent double-buffered LDS-DMA pipeline) grid=(%lld,%lld) block=256",
+                 m, gx, nt);
+        break;
+    default:
+        return dswx_fail(DSWX_ERR_ARG, "unknown kernel variant %d", variant);
+    }
     return DSWX_OK;
 }

@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--masks', action='store_true')
     ap.add_argument('--size', type=int, default=3660)
+    ap.add_argument('--quick', action='store_true', help='only the main shapes')
     ap.add_argument('--tile-align', type=int, default=256, help='1 = contiguous tiles')
     a = ap.parse_args()
     ctx = _capi.Context(0)
@@ -60,6 +61,15 @@ def main():
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
                                                      variant, tile_stride=batch.tile_stride), a.reps)
             out[label] = round(px * nbytes / (sum(ms) / len(ms)) / 1e6, 1)
+        for sel, ch in enumerate((2048, 8192, 32768, 131072)):
+            for nt in (0, 2):
+                run(f'record layout CHPX={ch} nt={nt >> 1}', (1 << 22) | (sel << 2) | nt, 21)
+        run('fused shape ppt=8 nt=1 (as is)', 2, 21)
+        run('fused shape ppt=8 nt=1 xcdmap', 2 | 2048, 21)
+        run('fused shape ppt=8 nt=1 block512', 2 | 4096, 21)
+        if a.quick:
+            print(json.dumps(out, indent=1))
+            return
         for nt in (0, 2):
             run(f'14 planes, one plane per block nt={nt >> 1}', 32768 | nt, 21)
             run(f'one plane per wave (7-wave blocks over 4096 px) nt={nt >> 1}', 262144 | nt, 21)
