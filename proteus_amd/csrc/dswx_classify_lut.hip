@@ -92,9 +92,10 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
     LutConsts lc;
     make_lut_consts(b.P, &lc);
     hipLaunchKernelGGL(dswx_build_tables, dim3(4), dim3(256), 0, s, b.P, tabs);
-    // launch bound: 4 waves per SIMD everywhere by default (5 spills with masks; 5 / 6 are within
-    // 1 % without), env DSWX_TUNE_LUT_WPS
-    const int wps = ctx->tune_lut_wps;
+    // launch bound (waves per SIMD), env DSWX_TUNE_LUT_WPS; default 4: 91 VGPRs without masks, 104
+    // with LAND / SHAD / OCEAN (5 and 6 spill to scratch there; without masks they give 67 VGPRs
+    // and measure 0-2 % slower than 4)
+    const int wps = ctx->tune_lut_wps > 0 ? ctx->tune_lut_wps : 4;
 #define LUT_LAUNCH(M, CH, W) hipLaunchKernelGGL((dswx_classify_lut<M, CH, W>), grid, block, 0, s, b, lc, tabs)
 #define LUT_SEL_W(M, CH) do { if (wps >= 6) LUT_LAUNCH(M, CH, 6); else if (wps == 5) LUT_LAUNCH(M, CH, 5); else LUT_LAUNCH(M, CH, 4); } while (0)
 #define LUT_SEL_C(M) do { if (lut_chunks == 4) LUT_SEL_W(M, 4); else LUT_SEL_W(M, 1); } while (0)

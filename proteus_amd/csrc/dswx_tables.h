@@ -25,7 +25,7 @@ struct Tables {
     uint8_t land8[256];    // LAND byte -> is_water(200) | psw_rule_class(201 or <100)<<1 | high_dev<<2
     uint2 chain[1024];     // [code | remap<<3 | shadow<<4 | cloud<<5 | snow<<6 | shadrule<<7 |
                            //  lcpsw<<8 | lchigh<<9] -> x = WTR-1-AEROSOL | WTR-2<<8 | WTR<<16 | BWTR<<24,
-                           //                           y = CONF | CLOUD<<8
+                           //                           y = CONF | CLOUD<<8 | valid<<16 | cloud_and_valid<<24
 };
 // WTR-1 "code": 0..4 = class, 5 = ocean masked (254), 6 = fill (255)
 
@@ -52,7 +52,10 @@ static __global__ __launch_bounds__(256) void dswx_build_tables(const DevParams 
         const uint32_t pc = ((i >> 4) & 1u) + 4u * ((i >> 5) & 1u);
         PxOut o;
         px_chain(P, w1, (i >> 3) & 1, pc, (i >> 6) & 1, (i >> 7) & 1, (i >> 8) & 1, (i >> 9) & 1, o);
-        t->chain[i] = make_uint2(o.wtr1a | o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24, o.conf | o.cloud << 8);
+        // y bits 16 / 24: the pixel's contributions to n_valid and n_cloud_and_valid (A3)
+        const uint32_t valid = code < 5u ? 1u : 0u, pc_nz = ((i >> 4) | (i >> 5)) & 1u;
+        t->chain[i] = make_uint2(o.wtr1a | o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24,
+                                 o.conf | o.cloud << 8 | valid << 16 | (valid & pc_nz) << 24);
     }
 }
 
@@ -102,6 +105,7 @@ __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C
                                           const uint2* __restrict__ s_chain, const u32x4 (&v)[6], const u32x2 vf,
                                           const u32x2 vl, const u32x2 vs, const u32x2 vo, bool has_l, bool in_range,
                                           uint32_t (&w1w)[8], uint32_t (&chx)[8], uint32_t (&chy)[8], uint32_t& cnt) {
+        uint32_t gsum = 0;
 #pragma unroll
         for (int wd = 0; wd < 4; ++wd) {
             // ---- two pixels at a time, packed int16
@@ -164,11 +168,10 @@ __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C
                 }
                 const uint2 ch = s_chain[idx2];
                 w1w[j] = word1; chx[j] = ch.x; chy[j] = ch.y;
-                // ---- A3
-                const uint32_t valid = (invalid ^ 1u) & ocean_nz & (in_range ? 1u : 0u);
-                cnt += valid + ((valid & (F >> 9)) << 16);
+                gsum += ch.y >> 16;                  // A3: valid | cloud_and_valid << 8, from the table
             }
         }
+        cnt += in_range ? (gsum & 0xffu) | (gsum >> 8) << 16 : 0u;
 }
 
 // table words of 8 pixels -> plane dwords, in the order DIAG[4], WTR-1[2], then (lo, hi)

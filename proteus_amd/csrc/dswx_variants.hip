@@ -627,7 +627,7 @@ int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& b, bool masks, 
         snprintf(info, info_len, "dswx_classify_ws<%s> (warp-specialised, LDS-DMA) grid=(%lld,%lld) block=256", m, gx, nt);
         break;
     case 4: {
-        const int wps = ctx->tune_lut_wps;
+        const int wps = ctx->tune_lut_wps > 0 ? ctx->tune_lut_wps : 4;
 #define WSLUT_LAUNCH(M, W) hipLaunchKernelGGL((dswx_classify_wslut<M, W>), grid, block, 0, s, b, lc, tabs)
         if (masks) { if (wps >= 5) WSLUT_LAUNCH(true, 5); else if (wps == 4) WSLUT_LAUNCH(true, 4); else WSLUT_LAUNCH(true, 3); }
         else if (ctx->tune_ablate == 1) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 1>), grid, block, 0, s, b, lc, tabs);
