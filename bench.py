@@ -34,6 +34,7 @@ def parse_args():
                     help='also stream LAND/SHAD/OCEAN planes (BASELINE config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--cpu-parallel-worker', type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -52,6 +53,58 @@ def cpu_baseline_sample():
             'sample': f'1 synthetic {TILE}x{TILE} L30 tile, numpy {np.__version__} '
                       f'oracle/dswx_oracle.py classify_tile, {dt:.2f} s, '
                       f'host has {os.cpu_count()} logical cores'}
+
+
+_WORKER_TILE = None
+
+
+def _cpu_worker_prepare(tile):
+    global _WORKER_TILE
+    from proteus_amd.synth import synth_tile
+    _WORKER_TILE = synth_tile(tile, TILE, TILE)
+    return tile
+
+
+def _cpu_worker_classify(_):
+    from oracle import dswx_oracle as o
+    t0 = time.perf_counter()
+    o.classify_tile(_WORKER_TILE['bands'], _WORKER_TILE['fmask'])
+    return time.perf_counter() - t0
+
+
+def cpu_parallel_main(workers):
+    """Child-process mode (never touches the GPU): `workers` processes, one synthetic tile
+    each, classified concurrently by the numpy oracle; prints one JSON object."""
+    import multiprocessing as mp
+    with mp.Pool(workers) as pool:
+        pool.map(_cpu_worker_prepare, range(workers), chunksize=1)
+        t0 = time.perf_counter()
+        per = pool.map(_cpu_worker_classify, range(workers), chunksize=1)
+        dt = time.perf_counter() - t0
+    print(json.dumps({'value': round(workers * TILE * TILE / dt / 1e6, 3), 'unit': 'Mpixels/s',
+                      'cores': workers,
+                      'sample': f'{workers} worker processes x 1 synthetic tile each, concurrently, '
+                                f'{dt:.2f} s wall (slowest worker {max(per):.2f} s)'}))
+
+
+def cpu_baseline_parallel():
+    """tile-parallel numpy oracle on min(cores, 32) worker processes (bounded by
+    free memory, ~4 GB per worker), run in a child process that never initialises the GPU."""
+    import subprocess
+    workers = min(os.cpu_count() or 1, 32)
+    try:
+        import psutil
+        workers = max(1, min(workers, int(psutil.virtual_memory().available // (4 << 30))))
+    except ImportError:
+        workers = min(workers, 8)
+    if workers < 2:
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-parallel-worker', str(workers)],
+                           capture_output=True, text=True, timeout=300)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:      # the baseline is a report, never a reason to lose the bench line
+        return {'error': str(e)[:200]}
 
 
 def parity_spot_check(ctx, batch, params, tile):
@@ -74,6 +127,9 @@ def parity_spot_check(ctx, batch, params, tile):
 
 def main():
     args = parse_args()
+    if args.cpu_parallel_worker:
+        cpu_parallel_main(args.cpu_parallel_worker)
+        return
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -171,6 +227,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_sample()
+            par = cpu_baseline_parallel()
+            if par:
+                out['cpu_baseline']['tile_parallel'] = par
         print(json.dumps(out), flush=True)
     batch.free()
     ctx.close()

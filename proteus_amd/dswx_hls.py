@@ -732,7 +732,10 @@ def _get_confidence_layer_ctable():
 
 
 # -----------------------------------------------------------------------------------
-# writers (:2601-2716, :2786-2958): tiled DEFLATE GeoTIFF, no overviews
+# writers (:2601-2716, :2786-2958) + save_as_cog (core.py:7-91): 512 x 512 tiled DEFLATE
+# GeoTIFF in cloud-optimized layout; integer layers carry NEAREST overviews 4/16/64/128 as
+# the reference builds them; Float32 files (RGB composites, DEM) get none (the reference's
+# CUBICSPLINE resampling for floats is GDAL-internal and not restated)
 # -----------------------------------------------------------------------------------
 def _makedirs(path):
     d = os.path.dirname(path)
@@ -743,9 +746,11 @@ def _makedirs(path):
 def _save_array(input_array, output_file, dswx_metadata_dict, geo_tags, description=None,
                 output_files_list=None, ctable=None, no_data_value=None):
     _makedirs(output_file)
+    integer = np.asarray(input_array).dtype.kind in 'uib'
     geotiff.write_geotiff(output_file, input_array, geo_tags=geo_tags,
                           metadata=dswx_metadata_dict, nodata=no_data_value,
-                          descriptions=[description] if description else None, colormap=ctable)
+                          descriptions=[description] if description else None, colormap=ctable,
+                          overviews=geotiff.COG_OVERVIEW_FACTORS if integer else None)
     if output_files_list is not None:
         output_files_list.append(output_file)
     logger.info(f'file saved: {output_file}')
@@ -762,7 +767,8 @@ def save_dswx_product(layers, output_file, dswx_metadata_dict, geo_tags,
     _makedirs(output_file)
     geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict,
                           nodata=UINT8_FILL_VALUE,
-                          descriptions=[band_description_dict[n] for n in names])
+                          descriptions=[band_description_dict[n] for n in names],
+                          overviews=geotiff.COG_OVERVIEW_FACTORS)
     if output_files_list is not None:
         output_files_list.append(output_file)
     logger.info(f'file saved: {output_file}')

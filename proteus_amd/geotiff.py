@@ -25,6 +25,7 @@ from xml.sax.saxutils import escape, unescape
 
 import numpy as np
 
+TAG_NEW_SUBFILE_TYPE = 254
 TAG_WIDTH, TAG_LENGTH, TAG_BITS, TAG_COMPRESSION, TAG_PHOTOMETRIC = 256, 257, 258, 259, 262
 TAG_STRIP_OFFSETS, TAG_SAMPLES, TAG_ROWS_PER_STRIP, TAG_STRIP_COUNTS = 273, 277, 278, 279
 TAG_PLANAR, TAG_PREDICTOR, TAG_COLORMAP = 284, 317, 320
@@ -109,10 +110,11 @@ def _parse_metadata_xml(text):
     return meta, desc
 
 
-def read_geotiff(path, window=None):
+def read_geotiff(path, window=None, overview=None):
     """Returns (array, GeoTiffInfo).  array is [H,W] for one band, [B,H,W] otherwise.
     window = (xoff, yoff, xsize, ysize) crops after decoding (the reference's
-    flag_debug read, :2187-2190)."""
+    flag_debug read, :2187-2190).  overview = k reads the k-th internal overview
+    (IFD k + 1) instead of the full-resolution image."""
     with open(path, 'rb') as fh:
         buf = fh.read()
     if len(buf) < 8:
@@ -128,6 +130,11 @@ def read_geotiff(path, window=None):
         raise GeoTiffError(f'{path}: BigTIFF is not supported')
     if magic != 42:
         raise GeoTiffError(f'{path}: not a TIFF file')
+    for _ in range(0 if overview is None else overview + 1):
+        (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
+        (ifd,) = struct.unpack(e + 'I', buf[ifd + 2 + 12 * n: ifd + 6 + 12 * n])
+        if not ifd:
+            raise GeoTiffError(f'{path}: no overview {overview}')
     (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
     tags = {}
     for k in range(n):
@@ -257,24 +264,27 @@ def geo_tags_from_geotransform(geotransform, epsg=None):
     return tags
 
 
-def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
-                  descriptions=None, colormap=None, tile=512, compress=True):
-    """array: [H,W] or [B,H,W] (planar multi-band).  colormap: {value: (r,g,b[,a])} or
-    [256][3] (single-band u8 only).  NaN nodata is written as 'nan' like GDAL does."""
-    arr = np.asarray(array)
-    if arr.ndim == 2:
-        arr = arr[None]
-    if arr.ndim != 3:
-        raise GeoTiffError('array must be [H,W] or [B,H,W]')
-    if arr.dtype == np.bool_:
-        arr = arr.astype(np.uint8)
+COG_OVERVIEW_FACTORS = (4, 16, 64, 128)      # reference core.py:37
+
+
+def overview_nearest(arr, factor):
+    """One NEAREST overview level the way `gdal.BuildOverviews('NEAREST', ...)` picks source
+    pixels from the full-resolution band (GDALResampleChunk_Near): overview size
+    ceil(N / factor), src = int(0.5 + dst * N / N_ovr).  Used by `save_as_cog`
+    (reference core.py:37-46: integer layers -> NEAREST, factors 4, 16, 64, 128).
+    GDAL is not in the reference tree: parity of this selection rule is unpinned."""
+    h, w = arr.shape[-2:]
+    oh, ow = (h + factor - 1) // factor, (w + factor - 1) // factor
+    ys = np.minimum((0.5 + np.arange(oh) * (h / oh)).astype(np.int64), h - 1)
+    xs = np.minimum((0.5 + np.arange(ow) * (w / ow)).astype(np.int64), w - 1)
+    return np.ascontiguousarray(arr[..., ys[:, None], xs[None, :]])
+
+
+def _encode_blocks(arr, tile, compress, predictor):
+    """[B,H,W] -> list of encoded tile blocks (band-major, row-major)."""
     B, H, W = arr.shape
-    kind = {'u': 1, 'i': 2, 'f': 3}.get(arr.dtype.kind)
-    if kind is None or arr.dtype.itemsize not in (1, 2, 4, 8):
-        raise GeoTiffError(f'unsupported dtype {arr.dtype}')
     dt = arr.dtype.newbyteorder('<')
-    predictor = 2 if (compress and kind != 3) else 1
-    blocks, offsets, counts = [], [], []
+    blocks = []
     across, down = (W + tile - 1) // tile, (H + tile - 1) // tile
     for b in range(B):
         for by in range(down):
@@ -289,22 +299,33 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
                     blk = d
                 raw = blk.tobytes()
                 blocks.append(zlib.compress(raw, 6) if compress else raw)
+    return blocks
 
-    entries = []
 
-    def add(tag, typ, values):
-        entries.append((tag, typ, values))
+def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
+                  descriptions=None, colormap=None, tile=512, compress=True, overviews=None):
+    """array: [H,W] or [B,H,W] (planar multi-band).  colormap: {value: (r,g,b[,a])} or
+    [256][3] (single-band u8 only).  NaN nodata is written as 'nan' like GDAL does.
 
-    add(TAG_WIDTH, 4, [W])
-    add(TAG_LENGTH, 4, [H])
-    add(TAG_BITS, 3, [arr.dtype.itemsize * 8] * B)
-    add(TAG_COMPRESSION, 3, [8 if compress else 1])
+    `overviews`: decimation factors (e.g. COG_OVERVIEW_FACTORS) -> internal reduced-resolution
+    IFDs (NEAREST) in cloud-optimized order, as `save_as_cog` (reference core.py:7-91) leaves the
+    file: all IFDs first (main, then overviews by descending size), then the block data of
+    the smallest overview ... the largest overview, the full-resolution image last; 512 x 512
+    tiles, DEFLATE, PREDICTOR=2 for integer types."""
+    arr = np.asarray(array)
+    if arr.ndim == 2:
+        arr = arr[None]
+    if arr.ndim != 3:
+        raise GeoTiffError('array must be [H,W] or [B,H,W]')
+    if arr.dtype == np.bool_:
+        arr = arr.astype(np.uint8)
+    B = arr.shape[0]
+    kind = {'u': 1, 'i': 2, 'f': 3}.get(arr.dtype.kind)
+    if kind is None or arr.dtype.itemsize not in (1, 2, 4, 8):
+        raise GeoTiffError(f'unsupported dtype {arr.dtype}')
+    predictor = 2 if (compress and kind != 3) else 1
     palette = colormap is not None and B == 1 and arr.dtype == np.uint8
-    add(TAG_PHOTOMETRIC, 3, [3 if palette else 1])
-    add(TAG_SAMPLES, 3, [B])
-    add(TAG_PLANAR, 3, [2 if B > 1 else 1])
-    if predictor == 2:
-        add(TAG_PREDICTOR, 3, [2])
+    cm_values = None
     if palette:
         cm = np.zeros((256, 3), dtype=np.uint32)
         if isinstance(colormap, dict):
@@ -312,69 +333,159 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
                 cm[int(v)] = rgb[:3]
         else:
             cm[:] = np.asarray(colormap)[:, :3]
-        add(TAG_COLORMAP, 3, (cm.T.reshape(-1) * 257).tolist())
-    add(TAG_TILE_W, 3, [tile])
-    add(TAG_TILE_L, 3, [tile])
-    add(TAG_TILE_OFFSETS, 4, None)           # patched below
-    add(TAG_TILE_COUNTS, 4, [len(x) for x in blocks])
-    if B > 1:
-        add(TAG_EXTRA_SAMPLES, 3, [0] * (B - 1))
-    add(TAG_SAMPLE_FORMAT, 3, [kind] * B)
-    for t, (typ, vals) in (geo_tags or {}).items():
-        add(t, typ, vals)
-    add(TAG_GDAL_METADATA, 2, _metadata_xml(metadata, descriptions))
+        cm_values = (cm.T.reshape(-1) * 257).tolist()
+    nodata_text = None
     if nodata is not None:
-        text = 'nan' if (isinstance(nodata, float) and np.isnan(nodata)) else \
+        nodata_text = 'nan' if (isinstance(nodata, float) and np.isnan(nodata)) else \
             (str(int(nodata)) if float(nodata).is_integer() else repr(float(nodata)))
-        add(TAG_GDAL_NODATA, 2, text)
-    entries.sort(key=lambda x: x[0])
 
-    # layout: header | IFD | out-of-line tag data | blocks
+    # level 0 = full resolution, then the overviews by descending size
+    levels = [arr]
+    for f in (overviews or ()):
+        if f > 1 and (arr.shape[1] > 1 or arr.shape[2] > 1):
+            levels.append(overview_nearest(arr, int(f)))
+    level_blocks = [_encode_blocks(lv, tile, compress, predictor) for lv in levels]
+
+    def entries_of(k):
+        lv = levels[k]
+        ent = []
+        if k > 0:
+            ent.append((TAG_NEW_SUBFILE_TYPE, 4, [1]))       # reduced-resolution image
+        ent += [(TAG_WIDTH, 4, [lv.shape[2]]), (TAG_LENGTH, 4, [lv.shape[1]]),
+                (TAG_BITS, 3, [arr.dtype.itemsize * 8] * B),
+                (TAG_COMPRESSION, 3, [8 if compress else 1]),
+                (TAG_PHOTOMETRIC, 3, [3 if palette else 1]),
+                (TAG_SAMPLES, 3, [B]), (TAG_PLANAR, 3, [2 if B > 1 else 1])]
+        if predictor == 2:
+            ent.append((TAG_PREDICTOR, 3, [2]))
+        if palette:
+            ent.append((TAG_COLORMAP, 3, cm_values))
+        ent += [(TAG_TILE_W, 3, [tile]), (TAG_TILE_L, 3, [tile]),
+                (TAG_TILE_OFFSETS, 4, None),                  # patched below
+                (TAG_TILE_COUNTS, 4, [len(x) for x in level_blocks[k]])]
+        if B > 1:
+            ent.append((TAG_EXTRA_SAMPLES, 3, [0] * (B - 1)))
+        ent.append((TAG_SAMPLE_FORMAT, 3, [kind] * B))
+        if k == 0:
+            for t, (typ, vals) in (geo_tags or {}).items():
+                ent.append((t, typ, vals))
+            ent.append((TAG_GDAL_METADATA, 2, _metadata_xml(metadata, descriptions)))
+        if nodata_text is not None:
+            ent.append((TAG_GDAL_NODATA, 2, nodata_text))
+        ent.sort(key=lambda x: x[0])
+        return ent
+
     def pack(typ, values):
         if typ == 2:
             return values.encode('latin-1', 'replace') + b'\x00'
         return struct.pack('<' + _TYPE_FMT[typ] * len(values), *values)
 
-    ifd_off = 8
-    ifd_size = 2 + 12 * len(entries) + 4
-    data_off = ifd_off + ifd_size
-    payloads = {}
-    cursor = data_off
-    for tag, typ, values in entries:
-        if tag == TAG_TILE_OFFSETS:
-            size = 4 * len(blocks)
-        else:
-            size = len(pack(typ, values))
-        if size > 4:
-            payloads[tag] = cursor
-            cursor += size + (size & 1)
-    blk_off = cursor
-    for x in blocks:
-        offsets.append(blk_off)
-        blk_off += len(x) + (len(x) & 1)
-    if blk_off >= 2 ** 32:
+    # layout: header | IFD 0 + its out-of-line data | IFD 1 + data | ... | blocks of the
+    # smallest level ... blocks of level 0
+    all_entries = [entries_of(k) for k in range(len(levels))]
+    ifd_offs, payload_offs = [], []
+    cursor = 8
+    for k, ent in enumerate(all_entries):
+        ifd_offs.append(cursor)
+        cursor += 2 + 12 * len(ent) + 4
+        pay = {}
+        for tag, typ, values in ent:
+            size = 4 * len(level_blocks[k]) if tag == TAG_TILE_OFFSETS else len(pack(typ, values))
+            if size > 4:
+                pay[tag] = cursor
+                cursor += size + (size & 1)
+        payload_offs.append(pay)
+    block_offs = [None] * len(levels)
+    for k in range(len(levels) - 1, -1, -1):
+        offs = []
+        for x in level_blocks[k]:
+            offs.append(cursor)
+            cursor += len(x) + (len(x) & 1)
+        block_offs[k] = offs
+    if cursor >= 2 ** 32:
         raise GeoTiffError('file would exceed 4 GiB (BigTIFF not supported)')
     with open(path, 'wb') as fh:
-        fh.write(struct.pack('<2sHI', b'II', 42, ifd_off))
-        fh.write(struct.pack('<H', len(entries)))
-        tail = []
-        for tag, typ, values in entries:
-            if tag == TAG_TILE_OFFSETS:
-                values = offsets
-            raw = pack(typ, values)
-            count = len(raw) if typ == 2 else len(values)
-            if len(raw) <= 4:
-                fh.write(struct.pack('<HHI', tag, typ, count) + raw.ljust(4, b'\x00'))
-            else:
-                fh.write(struct.pack('<HHII', tag, typ, count, payloads[tag]))
-                tail.append(raw + (b'\x00' if len(raw) & 1 else b''))
-        fh.write(struct.pack('<I', 0))
-        for raw in tail:
-            fh.write(raw)
-        for x in blocks:
-            fh.write(x)
-            if len(x) & 1:
-                fh.write(b'\x00')
+        fh.write(struct.pack('<2sHI', b'II', 42, ifd_offs[0]))
+        for k, ent in enumerate(all_entries):
+            fh.write(struct.pack('<H', len(ent)))
+            tail = []
+            for tag, typ, values in ent:
+                if tag == TAG_TILE_OFFSETS:
+                    values = block_offs[k]
+                raw = pack(typ, values)
+                count = len(raw) if typ == 2 else len(values)
+                if len(raw) <= 4:
+                    fh.write(struct.pack('<HHI', tag, typ, count) + raw.ljust(4, b'\x00'))
+                else:
+                    fh.write(struct.pack('<HHII', tag, typ, count, payload_offs[k][tag]))
+                    tail.append(raw + (b'\x00' if len(raw) & 1 else b''))
+            fh.write(struct.pack('<I', ifd_offs[k + 1] if k + 1 < len(levels) else 0))
+            for raw in tail:
+                fh.write(raw)
+        for k in range(len(levels) - 1, -1, -1):
+            for x in level_blocks[k]:
+                fh.write(x)
+                if len(x) & 1:
+                    fh.write(b'\x00')
+
+
+def cog_layout(path):
+    """Structural facts the reference's COG validator checks
+    (extern/validate_cloud_optimized_geotiff.py:176-297), read straight from the TIFF
+    directory chain: [{'ifd_offset', 'width', 'height', 'tile', 'first_block', 'reduced'}]
+    for the main image and every overview, in file order."""
+    with open(path, 'rb') as fh:
+        buf = fh.read()
+    e = '<' if buf[:2] == b'II' else '>'
+    (ifd,) = struct.unpack(e + 'I', buf[4:8])
+    out = []
+    while ifd:
+        (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
+        tags = {}
+        for k in range(n):
+            ent = buf[ifd + 2 + 12 * k: ifd + 14 + 12 * k]
+            tag, typ, count = struct.unpack(e + 'HHI', ent[:8])
+            size = _TYPE_SIZE.get(typ, 0) * count
+            if typ in (3, 4) and size:
+                raw = ent[8:8 + size] if size <= 4 else \
+                    buf[struct.unpack(e + 'I', ent[8:12])[0]:][:size]
+                tags[tag] = list(struct.unpack(e + _TYPE_FMT[typ] * count, raw))
+        out.append({'ifd_offset': ifd, 'width': tags[TAG_WIDTH][0], 'height': tags[TAG_LENGTH][0],
+                    'tile': (tags.get(TAG_TILE_W, [0])[0], tags.get(TAG_TILE_L, [0])[0]),
+                    'first_block': min(tags[TAG_TILE_OFFSETS]) if TAG_TILE_OFFSETS in tags else 0,
+                    'reduced': bool(tags.get(TAG_NEW_SUBFILE_TYPE, [0])[0] & 1)})
+        (ifd,) = struct.unpack(e + 'I', buf[ifd + 2 + 12 * n: ifd + 6 + 12 * n])
+    return out
+
+
+def validate_cog(path):
+    """Returns the list of layout errors (empty = valid), the rules of the reference's
+    validator (extern/validate_cloud_optimized_geotiff.py): main IFD at byte 8 (:176-213),
+    tiled when larger than 512 (:163-168), overviews by descending size with ascending
+    IFD offsets (:218-258), block data from the smallest overview to the main image,
+    all after the last IFD (:281-297)."""
+    lv = cog_layout(path)
+    errors = []
+    main, ovr = lv[0], lv[1:]
+    if main['ifd_offset'] != 8:
+        errors.append(f"The offset of the main IFD should be 8. It is {main['ifd_offset']} instead")
+    if (main['width'] > 512 or main['height'] > 512) and not main['tile'][0]:
+        errors.append('The file is greater than 512xH or Wx512, but is not tiled')
+    prev = main
+    for i, o in enumerate(ovr):
+        if not o['reduced']:
+            errors.append(f'IFD {i + 1} is not a reduced-resolution image')
+        if o['width'] > prev['width'] or o['height'] > prev['height']:
+            errors.append(f'Overview of index {i} has larger dimension than the previous level')
+        if o['ifd_offset'] < prev['ifd_offset']:
+            errors.append(f'The offset of the IFD for overview of index {i} is not ascending')
+        prev = o
+    if lv[-1]['first_block'] < lv[-1]['ifd_offset']:
+        errors.append('The offset of the first block of the smallest level should be after its IFD')
+    for i in range(len(lv) - 1):
+        if lv[i]['first_block'] < lv[i + 1]['first_block']:
+            errors.append(f'The offset of the first block of level {i} should be after the one of level {i + 1}')
+    return errors
 
 
 def write_png_palette(path, indices, colormap, transparent_index=None):

@@ -53,6 +53,11 @@ def test_runconfig_entry_point(tmp_path, sensor):
         assert info.nodata == (65535 if layer == 'DIAG' else 255)
         assert info.descriptions == [D.band_description_dict[layer]]
         assert info.geotransform == (600000.0, 30.0, 0.0, 4000020.0, 0.0, -30.0)
+        # save_as_cog (core.py:7-91): cloud-optimized layout with NEAREST overviews
+        assert geotiff.validate_cog(str(path)) == []
+        assert [x['width'] for x in geotiff.cog_layout(str(path))] == [512, 128, 32, 8, 4]
+        ovr, _ = geotiff.read_geotiff(str(path), overview=0)
+        assert np.array_equal(ovr, exp[layer][::4, ::4])
         md = info.metadata
         c = exp['counters']
         assert md['SPATIAL_COVERAGE'] == str(c['SPATIAL_COVERAGE'])

@@ -54,6 +54,56 @@ def test_geotiff_multiband_and_colormap(tmp_path):
     assert info.colormap[1].tolist() == [0, 0, 255] and info.colormap[0].tolist() == [255, 255, 255]
 
 
+@pytest.mark.parametrize('shape', [(3660, 3660), (700, 531), (513, 40)])
+def test_cog_overviews_and_layout(tmp_path, shape):
+    """save_as_cog (reference core.py:7-91): NEAREST overviews 4/16/64/128, all IFDs first, block
+    data from the smallest overview to the full-resolution image; checked with the rules of the
+    reference's validator (extern/validate_cloud_optimized_geotiff.py:176-297)."""
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 6, size=shape).astype(np.uint8)
+    p = str(tmp_path / 'cog.tif')
+    geotiff.write_geotiff(p, a, nodata=255, colormap={0: (255, 255, 255), 1: (0, 0, 255)},
+                          metadata={'K': 'v'}, overviews=geotiff.COG_OVERVIEW_FACTORS)
+    assert geotiff.validate_cog(p) == []
+    lv = geotiff.cog_layout(p)
+    assert [(x['height'], x['width']) for x in lv] == \
+        [shape] + [(-(-shape[0] // f), -(-shape[1] // f)) for f in geotiff.COG_OVERVIEW_FACTORS]
+    assert lv[0]['ifd_offset'] == 8 and all(x['tile'] == (512, 512) for x in lv)
+    back, info = geotiff.read_geotiff(p)
+    assert np.array_equal(back, a) and info.metadata == {'K': 'v'} and info.nodata == 255.0
+    for k, f in enumerate(geotiff.COG_OVERVIEW_FACTORS):
+        o, oi = geotiff.read_geotiff(p, overview=k)
+        h, w = o.shape
+        ys = (0.5 + np.arange(h) * (shape[0] / h)).astype(int)
+        xs = (0.5 + np.arange(w) * (shape[1] / w)).astype(int)
+        assert np.array_equal(o, a[np.ix_(ys, xs)]) and oi.nodata == 255.0
+        assert oi.colormap[1].tolist() == [0, 0, 255]
+    if shape[0] % 4 == 0 and shape[1] % 4 == 0:
+        assert np.array_equal(geotiff.read_geotiff(p, overview=0)[0], a[::4, ::4])
+    with pytest.raises(geotiff.GeoTiffError):
+        geotiff.read_geotiff(p, overview=4)
+
+
+def test_cog_validator_rejects_bad_layouts(tmp_path):
+    a = np.zeros((600, 600), np.uint16)
+    p = str(tmp_path / 'plain.tif')
+    geotiff.write_geotiff(p, a)                       # no overviews: still a valid layout
+    assert geotiff.validate_cog(p) == [] and len(geotiff.cog_layout(p)) == 1
+    # move the main IFD pointer: a file whose first IFD is not at byte 8 must be flagged
+    buf = bytearray(open(p, 'rb').read())
+    (ifd,) = struct.unpack('<I', buf[4:8])
+    (n,) = struct.unpack('<H', buf[ifd:ifd + 2])
+    ifd_bytes = bytes(buf[ifd:ifd + 2 + 12 * n + 4])
+    new_off = len(buf) + (len(buf) & 1)
+    buf += b'\x00' * (new_off - len(buf)) + ifd_bytes
+    buf[4:8] = struct.pack('<I', new_off)
+    q = str(tmp_path / 'moved.tif')
+    open(q, 'wb').write(bytes(buf))
+    assert np.array_equal(geotiff.read_geotiff(q)[0], a)
+    errs = geotiff.validate_cog(q)
+    assert any('main IFD' in e for e in errs) and any('after its IFD' in e for e in errs)
+
+
 def test_geotiff_reads_plain_strips(tmp_path):
     """A hand-made uncompressed, stripped, big-endian TIFF (what other writers produce)."""
     a = np.arange(6 * 5, dtype='>i2').reshape(6, 5)
