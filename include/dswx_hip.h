@@ -245,6 +245,13 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels,
 /* ---- device plumbing for hosts without another HIP binding ------------------- */
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_device_free(dswx_ctx_t* ctx, void* ptr);
+/* Page-locked host memory.  dswx_classify_host() recognises buffers allocated here (or
+ * registered with hipHostRegister) and, when EVERY plane pointer is page-locked and the mode
+ * is not 'cover', runs upload / classify / download as a three-stream pipeline over pieces
+ * of each tile instead of the synchronous copy-compute-copy sequence.  There is no
+ * reference counterpart (numpy arrays are pageable); results are identical. */
+int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out);
+int dswx_host_free(dswx_ctx_t* ctx, void* ptr);
 int dswx_memcpy_h2d(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);
 int dswx_memcpy_d2h(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);
 int dswx_memset_d(dswx_ctx_t* ctx, void* dst, int value, size_t bytes);

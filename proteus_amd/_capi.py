@@ -4,6 +4,7 @@ There is exactly one compute path: the HIP library.  If it is missing, or no
 MI355X is visible, every entry point here raises -- nothing falls back to numpy.
 """
 import ctypes
+import weakref
 import os
 
 import numpy as np
@@ -25,7 +26,7 @@ EXPORTED_SYMBOLS = (
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
     'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_classify_batch', 'dswx_synth_batch', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device', 'dswx_landcover_mask_host',
     'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
-    'dswx_device_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
+    'dswx_device_free', 'dswx_host_alloc', 'dswx_host_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info')
 
@@ -127,6 +128,8 @@ def load_library():
                                            ctypes.POINTER(PlanesIn), vp]),
         'dswx_device_malloc': (ctypes.c_int, [vp, ctypes.c_size_t, pp]),
         'dswx_device_free': (ctypes.c_int, [vp, vp]),
+        'dswx_host_alloc': (ctypes.c_int, [vp, ctypes.c_size_t, pp]),
+        'dswx_host_free': (ctypes.c_int, [vp, vp]),
         'dswx_memcpy_h2d': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t]),
         'dswx_memcpy_d2h': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t]),
         'dswx_memset_d': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_size_t]),
@@ -264,6 +267,9 @@ class Context:
         _check(self.lib.dswx_ctx_create(int(device), ctypes.byref(h)))
         self.handle = h
         self.device = int(device)
+        self._pinned = {}          # page-locked host spans: address -> bytes
+        self._pinned_pool = {}     # released spans by size
+        self._pinned_pool_bytes = 0
 
     def close(self):
         if self.handle:
@@ -275,6 +281,45 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    # ---- page-locked host arrays -----------------------------------------------
+    PINNED_POOL_CAP = 4 << 30      # bytes of released page-locked spans kept for reuse
+
+    def pinned_empty(self, shape, dtype):
+        """numpy array over page-locked memory (dswx_host_alloc).  When every plane handed to
+        classify_host() is such an array the library pipelines upload / classify / download
+        over three streams; outputs are then allocated page-locked as well.  Page-locking is
+        slow (~0.1 ms per MB), so released spans go to a per-context pool and are reused."""
+        dtype = np.dtype(dtype)
+        nbytes = max(int(np.prod(shape, dtype=np.int64)) * dtype.itemsize, 1)
+        if self._pinned_pool.get(nbytes):
+            addr = self._pinned_pool[nbytes].pop()
+            self._pinned_pool_bytes -= nbytes
+        else:
+            ptr = ctypes.c_void_p()
+            _check(self.lib.dswx_host_alloc(self.handle, nbytes, ctypes.byref(ptr)))
+            addr = ptr.value
+            self._pinned[addr] = nbytes
+        raw = (ctypes.c_char * nbytes).from_address(addr)
+        arr = np.frombuffer(raw, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape) \
+            if int(np.prod(shape, dtype=np.int64)) else np.empty(shape, dtype)
+
+        def release(ctx_ref=weakref.ref(self), addr=addr, nbytes=nbytes):
+            ctx = ctx_ref()
+            if ctx is None or not ctx.handle:
+                return
+            if ctx._pinned_pool_bytes + nbytes <= ctx.PINNED_POOL_CAP:
+                ctx._pinned_pool.setdefault(nbytes, []).append(addr)
+                ctx._pinned_pool_bytes += nbytes
+            else:
+                ctx._pinned.pop(addr, None)
+                ctx.lib.dswx_host_free(ctx.handle, ctypes.c_void_p(addr))
+        weakref.finalize(raw, release)
+        return arr
+
+    def is_pinned(self, arr):
+        a = arr.ctypes.data
+        return any(base <= a and a + arr.nbytes <= base + size for base, size in self._pinned.items())
 
     # ---- host-pointer path ----------------------------------------------------
     def classify_host(self, bands, fmask, params, *, land=None, shad=None, ocean=None,
@@ -316,6 +361,7 @@ class Context:
         pin.land = land.ctypes.data if land is not None else None
         pin.shad = shad.ctypes.data if shad is not None else None
         pin.ocean = ocean.ctypes.data if ocean is not None else None
+        pinned_in = all(self.is_pinned(a) for a in bands + [fmask, land, shad, ocean] if a is not None)
         pout = PlanesOut()
         res = {}
         for name in layers:
@@ -323,7 +369,7 @@ class Context:
                                                    else np.uint8)
             if name != 'diag' and name not in U8_LAYERS and name not in F64_LAYERS:
                 raise KeyError(name)
-            res[name] = np.empty(shape, dtype=dt)
+            res[name] = self.pinned_empty(shape, dt) if pinned_in else np.empty(shape, dtype=dt)
             setattr(pout, name, res[name].ctypes.data)
         cnt = np.zeros((n_tiles, 3), dtype=np.int64) if counters else None
         _check(self.lib.dswx_classify_host(

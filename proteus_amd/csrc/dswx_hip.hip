@@ -666,6 +666,8 @@ int dswx_ctx_create(int device, dswx_ctx_t** out) {
     if (const char* e = std::getenv("DSWX_TUNE_ABLATE")) c->tune_ablate = std::atoi(e);
     if (const char* e = std::getenv("DSWX_TUNE_PIPE_BLOCKS")) c->tune_pipe_blocks = std::atoi(e);
     if (const char* e = std::getenv("DSWX_TUNE_LUT_WPS")) c->tune_lut_wps = std::atoi(e);
+    if (const char* e = std::getenv("DSWX_HOST_PIPELINE")) c->host_pipeline = std::atoi(e);
+    if (const char* e = std::getenv("DSWX_HOST_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) c->host_chunks = v; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -683,6 +685,14 @@ int dswx_ctx_destroy(dswx_ctx_t* ctx) {
     if (ctx->cover) (void)hipFree(ctx->cover);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
+    if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
+    for (int i = 0; i < 3; ++i) {
+        if (ctx->pipe_in[i]) (void)hipEventDestroy(ctx->pipe_in[i]);
+        if (ctx->pipe_k[i]) (void)hipEventDestroy(ctx->pipe_k[i]);
+        if (ctx->pipe_out[i]) (void)hipEventDestroy(ctx->pipe_out[i]);
+    }
+    if (ctx->pipe_counters) (void)hipHostFree(ctx->pipe_counters);
     delete ctx;
     return DSWX_OK;
 }
@@ -904,6 +914,126 @@ int dswx_classify_batch(dswx_ctx_t* ctx, const dswx_params_t* params, const dswx
                                 geom->tile_stride, in, out, counters, stream);
 }
 
+// Is `p` page-locked host memory HIP knows about (hipHostMalloc / hipHostRegister)?
+static bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();          // plain malloc memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// Pipelined host path: every tile is cut into `host_chunks` flat pixel ranges (the chain is
+// per pixel, so any cut is legal outside 'cover' mode) that flow through three device slots:
+// chunk c+1 uploads on the H2D stream while chunk c is classified on the compute stream and
+// chunk c-1 downloads on the D2H stream.  Needs page-locked host buffers (dswx_host_alloc or
+// hipHostRegister), otherwise the copies are not asynchronous.  Counters are summed per tile
+// on the host from per-chunk partial counts.
+static int classify_host_pipelined(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t P,
+                                   const dswx_planes_in_t* in, const dswx_planes_out_t* out, int64_t* counters) {
+    constexpr int NSLOT = 3;
+    if (!ctx->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
+    if (!ctx->d2h_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+    for (int i = 0; i < NSLOT; ++i) {
+        if (!ctx->pipe_in[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->pipe_in[i], hipEventDisableTiming));
+        if (!ctx->pipe_k[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->pipe_k[i], hipEventDisableTiming));
+        if (!ctx->pipe_out[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->pipe_out[i], hipEventDisableTiming));
+    }
+    // chunk size: a multiple of 2048 pixels (one block of the fused kernel), >= 64 Ki pixels
+    int64_t chunk = (P + ctx->host_chunks - 1) / ctx->host_chunks;
+    if (chunk < 65536) chunk = 65536;
+    chunk = (chunk + 2047) / 2048 * 2048;
+    const int64_t per_tile = (P + chunk - 1) / chunk;
+    const int64_t n_chunks = per_tile * n_tiles;
+    if ((size_t)n_chunks > ctx->pipe_counters_cap) {
+        if (ctx->pipe_counters) HIP_TRY(hipHostFree(ctx->pipe_counters));
+        ctx->pipe_counters = nullptr; ctx->pipe_counters_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->pipe_counters), (size_t)n_chunks * 3 * sizeof(int64_t)));
+        ctx->pipe_counters_cap = (size_t)n_chunks;
+    }
+    // slot layout (offsets within one slot, all 256-byte aligned because chunk % 2048 == 0)
+    const uint8_t* const h_in_u8[4] = {in->fmask, in->land, in->shad, in->ocean};
+    uint8_t* const h_out_u8[8] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud,
+                                  out->browse};
+    double* const h_f64[3] = {out->mndwi, out->ndvi, out->awesh};
+    size_t off = 0, o_band[6], o_in_u8[4], o_diag, o_out_u8[8], o_f64[3], o_cnt;
+    for (int k = 0; k < 6; ++k) { o_band[k] = off; off += (size_t)chunk * 2; }
+    for (int i = 0; i < 4; ++i) { o_in_u8[i] = off; if (h_in_u8[i]) off += (size_t)chunk; }
+    o_diag = off; if (out->diag) off += (size_t)chunk * 2;
+    for (int i = 0; i < 8; ++i) { o_out_u8[i] = off; if (h_out_u8[i]) off += (size_t)chunk; }
+    for (int i = 0; i < 3; ++i) { o_f64[i] = off; if (h_f64[i]) off += (size_t)chunk * 8; }
+    o_cnt = off; off += 256;
+    const size_t slot_bytes = off;
+    if (slot_bytes * NSLOT > ctx->stage_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (ctx->stage) HIP_TRY(hipFree(ctx->stage));
+        ctx->stage = nullptr; ctx->stage_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->stage, slot_bytes * NSLOT));
+        ctx->stage_bytes = slot_bytes * NSLOT;
+    }
+    char* const arena = static_cast<char*>(ctx->stage);
+    hipStream_t sc = ctx->stream, sh = ctx->h2d_stream, sd = ctx->d2h_stream;
+    bool slot_used[NSLOT] = {false, false, false};
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int slot = (int)(c % NSLOT);
+        const int64_t tile = c / per_tile, px0 = (c % per_tile) * chunk;
+        const int64_t n = (P - px0 < chunk) ? P - px0 : chunk;
+        const size_t hoff = (size_t)tile * (size_t)P + (size_t)px0;
+        char* base = arena + slot_bytes * slot;
+        dswx_planes_in_t din{};
+        dswx_planes_out_t dout{};
+        // ---- upload (after the slot's previous download finished)
+        if (slot_used[slot]) HIP_TRY(hipStreamWaitEvent(sh, ctx->pipe_out[slot], 0));
+        for (int k = 0; k < 6; ++k) {
+            HIP_TRY(hipMemcpyAsync(base + o_band[k], in->band[k] + hoff, (size_t)n * 2, hipMemcpyHostToDevice, sh));
+            din.band[k] = reinterpret_cast<const int16_t*>(base + o_band[k]);
+        }
+        const uint8_t** const d_in_u8[4] = {&din.fmask, &din.land, &din.shad, &din.ocean};
+        for (int i = 0; i < 4; ++i)
+            if (h_in_u8[i]) {
+                HIP_TRY(hipMemcpyAsync(base + o_in_u8[i], h_in_u8[i] + hoff, (size_t)n, hipMemcpyHostToDevice, sh));
+                *d_in_u8[i] = reinterpret_cast<const uint8_t*>(base + o_in_u8[i]);
+            }
+        HIP_TRY(hipEventRecord(ctx->pipe_in[slot], sh));
+        // ---- classify
+        if (out->diag) dout.diag = reinterpret_cast<uint16_t*>(base + o_diag);
+        uint8_t** const d_out_u8[8] = {&dout.wtr1, &dout.wtr1_aerosol, &dout.wtr2, &dout.wtr, &dout.bwtr, &dout.conf,
+                                       &dout.cloud, &dout.browse};
+        for (int i = 0; i < 8; ++i) if (h_out_u8[i]) *d_out_u8[i] = reinterpret_cast<uint8_t*>(base + o_out_u8[i]);
+        double** const d_f64[3] = {&dout.mndwi, &dout.ndvi, &dout.awesh};
+        for (int i = 0; i < 3; ++i) if (h_f64[i]) *d_f64[i] = reinterpret_cast<double*>(base + o_f64[i]);
+        int64_t* dcnt = counters ? reinterpret_cast<int64_t*>(base + o_cnt) : nullptr;
+        HIP_TRY(hipStreamWaitEvent(sc, ctx->pipe_in[slot], 0));
+        const int rc = dswx_classify_device(ctx, params, 1, n, &din, &dout, dcnt, sc);
+        if (rc) { (void)hipDeviceSynchronize(); return rc; }
+        HIP_TRY(hipEventRecord(ctx->pipe_k[slot], sc));
+        // ---- download
+        HIP_TRY(hipStreamWaitEvent(sd, ctx->pipe_k[slot], 0));
+        if (out->diag) HIP_TRY(hipMemcpyAsync(out->diag + hoff, dout.diag, (size_t)n * 2, hipMemcpyDeviceToHost, sd));
+        for (int i = 0; i < 8; ++i)
+            if (h_out_u8[i]) HIP_TRY(hipMemcpyAsync(h_out_u8[i] + hoff, *d_out_u8[i], (size_t)n, hipMemcpyDeviceToHost, sd));
+        for (int i = 0; i < 3; ++i)
+            if (h_f64[i]) HIP_TRY(hipMemcpyAsync(h_f64[i] + hoff, *d_f64[i], (size_t)n * 8, hipMemcpyDeviceToHost, sd));
+        if (counters)
+            HIP_TRY(hipMemcpyAsync(ctx->pipe_counters + c * 3, dcnt, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, sd));
+        HIP_TRY(hipEventRecord(ctx->pipe_out[slot], sd));
+        slot_used[slot] = true;
+    }
+    HIP_TRY(hipStreamSynchronize(sd));
+    HIP_TRY(hipStreamSynchronize(sc));
+    HIP_TRY(hipStreamSynchronize(sh));
+    if (counters)
+        for (int64_t t = 0; t < n_tiles; ++t)
+            for (int j = 0; j < 3; ++j) {
+                int64_t sum = 0;
+                for (int64_t q = 0; q < per_tile; ++q) sum += ctx->pipe_counters[(t * per_tile + q) * 3 + j];
+                counters[t * 3 + j] = sum;
+            }
+    ctx->last_kernel += " x" + std::to_string(n_chunks) + " chunks, pipelined over 3 streams (pinned host buffers)";
+    return DSWX_OK;
+}
+
 int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t height,
                        int64_t width, const dswx_planes_in_t* in, const dswx_planes_out_t* out,
                        int64_t* counters) {
@@ -920,8 +1050,17 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
     const int64_t P = height * width;
     if (n_tiles == 0 || P == 0) return DSWX_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    // one tile at a time through a grow-only device arena: planes at 256-byte
-    // aligned offsets so the vector kernel is always eligible
+    if (ctx->host_pipeline && params->mask_adjacent_to_cloud_mode != DSWX_ADJ_COVER) {
+        bool pinned = true;
+        for (int k = 0; k < 6 && pinned; ++k) pinned = is_pinned_host(in->band[k]);
+        const void* const rest[] = {in->fmask, in->land, in->shad, in->ocean, out->diag, out->wtr1, out->wtr1_aerosol,
+                                    out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud, out->browse, out->mndwi,
+                                    out->ndvi, out->awesh};
+        for (const void* p : rest) pinned = pinned && (!p || is_pinned_host(p));
+        if (pinned) return classify_host_pipelined(ctx, params, n_tiles, P, in, out, counters);
+    }
+    // pageable host buffers (or 'cover' mode): one tile at a time through a grow-only device
+    // arena: planes at 256-byte aligned offsets so the vector kernel is always eligible
     auto rnd = [](size_t x) { return (x + 255) & ~size_t(255); };
     size_t off = 0;
     size_t o_band[6], o_fm, o_land = 0, o_shad = 0, o_ocean = 0;
@@ -1167,6 +1306,22 @@ int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out) {
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return DSWX_OK;
+}
+
+int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return DSWX_OK;
+}
+
+int dswx_host_free(dswx_ctx_t* ctx, void* ptr) {
+    if (!ctx) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (!ptr) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipHostFree(ptr));
     return DSWX_OK;
 }
 

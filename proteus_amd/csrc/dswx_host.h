@@ -22,6 +22,14 @@ struct dswx_ctx {
     // grow-only scratch of 'cover' mode: uncollapsed WTR-2 + pre-snow CLOUD planes
     void* cover = nullptr;
     size_t cover_bytes = 0;
+    // pipelined host path (pinned host buffers): copy streams, per-slot events, pinned counter scratch
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    hipEvent_t pipe_in[3] = {nullptr, nullptr, nullptr}, pipe_k[3] = {nullptr, nullptr, nullptr},
+               pipe_out[3] = {nullptr, nullptr, nullptr};
+    int64_t* pipe_counters = nullptr;      // hipHostMalloc, [pipe_counters_cap][3]
+    size_t pipe_counters_cap = 0;
+    int host_pipeline = 1;                 // env DSWX_HOST_PIPELINE=0 forces the synchronous path
+    int host_chunks = 8;                   // env DSWX_HOST_CHUNKS: pieces per tile of the pipelined path
     std::string last_kernel;
     int fused_variant = -1;  // env DSWX_FUSED_VARIANT -- unset (-1): automatic = 3 when every tile starts on a
                              // 256-byte boundary in every plane, else 0;  0: direct stores; 1: LDS-staged

@@ -474,23 +474,35 @@ def _harvest_hls_metadata(meta, md):
     return True
 
 
-def _load_hls_product_v2(file_list, image, md, flag_debug=False):
+def _load_hls_product_v2(file_list, image, md, flag_debug=False, alloc=None):
     """Reads the seven band files of an HLS v2 product.  Returns False on failure.
     Fill detection and clipping are NOT done here: the raw planes and the fill values go
     to the kernel (A0 of the hot path)."""
     logger.info('loading HLS v.2.0 layers:')
     image['fills'] = {}
-    for key in l30_v2_band_dict:
-        logger.info(f'    {key}')
+
+    def find(key):
         landsat = 'SPACECRAFT_NAME' not in md or 'LANDSAT' in md['SPACECRAFT_NAME'].upper()
         suffix = (l30_v2_band_dict if landsat else s30_v2_band_dict)[key]
-        path = next((f for f in file_list if suffix + '.tif' in f), None)
+        return suffix, next((f for f in file_list if suffix + '.tif' in f), None)
+
+    # an incomplete file list is reported before any raster is decoded
+    def missing(band_dict):
+        return [k for k, sfx in band_dict.items() if not any(sfx + '.tif' in f for f in file_list)]
+
+    if missing(l30_v2_band_dict) and missing(s30_v2_band_dict):
+        key = min(missing(l30_v2_band_dict), missing(s30_v2_band_dict), key=len)[0]
+        logger.info(f'ERROR band {key} not found within list of input file(s)')
+        return False
+    for key in l30_v2_band_dict:
+        logger.info(f'    {key}')
+        suffix, path = find(key)
         if path is None:
             logger.info(f'ERROR band {key} not found within list of input file(s)')
             return False
         try:
             arr, info = geotiff.read_geotiff(
-                path, window=(0, 0, 1000, 1000) if flag_debug else None)
+                path, window=(0, 0, 1000, 1000) if flag_debug else None, alloc=alloc)
         except (OSError, geotiff.GeoTiffError) as e:
             logger.info(f'ERROR could not open {path}: {e}')
             return False
@@ -922,7 +934,10 @@ def generate_dswx_layers(input_list,
     image = {}
     # HLS v1 (a single HDF4 file, :4972-4980) needs GDAL's HDF4 driver; every input goes
     # through the v2 per-band GeoTIFF loader, which reports what is missing
-    ok = _load_hls_product_v2(list(input_list), image, md, flag_debug=flag_debug)
+    # band planes are decoded straight into page-locked memory so that the library can
+    # pipeline upload / classify / download (dswx_host_alloc, include/dswx_hip.h)
+    ok = _load_hls_product_v2(list(input_list), image, md, flag_debug=flag_debug,
+                              alloc=lambda shape, dt: get_context(device).pinned_empty(shape, dt))
     if not ok:
         logger.info(f'ERROR could not read file(s): {input_list}')
         return False
@@ -976,8 +991,16 @@ def generate_dswx_layers(input_list,
     wanted = ['diag', 'wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud']
     if output_browse_image:
         wanted.append('browse')
-    res = ctx.classify_host(bands, image['fmask'], params, land=landcover_mask,
-                            shad=shadow_layer, ocean=ocean_mask, layers=tuple(wanted))
+    def like_bands(a):
+        # ancillary planes follow the bands into page-locked memory (one small copy)
+        if a is None or not ctx.is_pinned(bands[0]):
+            return a
+        p = ctx.pinned_empty(a.shape, np.uint8)
+        np.copyto(p, a, casting='unsafe')
+        return p
+    res = ctx.classify_host(bands, image['fmask'], params, land=like_bands(landcover_mask),
+                            shad=like_bands(shadow_layer), ocean=like_bands(ocean_mask),
+                            layers=tuple(wanted))
     logger.info(f'    per-pixel chain on GPU: {ctx.last_kernel_info()}')
     n_valid, n_cloud_and_valid, n_not_ocean = (int(v) for v in res['counters'][0])
 

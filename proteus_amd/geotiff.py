@@ -110,11 +110,12 @@ def _parse_metadata_xml(text):
     return meta, desc
 
 
-def read_geotiff(path, window=None, overview=None):
+def read_geotiff(path, window=None, overview=None, alloc=None):
     """Returns (array, GeoTiffInfo).  array is [H,W] for one band, [B,H,W] otherwise.
     window = (xoff, yoff, xsize, ysize) crops after decoding (the reference's
     flag_debug read, :2187-2190).  overview = k reads the k-th internal overview
-    (IFD k + 1) instead of the full-resolution image."""
+    (IFD k + 1) instead of the full-resolution image.  alloc(shape, dtype) -> ndarray lets the
+    caller own the destination memory (e.g. page-locked host memory for the GPU path)."""
     with open(path, 'rb') as fh:
         buf = fh.read()
     if len(buf) < 8:
@@ -191,7 +192,7 @@ def read_geotiff(path, window=None, overview=None):
     across, down = (W + bw - 1) // bw, (H + bh - 1) // bh
     planes = spp if planar == 2 else 1
     chunk_spp = 1 if planar == 2 else spp
-    out = np.zeros((spp, H, W), dtype=info.dtype)
+    out = np.zeros((spp, H, W), dtype=info.dtype) if alloc is None else alloc((spp, H, W), info.dtype)
     if len(offs) < planes * across * down:
         raise GeoTiffError(f'{path}: truncated block table')
     idx = 0

@@ -127,6 +127,55 @@ def test_seeded_tiles_vs_numpy_oracle(ctx, shape, cfg):
                                                c['n_not_ocean']]
 
 
+def _pinned_copy(ctx, a):
+    q = ctx.pinned_empty(a.shape, a.dtype)
+    q[...] = a
+    return q
+
+
+@pytest.mark.parametrize('chunks', ['1', '3', '8'])
+@pytest.mark.parametrize('geom', [(1, 333, 517, False), (3, 300, 301, True), (2, 1, 7, True), (1, 1100, 900, True)])
+def test_pinned_pipelined_host_path(monkeypatch, chunks, geom):
+    """dswx_classify_host from page-locked buffers (dswx_host_alloc): the three-stream pipeline over
+    flat pieces of each tile gives the same planes and the same per-tile counters as the C oracle,
+    for ragged piece sizes, several tiles, optional planes and the float64 debug indices."""
+    monkeypatch.setenv('DSWX_HOST_CHUNKS', chunks)
+    c = _capi.Context(0)
+    try:
+        n_tiles, h, w, masks = geom
+        tiles = [synth_tile(70 + t, h, w, with_masks=True) for t in range(n_tiles)]
+        stack = lambda f: np.stack([f(t) for t in tiles]) if n_tiles > 1 else f(tiles[0])
+        bands = [_pinned_copy(c, stack(lambda t, k=k: t['bands'][k])) for k in range(6)]
+        fmask = _pinned_copy(c, stack(lambda t: t['fmask']))
+        kw = {m: _pinned_copy(c, stack(lambda t, m=m: t[m])) for m in ('land', 'shad', 'ocean')} if masks else {}
+        assert c.is_pinned(bands[0]) and not c.is_pinned(np.zeros(4))
+        p = _capi.make_params(collapse_wtr_classes=True)
+        layers = ALL_LAYERS + ('browse', 'mndwi')
+        got = c.classify_host(bands, fmask, p, layers=layers, **kw)
+        assert 'pipelined over 3 streams' in c.last_kernel_info() and c.is_pinned(got['wtr'])
+        # the synchronous path on pageable copies of the same inputs is the comparator ...
+        ref = c.classify_host([np.array(b) for b in bands], np.array(fmask), p, layers=layers,
+                              **{k: np.array(v) for k, v in kw.items()})
+        assert 'pipelined' not in c.last_kernel_info()
+        for k in layers:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), k
+        assert np.array_equal(got['counters'], ref['counters'])
+        # ... and the C oracle pins both
+        for t in range(n_tiles):
+            tb = [np.array(b[t] if n_tiles > 1 else b) for b in bands]
+            tkw = {k: np.array(v[t] if n_tiles > 1 else v) for k, v in kw.items()}
+            exp = c_oracle.classify(p, tb, np.array(fmask[t] if n_tiles > 1 else fmask), **tkw)
+            for k in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+                assert np.array_equal(got[k][t] if n_tiles > 1 else got[k], exp[k]), (t, k)
+            assert got['counters'][t].tolist() == exp['counters'].tolist()
+        # 'cover' mode is a neighbourhood operation: it must take the whole-tile path
+        pc = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
+        c.classify_host(bands, fmask, pc, **kw)
+        assert 'pipelined' not in c.last_kernel_info()
+    finally:
+        c.close()
+
+
 def test_empty_inputs(ctx):
     p = _capi.default_params()
     for shape in [(0, 0), (0, 5), (3, 0)]:
