@@ -79,12 +79,19 @@ def library_path():
     return _build.LIB_PATH
 
 
-def load_library():
-    """dlopen the in-tree HIP library; raises if it has not been built."""
+_alt_libs = {}
+
+
+def load_library(path=None):
+    """dlopen the in-tree HIP library; raises if it has not been built.  `path` loads another
+    build of the same ABI next to it (tools/ab_variants.py: A/B of two builds in one process)."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    path = library_path()
+    if path is not None and path in _alt_libs:
+        return _alt_libs[path]
+    alt = path is not None
+    path = path or library_path()
     if not os.path.exists(path):
         raise RuntimeError(
             f'{path} is missing: the DSWx HIP extension has not been built '
@@ -142,12 +149,17 @@ def load_library():
         'dswx_last_kernel_info': (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_size_t]),
     }
     for name, (res, args) in sig.items():
+        if alt and not hasattr(lib, name):
+            continue                      # an older build of the same ABI version
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     if lib.dswx_abi_version() != DSWX_ABI_VERSION:
         raise RuntimeError('libdswx_hip.so ABI version mismatch; rebuild it')
-    _lib = lib
+    if alt:
+        _alt_libs[path] = lib
+    else:
+        _lib = lib
     return lib
 
 
@@ -261,8 +273,8 @@ class DeviceBuffer:
 class Context:
     """One per process and device (dswx_ctx_t)."""
 
-    def __init__(self, device=0):
-        self.lib = load_library()
+    def __init__(self, device=0, lib_path=None):
+        self.lib = load_library(lib_path)
         h = ctypes.c_void_p()
         _check(self.lib.dswx_ctx_create(int(device), ctypes.byref(h)))
         self.handle = h

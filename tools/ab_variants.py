@@ -3,6 +3,7 @@
 different DSWX_* environment knobs), as cdna_hip_programming.md rule 24 asks.
 
     python tools/ab_variants.py --tiles 64 --rounds 7 DSWX_TUNE_WPS=4 DSWX_TUNE_WPS=6 ...
+    python tools/ab_variants.py DSWX_TUNE_WPS=4 LIB=proteus_amd/_lib/ab/libdswx_prev.so   # two builds
 """
 import argparse
 import json
@@ -27,11 +28,15 @@ def main():
     ctxs = []
     for v in a.variants:
         saved = {}
+        lib_path = None
         for kv in v.split(','):
             k, val = kv.split('=')
+            if k == 'LIB':              # another build of the library (same ABI), e.g. the previous commit
+                lib_path = os.path.abspath(val)
+                continue
             saved[k] = os.environ.get(k)
             os.environ[k] = val
-        ctxs.append(_capi.Context(0))
+        ctxs.append(_capi.Context(0, lib_path=lib_path))
         for k, old in saved.items():
             if old is None:
                 os.environ.pop(k, None)
