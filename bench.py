@@ -143,8 +143,15 @@ def main():
     from proteus_amd import _capi, shard
     from proteus_amd.synth import SEED
 
-    torch.cuda.set_device(local_rank)
-    cp = shard.ControlPlane(backend='nccl', device=torch.device('cuda', local_rank))
+    if os.environ.get('DSWX_BENCH_SHARE_DEVICE') == '1':
+        # functional test of the N > 1 code path on a 1-GPU box: every rank on device 0, gloo as
+        # the control plane (RCCL refuses two ranks on one GPU).  Not a measurement.
+        local_rank = 0
+        torch.cuda.set_device(0)
+        cp = shard.ControlPlane(backend='gloo', device=None)
+    else:
+        torch.cuda.set_device(local_rank)
+        cp = shard.ControlPlane(backend='nccl', device=torch.device('cuda', local_rank))
 
     ctx = _capi.Context(local_rank)        # raises if the HIP extension / GPU is missing
     params = _capi.default_params()
