@@ -201,6 +201,23 @@ int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, in
                            double cos_azimuth, double min_slope_angle,
                            double max_sun_local_inc_angle, double pixel_spacing_x,
                            double pixel_spacing_y, uint8_t* shadow);
+/* The two angle tests pulled back onto the arguments of arccos / arctan (both monotonic):
+ *   degrees(arccos(q)) <= max_sun_local_inc_angle  <=>  *inc_q_min <= q <= 1
+ *   degrees(arctan(t)) <= min_slope_angle          <=>  t <= *slope_arg_max
+ * found by bisection over the doubles with libm.  dswx_shadow_layer_host/_device call this;
+ * a caller that wants the boundary of ITS math library (the Python host uses numpy's own
+ * arccos / arctan, as the reference does) computes the pair itself and calls the _q forms. */
+int dswx_shadow_thresholds(double min_slope_angle, double max_sun_local_inc_angle,
+                           double* slope_arg_max, double* inc_q_min);
+int dswx_shadow_layer_host_q(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width,
+                             int64_t margin, const double sun_vector[3], double sin_azimuth,
+                             double cos_azimuth, double slope_arg_max, double inc_q_min,
+                             double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow);
+int dswx_shadow_layer_device_q(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles,
+                               int64_t height, int64_t width, int64_t margin,
+                               const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                               double slope_arg_max, double inc_q_min, double pixel_spacing_x,
+                               double pixel_spacing_y, uint8_t* shadow, void* stream);
 /* Device-pointer form for `n_tiles` DEMs of equal size, asynchronous on `stream`. */
 int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles,
                              int64_t height, int64_t width, int64_t margin,
@@ -221,6 +238,14 @@ int dswx_landcover_mask_host(dswx_ctx_t* ctx, const uint8_t* worldcover_up3,
                              const uint8_t* copernicus, int64_t height, int64_t width,
                              const int32_t* forest_classes, int32_t n_forest_classes,
                              const int32_t thresholds[4], int32_t year_offset, uint8_t* land);
+
+/* Device-pointer form for `n_tiles` map pairs of equal size ([n_tiles][3H][3W] and
+ * [n_tiles][H][W]), asynchronous on `stream`. */
+int dswx_landcover_mask_device(dswx_ctx_t* ctx, const uint8_t* worldcover_up3,
+                               const uint8_t* copernicus, int64_t n_tiles, int64_t height,
+                               int64_t width, const int32_t* forest_classes,
+                               int32_t n_forest_classes, const int32_t thresholds[4],
+                               int32_t year_offset, uint8_t* land, void* stream);
 
 /* Deterministic synthetic HLS tiles written straight into HBM (SURVEY.md §8d;
  * same integer recipe as proteus_amd/synth.py).  Fills in->band[0..5], in->fmask

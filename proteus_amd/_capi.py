@@ -24,7 +24,7 @@ F64_LAYERS = ('mndwi', 'ndvi', 'awesh')
 EXPORTED_SYMBOLS = (
     'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
-    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_classify_batch', 'dswx_synth_batch', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device', 'dswx_landcover_mask_host',
+    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_classify_batch', 'dswx_synth_batch', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device', 'dswx_shadow_thresholds', 'dswx_shadow_layer_host_q', 'dswx_shadow_layer_device_q', 'dswx_landcover_mask_host', 'dswx_landcover_mask_device',
     'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_host_alloc', 'dswx_host_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
@@ -127,8 +127,19 @@ def load_library(path=None):
         'dswx_shadow_layer_device': (ctypes.c_int, [vp, vp, i64, i64, i64, i64,
                                                     ctypes.POINTER(ctypes.c_double * 3)] +
                                      [ctypes.c_double] * 6 + [vp, vp]),
+        'dswx_shadow_thresholds': (ctypes.c_int, [ctypes.c_double, ctypes.c_double,
+                                                  ctypes.POINTER(ctypes.c_double),
+                                                  ctypes.POINTER(ctypes.c_double)]),
+        'dswx_shadow_layer_host_q': (ctypes.c_int, [vp, vp, i64, i64, i64,
+                                                    ctypes.POINTER(ctypes.c_double * 3)] +
+                                     [ctypes.c_double] * 6 + [vp]),
+        'dswx_shadow_layer_device_q': (ctypes.c_int, [vp, vp, i64, i64, i64, i64,
+                                                      ctypes.POINTER(ctypes.c_double * 3)] +
+                                       [ctypes.c_double] * 6 + [vp, vp]),
         'dswx_landcover_mask_host': (ctypes.c_int, [vp, vp, vp, i64, i64, vp, ctypes.c_int32, vp,
                                                     ctypes.c_int32, vp]),
+        'dswx_landcover_mask_device': (ctypes.c_int, [vp, vp, vp, i64, i64, i64, vp, ctypes.c_int32,
+                                                      vp, ctypes.c_int32, vp, vp]),
         'dswx_stream_probe': (ctypes.c_int, [vp, i64, i64, i64, ctypes.POINTER(PlanesIn),
                                              ctypes.POINTER(PlanesOut), ctypes.c_int, vp]),
         'dswx_synth_fill': (ctypes.c_int, [vp, ctypes.c_uint64, i64, i64, i64, i64,
@@ -227,6 +238,64 @@ def make_params(thresholds=None, *, band_fills=None, fmask_fill=255.0,
                 if 0 <= int(v) <= 255 and int(v) == v:
                     p.aerosol_fmask_lut[row][int(v)] = 1
     return p
+
+
+def _bisect_doubles(pred, lo, hi):
+    """pred(lo) is False and pred(hi) True (or the reverse) for a predicate that is monotonic in
+    the double `x`; returns the two adjacent doubles (a, b), a < b, where it flips.  `pred` is
+    evaluated on ARRAYS (64 copies of the candidate) so that numpy takes the same SIMD loop it
+    takes for a raster."""
+    def ordered(d):
+        i = int(np.float64(d).view(np.int64))
+        return i if i >= 0 else -(i & 0x7fffffffffffffff)
+
+    def value(k):
+        return float(np.int64(k if k >= 0 else (-k) | -0x8000000000000000).view(np.float64))
+
+    def test(d):
+        with np.errstate(all='ignore'):
+            return bool(pred(np.full(64, d, dtype=np.float64))[17])
+    a, b = ordered(lo), ordered(hi)
+    fa = test(lo)
+    while b - a > 1:
+        m = a + (b - a) // 2
+        if test(value(m)) == fa:
+            a = m
+        else:
+            b = m
+    return value(a), value(b)
+
+
+_shadow_threshold_cache = {}
+
+
+def shadow_thresholds(min_slope_angle, max_sun_local_inc_angle):
+    """(slope_arg_max, inc_q_min) for dswx_shadow_layer_*_q: the reference's two tests
+    `degrees(arctan(t)) <= min_slope_angle` and `degrees(arccos(q)) <= max_sun_local_inc_angle`
+    (dswx_hls.py:4264-4281) as bounds on t and q, located with numpy's own array functions."""
+    key = (float(min_slope_angle), float(max_sun_local_inc_angle))
+    if key in _shadow_threshold_cache:
+        return _shadow_threshold_cache[key]
+    if np.isnan(key[0]) or np.isnan(key[1]):
+        raise ValueError('shadow angle threshold is NaN')
+    inc_ok = lambda q: np.degrees(np.arccos(q)) <= key[1]          # noqa: E731
+    slope_ok = lambda t: np.degrees(np.arctan(t)) <= key[0]        # noqa: E731
+    one = lambda f, v: bool(f(np.full(64, v, dtype=np.float64))[17])   # noqa: E731
+    with np.errstate(all='ignore'):
+        if not one(inc_ok, 1.0):
+            inc_q_min = 2.0                      # never
+        elif one(inc_ok, -1.0):
+            inc_q_min = -1.0                     # whenever arccos is defined
+        else:
+            inc_q_min = _bisect_doubles(inc_ok, -1.0, 1.0)[1]
+        if one(slope_ok, np.inf):
+            slope_arg_max = float('inf')
+        elif not one(slope_ok, -np.inf):
+            slope_arg_max = float('-inf')
+        else:
+            slope_arg_max = _bisect_doubles(slope_ok, -np.inf, np.inf)[0]
+    _shadow_threshold_cache[key] = (slope_arg_max, inc_q_min)
+    return slope_arg_max, inc_q_min
 
 
 def _host_ptr(arr):
@@ -410,18 +479,19 @@ class Context:
 
     def shadow_layer(self, dem, sun_vector, sin_azimuth, cos_azimuth, min_slope_angle,
                      max_sun_local_inc_angle, pixel_spacing_x=30, pixel_spacing_y=30, margin=0):
-        """Terrain shadow layer of one float32 DEM [H,W]; returns bool [H-2m, W-2m]."""
+        """Terrain shadow layer of one float32 DEM [H,W]; returns bool [H-2m, W-2m].  The two angle
+        thresholds are pulled back through numpy's arccos / arctan (shadow_thresholds)."""
         dem = np.ascontiguousarray(dem, dtype=np.float32)
         if dem.ndim != 2:
             raise ValueError('dem must be 2-D')
         h, w = dem.shape
         out = np.empty((max(h - 2 * margin, 0), max(w - 2 * margin, 0)), dtype=np.uint8)
         vec = (ctypes.c_double * 3)(*[float(v) for v in sun_vector])
-        _check(self.lib.dswx_shadow_layer_host(
+        slope_arg_max, inc_q_min = shadow_thresholds(min_slope_angle, max_sun_local_inc_angle)
+        _check(self.lib.dswx_shadow_layer_host_q(
             self.handle, _host_ptr(dem), h, w, int(margin), ctypes.byref(vec),
-            float(sin_azimuth), float(cos_azimuth), float(min_slope_angle),
-            float(max_sun_local_inc_angle), float(pixel_spacing_x), float(pixel_spacing_y),
-            _host_ptr(out)))
+            float(sin_azimuth), float(cos_azimuth), slope_arg_max, inc_q_min,
+            float(pixel_spacing_x), float(pixel_spacing_y), _host_ptr(out)))
         return out.astype(bool)
 
     def landcover_mask(self, worldcover_up3, copernicus, forest_classes, thresholds=(6, 3, 7, 3),
@@ -440,6 +510,28 @@ class Context:
             _host_ptr(fc) if fc.size else None, int(fc.size), _host_ptr(thr), int(year_offset),
             _host_ptr(out)))
         return out
+
+    def landcover_mask_device(self, wc_ptr, cg_ptr, n_tiles, height, width, forest_classes, out_ptr,
+                              thresholds=(6, 3, 7, 3), year_offset=0, stream=None):
+        """Device-pointer form: [n_tiles][3H][3W] + [n_tiles][H][W] -> [n_tiles][H][W], asynchronous."""
+        fc = np.ascontiguousarray(list(forest_classes or []), dtype=np.int32)
+        thr = np.ascontiguousarray(thresholds, dtype=np.int32)
+        _check(self.lib.dswx_landcover_mask_device(
+            self.handle, ctypes.c_void_p(wc_ptr), ctypes.c_void_p(cg_ptr), int(n_tiles), int(height),
+            int(width), _host_ptr(fc) if fc.size else None, int(fc.size), _host_ptr(thr),
+            int(year_offset), ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream) if stream else None))
+
+    def shadow_layer_device(self, dem_ptr, n_tiles, height, width, margin, sun_vector, sin_azimuth,
+                            cos_azimuth, min_slope_angle, max_sun_local_inc_angle, out_ptr,
+                            pixel_spacing_x=30, pixel_spacing_y=30, stream=None):
+        """Device-pointer form: [n_tiles][H][W] float32 DEMs -> [n_tiles][H-2m][W-2m] u8, asynchronous."""
+        vec = (ctypes.c_double * 3)(*[float(v) for v in sun_vector])
+        slope_arg_max, inc_q_min = shadow_thresholds(min_slope_angle, max_sun_local_inc_angle)
+        _check(self.lib.dswx_shadow_layer_device_q(
+            self.handle, ctypes.c_void_p(dem_ptr), int(n_tiles), int(height), int(width), int(margin),
+            ctypes.byref(vec), float(sin_azimuth), float(cos_azimuth), slope_arg_max, inc_q_min,
+            float(pixel_spacing_x), float(pixel_spacing_y),
+            ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream) if stream else None))
 
     def stream_probe(self, n_tiles, n_pixels, pin, pout, variant=0, stream=None, tile_stride=0):
         _check(self.lib.dswx_stream_probe(

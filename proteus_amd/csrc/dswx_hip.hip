@@ -232,6 +232,100 @@ __global__ __launch_bounds__(256) void dswx_cover_stage2(const KArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------
+// 'cover' mode, stage 2, bit-packed (default).  Same semantics as dswx_cover_stage2 above, but
+// the four per-pixel predicates live as BITMAPS: one block owns a 128-column x 256-row window
+// (halo 17 on every side -> 94 x 222 output pixels), one thread owns one window row as a
+// 128-bit word pair per mask.  A masked 4-neighbour dilation step is then
+//     x |= (x | x<<1 | x>>1 | row_above | row_below) & mask
+// on 128 bits: ~30 VALU and one 16-byte LDS exchange per thread and iteration, instead of
+// one LDS byte read-modify-write per cell (9604 cells x 17 iterations per 4096 outputs).
+//   phase A  waves build the bitmaps row by row with coalesced byte loads + wave ballots
+//   phase B  17 synchronous iterations (10 on snow within `area`, 7 on clear within area & water)
+//   phase C  waves walk the output rows again (coalesced), finish A11-A15 per pixel
+// Window edges are wrong by one more row / column per iteration; after 17 iterations
+// exactly the halo is contaminated, so the output region is exact.
+// ------------------------------------------------------------------------------
+constexpr int CB_W = 128, CB_H = 256, CB_HALO = 17, CB_OUT_W = CB_W - 2 * CB_HALO, CB_OUT_H = CB_H - 2 * CB_HALO;
+
+__global__ __launch_bounds__(256) void dswx_cover_stage2_bits(const KArgs a) {
+    typedef unsigned long long u64;
+    __shared__ u64 s_init[CB_H][8];          // per row: snow, area, area & water, clear0  (lo, hi each)
+    __shared__ u64 s_x[2][CB_H + 2][2];      // row exchange, double-buffered, zero guard rows
+    const int H = a.height, W = a.width;
+    const long long tile_base = (long long)blockIdx.z * a.tile_stride;
+    const int y0 = blockIdx.y * CB_OUT_H - CB_HALO, x0 = blockIdx.x * CB_OUT_W - CB_HALO;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = threadIdx.x;
+    if (t < 4) { s_x[t >> 1][(t & 1) ? CB_H + 1 : 0][0] = 0; s_x[t >> 1][(t & 1) ? CB_H + 1 : 0][1] = 0; }
+    // ---- phase A
+    for (int r = wave; r < CB_H; r += 4) {
+        const int y = y0 + r;
+        uint32_t bits[2] = {0u, 0u};          // snow | area << 1 | (area & water) << 2 | clear0 << 3
+        if (y >= 0 && y < H) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int x = x0 + 64 * h + lane;
+                if (x >= 0 && x < W) {
+                    const long long off = tile_base + (long long)y * W + x;
+                    const uint32_t fm = a.in.fmask[off], pc = a.cover_pc[off], w2 = a.cover_w2[off];
+                    const uint32_t clear0 = pc == 0u ? 1u : 0u, area = ((fm >> 2) & 1u) & clear0;
+                    const uint32_t water = (w2 - 1u) <= 3u ? 1u : 0u;
+                    bits[h] = ((fm >> 4) & 1u) | area << 1 | (area & water) << 2 | clear0 << 3;
+                }
+            }
+        }
+        u64 m[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[2 * k] = __ballot((bits[0] >> k) & 1u);
+            m[2 * k + 1] = __ballot((bits[1] >> k) & 1u);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_init[r][k] = m[k];
+        }
+    }
+    __syncthreads();
+    // ---- phase B: thread t owns window row t
+    u64 slo = s_init[t][0], shi = s_init[t][1];
+    const u64 alo = s_init[t][2], ahi = s_init[t][3], wlo = s_init[t][4], whi = s_init[t][5];
+    const u64 c0lo = s_init[t][6], c0hi = s_init[t][7];
+    int buf = 0;
+    auto step = [&](u64& lo, u64& hi, u64 mlo, u64 mhi) {
+        s_x[buf][t + 1][0] = lo; s_x[buf][t + 1][1] = hi;
+        __syncthreads();
+        const u64 nlo = lo | s_x[buf][t][0] | s_x[buf][t + 2][0] | (lo << 1) | (lo >> 1) | (hi << 63);
+        const u64 nhi = hi | s_x[buf][t][1] | s_x[buf][t + 2][1] | (hi << 1) | (hi >> 1) | (lo >> 63);
+        lo |= nlo & mlo; hi |= nhi & mhi;
+        buf ^= 1;
+    };
+    for (int it = 0; it < 10; ++it) step(slo, shi, alo, ahi);
+    u64 clo = ~slo & c0lo, chi = ~shi & c0hi;
+    for (int it = 0; it < 7; ++it) step(clo, chi, wlo, whi);
+    // final snow of the row -> LDS (buffer `buf` was last written two steps ago: free)
+    s_x[buf][t + 1][0] = slo & ~clo; s_x[buf][t + 1][1] = shi & ~chi;
+    __syncthreads();
+    // ---- phase C
+    for (int r = CB_HALO + wave; r < CB_H - CB_HALO; r += 4) {
+        const int y = y0 + r;
+        if (y >= H) break;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 64 * h + lane, x = x0 + c;
+            if (c < CB_HALO || c >= CB_W - CB_HALO || x >= W) continue;
+            const bool snow = (s_x[buf][r + 1][h] >> lane) & 1ull;
+            const long long off = tile_base + (long long)y * W + x;
+            PxOut o;
+            finish_px(a.P, a.cover_w2[off], a.cover_pc[off], snow, o);
+            if (a.out.wtr) a.out.wtr[off] = (uint8_t)o.wtr;
+            if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)o.bwtr;
+            if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
+            if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
+            if (a.out.browse) a.out.browse[off] = (uint8_t)o.browse;
+        }
+    }
+}
+
 // Sums the fused kernel's per-wave partial counts of one tile (block = tile) and
 // WRITES counters[tile]; the ragged-remainder kernel adds to them afterwards.
 __global__ __launch_bounds__(256) void dswx_counters_finish(const uint2* __restrict__ partials,
@@ -328,6 +422,13 @@ __global__ __launch_bounds__(256) void dswx_interpret_v1(const long long* __rest
 // numpy 1.23.5 the reference pins, value-based casting keeps those float32 as well:
 // borderline pixels can differ between the two -- SURVEY.md §7.)  Built without
 // fp contraction; hipcc's float32 division and sqrt are correctly rounded.
+//
+// No transcendental runs on the device: arccos and arctan are monotonic, so the host pulls
+// the two angle thresholds back onto their arguments by bisection over the doubles WITH THE
+// LIBRARY THE REFERENCE WOULD USE (the Python host: numpy's own arccos / arctan loops;
+// dswx_shadow_thresholds: libm) and the kernel compares the arguments.  That is both
+// cheaper (the kernel becomes HBM-bound) and closer to the reference than a device libm:
+// whichever way numpy rounds arccos at the threshold, the boundary moves with it.
 // ------------------------------------------------------------------------------
 struct ShadowArgs {
     const float* dem;        // [H][W], with margin
@@ -336,35 +437,35 @@ struct ShadowArgs {
     float spacing_x, neg_abs_spacing_y;
     double sun[3];           // target-to-sun unit vector (x, y, z)
     double sin_az, cos_az;
-    double min_slope_angle, max_sun_local_inc_angle;
+    // the two angle tests, pulled back through the (monotonic) arccos / arctan onto their
+    // arguments by the host (dswx_shadow_thresholds or the caller's own numpy):
+    //   degrees(arccos(q)) <= max_sun_local_inc_angle  <=>  inc_q_min <= q <= 1
+    //   degrees(arctan(t)) <= min_slope_angle          <=>  t <= slope_arg_max
+    double inc_q_min, slope_arg_max;
 };
 
-__global__ __launch_bounds__(256) void dswx_shadow_v1(const ShadowArgs a) {
-    const long long ow = a.width - 2 * a.margin, oh = a.height - 2 * a.margin;
-    const long long ox = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const long long oy = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
+    const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
+    const int ow = W - 2 * margin, oh = H - 2 * margin;
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= ow || oy >= oh) return;
-    const long long x = ox + a.margin, y = oy + a.margin, W = a.width, H = a.height;
-    const float* d = a.dem + (long long)blockIdx.z * H * W;
-    // np.gradient, edge_order 1, unit spacing: central differences inside,
-    // one-sided at the borders
-    float gx, gy;
-    if (x == 0) gx = d[y * W + 1] - d[y * W];
-    else if (x == W - 1) gx = d[y * W + x] - d[y * W + x - 1];
-    else gx = (d[y * W + x + 1] - d[y * W + x - 1]) / 2.0f;
-    if (y == 0) gy = d[W + x] - d[x];
-    else if (y == H - 1) gy = d[y * W + x] - d[(y - 1) * W + x];
-    else gy = (d[(y + 1) * W + x] - d[(y - 1) * W + x]) / 2.0f;
+    const int x = ox + margin, y = oy + margin;
+    const float* __restrict__ d = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W;
+    // np.gradient, edge_order 1, unit spacing: central differences inside ((f[i+1] - f[i-1]) / 2,
+    // and x / 2 == x * 0.5f exactly), one-sided first differences at the borders; branch-free
+    const int c = y * W + x;                       // H * W < 2^31 is checked on the host
+    const bool x_in = (x > 0) & (x < W - 1), y_in = (y > 0) & (y < H - 1);
+    const float gx = (d[x < W - 1 ? c + 1 : c] - d[x > 0 ? c - 1 : c]) * (x_in ? 0.5f : 1.0f);
+    const float gy = (d[y < H - 1 ? c + W : c] - d[y > 0 ? c - W : c]) * (y_in ? 0.5f : 1.0f);
     const float n0 = -gx / a.spacing_x;
     const float n1 = -gy / a.neg_abs_spacing_y;
     const float norm = sqrtf(n0 * n0 + n1 * n1 + 1.0f);
     const double dot = (double)n0 * a.sun[0] + (double)n1 * a.sun[1] + a.sun[2];
-    const double RAD2DEG = 180.0 / 3.141592653589793238462643383279502884;
-    const double inc_deg = acos(dot / (double)norm) * RAD2DEG;
-    const double slope_deg = atan((double)n0 * a.sin_az + (double)n1 * a.cos_az) * RAD2DEG;
-    const bool backslope = slope_deg <= a.min_slope_angle;
-    const bool low_inc = inc_deg <= a.max_sun_local_inc_angle;
-    a.shadow[(long long)blockIdx.z * oh * ow + oy * ow + ox] = (low_inc | !backslope) ? 1 : 0;
+    const double q = dot / (double)norm;                      // arccos argument (NaN-safe compares below)
+    const double t = (double)n0 * a.sin_az + (double)n1 * a.cos_az;   // arctan argument
+    const bool low_inc = (q >= a.inc_q_min) & (q <= 1.0);     // arccos(q > 1) is NaN: the test fails
+    const bool backslope = t <= a.slope_arg_max;
+    a.shadow[(size_t)blockIdx.z * (size_t)oh * (size_t)ow + (size_t)(oy * ow + ox)] = (low_inc | !backslope) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------
@@ -381,15 +482,57 @@ struct LandArgs {
     int low_class, high_class;   // year_offset, 100 + year_offset (as uint8)
 };
 
+__device__ __forceinline__ int land_class(const LandArgs& a, int water, int urban, int tree, int c) {
+    if (!((a.forest_bits[c >> 5] >> (c & 31)) & 1u)) tree = 0;
+    int v = 255;
+    if (tree >= a.thr_tree) v = 201;
+    if (urban >= a.thr_low) v = a.low_class;
+    if (urban >= a.thr_high) v = a.high_class;
+    if (water >= a.thr_water) v = 200;
+    return v;
+}
+
+// Four HLS pixels per thread (width % 4 == 0): three 12-byte row pieces of the WorldCover map as
+// dword loads (a wave reads 768 contiguous bytes per row), one dword of CGLS, one dword stored.
+// blockIdx.z = tile.  HBM-bound: 10 B read + 1 B written per pixel.
+__global__ __launch_bounds__(256) void dswx_landcover_v2(const LandArgs a) {
+    const long long xq = (long long)blockIdx.x * 64 + (threadIdx.x & 63);      // quad index
+    const long long y = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xq * 4 >= a.width || y >= a.height) return;
+    const long long W3 = 3 * a.width, tile = blockIdx.z;
+    const uint8_t* wc = a.wc3 + tile * 9 * a.height * a.width;
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};      // per pixel: water | urban << 8 | tree << 16
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(wc + (3 * y + i) * W3 + 12 * xq);
+        const uint32_t w[3] = {__builtin_nontemporal_load(row), __builtin_nontemporal_load(row + 1),
+                               __builtin_nontemporal_load(row + 2)};
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const uint32_t v = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            cnt[j / 3] += (uint32_t)((v == 80u) | (v == 90u) | (v == 95u)) + ((uint32_t)(v == 50u) << 8) +
+                          ((uint32_t)(v == 10u) << 16);
+        }
+    }
+    const long long o = tile * a.height * a.width + y * a.width + 4 * xq;
+    const uint32_t cg = *reinterpret_cast<const uint32_t*>(a.cgls + o);
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        out |= (uint32_t)land_class(a, cnt[k] & 0xff, (cnt[k] >> 8) & 0xff, cnt[k] >> 16, (cg >> (8 * k)) & 0xff) << (8 * k);
+    *reinterpret_cast<uint32_t*>(a.land + o) = out;
+}
+
 __global__ __launch_bounds__(256) void dswx_landcover_v1(const LandArgs a) {
     const long long x = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     const long long y = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.width || y >= a.height) return;
     int water = 0, urban = 0, tree = 0;
     const long long W3 = 3 * a.width;
+    const long long tile = blockIdx.z;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const uint8_t* row = a.wc3 + (3 * y + i) * W3 + 3 * x;
+        const uint8_t* row = a.wc3 + tile * 9 * a.height * a.width + (3 * y + i) * W3 + 3 * x;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int v = row[j];
@@ -398,14 +541,8 @@ __global__ __launch_bounds__(256) void dswx_landcover_v1(const LandArgs a) {
             tree += v == 10;
         }
     }
-    const int c = a.cgls[y * a.width + x];
-    if (!((a.forest_bits[c >> 5] >> (c & 31)) & 1u)) tree = 0;
-    int v = 255;
-    if (tree >= a.thr_tree) v = 201;
-    if (urban >= a.thr_low) v = a.low_class;
-    if (urban >= a.thr_high) v = a.high_class;
-    if (water >= a.thr_water) v = 200;
-    a.land[y * a.width + x] = (uint8_t)v;
+    const long long o = tile * a.height * a.width + y * a.width + x;
+    a.land[o] = (uint8_t)land_class(a, water, urban, tree, a.cgls[o]);
 }
 
 // ------------------------------------------------------------------------------
@@ -666,6 +803,7 @@ int dswx_ctx_create(int device, dswx_ctx_t** out) {
     if (const char* e = std::getenv("DSWX_TUNE_ABLATE")) c->tune_ablate = std::atoi(e);
     if (const char* e = std::getenv("DSWX_TUNE_PIPE_BLOCKS")) c->tune_pipe_blocks = std::atoi(e);
     if (const char* e = std::getenv("DSWX_TUNE_LUT_WPS")) c->tune_lut_wps = std::atoi(e);
+    if (const char* e = std::getenv("DSWX_COVER_KERNEL")) c->cover_kernel = std::atoi(e);
     if (const char* e = std::getenv("DSWX_HOST_PIPELINE")) c->host_pipeline = std::atoi(e);
     if (const char* e = std::getenv("DSWX_HOST_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) c->host_chunks = v; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -871,16 +1009,18 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             if (c2.out.conf) c2.out.conf += shift;
             if (c2.out.cloud) c2.out.cloud += shift;
             if (c2.out.browse) c2.out.browse += shift;
+            const bool bitmaps = ctx->cover_kernel != 0;
+            const int tw = bitmaps ? CB_OUT_W : CV_TILE, th = bitmaps ? CB_OUT_H : CV_TILE;
+            dim3 grid((unsigned)((width + tw - 1) / tw), (unsigned)((height + th - 1) / th), (unsigned)nt);
+            if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
             if (c2.out.wtr || c2.out.bwtr || c2.out.conf || c2.out.cloud || c2.out.browse) {
-                dim3 grid((unsigned)((width + CV_TILE - 1) / CV_TILE), (unsigned)((height + CV_TILE - 1) / CV_TILE),
-                          (unsigned)nt);
-                hipLaunchKernelGGL(dswx_cover_stage2, grid, dim3(256), 0, s, c2);
+                if (bitmaps) hipLaunchKernelGGL(dswx_cover_stage2_bits, grid, dim3(256), 0, s, c2);
+                else hipLaunchKernelGGL(dswx_cover_stage2, grid, dim3(256), 0, s, c2);
                 HIP_TRY(hipGetLastError());
             }
             const size_t len = strlen(info);
-            snprintf(info + len, sizeof info - len, " + dswx_cover_stage2 grid=(%lld,%lld,%lld)",
-                     (long long)((width + CV_TILE - 1) / CV_TILE), (long long)((height + CV_TILE - 1) / CV_TILE),
-                     (long long)nt);
+            snprintf(info + len, sizeof info - len, " + %s grid=(%u,%u,%u)",
+                     bitmaps ? "dswx_cover_stage2_bits" : "dswx_cover_stage2", grid.x, grid.y, grid.z);
         }
         if (any_index) {
             dim3 grid((unsigned)((n_pixels + 255) / 256), (unsigned)nt), block(256);
@@ -1144,32 +1284,82 @@ int dswx_interpret_layer_host(dswx_ctx_t* ctx, const int64_t* diag_decimal, int6
     return DSWX_OK;
 }
 
+// ---- terrain shadow: thresholds on the arccos / arctan ARGUMENTS --------------------------
+// doubles in numeric order as int64 (both zeros map to 0)
+static int64_t ord_of(double d) {
+    int64_t i;
+    std::memcpy(&i, &d, 8);
+    return i >= 0 ? i : -(i & 0x7fffffffffffffffLL);
+}
+static double dbl_of(int64_t k) {
+    int64_t i = k >= 0 ? k : (int64_t)(0x8000000000000000ULL | (uint64_t)(-k));
+    double d;
+    std::memcpy(&d, &i, 8);
+    return d;
+}
+static const double kRad2Deg = 180.0 / 3.141592653589793238462643383279502884;
+
+int dswx_shadow_thresholds(double min_slope_angle, double max_sun_local_inc_angle, double* slope_arg_max,
+                           double* inc_q_min) {
+    if (!slope_arg_max || !inc_q_min) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (std::isnan(min_slope_angle) || std::isnan(max_sun_local_inc_angle))
+        return dswx_fail(DSWX_ERR_ARG, "shadow angle threshold is NaN");
+    // smallest q in [-1, 1] with degrees(acos(q)) <= T (acos decreases); 2.0 if there is none
+    auto inc_ok = [&](double q) { return std::acos(q) * kRad2Deg <= max_sun_local_inc_angle; };
+    if (!inc_ok(1.0)) *inc_q_min = 2.0;
+    else if (inc_ok(-1.0)) *inc_q_min = -1.0;
+    else {
+        int64_t lo = ord_of(-1.0), hi = ord_of(1.0);          // !ok(lo), ok(hi)
+        while ((uint64_t)hi - (uint64_t)lo > 1) {
+            const int64_t mid = lo + (int64_t)(((uint64_t)hi - (uint64_t)lo) / 2);
+            if (inc_ok(dbl_of(mid))) hi = mid; else lo = mid;
+        }
+        *inc_q_min = dbl_of(hi);
+    }
+    // largest t with degrees(atan(t)) <= T (atan increases); +-inf when always / never
+    auto slope_ok = [&](double t) { return std::atan(t) * kRad2Deg <= min_slope_angle; };
+    const double inf = std::numeric_limits<double>::infinity();
+    if (slope_ok(inf)) *slope_arg_max = inf;
+    else if (!slope_ok(-inf)) *slope_arg_max = -inf;
+    else {
+        int64_t lo = ord_of(-inf), hi = ord_of(inf);          // ok(lo), !ok(hi); the span exceeds int64
+        while ((uint64_t)hi - (uint64_t)lo > 1) {
+            const int64_t mid = lo + (int64_t)(((uint64_t)hi - (uint64_t)lo) / 2);
+            if (slope_ok(dbl_of(mid))) lo = mid; else hi = mid;
+        }
+        *slope_arg_max = dbl_of(lo);
+    }
+    return DSWX_OK;
+}
+
 static int shadow_args(ShadowArgs* a, int64_t height, int64_t width, int64_t margin, const double sun_vector[3],
-                       double sin_azimuth, double cos_azimuth, double min_slope_angle,
-                       double max_sun_local_inc_angle, double pixel_spacing_x, double pixel_spacing_y) {
+                       double sin_azimuth, double cos_azimuth, double slope_arg_max, double inc_q_min,
+                       double pixel_spacing_x, double pixel_spacing_y) {
     if (!sun_vector) return dswx_fail(DSWX_ERR_ARG, "sun_vector is NULL");
     if (height < 2 || width < 2)
         return dswx_fail(DSWX_ERR_ARG, "Shape of array too small to calculate a numerical gradient, "
                                   "at least 2 elements are required.");
     if (margin < 0 || 2 * margin >= height || 2 * margin >= width) return dswx_fail(DSWX_ERR_ARG, "bad margin");
+    if (height > 2147483647LL / width) return dswx_fail(DSWX_ERR_ARG, "DEM larger than 2^31 pixels");
+    if (std::isnan(slope_arg_max) || std::isnan(inc_q_min)) return dswx_fail(DSWX_ERR_ARG, "shadow threshold is NaN");
     a->height = height; a->width = width; a->margin = margin;
     a->spacing_x = (float)pixel_spacing_x;
     a->neg_abs_spacing_y = (float)(-std::fabs(pixel_spacing_y));
     for (int i = 0; i < 3; ++i) a->sun[i] = sun_vector[i];
     a->sin_az = sin_azimuth; a->cos_az = cos_azimuth;
-    a->min_slope_angle = min_slope_angle; a->max_sun_local_inc_angle = max_sun_local_inc_angle;
+    a->slope_arg_max = slope_arg_max; a->inc_q_min = inc_q_min;
     return DSWX_OK;
 }
 
-int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
-                             int64_t margin, const double sun_vector[3], double sin_azimuth,
-                             double cos_azimuth, double min_slope_angle, double max_sun_local_inc_angle,
-                             double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream) {
+int dswx_shadow_layer_device_q(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
+                               int64_t margin, const double sun_vector[3], double sin_azimuth,
+                               double cos_azimuth, double slope_arg_max, double inc_q_min,
+                               double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream) {
     if (!ctx || !dem || !shadow) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     if (n_tiles < 0 || n_tiles > 65535) return dswx_fail(DSWX_ERR_ARG, "n_tiles out of range");
     ShadowArgs a;
-    int rc = shadow_args(&a, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, min_slope_angle,
-                         max_sun_local_inc_angle, pixel_spacing_x, pixel_spacing_y);
+    int rc = shadow_args(&a, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, slope_arg_max, inc_q_min,
+                         pixel_spacing_x, pixel_spacing_y);
     if (rc) return rc;
     if (n_tiles == 0) return DSWX_OK;
     a.dem = dem; a.shadow = shadow;
@@ -1178,19 +1368,30 @@ int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles,
     const long long ow = width - 2 * margin, oh = height - 2 * margin;
     dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
     if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
-    hipLaunchKernelGGL(dswx_shadow_v1, grid, block, 0, s, a);
+    hipLaunchKernelGGL(dswx_shadow_v2, grid, block, 0, s, a);
     HIP_TRY(hipGetLastError());
     return DSWX_OK;
 }
 
-int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
-                           const double sun_vector[3], double sin_azimuth, double cos_azimuth,
-                           double min_slope_angle, double max_sun_local_inc_angle, double pixel_spacing_x,
-                           double pixel_spacing_y, uint8_t* shadow) {
+int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
+                             int64_t margin, const double sun_vector[3], double sin_azimuth,
+                             double cos_azimuth, double min_slope_angle, double max_sun_local_inc_angle,
+                             double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream) {
+    double slope_arg_max, inc_q_min;
+    int rc = dswx_shadow_thresholds(min_slope_angle, max_sun_local_inc_angle, &slope_arg_max, &inc_q_min);
+    if (rc) return rc;
+    return dswx_shadow_layer_device_q(ctx, dem, n_tiles, height, width, margin, sun_vector, sin_azimuth, cos_azimuth,
+                                      slope_arg_max, inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow, stream);
+}
+
+int dswx_shadow_layer_host_q(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
+                             const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                             double slope_arg_max, double inc_q_min, double pixel_spacing_x,
+                             double pixel_spacing_y, uint8_t* shadow) {
     if (!ctx || !dem || !shadow) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     ShadowArgs chk;
-    int rc = shadow_args(&chk, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, min_slope_angle,
-                         max_sun_local_inc_angle, pixel_spacing_x, pixel_spacing_y);
+    int rc = shadow_args(&chk, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, slope_arg_max, inc_q_min,
+                         pixel_spacing_x, pixel_spacing_y);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t in_bytes = (size_t)height * (size_t)width * 4;
@@ -1202,9 +1403,9 @@ int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, in
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemcpyAsync(d_dem, dem, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        rc = dswx_shadow_layer_device(ctx, static_cast<const float*>(d_dem), 1, height, width, margin, sun_vector,
-                                      sin_azimuth, cos_azimuth, min_slope_angle, max_sun_local_inc_angle,
-                                      pixel_spacing_x, pixel_spacing_y, static_cast<uint8_t*>(d_out), s);
+        rc = dswx_shadow_layer_device_q(ctx, static_cast<const float*>(d_dem), 1, height, width, margin, sun_vector,
+                                        sin_azimuth, cos_azimuth, slope_arg_max, inc_q_min, pixel_spacing_x,
+                                        pixel_spacing_y, static_cast<uint8_t*>(d_out), s);
         if (rc == DSWX_OK) e = hipMemcpyAsync(shadow, d_out, out_px, hipMemcpyDeviceToHost, s);
         if (rc == DSWX_OK && e == hipSuccess) e = hipStreamSynchronize(s);
     }
@@ -1215,25 +1416,74 @@ int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, in
     return DSWX_OK;
 }
 
+int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
+                           const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                           double min_slope_angle, double max_sun_local_inc_angle, double pixel_spacing_x,
+                           double pixel_spacing_y, uint8_t* shadow) {
+    double slope_arg_max, inc_q_min;
+    int rc = dswx_shadow_thresholds(min_slope_angle, max_sun_local_inc_angle, &slope_arg_max, &inc_q_min);
+    if (rc) return rc;
+    return dswx_shadow_layer_host_q(ctx, dem, height, width, margin, sun_vector, sin_azimuth, cos_azimuth,
+                                    slope_arg_max, inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow);
+}
+
+static int land_args(LandArgs* a, int64_t height, int64_t width, const int32_t* forest_classes,
+                     int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset) {
+    if (!thresholds) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (height < 0 || width < 0 || n_forest_classes < 0 || (n_forest_classes > 0 && !forest_classes))
+        return dswx_fail(DSWX_ERR_ARG, "bad size");
+    std::memset(a, 0, sizeof *a);
+    for (int i = 0; i < n_forest_classes; ++i) {
+        const int c = forest_classes[i];
+        if (c >= 0 && c <= 255) a->forest_bits[c >> 5] |= 1u << (c & 31);
+    }
+    a->thr_tree = thresholds[0]; a->thr_low = thresholds[1]; a->thr_high = thresholds[2]; a->thr_water = thresholds[3];
+    // numpy stores the class through a uint8 array: values wrap modulo 256
+    a->low_class = (int)(uint8_t)(0 + year_offset);
+    a->high_class = (int)(uint8_t)(100 + year_offset);
+    a->height = height; a->width = width;
+    return DSWX_OK;
+}
+
+int dswx_landcover_mask_device(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
+                               int64_t n_tiles, int64_t height, int64_t width, const int32_t* forest_classes,
+                               int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset,
+                               uint8_t* land, void* stream) {
+    if (!ctx || !worldcover_up3 || !copernicus || !land) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles < 0 || n_tiles > 65535) return dswx_fail(DSWX_ERR_ARG, "n_tiles out of range");
+    LandArgs a;
+    int rc = land_args(&a, height, width, forest_classes, n_forest_classes, thresholds, year_offset);
+    if (rc) return rc;
+    if (n_tiles == 0 || height == 0 || width == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    a.wc3 = worldcover_up3; a.cgls = copernicus; a.land = land;
+    // four pixels per thread with dword loads when rows keep 4-byte alignment
+    const bool quad = width % 4 == 0 && aligned_to(worldcover_up3, 4) && aligned_to(copernicus, 4) && aligned_to(land, 4);
+    if (quad) {
+        dim3 grid((unsigned)((width / 4 + 63) / 64), (unsigned)((height + 3) / 4), (unsigned)n_tiles), block(256);
+        if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
+        hipLaunchKernelGGL(dswx_landcover_v2, grid, block, 0, s, a);
+    } else {
+        dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4), (unsigned)n_tiles), block(256);
+        if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
+        hipLaunchKernelGGL(dswx_landcover_v1, grid, block, 0, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
 int dswx_landcover_mask_host(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
                              int64_t height, int64_t width, const int32_t* forest_classes,
                              int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset,
                              uint8_t* land) {
     if (!ctx || !worldcover_up3 || !copernicus || !thresholds || !land) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
-    if (height < 0 || width < 0 || n_forest_classes < 0 || (n_forest_classes > 0 && !forest_classes))
-        return dswx_fail(DSWX_ERR_ARG, "bad size");
-    if (height == 0 || width == 0) return DSWX_OK;
-    LandArgs a;
-    std::memset(&a, 0, sizeof a);
-    for (int i = 0; i < n_forest_classes; ++i) {
-        const int c = forest_classes[i];
-        if (c >= 0 && c <= 255) a.forest_bits[c >> 5] |= 1u << (c & 31);
+    {
+        LandArgs chk;
+        int rc = land_args(&chk, height, width, forest_classes, n_forest_classes, thresholds, year_offset);
+        if (rc) return rc;
     }
-    a.thr_tree = thresholds[0]; a.thr_low = thresholds[1]; a.thr_high = thresholds[2]; a.thr_water = thresholds[3];
-    // numpy stores the class through a uint8 array: values wrap modulo 256
-    a.low_class = (int)(uint8_t)(0 + year_offset);
-    a.high_class = (int)(uint8_t)(100 + year_offset);
-    a.height = height; a.width = width;
+    if (height == 0 || width == 0) return DSWX_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t)height * (size_t)width;
     void* d_wc = nullptr; void* d_cg = nullptr; void* d_out = nullptr;
@@ -1243,18 +1493,17 @@ int dswx_landcover_mask_host(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, con
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemcpyAsync(d_wc, worldcover_up3, 9 * n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_cg, copernicus, n, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) {
-        a.wc3 = static_cast<const uint8_t*>(d_wc); a.cgls = static_cast<const uint8_t*>(d_cg);
-        a.land = static_cast<uint8_t*>(d_out);
-        dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4)), block(256);
-        hipLaunchKernelGGL(dswx_landcover_v1, grid, block, 0, s, a);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(land, d_out, n, hipMemcpyDeviceToHost, s);
+    int rc = DSWX_OK;
+    if (e == hipSuccess)
+        rc = dswx_landcover_mask_device(ctx, static_cast<const uint8_t*>(d_wc), static_cast<const uint8_t*>(d_cg), 1,
+                                        height, width, forest_classes, n_forest_classes, thresholds, year_offset,
+                                        static_cast<uint8_t*>(d_out), s);
+    if (e == hipSuccess && rc == DSWX_OK) e = hipMemcpyAsync(land, d_out, n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (d_wc) (void)hipFree(d_wc);
     if (d_cg) (void)hipFree(d_cg);
     if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
     if (e != hipSuccess) return dswx_fail(DSWX_ERR_HIP, "dswx_landcover_mask_host: %s", hipGetErrorString(e));
     return DSWX_OK;
 }

@@ -70,3 +70,33 @@ def test_no_device_fails_loudly():
         _capi.Context(0)
     assert e.value.code == _capi.ERR_NO_DEVICE
     assert 'no CPU fallback' in str(e.value)
+
+
+def test_shadow_thresholds_numpy_and_libm_agree():
+    """The pull-back of the two shadow angle tests onto the arccos / arctan arguments
+    (dswx_hls.py:4264-4281): numpy's bisection (the Python host) and the library's libm bisection
+    (dswx_shadow_thresholds; no GPU needed) find boundaries within a few ulps of each other, and
+    each is exact for its own math library."""
+    import ctypes
+    import numpy as np
+    lib = _capi.load_library()
+    for ms, mi in [(-5, 40), (0, 90), (10.5, 35.25), (-5, 179.9), (45.0, 1e-3), (-89.999, 120.0)]:
+        t_np, q_np = _capi.shadow_thresholds(ms, mi)
+        t_c, q_c = ctypes.c_double(), ctypes.c_double()
+        assert lib.dswx_shadow_thresholds(float(ms), float(mi), ctypes.byref(t_c), ctypes.byref(q_c)) == 0
+        for a, b in ((t_np, t_c.value), (q_np, q_c.value)):
+            assert abs(a - b) <= 8 * np.spacing(max(abs(a), abs(b), 1e-300)), (ms, mi, a, b)
+        # exactness against numpy on arrays (what the reference evaluates)
+        q = np.full(64, q_np)
+        assert (np.degrees(np.arccos(q)) <= mi).all()
+        assert not (np.degrees(np.arccos(np.nextafter(q, -2.0))) <= mi).any()
+        t = np.full(64, t_np)
+        assert (np.degrees(np.arctan(t)) <= ms).all()
+        assert not (np.degrees(np.arctan(np.nextafter(t, np.inf))) <= ms).any()
+    # degenerate thresholds
+    assert _capi.shadow_thresholds(-91, -1) == (float('-inf'), 2.0)
+    assert _capi.shadow_thresholds(90, 180) == (float('inf'), -1.0)
+    t_c, q_c = ctypes.c_double(), ctypes.c_double()
+    assert lib.dswx_shadow_thresholds(-91.0, -1.0, ctypes.byref(t_c), ctypes.byref(q_c)) == 0
+    assert (t_c.value, q_c.value) == (float('-inf'), 2.0)
+    assert lib.dswx_shadow_thresholds(float('nan'), 1.0, ctypes.byref(t_c), ctypes.byref(q_c)) != 0

@@ -246,6 +246,26 @@ def test_device_batch_and_synth(ctx, geom, tile_align):
     batch.free()
 
 
+@pytest.mark.parametrize('tile_align', [256, 1])
+def test_more_tiles_than_one_grid_dimension(ctx, tile_align):
+    """70,000 small tiles: the launch is split at 65,535 tiles (grid.y limit); tiles and counters
+    either side of the split match the oracle."""
+    n_tiles, h, w = 70000, 7, 11          # 77 px: nine 8-pixel groups + a 5-pixel tail
+    batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, tile_align=tile_align)
+    batch.synth(SEED, tile0=5)
+    p = _capi.default_params()
+    batch.classify(p)
+    ctx.synchronize()
+    cnt = batch.read_counters()
+    for t in (0, 1, 65534, 65535, 65536, 69999):
+        s = synth_tile(5 + t, h, w, with_masks=True)
+        exp = c_oracle.classify(p, s['bands'], s['fmask'], land=s['land'], shad=s['shad'], ocean=s['ocean'])
+        for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+            assert np.array_equal(batch.read_tile(key, t), exp[key]), (key, t)
+        assert cnt[t].tolist() == exp['counters'].tolist(), t
+    batch.free()
+
+
 def test_unaligned_device_pointers_take_generic_kernel(ctx):
     """Planes at odd byte offsets: still correct (dswx_classify_v1)."""
     h, w = 40, 40
@@ -434,10 +454,30 @@ def blobby_fmask(fmask, seed):
     return out
 
 
+@pytest.fixture(scope='module')
+def ctx_cover_bytes():
+    """Context running the byte-cell 'cover' stage 2 (the bit-packed kernel is the default)."""
+    import os
+    old = os.environ.get('DSWX_COVER_KERNEL')
+    os.environ['DSWX_COVER_KERNEL'] = '0'
+    try:
+        c = _capi.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop('DSWX_COVER_KERNEL')
+        else:
+            os.environ['DSWX_COVER_KERNEL'] = old
+    yield c
+    c.close()
+
+
+# window of the bit-packed kernel: 94 x 222 outputs per block -> sizes on and around its seams
 @pytest.mark.parametrize('shape', [(1, 1), (7, 9), (64, 64), (65, 63), (100, 37), (160, 160),
-                                   (333, 517)])
+                                   (333, 517), (222, 94), (223, 95), (445, 189), (500, 300)])
 @pytest.mark.parametrize('masks', [False, True])
-def test_cover_mode_vs_numpy_oracle(ctx, shape, masks):
+@pytest.mark.parametrize('kernel', ['bits', 'bytes'])
+def test_cover_mode_vs_numpy_oracle(ctx, ctx_cover_bytes, shape, masks, kernel):
+    ctx = ctx if kernel == 'bits' else ctx_cover_bytes
     h, w = shape
     s = synth_tile(900 + h, h, w, with_masks=True)
     fmask = blobby_fmask(s['fmask'], h * 1000 + w)
@@ -445,6 +485,7 @@ def test_cover_mode_vs_numpy_oracle(ctx, shape, masks):
     for collapse in (True, False):
         p = _capi.make_params(mask_adjacent_to_cloud_mode='cover', collapse_wtr_classes=collapse)
         got = ctx.classify_host(s['bands'], fmask, p, land=land, shad=shad, ocean=ocean)
+        assert ('dswx_cover_stage2_bits' in ctx.last_kernel_info()) == (kernel == 'bits')
         assert 'dswx_cover_stage2' in ctx.last_kernel_info()
         exp = o.classify_tile(s['bands'], fmask, landcover=land, shadow=shad, ocean_mask=ocean,
                               mask_adjacent_to_cloud_mode='cover', collapse=collapse)

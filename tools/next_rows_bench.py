@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Measurement of the SURVEY 8(f) rows next to the hot path, device-resident, HIP events:
+terrain shadow layer (f1), 'cover' mode (f2), LAND 3x3 aggregation (f3).  For each: time per
+3660^2 tile, achieved GB/s of the algorithmic bytes, and the numpy oracle on one host core on a
+bounded sample.  Prints one JSON object (profiles/r01_next_rows.json).
+
+    python tools/next_rows_bench.py [--tiles 8] [--reps 5] [--no-cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from proteus_amd import _capi                                   # noqa: E402
+from proteus_amd.synth import SEED, synth_dem, synth_landcover_inputs, synth_tile   # noqa: E402
+
+T, MARGIN = 3660, 50
+
+
+def timed(ctx, fn, reps):
+    fn()
+    ctx.synchronize()
+    ms = []
+    for _ in range(reps):
+        a, b = ctx.event(), ctx.event()
+        ctx.record(a)
+        fn()
+        ctx.record(b)
+        ms.append(ctx.elapsed_ms(a, b))
+        ctx.destroy_event(a)
+        ctx.destroy_event(b)
+    return sum(ms) / len(ms), min(ms)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--tiles', type=int, default=8)
+    ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--no-cpu', action='store_true')
+    a = ap.parse_args()
+    n = a.tiles
+    ctx = _capi.Context(0)
+    out = {'tiles_per_launch': n, 'tile': [T, T]}
+
+    # ---- f1 terrain shadow: [n][3760][3760] float32 -> [n][3660][3660] u8
+    H = W = T + 2 * MARGIN
+    dem = synth_dem(3, H, W)
+    d_dem = ctx.malloc(n * dem.nbytes)
+    d_sh = ctx.malloc(n * T * T)
+    for t in range(n):
+        d_dem.upload(dem, t * dem.nbytes)
+    az, el = np.radians(141.0), 35.0
+    zen = np.radians(90 - el)
+    sun = [np.sin(az) * np.sin(zen), np.cos(az) * np.sin(zen), np.cos(zen)]
+    avg, mn = timed(ctx, lambda: ctx.shadow_layer_device(d_dem.ptr, n, H, W, MARGIN, sun, np.sin(az), np.cos(az),
+                                                         -5.0, 40.0, d_sh.ptr), a.reps)
+    nbytes = n * (H * W * 4 + T * T)
+    out['f1_shadow'] = {'kernel': 'dswx_shadow', 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n,
+                        'algorithmic_bytes_per_tile': nbytes // n, 'GBps': nbytes / avg / 1e6,
+                        'Mpix_s': n * T * T / avg / 1e3}
+    d_dem.free()
+    d_sh.free()
+
+    # ---- f3 LAND aggregation: [n][10980][10980] u8 + [n][3660][3660] u8 -> [n][3660][3660] u8
+    wc, cg = synth_landcover_inputs(2, T, T)
+    d_wc, d_cg, d_land = ctx.malloc(n * wc.nbytes), ctx.malloc(n * cg.nbytes), ctx.malloc(n * T * T)
+    for t in range(n):
+        d_wc.upload(wc, t * wc.nbytes)
+        d_cg.upload(cg, t * cg.nbytes)
+    forest = [111, 113, 115, 116, 121, 123, 125, 126]
+    avg, mn = timed(ctx, lambda: ctx.landcover_mask_device(d_wc.ptr, d_cg.ptr, n, T, T, forest, d_land.ptr), a.reps)
+    nbytes = n * T * T * 11
+    out['f3_landcover'] = {'kernel': 'dswx_landcover_v2', 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n,
+                           'algorithmic_bytes_per_tile': T * T * 11, 'GBps': nbytes / avg / 1e6,
+                           'Mpix_s': n * T * T / avg / 1e3}
+    for b in (d_wc, d_cg, d_land):
+        b.free()
+
+    # ---- f2 'cover' mode: the split path on a device batch with masks
+    batch = _capi.DeviceBatch(ctx, n, T, T, masks=True)
+    batch.synth(SEED)
+    ctx.synchronize()
+    pc = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
+    pm = _capi.make_params(mask_adjacent_to_cloud_mode='mask')
+    avg, mn = timed(ctx, lambda: batch.classify(pc), a.reps)
+    info = ctx.last_kernel_info()
+    avg_m, _ = timed(ctx, lambda: batch.classify(pm), a.reps)
+    out['f2_cover_mode'] = {'kernel': info, 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n,
+                            'fused_mask_mode_ms_per_tile': avg_m / n,
+                            'algorithmic_bytes_per_tile': T * T * 24, 'GBps_of_24B_per_px': n * T * T * 24 / avg / 1e6,
+                            'Mpix_s': n * T * T / avg / 1e3}
+    batch.free()
+
+    if not a.no_cpu:
+        from oracle import dswx_oracle as o
+        S = 1500                                  # bounded sample, scaled to a full tile below
+        scale = (T * T) / (S * S)
+        t0 = time.perf_counter()
+        o.compute_opera_shadow_layer(dem[:S + 100, :S + 100], 141.0, 35.0, -5.0, 40.0)
+        out['f1_shadow']['cpu_oracle_s_per_tile'] = (time.perf_counter() - t0) * scale
+        t0 = time.perf_counter()
+        o.landcover_mask_from_warped(wc[:3 * S, :3 * S], cg[:S, :S], forest)
+        out['f3_landcover']['cpu_oracle_s_per_tile'] = (time.perf_counter() - t0) * scale
+        s = synth_tile(0, S, S, with_masks=True)
+        t0 = time.perf_counter()
+        o.classify_tile(s['bands'], s['fmask'], landcover=s['land'], shadow=s['shad'], ocean_mask=s['ocean'],
+                        mask_adjacent_to_cloud_mode='cover')
+        out['f2_cover_mode']['cpu_oracle_s_per_tile'] = (time.perf_counter() - t0) * scale
+        out['cpu_note'] = f'numpy oracle on one core, {S}x{S} sample scaled by area to 3660x3660'
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
