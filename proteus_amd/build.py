@@ -12,7 +12,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
-SOURCES = [os.path.join(CSRC, n) for n in ('dswx_hip.hip', 'dswx_classify_lut.hip', 'dswx_variants.hip', 'dswx_probes.hip')]
+SOURCES = [os.path.join(CSRC, n) for n in ('dswx_hip.hip', 'dswx_classify_lut.hip', 'dswx_layers.hip', 'dswx_host_path.hip',
+                                                  'dswx_variants.hip', 'dswx_probes.hip')]
 HEADERS = [os.path.join(CSRC, n) for n in ('dswx_device.h', 'dswx_host.h', 'dswx_tables.h')]
 INCLUDE = os.path.join(ROOT, 'include')
 LIB_DIR = os.path.join(PKG, '_lib')

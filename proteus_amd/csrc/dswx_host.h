@@ -47,6 +47,9 @@ struct dswx_ctx {
 
 // records a printf-style message for dswx_last_error() and returns `code`
 int dswx_fail(int code, const char* fmt, ...);
+// validates `p` and derives the kernel parameter block (integer thresholds, exact-quotient
+// constants, aerosol table); DSWX_ERR_ARG with a message for unusable thresholds
+int dswx_make_dev_params(const dswx_params_t* p, DevParams* d);
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \

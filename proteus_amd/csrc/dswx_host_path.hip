@@ -1,0 +1,233 @@
+// dswx_host_path.hip -- dswx_classify_host: the host-pointer entry of the classifier.
+// Pageable buffers: one tile at a time, copy -> classify -> copy on one stream.  Page-locked
+// buffers (dswx_host_alloc / hipHostRegister): pieces of every tile pipelined over three streams.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+
+#include "dswx_host.h"
+
+extern "C" {
+
+int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return DSWX_OK;
+}
+
+int dswx_host_free(dswx_ctx_t* ctx, void* ptr) {
+    if (!ctx) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (!ptr) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipHostFree(ptr));
+    return DSWX_OK;
+}
+
+// Is `p` page-locked host memory HIP knows about (hipHostMalloc / hipHostRegister)?
+static bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();          // plain malloc memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// Pipelined host path: every tile is cut into `host_chunks` flat pixel ranges (the chain is
+// per pixel, so any cut is legal outside 'cover' mode) that flow through three device slots:
+// chunk c+1 uploads on the H2D stream while chunk c is classified on the compute stream and
+// chunk c-1 downloads on the D2H stream.  Needs page-locked host buffers (dswx_host_alloc or
+// hipHostRegister), otherwise the copies are not asynchronous.  Counters are summed per tile
+// on the host from per-chunk partial counts.
+static int classify_host_pipelined(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t P,
+                                   const dswx_planes_in_t* in, const dswx_planes_out_t* out, int64_t* counters) {
+    constexpr int NSLOT = 3;
+    if (!ctx->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
+    if (!ctx->d2h_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+    for (int i = 0; i < NSLOT; ++i) {
+        if (!ctx->pipe_in[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->pipe_in[i], hipEventDisableTiming));
+        if (!ctx->pipe_k[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->pipe_k[i], hipEventDisableTiming));
+        if (!ctx->pipe_out[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->pipe_out[i], hipEventDisableTiming));
+    }
+    // chunk size: a multiple of 2048 pixels (one block of the fused kernel), >= 64 Ki pixels
+    int64_t chunk = (P + ctx->host_chunks - 1) / ctx->host_chunks;
+    if (chunk < 65536) chunk = 65536;
+    chunk = (chunk + 2047) / 2048 * 2048;
+    const int64_t per_tile = (P + chunk - 1) / chunk;
+    const int64_t n_chunks = per_tile * n_tiles;
+    if ((size_t)n_chunks > ctx->pipe_counters_cap) {
+        if (ctx->pipe_counters) HIP_TRY(hipHostFree(ctx->pipe_counters));
+        ctx->pipe_counters = nullptr; ctx->pipe_counters_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->pipe_counters), (size_t)n_chunks * 3 * sizeof(int64_t)));
+        ctx->pipe_counters_cap = (size_t)n_chunks;
+    }
+    // slot layout (offsets within one slot, all 256-byte aligned because chunk % 2048 == 0)
+    const uint8_t* const h_in_u8[4] = {in->fmask, in->land, in->shad, in->ocean};
+    uint8_t* const h_out_u8[8] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud,
+                                  out->browse};
+    double* const h_f64[3] = {out->mndwi, out->ndvi, out->awesh};
+    size_t off = 0, o_band[6], o_in_u8[4], o_diag, o_out_u8[8], o_f64[3], o_cnt;
+    for (int k = 0; k < 6; ++k) { o_band[k] = off; off += (size_t)chunk * 2; }
+    for (int i = 0; i < 4; ++i) { o_in_u8[i] = off; if (h_in_u8[i]) off += (size_t)chunk; }
+    o_diag = off; if (out->diag) off += (size_t)chunk * 2;
+    for (int i = 0; i < 8; ++i) { o_out_u8[i] = off; if (h_out_u8[i]) off += (size_t)chunk; }
+    for (int i = 0; i < 3; ++i) { o_f64[i] = off; if (h_f64[i]) off += (size_t)chunk * 8; }
+    o_cnt = off; off += 256;
+    const size_t slot_bytes = off;
+    if (slot_bytes * NSLOT > ctx->stage_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (ctx->stage) HIP_TRY(hipFree(ctx->stage));
+        ctx->stage = nullptr; ctx->stage_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->stage, slot_bytes * NSLOT));
+        ctx->stage_bytes = slot_bytes * NSLOT;
+    }
+    char* const arena = static_cast<char*>(ctx->stage);
+    hipStream_t sc = ctx->stream, sh = ctx->h2d_stream, sd = ctx->d2h_stream;
+    bool slot_used[NSLOT] = {false, false, false};
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int slot = (int)(c % NSLOT);
+        const int64_t tile = c / per_tile, px0 = (c % per_tile) * chunk;
+        const int64_t n = (P - px0 < chunk) ? P - px0 : chunk;
+        const size_t hoff = (size_t)tile * (size_t)P + (size_t)px0;
+        char* base = arena + slot_bytes * slot;
+        dswx_planes_in_t din{};
+        dswx_planes_out_t dout{};
+        // ---- upload (after the slot's previous download finished)
+        if (slot_used[slot]) HIP_TRY(hipStreamWaitEvent(sh, ctx->pipe_out[slot], 0));
+        for (int k = 0; k < 6; ++k) {
+            HIP_TRY(hipMemcpyAsync(base + o_band[k], in->band[k] + hoff, (size_t)n * 2, hipMemcpyHostToDevice, sh));
+            din.band[k] = reinterpret_cast<const int16_t*>(base + o_band[k]);
+        }
+        const uint8_t** const d_in_u8[4] = {&din.fmask, &din.land, &din.shad, &din.ocean};
+        for (int i = 0; i < 4; ++i)
+            if (h_in_u8[i]) {
+                HIP_TRY(hipMemcpyAsync(base + o_in_u8[i], h_in_u8[i] + hoff, (size_t)n, hipMemcpyHostToDevice, sh));
+                *d_in_u8[i] = reinterpret_cast<const uint8_t*>(base + o_in_u8[i]);
+            }
+        HIP_TRY(hipEventRecord(ctx->pipe_in[slot], sh));
+        // ---- classify
+        if (out->diag) dout.diag = reinterpret_cast<uint16_t*>(base + o_diag);
+        uint8_t** const d_out_u8[8] = {&dout.wtr1, &dout.wtr1_aerosol, &dout.wtr2, &dout.wtr, &dout.bwtr, &dout.conf,
+                                       &dout.cloud, &dout.browse};
+        for (int i = 0; i < 8; ++i) if (h_out_u8[i]) *d_out_u8[i] = reinterpret_cast<uint8_t*>(base + o_out_u8[i]);
+        double** const d_f64[3] = {&dout.mndwi, &dout.ndvi, &dout.awesh};
+        for (int i = 0; i < 3; ++i) if (h_f64[i]) *d_f64[i] = reinterpret_cast<double*>(base + o_f64[i]);
+        int64_t* dcnt = counters ? reinterpret_cast<int64_t*>(base + o_cnt) : nullptr;
+        HIP_TRY(hipStreamWaitEvent(sc, ctx->pipe_in[slot], 0));
+        const int rc = dswx_classify_device(ctx, params, 1, n, &din, &dout, dcnt, sc);
+        if (rc) { (void)hipDeviceSynchronize(); return rc; }
+        HIP_TRY(hipEventRecord(ctx->pipe_k[slot], sc));
+        // ---- download
+        HIP_TRY(hipStreamWaitEvent(sd, ctx->pipe_k[slot], 0));
+        if (out->diag) HIP_TRY(hipMemcpyAsync(out->diag + hoff, dout.diag, (size_t)n * 2, hipMemcpyDeviceToHost, sd));
+        for (int i = 0; i < 8; ++i)
+            if (h_out_u8[i]) HIP_TRY(hipMemcpyAsync(h_out_u8[i] + hoff, *d_out_u8[i], (size_t)n, hipMemcpyDeviceToHost, sd));
+        for (int i = 0; i < 3; ++i)
+            if (h_f64[i]) HIP_TRY(hipMemcpyAsync(h_f64[i] + hoff, *d_f64[i], (size_t)n * 8, hipMemcpyDeviceToHost, sd));
+        if (counters)
+            HIP_TRY(hipMemcpyAsync(ctx->pipe_counters + c * 3, dcnt, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, sd));
+        HIP_TRY(hipEventRecord(ctx->pipe_out[slot], sd));
+        slot_used[slot] = true;
+    }
+    HIP_TRY(hipStreamSynchronize(sd));
+    HIP_TRY(hipStreamSynchronize(sc));
+    HIP_TRY(hipStreamSynchronize(sh));
+    if (counters)
+        for (int64_t t = 0; t < n_tiles; ++t)
+            for (int j = 0; j < 3; ++j) {
+                int64_t sum = 0;
+                for (int64_t q = 0; q < per_tile; ++q) sum += ctx->pipe_counters[(t * per_tile + q) * 3 + j];
+                counters[t * 3 + j] = sum;
+            }
+    ctx->last_kernel += " x" + std::to_string(n_chunks) + " chunks, pipelined over 3 streams (pinned host buffers)";
+    return DSWX_OK;
+}
+
+int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t height,
+                       int64_t width, const dswx_planes_in_t* in, const dswx_planes_out_t* out,
+                       int64_t* counters) {
+    if (!ctx || !params || !in || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles < 0 || height < 0 || width < 0) return dswx_fail(DSWX_ERR_ARG, "negative size");
+    for (int k = 0; k < 6; ++k)
+        if (!in->band[k]) return dswx_fail(DSWX_ERR_ARG, "band[%d] is NULL", k);
+    if (!in->fmask) return dswx_fail(DSWX_ERR_ARG, "fmask is NULL");
+    {   // validate parameters before touching the device
+        DevParams tmp;
+        int rc = dswx_make_dev_params(params, &tmp);
+        if (rc) return rc;
+    }
+    const int64_t P = height * width;
+    if (n_tiles == 0 || P == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->host_pipeline && params->mask_adjacent_to_cloud_mode != DSWX_ADJ_COVER) {
+        bool pinned = true;
+        for (int k = 0; k < 6 && pinned; ++k) pinned = is_pinned_host(in->band[k]);
+        const void* const rest[] = {in->fmask, in->land, in->shad, in->ocean, out->diag, out->wtr1, out->wtr1_aerosol,
+                                    out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud, out->browse, out->mndwi,
+                                    out->ndvi, out->awesh};
+        for (const void* p : rest) pinned = pinned && (!p || is_pinned_host(p));
+        if (pinned) return classify_host_pipelined(ctx, params, n_tiles, P, in, out, counters);
+    }
+    // pageable host buffers (or 'cover' mode): one tile at a time through a grow-only device
+    // arena: planes at 256-byte aligned offsets so the vector kernel is always eligible
+    auto rnd = [](size_t x) { return (x + 255) & ~size_t(255); };
+    size_t off = 0;
+    size_t o_band[6], o_fm, o_land = 0, o_shad = 0, o_ocean = 0;
+    for (int k = 0; k < 6; ++k) { o_band[k] = off; off += rnd((size_t)P * 2); }
+    o_fm = off; off += rnd((size_t)P);
+    if (in->land) { o_land = off; off += rnd((size_t)P); }
+    if (in->shad) { o_shad = off; off += rnd((size_t)P); }
+    if (in->ocean) { o_ocean = off; off += rnd((size_t)P); }
+    size_t o_diag = off; if (out->diag) off += rnd((size_t)P * 2);
+    uint8_t* const h_u8[8] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud,
+                              out->browse};
+    size_t o_u8[8];
+    for (int i = 0; i < 8; ++i) { o_u8[i] = off; if (h_u8[i]) off += rnd((size_t)P); }
+    double* const h_f64[3] = {out->mndwi, out->ndvi, out->awesh};
+    size_t o_f64[3];
+    for (int i = 0; i < 3; ++i) { o_f64[i] = off; if (h_f64[i]) off += rnd((size_t)P * 8); }
+    size_t o_cnt = off; off += 256;
+    if (off > ctx->stage_bytes) {
+        if (ctx->stage) HIP_TRY(hipFree(ctx->stage));
+        ctx->stage = nullptr; ctx->stage_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->stage, off));
+        ctx->stage_bytes = off;
+    }
+    char* base = static_cast<char*>(ctx->stage);
+    hipStream_t s = ctx->stream;
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        const size_t sh = (size_t)t * (size_t)P;
+        dswx_planes_in_t din{};
+        dswx_planes_out_t dout{};
+        for (int k = 0; k < 6; ++k) {
+            HIP_TRY(hipMemcpyAsync(base + o_band[k], in->band[k] + sh, (size_t)P * 2, hipMemcpyHostToDevice, s));
+            din.band[k] = reinterpret_cast<const int16_t*>(base + o_band[k]);
+        }
+        HIP_TRY(hipMemcpyAsync(base + o_fm, in->fmask + sh, (size_t)P, hipMemcpyHostToDevice, s));
+        din.fmask = reinterpret_cast<const uint8_t*>(base + o_fm);
+        if (in->land) { HIP_TRY(hipMemcpyAsync(base + o_land, in->land + sh, (size_t)P, hipMemcpyHostToDevice, s)); din.land = reinterpret_cast<const uint8_t*>(base + o_land); }
+        if (in->shad) { HIP_TRY(hipMemcpyAsync(base + o_shad, in->shad + sh, (size_t)P, hipMemcpyHostToDevice, s)); din.shad = reinterpret_cast<const uint8_t*>(base + o_shad); }
+        if (in->ocean) { HIP_TRY(hipMemcpyAsync(base + o_ocean, in->ocean + sh, (size_t)P, hipMemcpyHostToDevice, s)); din.ocean = reinterpret_cast<const uint8_t*>(base + o_ocean); }
+        if (out->diag) dout.diag = reinterpret_cast<uint16_t*>(base + o_diag);
+        uint8_t** const d_u8[8] = {&dout.wtr1, &dout.wtr1_aerosol, &dout.wtr2, &dout.wtr, &dout.bwtr, &dout.conf, &dout.cloud,
+                                   &dout.browse};
+        for (int i = 0; i < 8; ++i) if (h_u8[i]) *d_u8[i] = reinterpret_cast<uint8_t*>(base + o_u8[i]);
+        double** const d_f64[3] = {&dout.mndwi, &dout.ndvi, &dout.awesh};
+        for (int i = 0; i < 3; ++i) if (h_f64[i]) *d_f64[i] = reinterpret_cast<double*>(base + o_f64[i]);
+        int64_t* dcnt = counters ? reinterpret_cast<int64_t*>(base + o_cnt) : nullptr;
+        int rc = dswx_classify_device_2d(ctx, params, 1, height, width, &din, &dout, dcnt, s);
+        if (rc) return rc;
+        if (out->diag) HIP_TRY(hipMemcpyAsync(out->diag + sh, dout.diag, (size_t)P * 2, hipMemcpyDeviceToHost, s));
+        for (int i = 0; i < 8; ++i)
+            if (h_u8[i]) HIP_TRY(hipMemcpyAsync(h_u8[i] + sh, *d_u8[i], (size_t)P, hipMemcpyDeviceToHost, s));
+        for (int i = 0; i < 3; ++i)
+            if (h_f64[i]) HIP_TRY(hipMemcpyAsync(h_f64[i] + sh, *d_f64[i], (size_t)P * 8, hipMemcpyDeviceToHost, s));
+        if (counters) HIP_TRY(hipMemcpyAsync(counters + t * 3, dcnt, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return DSWX_OK;
+}
+
+}  // extern "C"

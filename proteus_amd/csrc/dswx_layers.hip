@@ -1,0 +1,531 @@
+// dswx_layers.hip -- the layers either side of the fused classifier and the
+// synthetic-tile generator: generate_interpreted_layer on its own, the terrain shadow layer,
+// the LAND 3x3 aggregation, dswx_synth_*; kernels and their C-ABI entry points.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "dswx_host.h"
+
+// ------------------------------------------------------------------------------
+// generate_interpreted_layer (:1687-1707) on its own: DIAG in decimal (any integer,
+// as the reference's unit test feeds it) -> WTR-1 class; 32 and anything outside
+// the table -> 255.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dswx_interpret_v1(const long long* __restrict__ diag,
+                                                         uint8_t* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long d = diag[i];
+    uint32_t cls = 255u;
+    if (d >= 0 && d < 32) {
+        const uint32_t k = (uint32_t)d;
+        cls = ((CLS_B0 >> k) & 1u) | (((CLS_B1 >> k) & 1u) << 1) | (((CLS_B2 >> k) & 1u) << 2);
+    }
+    out[i] = (uint8_t)cls;
+}
+
+// ------------------------------------------------------------------------------
+// Terrain shadow layer (row f1): _compute_opera_shadow_layer :4215-4283 followed by
+// the margin crop of :4320 / :5170.  One thread per OUTPUT pixel.
+//
+// Arithmetic types follow what numpy >= 2 (NEP 50) gives the reference expressions on a
+// float32 DEM: np.gradient, the division by the pixel spacing, the squares, their sum,
+// `+ 1` and the sqrt stay float32; the products with the float64 sun-vector scalars,
+// the quotient, arccos / arctan / degrees and the comparisons are float64.  (Under the
+// numpy 1.23.5 the reference pins, value-based casting keeps those float32 as well:
+// borderline pixels can differ between the two -- SURVEY.md §7.)  Built without
+// fp contraction; hipcc's float32 division and sqrt are correctly rounded.
+//
+// No transcendental runs on the device: arccos and arctan are monotonic, so the host pulls
+// the two angle thresholds back onto their arguments by bisection over the doubles WITH THE
+// LIBRARY THE REFERENCE WOULD USE (the Python host: numpy's own arccos / arctan loops;
+// dswx_shadow_thresholds: libm) and the kernel compares the arguments.  That is both
+// cheaper (the kernel becomes HBM-bound) and closer to the reference than a device libm:
+// whichever way numpy rounds arccos at the threshold, the boundary moves with it.
+// ------------------------------------------------------------------------------
+struct ShadowArgs {
+    const float* dem;        // [H][W], with margin
+    uint8_t* shadow;         // [H - 2*margin][W - 2*margin]; 1 = not shadow, 0 = shadow
+    long long height, width, margin;
+    float spacing_x, neg_abs_spacing_y;
+    double sun[3];           // target-to-sun unit vector (x, y, z)
+    double sin_az, cos_az;
+    // the two angle tests, pulled back through the (monotonic) arccos / arctan onto their
+    // arguments by the host (dswx_shadow_thresholds or the caller's own numpy):
+    //   degrees(arccos(q)) <= max_sun_local_inc_angle  <=>  inc_q_min <= q <= 1
+    //   degrees(arctan(t)) <= min_slope_angle          <=>  t <= slope_arg_max
+    double inc_q_min, slope_arg_max;
+};
+
+__global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
+    const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
+    const int ow = W - 2 * margin, oh = H - 2 * margin;
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= ow || oy >= oh) return;
+    const int x = ox + margin, y = oy + margin;
+    const float* __restrict__ d = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W;
+    // np.gradient, edge_order 1, unit spacing: central differences inside ((f[i+1] - f[i-1]) / 2,
+    // and x / 2 == x * 0.5f exactly), one-sided first differences at the borders; branch-free
+    const int c = y * W + x;                       // H * W < 2^31 is checked on the host
+    const bool x_in = (x > 0) & (x < W - 1), y_in = (y > 0) & (y < H - 1);
+    const float gx = (d[x < W - 1 ? c + 1 : c] - d[x > 0 ? c - 1 : c]) * (x_in ? 0.5f : 1.0f);
+    const float gy = (d[y < H - 1 ? c + W : c] - d[y > 0 ? c - W : c]) * (y_in ? 0.5f : 1.0f);
+    const float n0 = -gx / a.spacing_x;
+    const float n1 = -gy / a.neg_abs_spacing_y;
+    const float norm = sqrtf(n0 * n0 + n1 * n1 + 1.0f);
+    const double dot = (double)n0 * a.sun[0] + (double)n1 * a.sun[1] + a.sun[2];
+    const double q = dot / (double)norm;                      // arccos argument (NaN-safe compares below)
+    const double t = (double)n0 * a.sin_az + (double)n1 * a.cos_az;   // arctan argument
+    const bool low_inc = (q >= a.inc_q_min) & (q <= 1.0);     // arccos(q > 1) is NaN: the test fails
+    const bool backslope = t <= a.slope_arg_max;
+    a.shadow[(size_t)blockIdx.z * (size_t)oh * (size_t)ow + (size_t)(oy * ow + ox)] = (low_inc | !backslope) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------
+// LAND layer (row f3): the per-pixel part of create_landcover_mask :994-1115.
+// One thread per HLS pixel: 3x3 WorldCover block -> three counts -> class hierarchy.
+// ------------------------------------------------------------------------------
+struct LandArgs {
+    const uint8_t* wc3;      // [3H][3W]
+    const uint8_t* cgls;     // [H][W]
+    uint8_t* land;           // [H][W]
+    long long height, width;
+    uint32_t forest_bits[8]; // 256-bit set of CGLS forest classes
+    int thr_tree, thr_low, thr_high, thr_water;
+    int low_class, high_class;   // year_offset, 100 + year_offset (as uint8)
+};
+
+__device__ __forceinline__ int land_class(const LandArgs& a, int water, int urban, int tree, int c) {
+    if (!((a.forest_bits[c >> 5] >> (c & 31)) & 1u)) tree = 0;
+    int v = 255;
+    if (tree >= a.thr_tree) v = 201;
+    if (urban >= a.thr_low) v = a.low_class;
+    if (urban >= a.thr_high) v = a.high_class;
+    if (water >= a.thr_water) v = 200;
+    return v;
+}
+
+// Four HLS pixels per thread (width % 4 == 0): three 12-byte row pieces of the WorldCover map as
+// dword loads (a wave reads 768 contiguous bytes per row), one dword of CGLS, one dword stored.
+// blockIdx.z = tile.  HBM-bound: 10 B read + 1 B written per pixel.
+__global__ __launch_bounds__(256) void dswx_landcover_v2(const LandArgs a) {
+    const long long xq = (long long)blockIdx.x * 64 + (threadIdx.x & 63);      // quad index
+    const long long y = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xq * 4 >= a.width || y >= a.height) return;
+    const long long W3 = 3 * a.width, tile = blockIdx.z;
+    const uint8_t* wc = a.wc3 + tile * 9 * a.height * a.width;
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};      // per pixel: water | urban << 8 | tree << 16
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(wc + (3 * y + i) * W3 + 12 * xq);
+        const uint32_t w[3] = {__builtin_nontemporal_load(row), __builtin_nontemporal_load(row + 1),
+                               __builtin_nontemporal_load(row + 2)};
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const uint32_t v = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            cnt[j / 3] += (uint32_t)((v == 80u) | (v == 90u) | (v == 95u)) + ((uint32_t)(v == 50u) << 8) +
+                          ((uint32_t)(v == 10u) << 16);
+        }
+    }
+    const long long o = tile * a.height * a.width + y * a.width + 4 * xq;
+    const uint32_t cg = *reinterpret_cast<const uint32_t*>(a.cgls + o);
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        out |= (uint32_t)land_class(a, cnt[k] & 0xff, (cnt[k] >> 8) & 0xff, cnt[k] >> 16, (cg >> (8 * k)) & 0xff) << (8 * k);
+    *reinterpret_cast<uint32_t*>(a.land + o) = out;
+}
+
+__global__ __launch_bounds__(256) void dswx_landcover_v1(const LandArgs a) {
+    const long long x = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const long long y = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.width || y >= a.height) return;
+    int water = 0, urban = 0, tree = 0;
+    const long long W3 = 3 * a.width;
+    const long long tile = blockIdx.z;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint8_t* row = a.wc3 + tile * 9 * a.height * a.width + (3 * y + i) * W3 + 3 * x;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int v = row[j];
+            water += (v == 80) | (v == 90) | (v == 95);
+            urban += v == 50;
+            tree += v == 10;
+        }
+    }
+    const long long o = tile * a.height * a.width + y * a.width + x;
+    a.land[o] = (uint8_t)land_class(a, water, urban, tree, a.cgls[o]);
+}
+
+// ------------------------------------------------------------------------------
+// Synthetic tiles (same integer recipe as proteus_amd/synth.py)
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ long long fieldu(unsigned long long h, int shift, int bits) {
+    return (long long)((h >> shift) & ((1ull << bits) - 1ull));
+}
+
+__global__ __launch_bounds__(256) void dswx_synth_v1(dswx_planes_in_t in, unsigned long long seed,
+                                                      long long tile0, long long n_pixels, int width,
+                                                      long long tile_stride) {
+    const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (px >= n_pixels) return;
+    const long long t = blockIdx.y;
+    const unsigned long long tile = (unsigned long long)(tile0 + t);
+    const long long off = t * tile_stride + px;
+    const unsigned long long K0 = 0x9E3779B97F4A7C15ull, K1 = 0xD1B54A32D192ED03ull;
+    const unsigned long long h0 = mix64(seed * K0 + tile * K1 + (unsigned long long)px);
+    const unsigned long long h1 = mix64(h0 + K0);
+    const unsigned long long h2 = mix64(h1 + K0);
+    const int cuts[5] = {14418, 26214, 42598, 55705, 64225};
+    const int mean[5][6] = {{350, 450, 350, 250, 150, 100},
+                            {500, 700, 600, 1300, 800, 500},
+                            {300, 600, 400, 3500, 1800, 900},
+                            {900, 1200, 1500, 2200, 2800, 2300},
+                            {6000, 6200, 6400, 6600, 3000, 2500}};
+    const int amps[5] = {300, 600, 600, 800, 2500};
+    const int draw = (int)fieldu(h0, 0, 16);
+    int stype = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) stype += draw >= cuts[k] ? 1 : 0;
+    const bool is_fill = stype == 5;
+    const int st = stype < 4 ? stype : 4;
+    const long long amp = amps[st];
+    const bool clip_evt = fieldu(h0, 16, 7) == 0;
+    const int clip_band = (int)((fieldu(h0, 23, 3) * 6) >> 3);
+    const long long clip_val = -fieldu(h0, 26, 8);
+    const bool wrap_evt = fieldu(h0, 34, 10) == 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const long long noise = fieldu(h1, 10 * b, 10);
+        long long v = mean[st][b] + ((noise * 2 * amp) >> 10) - amp;
+        if (wrap_evt && (b == 1 || b == 4)) v += 19000;
+        if (clip_evt && clip_band == b) v = clip_val;
+        if (is_fill) v = -9999;
+        const_cast<int16_t*>(in.band[b])[off] = (int16_t)v;
+    }
+    const long long aerosol = fieldu(h2, 0, 2);
+    const long long water = fieldu(h2, 2, 5) < 10, snow = fieldu(h2, 7, 5) < 2,
+                    shadow = fieldu(h2, 12, 5) < 3, adjacent = fieldu(h2, 17, 5) < 3,
+                    cloud = fieldu(h2, 22, 5) < 4, cirrus = fieldu(h2, 27, 5) < 1;
+    long long fm = (aerosol << 6) | (water << 5) | (snow << 4) | (shadow << 3) | (adjacent << 2) |
+                   (cloud << 1) | cirrus;
+    if (is_fill) fm = 255;
+    const_cast<uint8_t*>(in.fmask)[off] = (uint8_t)fm;
+    if (in.land) {
+        const int classes[8] = {200, 201, 21, 121, 50, 150, 99, 100};
+        const int cls = classes[fieldu(h2, 40, 3)];
+        const_cast<uint8_t*>(in.land)[off] = (uint8_t)(fieldu(h2, 32, 8) < 179 ? 255 : cls);
+    }
+    if (in.shad) const_cast<uint8_t*>(in.shad)[off] = (uint8_t)(fieldu(h2, 43, 5) >= 3 ? 1 : 0);
+    if (in.ocean) {
+        const unsigned long long row_band = (unsigned long long)(px / width) >> 5;
+        const unsigned long long hb = mix64(seed * K1 + tile * K0 + row_band + 0x5851F42D4C957F2Dull);
+        const_cast<uint8_t*>(in.ocean)[off] = (uint8_t)(fieldu(hb, 0, 8) >= 13 ? 1 : 0);
+    }
+}
+
+// ==============================================================================
+// host side
+// ==============================================================================
+extern "C" {
+
+int dswx_interpret_layer_host(dswx_ctx_t* ctx, const int64_t* diag_decimal, int64_t n, uint8_t* out) {
+    if (!ctx || (n > 0 && (!diag_decimal || !out))) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (n < 0) return dswx_fail(DSWX_ERR_ARG, "negative size");
+    if (n == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, (size_t)n * 8));
+    hipError_t e = hipMalloc(&d_out, (size_t)n);
+    if (e != hipSuccess) { (void)hipFree(d_in); return dswx_fail(DSWX_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    hipStream_t s = ctx->stream;
+    e = hipMemcpyAsync(d_in, diag_decimal, (size_t)n * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dswx_interpret_v1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                           static_cast<const long long*>(d_in), static_cast<uint8_t*>(d_out), (long long)n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return dswx_fail(DSWX_ERR_HIP, "dswx_interpret_layer_host: %s", hipGetErrorString(e));
+    return DSWX_OK;
+}
+
+// ---- terrain shadow: thresholds on the arccos / arctan ARGUMENTS --------------------------
+// doubles in numeric order as int64 (both zeros map to 0)
+static int64_t ord_of(double d) {
+    int64_t i;
+    std::memcpy(&i, &d, 8);
+    return i >= 0 ? i : -(i & 0x7fffffffffffffffLL);
+}
+static double dbl_of(int64_t k) {
+    int64_t i = k >= 0 ? k : (int64_t)(0x8000000000000000ULL | (uint64_t)(-k));
+    double d;
+    std::memcpy(&d, &i, 8);
+    return d;
+}
+static const double kRad2Deg = 180.0 / 3.141592653589793238462643383279502884;
+
+int dswx_shadow_thresholds(double min_slope_angle, double max_sun_local_inc_angle, double* slope_arg_max,
+                           double* inc_q_min) {
+    if (!slope_arg_max || !inc_q_min) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (std::isnan(min_slope_angle) || std::isnan(max_sun_local_inc_angle))
+        return dswx_fail(DSWX_ERR_ARG, "shadow angle threshold is NaN");
+    // smallest q in [-1, 1] with degrees(acos(q)) <= T (acos decreases); 2.0 if there is none
+    auto inc_ok = [&](double q) { return std::acos(q) * kRad2Deg <= max_sun_local_inc_angle; };
+    if (!inc_ok(1.0)) *inc_q_min = 2.0;
+    else if (inc_ok(-1.0)) *inc_q_min = -1.0;
+    else {
+        int64_t lo = ord_of(-1.0), hi = ord_of(1.0);          // !ok(lo), ok(hi)
+        while ((uint64_t)hi - (uint64_t)lo > 1) {
+            const int64_t mid = lo + (int64_t)(((uint64_t)hi - (uint64_t)lo) / 2);
+            if (inc_ok(dbl_of(mid))) hi = mid; else lo = mid;
+        }
+        *inc_q_min = dbl_of(hi);
+    }
+    // largest t with degrees(atan(t)) <= T (atan increases); +-inf when always / never
+    auto slope_ok = [&](double t) { return std::atan(t) * kRad2Deg <= min_slope_angle; };
+    const double inf = std::numeric_limits<double>::infinity();
+    if (slope_ok(inf)) *slope_arg_max = inf;
+    else if (!slope_ok(-inf)) *slope_arg_max = -inf;
+    else {
+        int64_t lo = ord_of(-inf), hi = ord_of(inf);          // ok(lo), !ok(hi); the span exceeds int64
+        while ((uint64_t)hi - (uint64_t)lo > 1) {
+            const int64_t mid = lo + (int64_t)(((uint64_t)hi - (uint64_t)lo) / 2);
+            if (slope_ok(dbl_of(mid))) lo = mid; else hi = mid;
+        }
+        *slope_arg_max = dbl_of(lo);
+    }
+    return DSWX_OK;
+}
+
+static int shadow_args(ShadowArgs* a, int64_t height, int64_t width, int64_t margin, const double sun_vector[3],
+                       double sin_azimuth, double cos_azimuth, double slope_arg_max, double inc_q_min,
+                       double pixel_spacing_x, double pixel_spacing_y) {
+    if (!sun_vector) return dswx_fail(DSWX_ERR_ARG, "sun_vector is NULL");
+    if (height < 2 || width < 2)
+        return dswx_fail(DSWX_ERR_ARG, "Shape of array too small to calculate a numerical gradient, "
+                                  "at least 2 elements are required.");
+    if (margin < 0 || 2 * margin >= height || 2 * margin >= width) return dswx_fail(DSWX_ERR_ARG, "bad margin");
+    if (height > 2147483647LL / width) return dswx_fail(DSWX_ERR_ARG, "DEM larger than 2^31 pixels");
+    if (std::isnan(slope_arg_max) || std::isnan(inc_q_min)) return dswx_fail(DSWX_ERR_ARG, "shadow threshold is NaN");
+    a->height = height; a->width = width; a->margin = margin;
+    a->spacing_x = (float)pixel_spacing_x;
+    a->neg_abs_spacing_y = (float)(-std::fabs(pixel_spacing_y));
+    for (int i = 0; i < 3; ++i) a->sun[i] = sun_vector[i];
+    a->sin_az = sin_azimuth; a->cos_az = cos_azimuth;
+    a->slope_arg_max = slope_arg_max; a->inc_q_min = inc_q_min;
+    return DSWX_OK;
+}
+
+int dswx_shadow_layer_device_q(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
+                               int64_t margin, const double sun_vector[3], double sin_azimuth,
+                               double cos_azimuth, double slope_arg_max, double inc_q_min,
+                               double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream) {
+    if (!ctx || !dem || !shadow) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles < 0 || n_tiles > 65535) return dswx_fail(DSWX_ERR_ARG, "n_tiles out of range");
+    ShadowArgs a;
+    int rc = shadow_args(&a, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, slope_arg_max, inc_q_min,
+                         pixel_spacing_x, pixel_spacing_y);
+    if (rc) return rc;
+    if (n_tiles == 0) return DSWX_OK;
+    a.dem = dem; a.shadow = shadow;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const long long ow = width - 2 * margin, oh = height - 2 * margin;
+    dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
+    if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
+    hipLaunchKernelGGL(dswx_shadow_v2, grid, block, 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
+                             int64_t margin, const double sun_vector[3], double sin_azimuth,
+                             double cos_azimuth, double min_slope_angle, double max_sun_local_inc_angle,
+                             double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream) {
+    double slope_arg_max, inc_q_min;
+    int rc = dswx_shadow_thresholds(min_slope_angle, max_sun_local_inc_angle, &slope_arg_max, &inc_q_min);
+    if (rc) return rc;
+    return dswx_shadow_layer_device_q(ctx, dem, n_tiles, height, width, margin, sun_vector, sin_azimuth, cos_azimuth,
+                                      slope_arg_max, inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow, stream);
+}
+
+int dswx_shadow_layer_host_q(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
+                             const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                             double slope_arg_max, double inc_q_min, double pixel_spacing_x,
+                             double pixel_spacing_y, uint8_t* shadow) {
+    if (!ctx || !dem || !shadow) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    ShadowArgs chk;
+    int rc = shadow_args(&chk, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, slope_arg_max, inc_q_min,
+                         pixel_spacing_x, pixel_spacing_y);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t in_bytes = (size_t)height * (size_t)width * 4;
+    const size_t out_px = (size_t)(height - 2 * margin) * (size_t)(width - 2 * margin);
+    void* d_dem = nullptr;
+    void* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_dem, in_bytes));
+    hipError_t e = hipMalloc(&d_out, out_px);
+    hipStream_t s = ctx->stream;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dem, dem, in_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        rc = dswx_shadow_layer_device_q(ctx, static_cast<const float*>(d_dem), 1, height, width, margin, sun_vector,
+                                        sin_azimuth, cos_azimuth, slope_arg_max, inc_q_min, pixel_spacing_x,
+                                        pixel_spacing_y, static_cast<uint8_t*>(d_out), s);
+        if (rc == DSWX_OK) e = hipMemcpyAsync(shadow, d_out, out_px, hipMemcpyDeviceToHost, s);
+        if (rc == DSWX_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(d_dem);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return dswx_fail(DSWX_ERR_HIP, "dswx_shadow_layer_host: %s", hipGetErrorString(e));
+    return DSWX_OK;
+}
+
+int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
+                           const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                           double min_slope_angle, double max_sun_local_inc_angle, double pixel_spacing_x,
+                           double pixel_spacing_y, uint8_t* shadow) {
+    double slope_arg_max, inc_q_min;
+    int rc = dswx_shadow_thresholds(min_slope_angle, max_sun_local_inc_angle, &slope_arg_max, &inc_q_min);
+    if (rc) return rc;
+    return dswx_shadow_layer_host_q(ctx, dem, height, width, margin, sun_vector, sin_azimuth, cos_azimuth,
+                                    slope_arg_max, inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow);
+}
+
+static int land_args(LandArgs* a, int64_t height, int64_t width, const int32_t* forest_classes,
+                     int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset) {
+    if (!thresholds) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (height < 0 || width < 0 || n_forest_classes < 0 || (n_forest_classes > 0 && !forest_classes))
+        return dswx_fail(DSWX_ERR_ARG, "bad size");
+    std::memset(a, 0, sizeof *a);
+    for (int i = 0; i < n_forest_classes; ++i) {
+        const int c = forest_classes[i];
+        if (c >= 0 && c <= 255) a->forest_bits[c >> 5] |= 1u << (c & 31);
+    }
+    a->thr_tree = thresholds[0]; a->thr_low = thresholds[1]; a->thr_high = thresholds[2]; a->thr_water = thresholds[3];
+    // numpy stores the class through a uint8 array: values wrap modulo 256
+    a->low_class = (int)(uint8_t)(0 + year_offset);
+    a->high_class = (int)(uint8_t)(100 + year_offset);
+    a->height = height; a->width = width;
+    return DSWX_OK;
+}
+
+int dswx_landcover_mask_device(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
+                               int64_t n_tiles, int64_t height, int64_t width, const int32_t* forest_classes,
+                               int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset,
+                               uint8_t* land, void* stream) {
+    if (!ctx || !worldcover_up3 || !copernicus || !land) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles < 0 || n_tiles > 65535) return dswx_fail(DSWX_ERR_ARG, "n_tiles out of range");
+    LandArgs a;
+    int rc = land_args(&a, height, width, forest_classes, n_forest_classes, thresholds, year_offset);
+    if (rc) return rc;
+    if (n_tiles == 0 || height == 0 || width == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    a.wc3 = worldcover_up3; a.cgls = copernicus; a.land = land;
+    // four pixels per thread with dword loads when rows keep 4-byte alignment
+    const bool quad = width % 4 == 0 && aligned_to(worldcover_up3, 4) && aligned_to(copernicus, 4) && aligned_to(land, 4);
+    if (quad) {
+        dim3 grid((unsigned)((width / 4 + 63) / 64), (unsigned)((height + 3) / 4), (unsigned)n_tiles), block(256);
+        if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
+        hipLaunchKernelGGL(dswx_landcover_v2, grid, block, 0, s, a);
+    } else {
+        dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4), (unsigned)n_tiles), block(256);
+        if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
+        hipLaunchKernelGGL(dswx_landcover_v1, grid, block, 0, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_landcover_mask_host(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
+                             int64_t height, int64_t width, const int32_t* forest_classes,
+                             int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset,
+                             uint8_t* land) {
+    if (!ctx || !worldcover_up3 || !copernicus || !thresholds || !land) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    {
+        LandArgs chk;
+        int rc = land_args(&chk, height, width, forest_classes, n_forest_classes, thresholds, year_offset);
+        if (rc) return rc;
+    }
+    if (height == 0 || width == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)height * (size_t)width;
+    void* d_wc = nullptr; void* d_cg = nullptr; void* d_out = nullptr;
+    hipError_t e = hipMalloc(&d_wc, 9 * n);
+    if (e == hipSuccess) e = hipMalloc(&d_cg, n);
+    if (e == hipSuccess) e = hipMalloc(&d_out, n);
+    hipStream_t s = ctx->stream;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_wc, worldcover_up3, 9 * n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cg, copernicus, n, hipMemcpyHostToDevice, s);
+    int rc = DSWX_OK;
+    if (e == hipSuccess)
+        rc = dswx_landcover_mask_device(ctx, static_cast<const uint8_t*>(d_wc), static_cast<const uint8_t*>(d_cg), 1,
+                                        height, width, forest_classes, n_forest_classes, thresholds, year_offset,
+                                        static_cast<uint8_t*>(d_out), s);
+    if (e == hipSuccess && rc == DSWX_OK) e = hipMemcpyAsync(land, d_out, n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d_wc) (void)hipFree(d_wc);
+    if (d_cg) (void)hipFree(d_cg);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return dswx_fail(DSWX_ERR_HIP, "dswx_landcover_mask_host: %s", hipGetErrorString(e));
+    return DSWX_OK;
+}
+
+static int synth_impl(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0, int64_t n_tiles, int64_t height,
+                      int64_t width, int64_t tile_stride, const dswx_planes_in_t* in, void* stream) {
+    if (!ctx || !in) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_tiles < 0 || height < 0 || width < 0 || tile0 < 0) return dswx_fail(DSWX_ERR_ARG, "negative size");
+    for (int k = 0; k < 6; ++k)
+        if (!in->band[k]) return dswx_fail(DSWX_ERR_ARG, "band[%d] is NULL", k);
+    if (!in->fmask) return dswx_fail(DSWX_ERR_ARG, "fmask is NULL");
+    const int64_t P = height * width;
+    if (tile_stride == 0) tile_stride = P;
+    if (tile_stride < P) return dswx_fail(DSWX_ERR_ARG, "tile_stride smaller than the tile");
+    if (n_tiles == 0 || P == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int64_t max_y = 65535;
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += max_y) {
+        const int64_t nt = (n_tiles - t0 < max_y) ? n_tiles - t0 : max_y;
+        dswx_planes_in_t b = *in;
+        const int64_t shift = t0 * tile_stride;
+        for (int k = 0; k < 6; ++k) b.band[k] += shift;
+        b.fmask += shift;
+        if (b.land) b.land += shift;
+        if (b.shad) b.shad += shift;
+        if (b.ocean) b.ocean += shift;
+        dim3 grid((unsigned)((P + 255) / 256), (unsigned)nt), block(256);
+        hipLaunchKernelGGL(dswx_synth_v1, grid, block, 0, s, b, (unsigned long long)seed,
+                           (long long)(tile0 + t0), (long long)P, (int)width, (long long)tile_stride);
+        HIP_TRY(hipGetLastError());
+    }
+    return DSWX_OK;
+}
+
+int dswx_synth_fill(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0, int64_t n_tiles, int64_t height,
+                    int64_t width, const dswx_planes_in_t* in, void* stream) {
+    return synth_impl(ctx, seed, tile0, n_tiles, height, width, 0, in, stream);
+}
+
+int dswx_synth_batch(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0, const dswx_batch_geom_t* geom,
+                     const dswx_planes_in_t* in, void* stream) {
+    if (!geom) return dswx_fail(DSWX_ERR_ARG, "geom is NULL");
+    return synth_impl(ctx, seed, tile0, geom->n_tiles, geom->height, geom->width, geom->tile_stride, in, stream);
+}
+
+}  // extern "C"
