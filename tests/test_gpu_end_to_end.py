@@ -35,6 +35,100 @@ def test_units():
     assert np.array_equal(output_array, expected_output_array)
 
 
+def test_workflow(tmp_path):
+    """The reference's tests/test_dswx_hls_workflow.py:17-120 restated: same parser, same
+    create_logger / parse_runconfig_file / generate_dswx_layers call with the full keyword
+    list, same compare_dswx_hls_products loop over a ref_dir.  The Zenodo dataset is replaced
+    by a synthetic S30 tile and the ref_dir is written from the oracle's layers."""
+    from proteus_amd.dswx_hls import (get_dswx_hls_cli_parser, generate_dswx_layers, create_logger,
+                                      parse_runconfig_file, compare_dswx_hls_products)
+    dataset_dir = str(tmp_path / 's30_synthetic')
+    user_runconfig_file, _, _, s = synth_hls.make(dataset_dir, sensor='S30', size=1100, tile=31)
+    output_dir = os.path.join(dataset_dir, 'output')
+    ref_dir = os.path.join(dataset_dir, 'ref_dir')
+
+    parser = get_dswx_hls_cli_parser()
+    args = parser.parse_args([user_runconfig_file])
+    create_logger(args.log_file)
+    runconfig_constants = parse_runconfig_file(user_runconfig_file=user_runconfig_file, args=args)
+    args.flag_debug = True            # as the reference test: the 1000 x 1000 window
+
+    assert generate_dswx_layers(
+        args.input_list,
+        args.output_file,
+        hls_thresholds=runconfig_constants.hls_thresholds,
+        dem_file=args.dem_file,
+        dem_file_description=args.dem_file_description,
+        output_interpreted_band=args.output_interpreted_band,
+        output_rgb_file=args.output_rgb_file,
+        output_infrared_rgb_file=args.output_infrared_rgb_file,
+        output_binary_water=args.output_binary_water,
+        output_confidence_layer=args.output_confidence_layer,
+        output_diagnostic_layer=args.output_diagnostic_layer,
+        output_non_masked_dswx=args.output_non_masked_dswx,
+        output_shadow_masked_dswx=args.output_shadow_masked_dswx,
+        output_landcover=args.output_landcover,
+        output_shadow_layer=args.output_shadow_layer,
+        output_cloud_layer=args.output_cloud_layer,
+        output_dem_layer=args.output_dem_layer,
+        output_browse_image=args.output_browse_image,
+        browse_image_height=args.browse_image_height,
+        browse_image_width=args.browse_image_width,
+        landcover_file=args.landcover_file,
+        landcover_file_description=args.landcover_file_description,
+        worldcover_file=args.worldcover_file,
+        worldcover_file_description=args.worldcover_file_description,
+        shoreline_shapefile=args.shoreline_shapefile,
+        shoreline_shapefile_description=args.shoreline_shapefile_description,
+        flag_offset_and_scale_inputs=args.flag_offset_and_scale_inputs,
+        scratch_dir=args.scratch_dir,
+        product_id=args.product_id,
+        product_version=args.product_version,
+        check_ancillary_inputs_coverage=args.check_ancillary_inputs_coverage,
+        apply_aerosol_class_remapping=args.apply_aerosol_class_remapping,
+        aerosol_not_water_to_high_conf_water_fmask_values=
+            args.aerosol_not_water_to_high_conf_water_fmask_values,
+        aerosol_water_moderate_conf_to_high_conf_water_fmask_values=
+            args.aerosol_water_moderate_conf_to_high_conf_water_fmask_values,
+        aerosol_partial_surface_water_conservative_to_high_conf_water_fmask_values=
+            args.aerosol_partial_surface_water_conservative_to_high_conf_water_fmask_values,
+        aerosol_partial_surface_aggressive_to_high_conf_water_fmask_values=
+            args.aerosol_partial_surface_aggressive_to_high_conf_water_fmask_values,
+        shadow_masking_algorithm=args.shadow_masking_algorithm,
+        min_slope_angle=args.min_slope_angle,
+        max_sun_local_inc_angle=args.max_sun_local_inc_angle,
+        mask_adjacent_to_cloud_mode=args.mask_adjacent_to_cloud_mode,
+        forest_mask_landcover_classes=args.forest_mask_landcover_classes,
+        ocean_masking_shoreline_distance_km=args.ocean_masking_shoreline_distance_km,
+        flag_debug=args.flag_debug)
+
+    # ref_dir: the oracle's layers on the same 1000 x 1000 window, written with the product's
+    # own metadata (the comparison ignores only the keys the reference's comparison ignores)
+    exp = o.classify_tile([b[:1000, :1000] for b in s['bands']], s['fmask'][:1000, :1000], collapse=True)
+    os.makedirs(ref_dir)
+    n_ref = 0
+    for layer, stem in LAYER_FILES.items():
+        name = f'dswx_hls_synth_v1.0_{stem}.tif'
+        _, info = geotiff.read_geotiff(os.path.join(output_dir, name))
+        geotiff.write_geotiff(os.path.join(ref_dir, name), exp[layer], geo_tags=info.geo_tags,
+                              metadata=info.metadata, nodata=info.nodata, descriptions=info.descriptions)
+        n_ref += 1
+    import glob
+    ref_files = glob.glob(os.path.join(ref_dir, '*'))
+    assert len(ref_files) == n_ref == 7
+    for ref_file in ref_files:
+        ref_basename = os.path.basename(ref_file)
+        output_file = os.path.join(output_dir, ref_basename)
+        assert compare_dswx_hls_products(ref_file, output_file)
+    # and the comparison does fail on a one-pixel difference
+    arr, info = geotiff.read_geotiff(ref_files[0])
+    arr = arr.copy()
+    arr[10, 10] ^= 1
+    geotiff.write_geotiff(ref_files[0], arr, geo_tags=info.geo_tags, metadata=info.metadata,
+                          nodata=info.nodata, descriptions=info.descriptions)
+    assert not compare_dswx_hls_products(ref_files[0], os.path.join(output_dir, os.path.basename(ref_files[0])))
+
+
 @pytest.mark.parametrize('sensor', ['L30', 'S30'])
 def test_runconfig_entry_point(tmp_path, sensor):
     rcfile, files, _, s = synth_hls.make(str(tmp_path), sensor=sensor, size=512, tile=9)
