@@ -13,6 +13,7 @@ is doubled; WRITE_SIZE is exact for streaming stores.  FETCH and WRITE come from
 SEPARATE --pmc passes.
 
 usage: tools/summarize_profiles.py ROUND TILES [--masks] [--src gpurun_out/prof]
+(the raw rocprofv3 output comes from tools/run_profiles.sh on the GPU box)
 """
 import argparse
 import csv
@@ -82,6 +83,23 @@ def main():
         summary['algorithmic']['total']
     summary['achieved_GBps_from_trace'] = summary['algorithmic']['total'] / \
         summary['kernel_trace']['avg_ns']
+    # optional third pass: SQ wave-cycle breakdown (quad-cycles; WAIT_ANY + WAIT_INST_ANY +
+    # ACTIVE_INST_ANY ~ WAVE_CYCLES, MI355X_MICROARCH.md section rocprofv3 PMC slots)
+    sq_files = sorted(glob.glob(os.path.join(a.src, 'pmc_sq', '**', '*counter_collection.csv'), recursive=True),
+                      key=os.path.getmtime)
+    if sq_files:
+        acc = {}
+        for r in csv.DictReader(open(sq_files[-1])):
+            if a.kernel in r['Kernel_Name']:
+                acc.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+        sq = {k: sum(v) / len(v) for k, v in acc.items()}
+        wc = sq.get('SQ_WAVE_CYCLES')
+        summary['sq'] = {'per_launch_avg': sq}
+        if wc:
+            summary['sq']['fraction_of_wave_cycles'] = {
+                k: round(sq[k] / wc, 4) for k in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY',
+                                                  'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_SCA', 'SQ_ACTIVE_INST_LDS')
+                if k in sq}
     json.dump(summary, open(os.path.join(out, f'{tag}_summary.json'), 'w'), indent=1)
     tpath = os.path.join(out, 'pmc_traffic.json')
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
