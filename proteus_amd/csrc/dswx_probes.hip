@@ -294,6 +294,71 @@ __global__ __launch_bounds__(256) void dswx_record_probe_k(const uint8_t* __rest
     for (int k = 0; k < 6; ++k) stg<u32x2, NT>(orec + (2LL + k) * CHPX + j * 2048 + t * 8, y + (uint32_t)k);
 }
 
+// Cache-policy probe: the fused kernel's access shape through buffer instructions whose
+// `aux` bits select the policy (bit 0 = sc0, bit 1 = nt, bit 4 = sc1) separately for loads
+// and stores.  One descriptor per plane and tile (built from wave-uniform values).
+typedef unsigned int bu32x4 __attribute__((__vector_size__(16)));
+typedef unsigned int bu32x2 __attribute__((__vector_size__(8)));
+template <int LAUX, int SAUX>
+__global__ __launch_bounds__(256) void dswx_policy_probe_k(const KArgs a) {
+    const long long tile_off = (long long)blockIdx.y * a.tile_stride;
+    const unsigned px = blockIdx.x * 2048u + threadIdx.x * 8u;
+    if (px + 8u > (unsigned)a.n_pixels) return;
+    const int n = (int)a.n_pixels;
+    bu32x4 x = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in.band[k] + tile_off), 0, n * 2, 0x00020000);
+        x ^= __builtin_amdgcn_raw_buffer_load_b128(rs, px * 2u, 0, LAUX);
+    }
+    auto rf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in.fmask + tile_off), 0, n, 0x00020000);
+    const bu32x2 f = __builtin_amdgcn_raw_buffer_load_b64(rf, px, 0, LAUX);
+    bu32x2 y = {x[0] ^ x[2] ^ f[0], x[1] ^ x[3] ^ f[1]};
+    auto rd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out.diag + tile_off), 0, n * 2, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(x, rd, px * 2u, 0, SAUX);
+    uint8_t* const planes[6] = {a.out.wtr1, a.out.wtr2, a.out.wtr, a.out.bwtr, a.out.conf, a.out.cloud};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        auto rp = __builtin_amdgcn_make_buffer_rsrc((void*)(planes[k] + tile_off), 0, n, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(y + (unsigned)k, rp, px, 0, SAUX);
+    }
+}
+
+// Store-policy probe with GLOBAL instructions: the fused shape, builtin non-temporal loads,
+// stores as inline asm so that the sc bits can be combined with nt (the builtins offer
+// only plain and nt).  SP: 0 = nt, 1 = sc1 nt, 2 = sc0 sc1 nt, 3 = sc1, 4 = builtin nt (control).
+template <int SP>
+__device__ __forceinline__ void st16_pol(void* p, u32x4 v) {
+    if (SP == 0) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    else if (SP == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    else if (SP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    else if (SP == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else stg<u32x4, true>(p, v);
+}
+template <int SP>
+__device__ __forceinline__ void st8_pol(void* p, u32x2 v) {
+    if (SP == 0) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    else if (SP == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    else if (SP == 2) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    else if (SP == 3) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else stg<u32x2, true>(p, v);
+}
+template <int SP>
+__global__ __launch_bounds__(256) void dswx_store_policy_probe_k(const KArgs a) {
+    const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (grp >= (a.n_pixels >> 3)) return;
+    const long long off = (long long)blockIdx.y * a.tile_stride + grp * 8;
+    u32x4 x = ldg<u32x4, true>(a.in.band[0] + off);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) x ^= ldg<u32x4, true>(a.in.band[k] + off);
+    const u32x2 f = ldg<u32x2, true>(a.in.fmask + off);
+    u32x2 y; y.x = x.x ^ x.z ^ f.x; y.y = x.y ^ x.w ^ f.y;
+    st16_pol<SP>(a.out.diag + off, x);
+    uint8_t* const planes[6] = {a.out.wtr1, a.out.wtr2, a.out.wtr, a.out.bwtr, a.out.conf, a.out.cloud};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st8_pol<SP>(planes[k] + off, y + (uint32_t)k);
+}
+
 // Plane-specialised waves: block = 7 waves over a 4096-px chunk; wave k reads only input
 // plane k (8 KiB of an int16 plane, 4 KiB of Fmask) and then writes only output plane k
 // (8 KiB of DIAG, 4 KiB of a u8 layer).  Same bytes as the fused kernel; this is what a
@@ -517,6 +582,41 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, int64_
         dim3 grid((unsigned)(total / 4096)), block(448);
         if (variant & 2) hipLaunchKernelGGL(dswx_plane_per_wave_k<true>, grid, block, 0, s, a, total);
         else hipLaunchKernelGGL(dswx_plane_per_wave_k<false>, grid, block, 0, s, a, total);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & (1 << 24)) {  // store-policy probe (global instructions): bits 2-4 = SP
+        const int sp = (variant >> 2) & 7;
+        dim3 grid((unsigned)(((n_pixels >> 3) + 255) / 256), (unsigned)n_tiles), block(256);
+        switch (sp) {
+        case 0: hipLaunchKernelGGL(dswx_store_policy_probe_k<0>, grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL(dswx_store_policy_probe_k<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(dswx_store_policy_probe_k<2>, grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL(dswx_store_policy_probe_k<3>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(dswx_store_policy_probe_k<4>, grid, block, 0, s, a); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & (1 << 23)) {  // cache-policy probe: bits 2-4 = load policy index, bits 5-7 = store policy index
+        const int li = (variant >> 2) & 7, si = (variant >> 5) & 7;
+        dim3 grid((unsigned)((n_pixels + 2047) / 2048), (unsigned)n_tiles), block(256);
+        if (n_pixels * 2 > 2147483647LL) return dswx_fail(DSWX_ERR_ARG, "tile too large for the policy probe");
+        // policy table: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt, 6 sc0, 7 sc0 nt
+#define POL_S(L, SI) do { switch (SI) { \
+        case 0: hipLaunchKernelGGL((dswx_policy_probe_k<L, 0>), grid, block, 0, s, a); break; \
+        case 1: hipLaunchKernelGGL((dswx_policy_probe_k<L, 2>), grid, block, 0, s, a); break; \
+        case 2: hipLaunchKernelGGL((dswx_policy_probe_k<L, 16>), grid, block, 0, s, a); break; \
+        case 3: hipLaunchKernelGGL((dswx_policy_probe_k<L, 17>), grid, block, 0, s, a); break; \
+        case 4: hipLaunchKernelGGL((dswx_policy_probe_k<L, 18>), grid, block, 0, s, a); break; \
+        case 5: hipLaunchKernelGGL((dswx_policy_probe_k<L, 19>), grid, block, 0, s, a); break; \
+        case 6: hipLaunchKernelGGL((dswx_policy_probe_k<L, 1>), grid, block, 0, s, a); break; \
+        default: hipLaunchKernelGGL((dswx_policy_probe_k<L, 3>), grid, block, 0, s, a); break; } } while (0)
+        switch (li) {
+        case 0: POL_S(0, si); break; case 1: POL_S(2, si); break; case 2: POL_S(16, si); break;
+        case 3: POL_S(17, si); break; case 4: POL_S(18, si); break; case 5: POL_S(19, si); break;
+        case 6: POL_S(1, si); break; default: POL_S(3, si); break;
+        }
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }

@@ -36,6 +36,8 @@ def main():
     ap.add_argument('--masks', action='store_true')
     ap.add_argument('--size', type=int, default=3660)
     ap.add_argument('--quick', action='store_true', help='only the main shapes')
+    ap.add_argument('--store-policies', action='store_true', help='A/B of store cache policies (global instr)')
+    ap.add_argument('--policies', action='store_true', help='cache-policy grid of the fused shape')
     ap.add_argument('--tile-align', type=int, default=256, help='1 = contiguous tiles')
     a = ap.parse_args()
     ctx = _capi.Context(0)
@@ -61,6 +63,27 @@ def main():
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
                                                      variant, tile_stride=batch.tile_stride), a.reps)
             out[label] = round(px * nbytes / (sum(ms) / len(ms)) / 1e6, 1)
+        if a.store_policies:
+            # interleaved rounds: same-process A/B of the store policies with global instructions
+            names = ('asm nt', 'asm sc1 nt', 'asm sc0 sc1 nt', 'asm sc1', 'builtin nt')
+            acc = {n: [] for n in names}
+            for _ in range(7):
+                for sp, n in enumerate(names):
+                    ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
+                                                             (1 << 24) | (sp << 2), tile_stride=batch.tile_stride), 4)
+                    acc[n].append(px * 21 / (sum(ms) / len(ms)) / 1e6)
+            for n in names:
+                v = sorted(acc[n])
+                out[f'store policy [{n}]'] = {'median': round(v[len(v) // 2], 1), 'min': round(v[0], 1), 'max': round(v[-1], 1)}
+            print(json.dumps(out, indent=1))
+            return
+        if a.policies:
+            names = ('plain', 'nt', 'sc1', 'sc0 sc1', 'sc1 nt', 'sc0 sc1 nt', 'sc0', 'sc0 nt')
+            for li, ln in enumerate(names):
+                for si, sn in enumerate(names):
+                    run(f'policy probe: loads [{ln}] stores [{sn}]', (1 << 23) | (li << 2) | (si << 5), 21)
+            print(json.dumps(out, indent=1))
+            return
         for sel, ch in enumerate((2048, 8192, 32768, 131072)):
             for nt in (0, 2):
                 run(f'record layout CHPX={ch} nt={nt >> 1}', (1 << 22) | (sel << 2) | nt, 21)
