@@ -19,6 +19,7 @@ The georeferencing is carried opaquely: the projection of the output product is 
 set of GeoKey tags of the input (the reference copies `GetProjection()` the same
 way, :2256-2258 -> :2668).  BigTIFF and LZW are not supported.
 """
+import os
 import struct
 import zlib
 from xml.sax.saxutils import escape, unescape
@@ -195,25 +196,32 @@ def read_geotiff(path, window=None, overview=None, alloc=None):
     out = np.zeros((spp, H, W), dtype=info.dtype) if alloc is None else alloc((spp, H, W), info.dtype)
     if len(offs) < planes * across * down:
         raise GeoTiffError(f'{path}: truncated block table')
-    idx = 0
-    for p in range(planes):
-        for by in range(down):
-            for bx in range(across):
-                raw = buf[offs[idx]: offs[idx] + cnts[idx]]
-                idx += 1
-                if comp != 1:
-                    raw = zlib.decompress(raw)
-                rows = bh if tiled else min(bh, H - by * bh)
-                need = rows * bw * chunk_spp * dt.itemsize
-                blk = np.frombuffer(raw[:need], dtype=dt).reshape(rows, bw, chunk_spp)
-                if predictor == 2:
-                    blk = np.cumsum(blk.astype(info.dtype), axis=1, dtype=info.dtype)
-                y0, x0 = by * bh, bx * bw
-                hh, ww = min(rows, H - y0), min(bw, W - x0)
-                if planar == 2:
-                    out[p, y0:y0 + hh, x0:x0 + ww] = blk[:hh, :ww, 0]
-                else:
-                    out[:, y0:y0 + hh, x0:x0 + ww] = np.moveaxis(blk[:hh, :ww, :], 2, 0)
+    def decode(idx):
+        # blocks write disjoint windows of `out`: safe to run concurrently
+        p, rem = divmod(idx, across * down)
+        by, bx = divmod(rem, across)
+        raw = buf[offs[idx]: offs[idx] + cnts[idx]]
+        if comp != 1:
+            raw = zlib.decompress(raw)
+        rows = bh if tiled else min(bh, H - by * bh)
+        need = rows * bw * chunk_spp * dt.itemsize
+        blk = np.frombuffer(raw[:need], dtype=dt).reshape(rows, bw, chunk_spp)
+        if predictor == 2:
+            blk = np.cumsum(blk.astype(info.dtype), axis=1, dtype=info.dtype)
+        y0, x0 = by * bh, bx * bw
+        hh, ww = min(rows, H - y0), min(bw, W - x0)
+        if planar == 2:
+            out[p, y0:y0 + hh, x0:x0 + ww] = blk[:hh, :ww, 0]
+        else:
+            out[:, y0:y0 + hh, x0:x0 + ww] = np.moveaxis(blk[:hh, :ww, :], 2, 0)
+
+    n_blocks = planes * across * down
+    pool = _io_pool() if (comp != 1 and n_blocks > 1) else None
+    if pool:
+        list(pool.map(decode, range(n_blocks)))
+    else:
+        for i in range(n_blocks):
+            decode(i)
 
     nod = one(TAG_GDAL_NODATA)
     if nod is not None:
@@ -281,26 +289,46 @@ def overview_nearest(arr, factor):
     return np.ascontiguousarray(arr[..., ys[:, None], xs[None, :]])
 
 
+_pool = None
+
+
+def _io_pool():
+    """Thread pool for block (de)compression: zlib and the numpy block copies release the GIL, so
+    DEFLATE -- which dominates the wall time of a product run -- scales over host cores.  The
+    encoded bytes do not depend on the thread count.  DSWX_IO_THREADS overrides (1 = serial)."""
+    global _pool
+    n = int(os.environ.get('DSWX_IO_THREADS', '0')) or min(16, os.cpu_count() or 1)
+    if n <= 1:
+        return None
+    if _pool is None or _pool._max_workers != n:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix='dswx-io')
+    return _pool
+
+
 def _encode_blocks(arr, tile, compress, predictor):
     """[B,H,W] -> list of encoded tile blocks (band-major, row-major)."""
     B, H, W = arr.shape
     dt = arr.dtype.newbyteorder('<')
-    blocks = []
     across, down = (W + tile - 1) // tile, (H + tile - 1) // tile
-    for b in range(B):
-        for by in range(down):
-            for bx in range(across):
-                blk = np.zeros((tile, tile), dtype=dt)
-                y0, x0 = by * tile, bx * tile
-                hh, ww = min(tile, H - y0), min(tile, W - x0)
-                blk[:hh, :ww] = arr[b, y0:y0 + hh, x0:x0 + ww]
-                if predictor == 2:
-                    d = blk.copy()
-                    d[:, 1:] = blk[:, 1:] - blk[:, :-1]
-                    blk = d
-                raw = blk.tobytes()
-                blocks.append(zlib.compress(raw, 6) if compress else raw)
-    return blocks
+
+    def encode(idx):
+        b, rem = divmod(idx, across * down)
+        by, bx = divmod(rem, across)
+        blk = np.zeros((tile, tile), dtype=dt)
+        y0, x0 = by * tile, bx * tile
+        hh, ww = min(tile, H - y0), min(tile, W - x0)
+        blk[:hh, :ww] = arr[b, y0:y0 + hh, x0:x0 + ww]
+        if predictor == 2:
+            d = blk.copy()
+            d[:, 1:] = blk[:, 1:] - blk[:, :-1]
+            blk = d
+        raw = blk.tobytes()
+        return zlib.compress(raw, 6) if compress else raw
+
+    n = B * across * down
+    pool = _io_pool() if (compress and n > 1) else None
+    return list(pool.map(encode, range(n))) if pool else [encode(i) for i in range(n)]
 
 
 def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
