@@ -107,6 +107,32 @@ def cpu_baseline_parallel():
         return {'error': str(e)[:200]}
 
 
+def single_tile_leg(ctx, params, masks, reps=50):
+    """BASELINE.json configs[1] beside the headline: ONE device-resident 3660 x 3660 tile classified
+    repeatedly.  Its 281 MB working set is partly served by the 256 MiB Infinity Cache and a launch
+    lasts < 0.1 ms, so this is a latency figure, not an HBM figure."""
+    from proteus_amd import _capi
+    from proteus_amd.synth import SEED
+    b1 = _capi.DeviceBatch(ctx, 1, TILE, TILE, masks=masks)
+    b1.synth(SEED, tile0=7)
+    for _ in range(5):
+        b1.classify(params)
+    ctx.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.record(e0)
+    for _ in range(reps):
+        b1.classify(params)
+    ctx.record(e1)
+    ctx.synchronize()
+    ms = ctx.elapsed_ms(e0, e1) / reps
+    ctx.destroy_event(e0)
+    ctx.destroy_event(e1)
+    b1.free()
+    return {'value': round(TILE * TILE / ms / 1e3, 1), 'unit': 'Mpixels/s', 'ms_per_launch': round(ms, 4),
+            'note': 'BASELINE configs[1]: one resident tile, back-to-back launches incl. the counters kernel; '
+                    'working set 281 MB (Infinity-Cache assisted), launch-latency bound'}
+
+
 def parity_spot_check(ctx, batch, params, tile):
     """Not timed: one tile of the batch against the scalar C oracle."""
     import numpy as np
@@ -232,6 +258,8 @@ def main():
                          'traffic_source': pmc_note},
             'parity_check': parity,
         }
+        if world == 1:
+            out['single_tile'] = single_tile_leg(ctx, params, args.masks)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_sample()
             par = cpu_baseline_parallel()

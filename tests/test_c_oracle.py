@@ -78,3 +78,39 @@ def test_quotient_predicate_exhaustive():
         results = list(ex.map(_predicate_job, jobs, chunksize=4))
     bad = [(j, r) for j, r in zip(jobs, results) if r[0] != 0]
     assert not bad, bad[:5]
+
+
+def test_c_oracle_under_ubsan(tmp_path):
+    """The scalar C oracle rebuilt with -fsanitize=undefined -fno-sanitize-recover: the golden DIAG
+    vectors (int16 extremes, wrap-around sums, n/0 and 0/0 quotients) and a golden tile run clean
+    and give the same layers.  In a child process, so that a sanitizer abort is a test failure."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(['make', '-C', os.path.join(root, 'oracle'), 'ubsan'], capture_output=True, text=True)
+    if r.returncode != 0 and 'sanitize' in (r.stderr + r.stdout):
+        pytest.skip('this gcc has no libubsan')
+    assert r.returncode == 0, r.stderr
+    code = (
+        "import numpy as np\n"
+        "from tests import _golden as G\n"
+        "from tests.test_c_oracle import params_of_case, check_case\n"
+        "from oracle import c_oracle\n"
+        "from proteus_amd import _capi\n"
+        "z = G.load('diag_vectors.npz')\n"
+        "n = z['bands'].shape[0]\n"
+        "cols = [np.ascontiguousarray(z['bands'][:, i]).reshape(1, n) for i in range(6)]\n"
+        "p = _capi.make_params(dict(zip(G.THR_KEYS, z['thr_fractional'].tolist())), band_fills=[None] * 6,\n"
+        "                      fmask_fill=None, clip_negative_reflectance=False)\n"
+        "c_oracle.classify(p, cols, np.zeros((1, n), np.uint8))\n"
+        "for name in G.tile_case_names()[:3]:\n"
+        "    c = G.tile_case(name)\n"
+        "    res = c_oracle.classify(params_of_case(c, True), c['bands'], c['fmask'], land=c['land'],\n"
+        "                            shad=c['shad'], ocean=c['ocean'])\n"
+        "    check_case(res, c, True, name)\n"
+        "print('ubsan-clean')\n")
+    env = dict(os.environ, DSWX_ORACLE_LIB=os.path.join(root, 'oracle', '_build', 'libdswx_oracle_ubsan.so'),
+               PYTHONPATH=root)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0 and 'ubsan-clean' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
