@@ -262,6 +262,17 @@ __global__ __launch_bounds__(256) void dswx_cover_stage2_bits(const KArgs a) {
     const int y0 = blockIdx.y * CB_OUT_H - CB_HALO, x0 = blockIdx.x * CB_OUT_W - CB_HALO;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = threadIdx.x;
     if (t < 4) { s_x[t >> 1][(t & 1) ? CB_H + 1 : 0][0] = 0; s_x[t >> 1][(t & 1) ? CB_H + 1 : 0][1] = 0; }
+    // A11-A15 as a table over (WTR-2 code, preliminary CLOUD bits, snow): filled once per block by
+    // finish_px itself, looked up per pixel in phase C
+    __shared__ uint32_t s_fin[128];          // WTR | BWTR << 8 | CONF << 16 | CLOUD << 24
+    __shared__ uint8_t s_fbr[128];           // browse
+    if (t < 128) {
+        const uint32_t c = t & 7u, b = (t >> 3) & 7u;
+        PxOut o;
+        finish_px(a.P, c < 5u ? c : (c == 5u ? 254u : 255u), (b & 1u) | ((b & 6u) << 1), (t >> 6) != 0, o);
+        s_fin[t] = o.wtr | o.bwtr << 8 | o.conf << 16 | o.cloud << 24;
+        s_fbr[t] = (uint8_t)o.browse;
+    }
     // ---- phase A
     for (int r = wave; r < CB_H; r += 4) {
         const int y = y0 + r;
@@ -318,15 +329,16 @@ __global__ __launch_bounds__(256) void dswx_cover_stage2_bits(const KArgs a) {
         for (int h = 0; h < 2; ++h) {
             const int c = 64 * h + lane, x = x0 + c;
             if (c < CB_HALO || c >= CB_W - CB_HALO || x >= W) continue;
-            const bool snow = (s_x[buf][r + 1][h] >> lane) & 1ull;
+            const uint32_t snow = (uint32_t)(s_x[buf][r + 1][h] >> lane) & 1u;
             const long long off = tile_base + (long long)y * W + x;
-            PxOut o;
-            finish_px(a.P, a.cover_w2[off], a.cover_pc[off], snow, o);
-            if (a.out.wtr) a.out.wtr[off] = (uint8_t)o.wtr;
-            if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)o.bwtr;
-            if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
-            if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
-            if (a.out.browse) a.out.browse[off] = (uint8_t)o.browse;
+            const uint32_t w2 = a.cover_w2[off], pc = a.cover_pc[off];
+            const uint32_t idx = (w2 < 5u ? w2 : w2 - 249u) | ((pc & 1u) | ((pc >> 1) & 6u)) << 3 | snow << 6;
+            const uint32_t e = s_fin[idx];
+            if (a.out.wtr) a.out.wtr[off] = (uint8_t)e;
+            if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)(e >> 8);
+            if (a.out.conf) a.out.conf[off] = (uint8_t)(e >> 16);
+            if (a.out.cloud) a.out.cloud[off] = (uint8_t)(e >> 24);
+            if (a.out.browse) a.out.browse[off] = s_fbr[idx];
         }
     }
 }
