@@ -487,6 +487,24 @@ __global__ __launch_bounds__(256) void dswx_flat_copy_k(const u32x4* __restrict_
     else if (x.x == 0x9E3779B9u && x.y == 0x7F4A7C15u) dst[0] = x;   // keep the load alive
 }
 
+// Steadily mixed two-stream copy: every block reads 13 x 4 KiB contiguous and writes
+// 8 x 4 KiB contiguous (16 B per lane), so that the 13 : 8 read : write ratio of the fused
+// kernel holds at every moment of the launch.  (dswx_flat_copy_k above reads one word per
+// thread and lets only the first 8/13 of the grid write: its last 5/13 is a pure-read tail.)
+template <bool NT>
+__global__ __launch_bounds__(256) void dswx_steady_copy_k(const u32x4* __restrict__ src, u32x4* __restrict__ dst,
+                                                          long long n_blocks) {
+    const long long b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const u32x4* s = src + b * 13 * 256 + threadIdx.x;
+    u32x4* d = dst + b * 8 * 256 + threadIdx.x;
+    u32x4 v[13];
+#pragma unroll
+    for (int j = 0; j < 13; ++j) v[j] = ldg<u32x4, NT>(s + j * 256);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) stg<u32x4, NT>(d + j * 256, v[j] ^ v[(j + 5) % 13] ^ v[12 - (j & 3)]);
+}
+
 // Write-path calibration (outputs meaningless).  WMODE 0: one flat stream of
 // 16-byte stores; 1: seven planes, each BLOCK writes 4 KiB of ONE plane
 // (blockIdx.z = plane); 2: seven planes, each WAVE of a block writes 1 KiB pieces
@@ -548,6 +566,15 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, int64_
     // block512 << 12 ; bit 8: flat two-stream copy of
     // the same byte counts (needs the planes laid out as DeviceBatch does:
     // band[0..5], fmask contiguous; diag, wtr1.. contiguous)
+    if ((variant & 256) && (variant & 1024)) {   // steadily mixed two-stream copy, bit 1 = nt
+        const long long total = n_tiles * n_pixels;
+        const long long n_blocks = total / 4096;             // 4096 px = 13 + 8 blocks of 4 KiB
+        dim3 grid((unsigned)n_blocks), block(256);
+        if (variant & 2) hipLaunchKernelGGL(dswx_steady_copy_k<true>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n_blocks);
+        else hipLaunchKernelGGL(dswx_steady_copy_k<false>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n_blocks);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
     if (variant & 256) {
         const long long total = n_tiles * n_pixels;
         const long long n16_in = total * 13 / 16, n16_out = total * 8 / 16;

@@ -59,6 +59,12 @@ def main():
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
                                                      variant, tile_stride=batch.tile_stride), a.reps)
             out[f'flat 2-stream copy nt={int(bool(variant & 2))}'] = round(px * 21 / (sum(ms) / len(ms)) / 1e6, 1)
+        for variant in (256 | 1024, 256 | 1024 | 2):
+            ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
+                                                     variant, tile_stride=batch.tile_stride), a.reps)
+            npx = (px // 4096) * 4096
+            out[f'steady 13:8 two-stream copy nt={int(bool(variant & 2))}'] = round(npx * 21 / (sum(ms) / len(ms)) / 1e6, 1)
+
         def run(label, variant, nbytes):
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
                                                      variant, tile_stride=batch.tile_stride), a.reps)
