@@ -65,6 +65,13 @@ def main():
             npx = (px // 4096) * 4096
             out[f'steady 13:8 two-stream copy nt={int(bool(variant & 2))}'] = round(npx * 21 / (sum(ms) / len(ms)) / 1e6, 1)
 
+        for variant in (256 | 1024 | 4, 256 | 1024 | 4 | 2):
+            ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
+                                                     variant, tile_stride=batch.tile_stride), a.reps)
+            nb = px * 13 // 16 // 832
+            out[f'steady 13:8 copy, one word per thread nt={int(bool(variant & 2))}'] = \
+                round(nb * 832 * 16 * 21 / 13 / (sum(ms) / len(ms)) / 1e6, 1)
+
         def run(label, variant, nbytes):
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
                                                      variant, tile_stride=batch.tile_stride), a.reps)
