@@ -453,6 +453,55 @@ __global__ __launch_bounds__(256) void dswx_ws_probe_k(const KArgs a) {
     }
 }
 
+// THIN warp-specialised data movement: block = 1024 threads (16 waves) over a 2048-px chunk.
+// Every wave issues at most TWO 1-KiB LDS-DMA loads (26 pieces over 16 waves) and exactly
+// ONE 1-KiB store (16 output pieces), i.e. the per-wave request count of the thin copy probes.
+// Phase B folds 2 pixels per thread.  LDS 42 KiB, 2 blocks per CU.
+template <bool NT>
+__global__ __launch_bounds__(1024) void dswx_ws_thin_probe_k(const KArgs a) {
+    constexpr int PX = 2048;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_in[6 * PX * 2 + PX];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_out[PX * 2 + 6 * PX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
+    const long long px0 = (long long)blockIdx.x * PX;
+    if (px0 + PX > a.n_pixels) return;       // probe only: whole chunks
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int piece = wave + 16 * h;      // 0..23: plane piece/4, KiB piece%4; 24, 25: fmask halves
+        if (piece < 24) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(a.in.band[piece >> 2]) + (tile_base + px0) * 2 + (piece & 3) * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 16), (lptr_t)(lds_in + piece * 1024), 16, 0, NT ? 2 : 0);
+        } else if (piece < 26) {
+            const uint8_t* src = a.in.fmask + tile_base + px0 + (piece - 24) * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 16), (lptr_t)(lds_in + piece * 1024), 16, 0, NT ? 2 : 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // phase B: 2 pixels per thread
+    const int t = threadIdx.x;
+    uint32_t x = *reinterpret_cast<const uint32_t*>(lds_in + t * 4);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) x ^= *reinterpret_cast<const uint32_t*>(lds_in + k * (PX * 2) + t * 4);
+    const uint32_t f = *reinterpret_cast<const uint16_t*>(lds_in + 6 * (PX * 2) + t * 2);
+    *reinterpret_cast<uint32_t*>(lds_out + t * 4) = x;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) *reinterpret_cast<uint16_t*>(lds_out + PX * 2 + k * PX + t * 2) = (uint16_t)(x ^ f ^ (uint32_t)k);
+    __syncthreads();
+    // phase C: wave w stores output piece w (4 of DIAG, then 2 per u8 plane)
+    uint8_t* const planes[7] = {reinterpret_cast<uint8_t*>(a.out.diag), a.out.wtr1, a.out.wtr2, a.out.wtr,
+                                a.out.bwtr, a.out.conf, a.out.cloud};
+    if (wave < 4) {
+        stg<u32x4, NT>(planes[0] + (tile_base + px0) * 2 + wave * 1024 + lane * 16,
+                       *reinterpret_cast<const u32x4*>(lds_out + wave * 1024 + lane * 16));
+    } else {
+        const int u = (wave - 4) >> 1, sub = (wave - 4) & 1;
+        stg<u32x4, NT>(planes[1 + u] + tile_base + px0 + sub * 1024 + lane * 16,
+                       *reinterpret_cast<const u32x4*>(lds_out + PX * 2 + u * PX + sub * 1024 + lane * 16));
+    }
+}
+
 // Write-shape grid: every wave writes R consecutive 1 KiB pieces (16 B per lane) to each of P
 // of the six u8 output planes, plane after plane; the grid covers all six planes.  Tells
 // run length per plane (R KiB) from planes-per-wave (P) in the store efficiency.
@@ -508,14 +557,25 @@ __global__ __launch_bounds__(256) void dswx_steady_copy_k(const u32x4* __restric
 // The same steady 13 : 8 mix with ONE word per thread: blocks of 13 waves, every wave loads
 // 1 KiB, waves 0..7 also store 1 KiB.  Separates "fat threads" from "traffic mix" as the
 // reason why dswx_steady_copy_k is slower than dswx_flat_copy_k.
-template <bool NT>
+// L = words per thread: 1 is "thin"; larger L makes the same waves fatter (L loads in flight per
+// thread, then L stores) without changing the addresses a block covers.
+template <bool NT, int L>
 __global__ __launch_bounds__(832) void dswx_steady_copy_small_k(const u32x4* __restrict__ src, u32x4* __restrict__ dst,
                                                                 long long n_blocks) {
     const long long b = blockIdx.x;
     if (b >= n_blocks) return;
-    const u32x4 v = ldg<u32x4, NT>(src + b * 832 + threadIdx.x);
-    if (threadIdx.x < 512) stg<u32x4, NT>(dst + b * 512 + threadIdx.x, v);
-    else if (v.x == 0x9E3779B9u && v.y == 0x7F4A7C15u) dst[0] = v;   // keep the load alive
+    u32x4 v[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) v[j] = ldg<u32x4, NT>(src + (b * L + j) * 832 + threadIdx.x);
+    if (threadIdx.x < 512) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) stg<u32x4, NT>(dst + (b * L + j) * 512 + threadIdx.x, L == 1 ? v[j] : v[j] ^ v[(j + 1) % L]);
+    } else {
+        u32x4 x = v[0];
+#pragma unroll
+        for (int j = 1; j < L; ++j) x ^= v[j];
+        if (x.x == 0x9E3779B9u && x.y == 0x7F4A7C15u) dst[0] = x;   // keep the loads alive
+    }
 }
 
 // Write-path calibration (outputs meaningless).  WMODE 0: one flat stream of
@@ -579,12 +639,16 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, int64_
     // block512 << 12 ; bit 8: flat two-stream copy of
     // the same byte counts (needs the planes laid out as DeviceBatch does:
     // band[0..5], fmask contiguous; diag, wtr1.. contiguous)
-    if ((variant & 256) && (variant & 1024) && (variant & 4)) {   // same mix, one word per thread
+    if ((variant & 256) && (variant & 1024) && (variant & 4)) {   // same mix, L words per thread: bits 4-5 = log2 L
         const long long total = n_tiles * n_pixels;
-        const long long n_blocks = total * 13 / 16 / 832;
+        const int lg = (variant >> 4) & 3;
+        const long long n_blocks = (total * 13 / 16 / 832) >> lg;
         dim3 grid((unsigned)n_blocks), block(832);
-        if (variant & 2) hipLaunchKernelGGL(dswx_steady_copy_small_k<true>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n_blocks);
-        else hipLaunchKernelGGL(dswx_steady_copy_small_k<false>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n_blocks);
+        const u32x4* sp = (const u32x4*)in->band[0];
+        u32x4* dp = (u32x4*)out->diag;
+#define SMALL(N, LL) hipLaunchKernelGGL((dswx_steady_copy_small_k<N, LL>), grid, block, 0, s, sp, dp, n_blocks)
+        if (variant & 2) { if (lg == 0) SMALL(true, 1); else if (lg == 1) SMALL(true, 2); else if (lg == 2) SMALL(true, 4); else SMALL(true, 8); }
+        else { if (lg == 0) SMALL(false, 1); else if (lg == 1) SMALL(false, 2); else if (lg == 2) SMALL(false, 4); else SMALL(false, 8); }
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }
@@ -616,6 +680,13 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, int64_
 #define WG(PP, RR) do { if (wnt) hipLaunchKernelGGL((dswx_write_grid_k<PP, RR, true>), grid, block, 0, s, a, total); else hipLaunchKernelGGL((dswx_write_grid_k<PP, RR, false>), grid, block, 0, s, a, total); } while (0)
 #define WG_R(PP) do { if (ri == 0) WG(PP, 1); else if (ri == 1) WG(PP, 2); else if (ri == 2) WG(PP, 4); else WG(PP, 8); } while (0)
         if (pi == 0) WG_R(1); else if (pi == 1) WG_R(2); else if (pi == 2) WG_R(3); else WG_R(6);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if ((variant & 524288) && (variant & 4)) {  // thin warp-specialised data movement (16 waves per 2048 px)
+        dim3 grid((unsigned)(n_pixels / 2048), (unsigned)n_tiles), block(1024);
+        if (variant & 2) hipLaunchKernelGGL(dswx_ws_thin_probe_k<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(dswx_ws_thin_probe_k<false>, grid, block, 0, s, a);
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }

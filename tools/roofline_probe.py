@@ -65,12 +65,14 @@ def main():
             npx = (px // 4096) * 4096
             out[f'steady 13:8 two-stream copy nt={int(bool(variant & 2))}'] = round(npx * 21 / (sum(ms) / len(ms)) / 1e6, 1)
 
-        for variant in (256 | 1024 | 4, 256 | 1024 | 4 | 2):
-            ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
-                                                     variant, tile_stride=batch.tile_stride), a.reps)
-            nb = px * 13 // 16 // 832
-            out[f'steady 13:8 copy, one word per thread nt={int(bool(variant & 2))}'] = \
-                round(nb * 832 * 16 * 21 / 13 / (sum(ms) / len(ms)) / 1e6, 1)
+        for lg in (0, 1, 2, 3):
+            for nt in (0, 2):
+                variant = 256 | 1024 | 4 | (lg << 4) | nt
+                ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
+                                                         variant, tile_stride=batch.tile_stride), a.reps)
+                nb = (px * 13 // 16 // 832) >> lg
+                out[f'steady 13:8 copy, {1 << lg} word(s) per thread nt={nt >> 1}'] = \
+                    round((nb << lg) * 832 * 16 * 21 / 13 / (sum(ms) / len(ms)) / 1e6, 1)
 
         def run(label, variant, nbytes):
             ms = timed(ctx, lambda: ctx.stream_probe(a.tiles, batch.n_pixels, batch.pin, batch.pout,
@@ -101,6 +103,9 @@ def main():
             for nt in (0, 2):
                 run(f'record layout CHPX={ch} nt={nt >> 1}', (1 << 22) | (sel << 2) | nt, 21)
         run('fused shape ppt=8 nt=1 (as is)', 2, 21)
+        run('warp-specialised (4 fat waves) nt=1', 524288 | 2, 21)
+        run('warp-specialised THIN (16 waves, <= 2 loads + 1 store each) nt=0', 524288 | 4, 21)
+        run('warp-specialised THIN (16 waves, <= 2 loads + 1 store each) nt=1', 524288 | 4 | 2, 21)
         run('fused shape ppt=8 nt=1 xcdmap', 2 | 2048, 21)
         run('fused shape ppt=8 nt=1 block512', 2 | 4096, 21)
         if a.quick:
