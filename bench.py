@@ -246,6 +246,7 @@ def main():
                        'tiles_per_gpu': n_tiles, 'tile': [TILE, TILE], 'tile_stride_px': batch.tile_stride,
                        'planes_in': 10 if args.masks else 7, 'planes_out': 7,
                        'sharding': f'tiles by rank x{world}, no collective',
+                       'control_plane': cp.backend,
                        'kernel': kernel_info},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),

@@ -39,6 +39,7 @@ class ControlPlane:
         self.rank, self.local_rank, self.world = env_rank()
         self.dist = None
         self.device = device
+        self.backend = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -46,7 +47,22 @@ class ControlPlane:
             if backend == 'nccl' and device is not None:
                 kw['device_id'] = device
             if not dist.is_initialized():
-                dist.init_process_group(backend, **kw)
+                try:
+                    dist.init_process_group(backend, **kw)
+                    self.backend = backend
+                except Exception as e:                      # noqa: BLE001
+                    # The control plane only carries a barrier and a MAX of one double: if RCCL
+                    # cannot come up on this node, gloo does the same job and the measurement
+                    # stays valid (there is no data-path collective to lose).
+                    if backend == 'gloo':
+                        raise
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                    dist.init_process_group('gloo')
+                    self.backend = f'gloo (fallback: {backend} init failed: {str(e)[:120]})'
+                    self.device = None
+            else:
+                self.backend = dist.get_backend()
             self.dist = dist
 
     def barrier(self):
