@@ -168,6 +168,10 @@ def test_pinned_pipelined_host_path(monkeypatch, chunks, geom):
             for k in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
                 assert np.array_equal(got[k][t] if n_tiles > 1 else got[k], exp[k]), (t, k)
             assert got['counters'][t].tolist() == exp['counters'].tolist()
+        # a subset of the layers and no counters through the same pipeline
+        sub = c.classify_host(bands, fmask, p, layers=('conf', 'wtr'), counters=False, **kw)
+        assert 'pipelined' in c.last_kernel_info() and set(sub) == {'conf', 'wtr'}
+        assert np.array_equal(sub['conf'], ref['conf']) and np.array_equal(sub['wtr'], ref['wtr'])
         # 'cover' mode is a neighbourhood operation: it must take the whole-tile path
         pc = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
         c.classify_host(bands, fmask, pc, **kw)
