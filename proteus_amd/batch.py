@@ -47,7 +47,10 @@ def _worker(device, runconfigs):
                       'output_non_masked_dswx', 'output_shadow_masked_dswx', 'output_landcover',
                       'output_shadow_layer', 'output_cloud_layer', 'output_dem_layer',
                       'output_browse_image', 'scratch_dir', 'product_id', 'product_version',
-                      'landcover_mask', 'shadow_layer', 'ocean_mask'):
+                      'dem_file', 'dem_file_description', 'landcover_file',
+                      'landcover_file_description', 'worldcover_file', 'worldcover_file_description',
+                      'shoreline_shapefile', 'shoreline_shapefile_description',
+                      'flag_offset_and_scale_inputs', 'landcover_mask', 'shadow_layer', 'ocean_mask'):
                 kw[k] = getattr(args, k)
             ok = D.generate_dswx_layers(args.input_list, args.output_file,
                                         hls_thresholds=consts.hls_thresholds, device=device, **kw)

@@ -15,13 +15,15 @@ numpy implementation of that chain in this package: without the built library or
 without a GPU, generate_dswx_layers raises.
 
 What stays on the host and is NOT re-implemented here (out of scope):
-GDAL reprojection of DEM / land cover / shoreline, the terrain-shadow and land-cover
-builders, COG overviews and validation.  GDAL is not installed in this image, so raster
-I/O goes through proteus_amd.geotiff; ancillary layers can be handed over already on
-the HLS grid with the `landcover_mask=`, `shadow_layer=` and `ocean_mask=` keyword
-extensions (arrays or GeoTIFF paths).  Passing `dem_file`, `landcover_file`,
-`worldcover_file` or `shoreline_shapefile` (which need warping) raises
-NotImplementedError.
+GDAL reprojection of DEM / land cover / shoreline, hillshade ('otsu' shadow masking) and HDF4
+input.  GDAL is not installed in this image, so raster I/O goes through proteus_amd.geotiff.
+Ancillary FILES are accepted when they are already on the product grid -- `dem_file` on the HLS
+grid with a margin (-> GPU terrain-shadow kernel, SHAD and DEM layers), `landcover_file` on the
+HLS grid and `worldcover_file` on the grid three times finer (-> GPU LAND aggregation) -- i.e.
+what the reference's own `_warp` calls would hand to its per-pixel code; anything that still
+needs warping, and `shoreline_shapefile`, raises NotImplementedError.  Pre-gridded planes can
+also be handed over directly with the `landcover_mask=`, `shadow_layer=` and `ocean_mask=`
+keyword extensions (arrays or GeoTIFF paths).
 """
 import argparse
 import glob
@@ -798,6 +800,99 @@ def _as_plane(value, shape, name, dtype=np.uint8):
     return np.ascontiguousarray(arr, dtype=dtype)
 
 
+landcover_mask_type = 'standard'                                   # :41
+landcover_threshold_dict = {'standard': [6, 3, 7, 3], 'water heavy': [6, 3, 7, 1]}   # :270-271
+dswx_hls_landcover_classes_dict = {'low_intensity_developed_offset': 0,             # :252-264
+                                   'high_intensity_developed_offset': 100,
+                                   'water': 200, 'evergreen_forest': 201,
+                                   'fill_value': UINT8_FILL_VALUE}
+
+
+def _get_landcover_mask_ctable():
+    """LAND layer colours (:1595-1636)."""
+    ct = {dswx_hls_landcover_classes_dict['evergreen_forest']: (0, 255, 0),
+          dswx_hls_landcover_classes_dict['water']: (0, 0, 255)}
+    for i in range(100):
+        ct[dswx_hls_landcover_classes_dict['low_intensity_developed_offset'] + i] = (255, 0, 255)
+        ct[dswx_hls_landcover_classes_dict['high_intensity_developed_offset'] + i] = (255, 0, 0)
+    ct[dswx_hls_landcover_classes_dict['fill_value']] = FILL_VALUE_RGBA[:3]
+    return ct
+
+
+def _grid_margin(info, geotransform, length, width, scale=1):
+    """If the raster described by `info` is on the HLS grid refined `scale` times and covers it
+    with the same margin on all four sides, returns that margin in (refined) pixels; else None.
+    This is the test for "already warped": the reference gets there with gdal.Warp
+    (`_warp` :4320-4420), which stays outside this package."""
+    gt = info.geotransform
+    if gt is None or gt[2] != 0 or gt[4] != 0:
+        return None
+    dx, dy = geotransform[1] / scale, geotransform[5] / scale
+    if abs(gt[1] - dx) > 1e-9 * abs(dx) or abs(gt[5] - dy) > 1e-9 * abs(dy):
+        return None
+    mx, my = (geotransform[0] - gt[0]) / dx, (geotransform[3] - gt[3]) / dy
+    m = round(mx)
+    if m < 0 or abs(mx - m) > 1e-6 or abs(my - m) > 1e-6:
+        return None
+    if (info.height, info.width) != (scale * length + 2 * m, scale * width + 2 * m):
+        return None
+    return m
+
+
+def _worldcover_year(metadata, worldcover_file_description):
+    """Year of the ESA WorldCover map (:1060-1094): mid-point of time_start / time_end, else the
+    first year 2000..2099 named in the file description, else 2000."""
+    if 'time_start' in metadata and 'time_end' in metadata:
+        fmt = '%Y-%m-%dT%H:%M:%SZ'
+        t0, t1 = (datetime.strptime(metadata[k], fmt) for k in ('time_start', 'time_end'))
+        year = (t0 + (t1 - t0) / 2.0).year
+        logger.info(f'    ESA WorldCover map year: {year} (source: WorldCover file metadata)')
+        return year
+    logger.warning('WARNING Could not read the ESA WorldCover 10m metadata fields `time_start`'
+                   ' and/or `time_end`')
+    if worldcover_file_description:
+        for year in range(2000, 2100):
+            if str(year) in worldcover_file_description:
+                logger.info(f'    ESA WorldCover map year: {year} (source: WorldCover file description)')
+                return year
+    logger.warning('WARNING Considering the ESA WorldCover 10m data year as 2000.')
+    return 2000
+
+
+def create_landcover_mask(copernicus_landcover_file, worldcover_file, worldcover_file_description,
+                          output_file, scratch_dir, mask_type, geotransform, projection, length, width,
+                          forest_mask_landcover_classes, dswx_metadata_dict=None,
+                          output_files_list=None, temp_files_list=None, *, geo_tags=None, device=None):
+    """LAND layer from the Copernicus CGLS 100 m and ESA WorldCover 10 m maps (:906-1115) with the
+    3 x 3 aggregation and class hierarchy on the GPU (dswx_landcover_mask_host).  The two
+    reprojections of the reference (`_warp`, nearest, :970-992) are GDAL's: here both rasters must
+    already be on the product grid -- CGLS on the HLS grid, WorldCover on the grid three times
+    finer -- otherwise NotImplementedError.  Returns the uint8 mask (None if a file is missing)."""
+    logger.info('creating LAND layer combining Copernicus Landcover 100m and ESA WorldCover 10m maps')
+    for f in (copernicus_landcover_file, worldcover_file):
+        if not os.path.isfile(f):
+            logger.error(f'ERROR file not found: {f}')
+            return None
+    cg, cg_info = geotiff.read_geotiff(copernicus_landcover_file)
+    wc, wc_info = geotiff.read_geotiff(worldcover_file)
+    if _grid_margin(cg_info, geotransform, length, width) != 0 or \
+            _grid_margin(wc_info, geotransform, length, width, scale=3) != 0:
+        raise NotImplementedError(
+            'landcover_file / worldcover_file are not on the product grid (CGLS: HLS grid; WorldCover: '
+            '3x finer): reprojecting them needs GDAL, which stays on the host and is outside this '
+            'drop-in (SURVEY.md section 2)')
+    logger.info(f'    CGLS Land Cover 100m forest classes: {forest_mask_landcover_classes}')
+    year = _worldcover_year(wc_info.metadata, worldcover_file_description)
+    land = get_context(device).landcover_mask(
+        wc, cg, forest_mask_landcover_classes, thresholds=landcover_threshold_dict[mask_type.lower()],
+        year_offset=year - 2000)
+    if output_file:
+        _save_array(land, output_file, dswx_metadata_dict, geo_tags,
+                    description=band_description_dict['LAND'], output_files_list=output_files_list,
+                    ctable=_get_landcover_mask_ctable(), no_data_value=UINT8_FILL_VALUE)
+    return land
+
+
 # -----------------------------------------------------------------------------------
 # the orchestrator (:4610-5417)
 # -----------------------------------------------------------------------------------
@@ -920,14 +1015,15 @@ def generate_dswx_layers(input_list,
         msg = f'ERROR mask adjacent to cloud/cloud-shadow mode: {mask_adjacent_to_cloud_mode}'
         logger.info(msg)
         raise Exception(msg)
-    for name, val in (('dem_file', dem_file), ('landcover_file', landcover_file),
-                      ('worldcover_file', worldcover_file),
-                      ('shoreline_shapefile', shoreline_shapefile)):
-        if val is not None:
-            raise NotImplementedError(
-                f'{name}: reprojecting ancillary inputs needs GDAL, which stays on the host and '
-                'is outside this drop-in (SURVEY.md §2); pass the layer already on the HLS grid '
-                'with landcover_mask= / shadow_layer= / ocean_mask=')
+    if shoreline_shapefile is not None:
+        raise NotImplementedError(
+            'shoreline_shapefile: rasterising the shoreline needs GDAL/OGR, which stays on the host '
+            'and is outside this drop-in (SURVEY.md section 2); pass the ocean mask already on the '
+            'HLS grid with ocean_mask=')
+    if dem_file is not None and shadow_masking_algorithm == 'otsu':
+        raise NotImplementedError(
+            "shadow_masking_algorithm 'otsu' thresholds GDAL's hillshade (gdal.DEMProcessing, "
+            ":4160-4212), which stays on the host; use 'sun_local_inc_angle' (the default)")
     os.makedirs(scratch_dir, exist_ok=True)
 
     md = _get_dswx_metadata_dict(product_id, product_version)
@@ -942,7 +1038,9 @@ def generate_dswx_layers(input_list,
         logger.info(f'ERROR could not read file(s): {input_list}')
         return False
     version = '2.0'
-    _populate_dswx_metadata_datasets(md, image['hls_dataset_name'])
+    _populate_dswx_metadata_datasets(md, image['hls_dataset_name'], dem_file, dem_file_description,
+                                     landcover_file, landcover_file_description,
+                                     worldcover_file, worldcover_file_description)
     _populate_dswx_metadata_processing_parameters(
         md, apply_ocean_masking, apply_aerosol_class_remapping, aerosol_lists,
         shadow_masking_algorithm, min_slope_angle, max_sun_local_inc_angle,
@@ -965,6 +1063,42 @@ def generate_dswx_layers(input_list,
     logger.info(f'    mean elevation angle: {sun_elevation_angle}')
 
     shape = (length, width)
+    dem = None
+    early_list = []
+    if dem_file is not None:
+        # :5161-5186 with the warp taken out: the DEM must already be on the HLS grid with a
+        # margin of DEM_MARGIN_IN_PIXELS (what `_warp(..., margin_in_pixels=50)` hands over)
+        logger.info(f'Preparing DEM file: {dem_file}')
+        dem_with_margin, dem_info = geotiff.read_geotiff(dem_file)
+        margin = _grid_margin(dem_info, image['geotransform'], length, width)
+        if margin is None or dem_with_margin.ndim != 2:
+            raise NotImplementedError(
+                'dem_file is not on the HLS grid (same pixel size, same margin on all sides): '
+                'reprojecting it needs GDAL, which stays on the host and is outside this drop-in '
+                '(SURVEY.md section 2); warp it first or pass shadow_layer=')
+        if margin > DEM_MARGIN_IN_PIXELS:
+            k = margin - DEM_MARGIN_IN_PIXELS
+            dem_with_margin = dem_with_margin[k:-k, k:-k]
+            margin = DEM_MARGIN_IN_PIXELS
+        elif margin < DEM_MARGIN_IN_PIXELS:
+            logger.warning(f'WARNING DEM margin is {margin} pixels, the reference uses '
+                           f'{DEM_MARGIN_IN_PIXELS}: slopes along the tile border differ')
+        dem_with_margin = np.ascontiguousarray(dem_with_margin, dtype=np.float32)
+        shadow_layer = _compute_opera_shadow_layer(
+            dem_with_margin, sun_azimuth_angle, sun_elevation_angle, min_slope_angle,
+            max_sun_local_inc_angle, margin=margin)
+        dem = dem_with_margin[margin:dem_with_margin.shape[0] - margin,
+                              margin:dem_with_margin.shape[1] - margin]
+        if output_dem_layer:
+            _save_array(dem, output_dem_layer, md, geo_tags, description=band_description_dict['DEM'],
+                        output_files_list=early_list, no_data_value=float('nan'))
+    if landcover_file is not None and worldcover_file is not None:
+        landcover_mask = create_landcover_mask(
+            landcover_file, worldcover_file, worldcover_file_description, output_landcover, scratch_dir,
+            landcover_mask_type, image['geotransform'], None, length, width,
+            forest_mask_landcover_classes, dswx_metadata_dict=md, output_files_list=early_list,
+            geo_tags=geo_tags, device=device)
+        output_landcover = None          # saved by create_landcover_mask, as in the reference
     landcover_mask = _as_plane(landcover_mask, shape, 'landcover_mask')
     shadow_layer = _as_plane(shadow_layer, shape, 'shadow_layer')
     ocean_mask = _as_plane(ocean_mask, shape, 'ocean_mask')
@@ -1016,7 +1150,7 @@ def generate_dswx_layers(input_list,
                 f' {md["SPATIAL_COVERAGE_EXCLUDING_MASKED_OCEAN"]}')
     logger.info(f'    cloud coverage [%]:  {md["CLOUD_COVERAGE"]}')
 
-    build_list, output_files_list = [], []
+    build_list, output_files_list = early_list, []
     collapse = FLAG_COLLAPSE_WTR_CLASSES
     if shadow_layer is not None and output_shadow_layer:
         _save_array(shadow_layer, output_shadow_layer, md, geo_tags,

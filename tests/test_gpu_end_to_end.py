@@ -263,3 +263,61 @@ def test_batch_driver_single_gpu(tmp_path):
     # a broken runconfig is reported, the others still run
     ok, results = batch.run_batch([rcs[0], str(tmp_path / 'missing.yaml')], 1)
     assert not ok and results[0]['ok'] and not results[1]['ok']
+
+
+def test_mixed_stream_with_terrain_shadow_and_landcover(tmp_path):
+    """BASELINE.json configs[4] on one GPU: a mixed HLS.L30 / HLS.S30 stream through the node-level
+    driver with the terrain-shadow layer computed from a DEM and the LAND layer from CGLS +
+    WorldCover (both GPU kernels, rasters already on the product grid), WTR-2 / CONF / SHAD / LAND
+    / DEM validated against the oracle."""
+    from proteus_amd import batch
+    from proteus_amd.synth import synth_dem, synth_landcover_inputs
+    size, rcs = 240, []
+    for t in range(4):
+        rcfile, _, _, _ = synth_hls.make(str(tmp_path / f'tile{t}'), sensor=('L30', 'S30')[t % 2], size=size,
+                                         tile=40 + t, product_id=f'M{t}', ancillary=True)
+        rcs.append(rcfile)
+    ok, results = batch.run_batch(rcs, 1)
+    assert ok, results
+    forest = [20, 50, 111, 113, 115, 116, 121, 123, 125, 126]     # defaults/dswx_hls.yaml
+    for t in range(4):
+        s = synth_hls.synth_tile(40 + t, size, size)
+        dem = synth_dem(40 + t, size + 100, size + 100)
+        # sun angles of the synthetic product: azimuth 143.2, zenith 34.5 (tools/make_synthetic_hls.py)
+        shad = o.compute_opera_shadow_layer(dem, 143.2, 90 - 34.5, -5, 40)[50:-50, 50:-50]
+        wc, cg = synth_landcover_inputs(40 + t, size, size)
+        land = o.landcover_mask_from_warped(wc, cg, forest, year=2021)
+        exp = o.classify_tile(s['bands'], s['fmask'], landcover=land, shadow=shad, collapse=True)
+        out = tmp_path / f'tile{t}' / 'output'
+        read = lambda stem: geotiff.read_geotiff(str(out / f'M{t}_v1.0_{stem}.tif'))   # noqa: E731
+        assert np.array_equal(read('B08_SHAD')[0], shad.astype(np.uint8))
+        assert np.array_equal(read('B07_LAND')[0], land)
+        demr, info = read('B10_DEM')
+        assert demr.dtype == np.float32 and np.array_equal(demr, dem[50:-50, 50:-50]) and np.isnan(info.nodata)
+        for layer, stem in (('WTR-2', 'B06_WTR-2'), ('CONF', 'B03_CONF'), ('WTR', 'B01_WTR'), ('DIAG', 'B04_DIAG')):
+            arr, info = read(stem)
+            assert np.array_equal(arr, exp[layer]), (t, layer)
+        md = info.metadata
+        assert md['DEM_SOURCE'] == 'Synthetic DEM' and md['WORLDCOVER_SOURCE'] == 'Synthetic ESA WorldCover 10m 2021'
+        assert md['SPACECRAFT_NAME'] == ('Landsat-8', 'Sentinel-2A')[t % 2]
+        # the shadow and land-cover rules did change pixels, or the test is vacuous
+        plain = o.classify_tile(s['bands'], s['fmask'], collapse=True)
+        assert not np.array_equal(plain['WTR-2'], exp['WTR-2'])
+
+
+def test_ancillary_files_off_grid_are_refused(tmp_path):
+    """Rasters that would need gdal.Warp are refused loudly, not resampled silently."""
+    rcfile, files, _, _ = synth_hls.make(str(tmp_path), size=64, ancillary=True, dem_margin=50)
+    bad = str(tmp_path / 'dem_shifted.tif')
+    dem, info = geotiff.read_geotiff(str(tmp_path / 'ancillary' / 'dem.tif'))
+    gt = list(info.geotransform)
+    gt[0] += 7.0                                      # off the grid by a fraction of a pixel
+    geotiff.write_geotiff(bad, dem, geo_tags=geotiff.geo_tags_from_geotransform(tuple(gt), 32615))
+    with pytest.raises(NotImplementedError, match='not on the HLS grid'):
+        D.generate_dswx_layers(files, dem_file=bad, scratch_dir=str(tmp_path))
+    with pytest.raises(NotImplementedError, match='otsu'):
+        D.generate_dswx_layers(files, dem_file=str(tmp_path / 'ancillary' / 'dem.tif'),
+                               shadow_masking_algorithm='otsu', scratch_dir=str(tmp_path))
+    with pytest.raises(NotImplementedError, match='shoreline'):
+        D.generate_dswx_layers(files, shoreline_shapefile='coast.shp', apply_ocean_masking=True,
+                               scratch_dir=str(tmp_path))

@@ -282,8 +282,31 @@ def test_generate_rejects_bad_parameters(tmp_path):
         D.generate_dswx_layers(files, shadow_masking_algorithm='magic')
     with pytest.raises(Exception, match='ERROR mask adjacent to cloud/cloud-shadow mode'):
         D.generate_dswx_layers(files, mask_adjacent_to_cloud_mode='bogus')
+    # what still needs GDAL is refused before anything is loaded
     with pytest.raises(NotImplementedError, match='GDAL'):
-        D.generate_dswx_layers(files, dem_file='dem.tif')
+        D.generate_dswx_layers(files, shoreline_shapefile='coast.shp', apply_ocean_masking=True)
+    with pytest.raises(NotImplementedError, match='otsu'):
+        D.generate_dswx_layers(files, dem_file='dem.tif', shadow_masking_algorithm='otsu')
+
+
+def test_grid_margin_detection():
+    """`_grid_margin`: is an ancillary raster already on the product grid (what gdal.Warp would
+    have produced), and with which margin."""
+    gt = (600000.0, 30.0, 0.0, 4000020.0, 0.0, -30.0)
+
+    def info(gtx, h, w):
+        i = geotiff.GeoTiffInfo()
+        i.geo_tags = geotiff.geo_tags_from_geotransform(gtx)
+        i.height, i.width = h, w
+        return i
+    assert D._grid_margin(info(gt, 100, 120), gt, 100, 120) == 0
+    m50 = (gt[0] - 50 * 30, 30.0, 0.0, gt[3] + 50 * 30, 0.0, -30.0)
+    assert D._grid_margin(info(m50, 200, 220), gt, 100, 120) == 50
+    assert D._grid_margin(info(m50, 200, 221), gt, 100, 120) is None          # asymmetric cover
+    assert D._grid_margin(info((gt[0] + 7, 30.0, 0.0, gt[3], 0.0, -30.0), 100, 120), gt, 100, 120) is None
+    assert D._grid_margin(info((gt[0], 10.0, 0.0, gt[3], 0.0, -10.0), 300, 360), gt, 100, 120) is None
+    assert D._grid_margin(info((gt[0], 10.0, 0.0, gt[3], 0.0, -10.0), 300, 360), gt, 100, 120, scale=3) == 0
+    assert D._grid_margin(info((gt[0] + 30, 30.0, 0.0, gt[3], 0.0, -30.0), 100, 120), gt, 100, 120) is None   # inside
 
 
 def test_generate_returns_false_on_unreadable_input(tmp_path):

@@ -17,13 +17,14 @@ import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from proteus_amd import geotiff                      # noqa: E402
-from proteus_amd.synth import synth_tile             # noqa: E402
+from proteus_amd.synth import synth_tile, synth_dem, synth_landcover_inputs   # noqa: E402
 
 L30 = {'blue': 'B02', 'green': 'B03', 'red': 'B04', 'nir': 'B05', 'swir1': 'B06', 'swir2': 'B07'}
 S30 = {'blue': 'B02', 'green': 'B03', 'red': 'B04', 'nir': 'B8A', 'swir1': 'B11', 'swir2': 'B12'}
 
 
-def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx_hls_synth'):
+def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx_hls_synth',
+         ancillary=False, dem_margin=50):
     in_dir = os.path.join(out_dir, 'input')
     os.makedirs(in_dir, exist_ok=True)
     s = synth_tile(tile, size, size, with_masks=masks)
@@ -58,17 +59,39 @@ def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx
         for k in ('land', 'shad', 'ocean'):
             mask_files[k] = os.path.join(mdir, f'{k}.tif')
             geotiff.write_geotiff(mask_files[k], s[k], geo_tags=geo)
+    anc = {}
+    if ancillary:
+        # ancillary rasters ALREADY on the product grid (what the reference's gdal.Warp calls
+        # hand to its per-pixel code): DEM with a margin, CGLS on the HLS grid, WorldCover 3x finer
+        adir = os.path.join(out_dir, 'ancillary')
+        os.makedirs(adir, exist_ok=True)
+        m = dem_margin
+        dem = synth_dem(tile, size + 2 * m, size + 2 * m)
+        gt_dem = (gt[0] - m * gt[1], gt[1], 0.0, gt[3] - m * gt[5], 0.0, gt[5])
+        anc['dem_file'] = os.path.join(adir, 'dem.tif')
+        geotiff.write_geotiff(anc['dem_file'], dem, geo_tags=geotiff.geo_tags_from_geotransform(gt_dem, 32615),
+                              nodata=float('nan'))
+        anc['dem_file_description'] = 'Synthetic DEM'
+        wc, cg = synth_landcover_inputs(tile, size, size)
+        anc['landcover_file'] = os.path.join(adir, 'cgls.tif')
+        geotiff.write_geotiff(anc['landcover_file'], cg, geo_tags=geo)
+        anc['landcover_file_description'] = 'Synthetic CGLS 100m'
+        gt3 = (gt[0], gt[1] / 3, 0.0, gt[3], 0.0, gt[5] / 3)
+        anc['worldcover_file'] = os.path.join(adir, 'worldcover.tif')
+        geotiff.write_geotiff(anc['worldcover_file'], wc, geo_tags=geotiff.geo_tags_from_geotransform(gt3, 32615),
+                              metadata={'time_start': '2021-01-01T00:00:00Z', 'time_end': '2021-12-31T23:59:59Z'})
+        anc['worldcover_file_description'] = 'Synthetic ESA WorldCover 10m 2021'
     rc = {'runconfig': {'name': 'dswx_hls_workflow_synthetic', 'groups': {
         'pge_name_group': {'pge_name': 'DSWX_HLS_PGE'},
         'input_file_group': {'input_file_path': [in_dir]},
-        'dynamic_ancillary_file_group': {},
+        'dynamic_ancillary_file_group': dict(anc),
         'primary_executable': {'product_type': 'DSWX_HLS'},
         'product_path_group': {'product_path': out_dir,
                                'scratch_path': os.path.join(out_dir, 'scratch'),
                                'output_dir': os.path.join(out_dir, 'output'),
                                'product_id': product_id, 'product_version': 1.0},
-        'processing': {'check_ancillary_inputs_coverage': False, 'save_land': False,
-                       'save_shad': False, 'save_dem': False},
+        'processing': {'check_ancillary_inputs_coverage': False, 'save_land': bool(ancillary),
+                       'save_shad': bool(ancillary), 'save_dem': bool(ancillary)},
         'browse_image_group': {'save_browse': False}}}}
     rc_path = os.path.join(out_dir, 'runconfig.yaml')
     with open(rc_path, 'w') as fh:
