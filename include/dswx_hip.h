@@ -218,6 +218,21 @@ int dswx_shadow_layer_device_q(dswx_ctx_t* ctx, const float* dem, int64_t n_tile
                                const double sun_vector[3], double sin_azimuth, double cos_azimuth,
                                double slope_arg_max, double inc_q_min, double pixel_spacing_x,
                                double pixel_spacing_y, uint8_t* shadow, void* stream);
+/* float32 variants: the value-based casting of numpy < 2 (the reference pins numpy 1.23.5), under
+ * which the float64 sun scalars do not upcast the float32 DEM arrays, so every product, sum,
+ * quotient, arccos / arctan / degrees and comparison of dswx_hls.py:4264-4281 is float32 (scalars
+ * rounded to float32 first).  Thresholds are float32 values located with float32 arccos / arctan
+ * (proteus_amd._capi.shadow_thresholds(..., float32=True)).  The _q forms above reproduce numpy >= 2
+ * (NEP 50), where those steps are float64. */
+int dswx_shadow_layer_host_q32(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width,
+                               int64_t margin, const double sun_vector[3], double sin_azimuth,
+                               double cos_azimuth, float slope_arg_max, float inc_q_min,
+                               double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow);
+int dswx_shadow_layer_device_q32(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles,
+                                 int64_t height, int64_t width, int64_t margin,
+                                 const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                                 float slope_arg_max, float inc_q_min, double pixel_spacing_x,
+                                 double pixel_spacing_y, uint8_t* shadow, void* stream);
 /* Device-pointer form for `n_tiles` DEMs of equal size, asynchronous on `stream`. */
 int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles,
                              int64_t height, int64_t width, int64_t margin,

@@ -371,22 +371,30 @@ def classify_tile(bands, fmask, thr=None, *, landcover=None, shadow=None,
 # ---------------------------------------------------------------------------
 def compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
                                min_slope_angle, max_sun_local_inc_angle,
-                               pixel_spacing_x=30, pixel_spacing_y=30):
+                               pixel_spacing_x=30, pixel_spacing_y=30, legacy_promotion=False):
     """Same expressions, hence the same float32/float64 promotion as the reference gets
     from whichever numpy runs it (numpy >= 2 here: the products with the float64 sun
-    scalars are float64; numpy 1.23.5, which the reference pins, keeps them float32)."""
+    scalars are float64; numpy 1.23.5, which the reference pins, keeps them float32).
+    legacy_promotion=True restates the numpy < 2 behaviour under numpy >= 2 by rounding the
+    five sun scalars to float32 first, which is all that value-based casting does to these
+    expressions (UNPINNED: no numpy < 2 in this image to run the reference under)."""
     sun_azimuth = np.radians(sun_azimuth_angle)
     sun_zenith = np.radians(90 - sun_elevation_angle)
     to_sun = [np.sin(sun_azimuth) * np.sin(sun_zenith),
               np.cos(sun_azimuth) * np.sin(sun_zenith),
               np.cos(sun_zenith)]
+    if legacy_promotion:
+        to_sun = [np.float32(v) for v in to_sun]
+        sun_azimuth = np.float64(sun_azimuth)
+        sin_az, cos_az = np.float32(np.sin(sun_azimuth)), np.float32(np.cos(sun_azimuth))
+    else:
+        sin_az, cos_az = np.sin(sun_azimuth), np.cos(sun_azimuth)
     grad_y, grad_x = np.gradient(dem)
     normal = [-grad_x / pixel_spacing_x, -grad_y / - abs(pixel_spacing_y), 1]
     norm = np.sqrt(normal[0] ** 2 + normal[1] ** 2 + 1)
     sun_inc_angle_degrees = np.degrees(np.arccos(
         (normal[0] * to_sun[0] + normal[1] * to_sun[1] + normal[2] * to_sun[2]) / norm))
-    directional_slope_angle = np.degrees(np.arctan(
-        normal[0] * np.sin(sun_azimuth) + normal[1] * np.cos(sun_azimuth)))
+    directional_slope_angle = np.degrees(np.arctan(normal[0] * sin_az + normal[1] * cos_az))
     backslope = directional_slope_angle <= min_slope_angle
     low_inc = sun_inc_angle_degrees <= max_sun_local_inc_angle
     return low_inc | (~backslope)

@@ -24,7 +24,7 @@ F64_LAYERS = ('mndwi', 'ndvi', 'awesh')
 EXPORTED_SYMBOLS = (
     'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
-    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_classify_batch', 'dswx_synth_batch', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device', 'dswx_shadow_thresholds', 'dswx_shadow_layer_host_q', 'dswx_shadow_layer_device_q', 'dswx_landcover_mask_host', 'dswx_landcover_mask_device',
+    'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_classify_batch', 'dswx_synth_batch', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device', 'dswx_shadow_thresholds', 'dswx_shadow_layer_host_q', 'dswx_shadow_layer_device_q', 'dswx_shadow_layer_host_q32', 'dswx_shadow_layer_device_q32', 'dswx_landcover_mask_host', 'dswx_landcover_mask_device',
     'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_host_alloc', 'dswx_host_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
@@ -136,6 +136,15 @@ def load_library(path=None):
         'dswx_shadow_layer_device_q': (ctypes.c_int, [vp, vp, i64, i64, i64, i64,
                                                       ctypes.POINTER(ctypes.c_double * 3)] +
                                        [ctypes.c_double] * 6 + [vp, vp]),
+        'dswx_shadow_layer_host_q32': (ctypes.c_int, [vp, vp, i64, i64, i64,
+                                                      ctypes.POINTER(ctypes.c_double * 3),
+                                                      ctypes.c_double, ctypes.c_double, ctypes.c_float,
+                                                      ctypes.c_float, ctypes.c_double, ctypes.c_double, vp]),
+        'dswx_shadow_layer_device_q32': (ctypes.c_int, [vp, vp, i64, i64, i64, i64,
+                                                        ctypes.POINTER(ctypes.c_double * 3),
+                                                        ctypes.c_double, ctypes.c_double, ctypes.c_float,
+                                                        ctypes.c_float, ctypes.c_double, ctypes.c_double,
+                                                        vp, vp]),
         'dswx_landcover_mask_host': (ctypes.c_int, [vp, vp, vp, i64, i64, vp, ctypes.c_int32, vp,
                                                     ctypes.c_int32, vp]),
         'dswx_landcover_mask_device': (ctypes.c_int, [vp, vp, vp, i64, i64, i64, vp, ctypes.c_int32,
@@ -240,21 +249,24 @@ def make_params(thresholds=None, *, band_fills=None, fmask_fill=255.0,
     return p
 
 
-def _bisect_doubles(pred, lo, hi):
+def _bisect_floats(pred, lo, hi, dtype=np.float64):
     """pred(lo) is False and pred(hi) True (or the reverse) for a predicate that is monotonic in
-    the double `x`; returns the two adjacent doubles (a, b), a < b, where it flips.  `pred` is
-    evaluated on ARRAYS (64 copies of the candidate) so that numpy takes the same SIMD loop it
-    takes for a raster."""
+    the float `x` of `dtype`; returns the two adjacent floats (a, b), a < b, where it flips.
+    `pred` is evaluated on ARRAYS (64 copies of the candidate) so that numpy takes the same SIMD
+    loop it takes for a raster."""
+    dtype = np.dtype(dtype)
+    itype, sign = (np.int64, 0x7fffffffffffffff) if dtype == np.float64 else (np.int32, 0x7fffffff)
+
     def ordered(d):
-        i = int(np.float64(d).view(np.int64))
-        return i if i >= 0 else -(i & 0x7fffffffffffffff)
+        i = int(dtype.type(d).view(itype))
+        return i if i >= 0 else -(i & sign)
 
     def value(k):
-        return float(np.int64(k if k >= 0 else (-k) | -0x8000000000000000).view(np.float64))
+        return float(itype(k if k >= 0 else (-k) | (-sign - 1)).view(dtype))
 
     def test(d):
         with np.errstate(all='ignore'):
-            return bool(pred(np.full(64, d, dtype=np.float64))[17])
+            return bool(pred(np.full(64, d, dtype=dtype))[17])
     a, b = ordered(lo), ordered(hi)
     fa = test(lo)
     while b - a > 1:
@@ -269,31 +281,34 @@ def _bisect_doubles(pred, lo, hi):
 _shadow_threshold_cache = {}
 
 
-def shadow_thresholds(min_slope_angle, max_sun_local_inc_angle):
+def shadow_thresholds(min_slope_angle, max_sun_local_inc_angle, float32=False):
     """(slope_arg_max, inc_q_min) for dswx_shadow_layer_*_q: the reference's two tests
     `degrees(arctan(t)) <= min_slope_angle` and `degrees(arccos(q)) <= max_sun_local_inc_angle`
-    (dswx_hls.py:4264-4281) as bounds on t and q, located with numpy's own array functions."""
-    key = (float(min_slope_angle), float(max_sun_local_inc_angle))
+    (dswx_hls.py:4264-4281) as bounds on t and q, located with numpy's own array functions.
+    float32=True: the same in float32 arithmetic (numpy < 2 value-based casting) for the _q32 forms."""
+    key = (float(min_slope_angle), float(max_sun_local_inc_angle), bool(float32))
     if key in _shadow_threshold_cache:
         return _shadow_threshold_cache[key]
     if np.isnan(key[0]) or np.isnan(key[1]):
         raise ValueError('shadow angle threshold is NaN')
+    dt = np.float32 if float32 else np.float64
+    # a Python-float threshold is a weak scalar: the comparison runs in the array's dtype
     inc_ok = lambda q: np.degrees(np.arccos(q)) <= key[1]          # noqa: E731
     slope_ok = lambda t: np.degrees(np.arctan(t)) <= key[0]        # noqa: E731
-    one = lambda f, v: bool(f(np.full(64, v, dtype=np.float64))[17])   # noqa: E731
+    one = lambda f, v: bool(f(np.full(64, v, dtype=dt))[17])       # noqa: E731
     with np.errstate(all='ignore'):
         if not one(inc_ok, 1.0):
             inc_q_min = 2.0                      # never
         elif one(inc_ok, -1.0):
             inc_q_min = -1.0                     # whenever arccos is defined
         else:
-            inc_q_min = _bisect_doubles(inc_ok, -1.0, 1.0)[1]
+            inc_q_min = _bisect_floats(inc_ok, -1.0, 1.0, dt)[1]
         if one(slope_ok, np.inf):
             slope_arg_max = float('inf')
         elif not one(slope_ok, -np.inf):
             slope_arg_max = float('-inf')
         else:
-            slope_arg_max = _bisect_doubles(slope_ok, -np.inf, np.inf)[0]
+            slope_arg_max = _bisect_floats(slope_ok, -np.inf, np.inf, dt)[0]
     _shadow_threshold_cache[key] = (slope_arg_max, inc_q_min)
     return slope_arg_max, inc_q_min
 
@@ -478,20 +493,22 @@ class Context:
         return out
 
     def shadow_layer(self, dem, sun_vector, sin_azimuth, cos_azimuth, min_slope_angle,
-                     max_sun_local_inc_angle, pixel_spacing_x=30, pixel_spacing_y=30, margin=0):
+                     max_sun_local_inc_angle, pixel_spacing_x=30, pixel_spacing_y=30, margin=0,
+                     float32=False):
         """Terrain shadow layer of one float32 DEM [H,W]; returns bool [H-2m, W-2m].  The two angle
-        thresholds are pulled back through numpy's arccos / arctan (shadow_thresholds)."""
+        thresholds are pulled back through numpy's arccos / arctan (shadow_thresholds).
+        float32=True reproduces numpy < 2 value-based casting (all-float32 arithmetic)."""
         dem = np.ascontiguousarray(dem, dtype=np.float32)
         if dem.ndim != 2:
             raise ValueError('dem must be 2-D')
         h, w = dem.shape
         out = np.empty((max(h - 2 * margin, 0), max(w - 2 * margin, 0)), dtype=np.uint8)
         vec = (ctypes.c_double * 3)(*[float(v) for v in sun_vector])
-        slope_arg_max, inc_q_min = shadow_thresholds(min_slope_angle, max_sun_local_inc_angle)
-        _check(self.lib.dswx_shadow_layer_host_q(
-            self.handle, _host_ptr(dem), h, w, int(margin), ctypes.byref(vec),
-            float(sin_azimuth), float(cos_azimuth), slope_arg_max, inc_q_min,
-            float(pixel_spacing_x), float(pixel_spacing_y), _host_ptr(out)))
+        slope_arg_max, inc_q_min = shadow_thresholds(min_slope_angle, max_sun_local_inc_angle, float32)
+        fn = self.lib.dswx_shadow_layer_host_q32 if float32 else self.lib.dswx_shadow_layer_host_q
+        _check(fn(self.handle, _host_ptr(dem), h, w, int(margin), ctypes.byref(vec),
+                  float(sin_azimuth), float(cos_azimuth), slope_arg_max, inc_q_min,
+                  float(pixel_spacing_x), float(pixel_spacing_y), _host_ptr(out)))
         return out.astype(bool)
 
     def landcover_mask(self, worldcover_up3, copernicus, forest_classes, thresholds=(6, 3, 7, 3),

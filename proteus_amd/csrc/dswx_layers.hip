@@ -59,6 +59,10 @@ struct ShadowArgs {
     double inc_q_min, slope_arg_max;
 };
 
+// F32: the value-based casting of numpy < 2 (what the reference pins: numpy 1.23.5), where the
+// float64 sun scalars do NOT upcast the float32 arrays -- every product, sum, quotient, arccos,
+// arctan, degrees and comparison of :4264-4281 is float32, the scalars rounded to float32 first.
+template <bool F32>
 __global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
     const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
     const int ow = W - 2 * margin, oh = H - 2 * margin;
@@ -75,11 +79,19 @@ __global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
     const float n0 = -gx / a.spacing_x;
     const float n1 = -gy / a.neg_abs_spacing_y;
     const float norm = sqrtf(n0 * n0 + n1 * n1 + 1.0f);
-    const double dot = (double)n0 * a.sun[0] + (double)n1 * a.sun[1] + a.sun[2];
-    const double q = dot / (double)norm;                      // arccos argument (NaN-safe compares below)
-    const double t = (double)n0 * a.sin_az + (double)n1 * a.cos_az;   // arctan argument
-    const bool low_inc = (q >= a.inc_q_min) & (q <= 1.0);     // arccos(q > 1) is NaN: the test fails
-    const bool backslope = t <= a.slope_arg_max;
+    bool low_inc, backslope;
+    if (F32) {
+        const float qf = (n0 * (float)a.sun[0] + n1 * (float)a.sun[1] + (float)a.sun[2]) / norm;
+        const float tf = n0 * (float)a.sin_az + n1 * (float)a.cos_az;
+        low_inc = (qf >= (float)a.inc_q_min) & (qf <= 1.0f);      // thresholds are float32 values here
+        backslope = tf <= (float)a.slope_arg_max;
+    } else {
+        const double dot = (double)n0 * a.sun[0] + (double)n1 * a.sun[1] + a.sun[2];
+        const double q = dot / (double)norm;                      // arccos argument (NaN-safe compares below)
+        const double t = (double)n0 * a.sin_az + (double)n1 * a.cos_az;   // arctan argument
+        low_inc = (q >= a.inc_q_min) & (q <= 1.0);                // arccos(q > 1) is NaN: the test fails
+        backslope = t <= a.slope_arg_max;
+    }
     a.shadow[(size_t)blockIdx.z * (size_t)oh * (size_t)ow + (size_t)(oy * ow + ox)] = (low_inc | !backslope) ? 1 : 0;
 }
 
@@ -329,10 +341,11 @@ static int shadow_args(ShadowArgs* a, int64_t height, int64_t width, int64_t mar
     return DSWX_OK;
 }
 
-int dswx_shadow_layer_device_q(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
-                               int64_t margin, const double sun_vector[3], double sin_azimuth,
-                               double cos_azimuth, double slope_arg_max, double inc_q_min,
-                               double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream) {
+static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
+                              int64_t margin, const double sun_vector[3], double sin_azimuth,
+                              double cos_azimuth, double slope_arg_max, double inc_q_min,
+                              double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream,
+                              bool f32) {
     if (!ctx || !dem || !shadow) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     if (n_tiles < 0 || n_tiles > 65535) return dswx_fail(DSWX_ERR_ARG, "n_tiles out of range");
     ShadowArgs a;
@@ -346,9 +359,27 @@ int dswx_shadow_layer_device_q(dswx_ctx_t* ctx, const float* dem, int64_t n_tile
     const long long ow = width - 2 * margin, oh = height - 2 * margin;
     dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
     if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
-    hipLaunchKernelGGL(dswx_shadow_v2, grid, block, 0, s, a);
+    if (f32) hipLaunchKernelGGL(dswx_shadow_v2<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(dswx_shadow_v2<false>, grid, block, 0, s, a);
     HIP_TRY(hipGetLastError());
     return DSWX_OK;
+}
+
+int dswx_shadow_layer_device_q(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
+                               int64_t margin, const double sun_vector[3], double sin_azimuth,
+                               double cos_azimuth, double slope_arg_max, double inc_q_min,
+                               double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream) {
+    return shadow_device_impl(ctx, dem, n_tiles, height, width, margin, sun_vector, sin_azimuth, cos_azimuth,
+                              slope_arg_max, inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow, stream, false);
+}
+
+int dswx_shadow_layer_device_q32(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
+                                 int64_t margin, const double sun_vector[3], double sin_azimuth,
+                                 double cos_azimuth, float slope_arg_max, float inc_q_min,
+                                 double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream) {
+    return shadow_device_impl(ctx, dem, n_tiles, height, width, margin, sun_vector, sin_azimuth, cos_azimuth,
+                              (double)slope_arg_max, (double)inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow,
+                              stream, true);
 }
 
 int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
@@ -362,10 +393,10 @@ int dswx_shadow_layer_device(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles,
                                       slope_arg_max, inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow, stream);
 }
 
-int dswx_shadow_layer_host_q(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
-                             const double sun_vector[3], double sin_azimuth, double cos_azimuth,
-                             double slope_arg_max, double inc_q_min, double pixel_spacing_x,
-                             double pixel_spacing_y, uint8_t* shadow) {
+static int shadow_host_impl(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
+                            const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                            double slope_arg_max, double inc_q_min, double pixel_spacing_x,
+                            double pixel_spacing_y, uint8_t* shadow, bool f32) {
     if (!ctx || !dem || !shadow) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     ShadowArgs chk;
     int rc = shadow_args(&chk, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, slope_arg_max, inc_q_min,
@@ -381,9 +412,9 @@ int dswx_shadow_layer_host_q(dswx_ctx_t* ctx, const float* dem, int64_t height, 
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemcpyAsync(d_dem, dem, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        rc = dswx_shadow_layer_device_q(ctx, static_cast<const float*>(d_dem), 1, height, width, margin, sun_vector,
-                                        sin_azimuth, cos_azimuth, slope_arg_max, inc_q_min, pixel_spacing_x,
-                                        pixel_spacing_y, static_cast<uint8_t*>(d_out), s);
+        rc = shadow_device_impl(ctx, static_cast<const float*>(d_dem), 1, height, width, margin, sun_vector,
+                                sin_azimuth, cos_azimuth, slope_arg_max, inc_q_min, pixel_spacing_x,
+                                pixel_spacing_y, static_cast<uint8_t*>(d_out), s, f32);
         if (rc == DSWX_OK) e = hipMemcpyAsync(shadow, d_out, out_px, hipMemcpyDeviceToHost, s);
         if (rc == DSWX_OK && e == hipSuccess) e = hipStreamSynchronize(s);
     }
@@ -392,6 +423,22 @@ int dswx_shadow_layer_host_q(dswx_ctx_t* ctx, const float* dem, int64_t height, 
     if (rc) return rc;
     if (e != hipSuccess) return dswx_fail(DSWX_ERR_HIP, "dswx_shadow_layer_host: %s", hipGetErrorString(e));
     return DSWX_OK;
+}
+
+int dswx_shadow_layer_host_q(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
+                             const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                             double slope_arg_max, double inc_q_min, double pixel_spacing_x,
+                             double pixel_spacing_y, uint8_t* shadow) {
+    return shadow_host_impl(ctx, dem, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, slope_arg_max,
+                            inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow, false);
+}
+
+int dswx_shadow_layer_host_q32(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,
+                               const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                               float slope_arg_max, float inc_q_min, double pixel_spacing_x,
+                               double pixel_spacing_y, uint8_t* shadow) {
+    return shadow_host_impl(ctx, dem, height, width, margin, sun_vector, sin_azimuth, cos_azimuth,
+                            (double)slope_arg_max, (double)inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow, true);
 }
 
 int dswx_shadow_layer_host(dswx_ctx_t* ctx, const float* dem, int64_t height, int64_t width, int64_t margin,

@@ -406,7 +406,7 @@ DEM_MARGIN_IN_PIXELS = 50                 # :58
 
 def _compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
                                 min_slope_angle, max_sun_local_inc_angle,
-                                pixel_spacing_x=30, pixel_spacing_y=30, margin=0):
+                                pixel_spacing_x=30, pixel_spacing_y=30, margin=0, numpy_promotion=None):
     """Terrain shadow mask from sun local-incidence and back-slope angles on the GPU
     (:4215-4283); True = not shadow, False = shadow, same shape as `dem` (or cropped by
     `margin` on all sides, fusing _crop_2d_array_all_sides :4320).  The five float64 sun
@@ -421,10 +421,16 @@ def _compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
     if dem.ndim != 2 or min(dem.shape) < 2:
         raise ValueError('Shape of array too small to calculate a numerical gradient, '
                          'at least 2 elements are required.')
+    # which numpy does the caller want to agree with?  'nep50' (numpy >= 2, default: what the
+    # reference computes when run under a current numpy) or 'legacy' (numpy < 2 value-based
+    # casting, what it computes under the numpy 1.23.5 it pins): env DSWX_NUMPY_PROMOTION
+    mode = (numpy_promotion or os.environ.get('DSWX_NUMPY_PROMOTION', 'nep50')).lower()
+    if mode not in ('nep50', 'legacy'):
+        raise ValueError(f"numpy_promotion must be 'nep50' or 'legacy', not {mode!r}")
     return get_context().shadow_layer(
         dem, target_to_sun_unit_vector, np.sin(sun_azimuth), np.cos(sun_azimuth),
         min_slope_angle, max_sun_local_inc_angle, pixel_spacing_x, pixel_spacing_y,
-        margin=margin)
+        margin=margin, float32=(mode == 'legacy'))
 
 
 def _crop_2d_array_all_sides(input_2d_array, margin):

@@ -100,3 +100,18 @@ def test_shadow_thresholds_numpy_and_libm_agree():
     assert lib.dswx_shadow_thresholds(-91.0, -1.0, ctypes.byref(t_c), ctypes.byref(q_c)) == 0
     assert (t_c.value, q_c.value) == (float('-inf'), 2.0)
     assert lib.dswx_shadow_thresholds(float('nan'), 1.0, ctypes.byref(t_c), ctypes.byref(q_c)) != 0
+
+
+def test_shadow_thresholds_float32():
+    """float32 pull-back (numpy < 2 promotion): exact for numpy's float32 arccos / arctan loops."""
+    import numpy as np
+    for ms, mi in [(-5, 40), (0, 90), (10.5, 35.25), (-5, 179.9), (45.0, 1e-3)]:
+        t, q = _capi.shadow_thresholds(ms, mi, float32=True)
+        assert np.float32(t) == t and np.float32(q) == q          # float32 values
+        qa = np.full(64, q, np.float32)
+        assert (np.degrees(np.arccos(qa)) <= mi).all()
+        assert not (np.degrees(np.arccos(np.nextafter(qa, np.float32(-2)))) <= mi).any()
+        ta = np.full(64, t, np.float32)
+        assert (np.degrees(np.arctan(ta)) <= ms).all()
+        assert not (np.degrees(np.arctan(np.nextafter(ta, np.float32(np.inf)))) <= ms).any()
+    assert _capi.shadow_thresholds(-91, -1, float32=True) == (float('-inf'), 2.0)

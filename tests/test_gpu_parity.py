@@ -593,6 +593,35 @@ def test_shadow_layer_random_geometry_sweep(ctx):
                                           int(np.count_nonzero(got != exp)))
 
 
+def test_shadow_layer_legacy_float32_promotion(ctx):
+    """numpy < 2 value-based casting (the numpy 1.23.5 the reference pins): all-float32 arithmetic.
+    UNPINNED against the reference (no numpy < 2 here); pinned against the oracle's restatement of
+    that casting, bit-exact over random geometries, and through the host mirror's switch."""
+    from proteus_amd import dswx_hls as D
+    from proteus_amd.synth import synth_dem
+    rng = np.random.default_rng(7)
+    base = synth_dem(12, 600, 500)
+    n_diff = 0
+    for k in range(16):
+        az, el = rng.uniform(0, 360), rng.uniform(1, 89)
+        min_slope = (-5, 0, float(rng.uniform(-30, 30)))[k % 3]
+        max_inc = (40, 90, float(rng.uniform(5, 120)))[(k // 2) % 3]
+        margin = (0, 50)[k % 2]
+        got = D._compute_opera_shadow_layer(base, az, el, min_slope, max_inc, margin=margin,
+                                            numpy_promotion='legacy')
+        with np.errstate(all='ignore'):
+            exp = o.compute_opera_shadow_layer(base, az, el, min_slope, max_inc, legacy_promotion=True)
+            exp64 = o.compute_opera_shadow_layer(base, az, el, min_slope, max_inc)
+        if margin:
+            exp, exp64 = exp[margin:-margin, margin:-margin], exp64[margin:-margin, margin:-margin]
+        assert np.array_equal(got, exp), (k, az, el, min_slope, max_inc, margin)
+        n_diff += int(np.count_nonzero(exp != exp64))
+    # the two promotions differ on borderline pixels only
+    assert n_diff < 16 * 1e-4 * base.size
+    with pytest.raises(ValueError, match='numpy_promotion'):
+        D._compute_opera_shadow_layer(base, 10, 10, -5, 40, numpy_promotion='bogus')
+
+
 def _sun(az_deg, el_deg):
     """(sun vector, sin az, cos az) formed exactly as the reference forms them (:4246-4253, :4276-4277)."""
     az, zen = np.radians(az_deg), np.radians(90 - el_deg)
