@@ -1021,6 +1021,11 @@ def generate_dswx_layers(input_list,
         msg = f'ERROR mask adjacent to cloud/cloud-shadow mode: {mask_adjacent_to_cloud_mode}'
         logger.info(msg)
         raise Exception(msg)
+    if flag_offset_and_scale_inputs:
+        raise NotImplementedError(
+            'flag_offset_and_scale_inputs: the reference then converts every band to float32 '
+            'reflectance (:2300-2302) and runs the whole chain on those floats; this library '
+            'implements the int16 path the production configuration uses (the flag defaults to False)')
     if shoreline_shapefile is not None:
         raise NotImplementedError(
             'shoreline_shapefile: rasterising the shoreline needs GDAL/OGR, which stays on the host '
