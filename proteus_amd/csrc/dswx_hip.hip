@@ -851,6 +851,13 @@ int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out) {
     if (!ctx || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
+    // DSWX_MALLOC_FLAGS (experiments): hipExtMallocWithFlags flags, e.g. 4 = hipDeviceMallocContiguous
+    static const int flags = [] { const char* e = std::getenv("DSWX_MALLOC_FLAGS"); return e ? std::atoi(e) : 0; }();
+    if (flags) {
+        const hipError_t e = hipExtMallocWithFlags(out, bytes ? bytes : 1, (unsigned)flags);
+        if (e == hipSuccess) return DSWX_OK;
+        (void)hipGetLastError();          // fall back to the default allocator
+    }
     HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
     return DSWX_OK;
 }
