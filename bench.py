@@ -260,12 +260,18 @@ def main():
             'parity_check': parity,
         }
         if world == 1:
-            out['single_tile'] = single_tile_leg(ctx, params, args.masks)
+            try:
+                out['single_tile'] = single_tile_leg(ctx, params, args.masks)
+            except Exception as e:
+                out['single_tile'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline_sample()
-            par = cpu_baseline_parallel()
-            if par:
-                out['cpu_baseline']['tile_parallel'] = par
+            try:
+                out['cpu_baseline'] = cpu_baseline_sample()
+                par = cpu_baseline_parallel()
+                if par:
+                    out['cpu_baseline']['tile_parallel'] = par
+            except Exception as e:      # a reported baseline must never cost the bench line
+                out['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         print(json.dumps(out), flush=True)
     batch.free()
     ctx.close()
