@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Soak test: random parameters x random rasters (synthetic tiles, uniform int16 noise, values
+hugging the thresholds) through dswx_classify_host, every layer and the counters compared with
+the scalar C oracle.  Exit code 1 and a JSON description of the first mismatch on failure.
+
+    python tools/fuzz_parity.py [--iters 300] [--seed 1] [--variant N]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import c_oracle                         # noqa: E402  (checker)
+from proteus_amd import _capi                       # noqa: E402
+from proteus_amd.synth import synth_tile            # noqa: E402
+from tests.test_gpu_parity import _random_case, ALL_LAYERS   # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=300)
+    ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--variant', default=None, help='DSWX_FUSED_VARIANT for this run')
+    a = ap.parse_args()
+    if a.variant is not None:
+        os.environ['DSWX_FUSED_VARIANT'] = a.variant
+    ctx = _capi.Context(0)
+    rng = np.random.default_rng(a.seed)
+    kernels = {}
+    for it in range(a.iters):
+        cs = _random_case(rng)
+        kind = it % 4
+        h, w = int(rng.integers(1, 200)), int(rng.integers(1, 260))
+        if kind == 3:
+            h, w = int(rng.integers(200, 700)), 8 * int(rng.integers(30, 120))
+        s = synth_tile(5000 + it, h, w, with_masks=True)
+        bands = [b.copy() for b in s['bands']]
+        fmask = s['fmask'].copy()
+        if kind == 1:          # uniform int16 noise incl. the extremes, random Fmask bytes
+            bands = [rng.integers(-32768, 32768, size=(h, w)).astype(np.int16) for _ in range(6)]
+            fmask = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+        elif kind == 2:        # values hugging the integer thresholds and the quotient ties
+            t = cs['thr']
+            for b, key in zip(bands, ('pswt_2_blue', None, None, 'pswt_1_nir', 'pswt_1_swir1', 'pswt_2_swir2')):
+                if key is not None and abs(t[key]) < 30000:
+                    b[...] = (int(t[key]) + rng.integers(-2, 3, size=(h, w))).astype(np.int16)
+            g = rng.integers(1, 3000, size=(h, w))
+            bands[1][...] = g
+            bands[4][...] = np.clip((g * (1 - t['wigt']) / (1 + t['wigt'] + 1e-9)).astype(np.int64)
+                                    + rng.integers(-1, 2, size=(h, w)), -32768, 32767)
+        p = _capi.make_params(
+            cs['thr'], band_fills=cs['fills'], fmask_fill=cs['fmask_fill'],
+            clip_negative_reflectance=cs['clip'], mask_adjacent_to_cloud_mode=cs['mode'],
+            apply_aerosol_class_remapping=cs['aerosol'], aerosol_fmask_values=cs['lists'],
+            collapse_wtr_classes=cs['collapse'], aerosol_max_nir=cs['aer_nir'])
+        kw = {k: s[k] for k in ('land', 'shad', 'ocean') if cs[k]}
+        got = ctx.classify_host(bands, fmask, p, **kw)
+        kernels[ctx.last_kernel_info().split(' ')[0]] = kernels.get(ctx.last_kernel_info().split(' ')[0], 0) + 1
+        exp = c_oracle.classify(p, bands, fmask, **kw)
+        bad = [k for k in ALL_LAYERS if not np.array_equal(got[k], exp[k])]
+        if got['counters'][0].tolist() != exp['counters'].tolist():
+            bad.append('counters')
+        if bad:
+            print(json.dumps({'ok': False, 'iteration': it, 'kind': kind, 'shape': [h, w], 'layers': bad,
+                              'case': {k: (v if not isinstance(v, dict) else v) for k, v in cs.items()}},
+                             default=str))
+            return 1
+    print(json.dumps({'ok': True, 'iterations': a.iters, 'seed': a.seed, 'kernels': kernels}))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
