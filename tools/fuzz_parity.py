@@ -20,17 +20,80 @@ from proteus_amd.synth import synth_tile            # noqa: E402
 from tests.test_gpu_parity import _random_case, ALL_LAYERS   # noqa: E402
 
 
+def device_batch_soak(ctx, rng, a, kernels):
+    """Device-resident batches with random geometry: tile count, ragged tile sizes, tile-stride
+    alignment (1 / 8 / 16 / 64 / 256 px), plane skews (pointer alignment), optional planes and layers,
+    counters on / off, 'mask' / 'ignore' / 'cover'; every tile against the oracle."""
+    from oracle import dswx_oracle as o
+    from tests.test_c_oracle import NAME
+    for it in range(a.iters):
+        cs = _random_case(rng)
+        n_tiles = int(rng.integers(1, 6))
+        h, w = int(rng.integers(1, 120)), int(rng.integers(1, 150))
+        align = int(rng.choice([1, 8, 16, 64, 256]))
+        masks = bool(rng.integers(2))
+        os.environ['DSWX_PLANE_SKEW'] = str(int(rng.choice([0, 0, 16, 48, 272])))
+        extra = tuple(x for x in ('wtr1_aerosol', 'browse') if rng.integers(2))
+        batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=masks, extra_layers=extra, tile_align=align)
+        batch.synth(777 + it, tile0=it)
+        mode = str(rng.choice(['mask', 'ignore', 'cover']))
+        p = _capi.make_params(
+            cs['thr'], clip_negative_reflectance=cs['clip'], mask_adjacent_to_cloud_mode=mode,
+            apply_aerosol_class_remapping=cs['aerosol'], aerosol_fmask_values=cs['lists'],
+            collapse_wtr_classes=cs['collapse'],
+            aerosol_max_nir=None if mode == 'cover' else cs['aer_nir'])   # the numpy oracle fixes it at 1000
+        use_counters = bool(rng.integers(4))
+        batch.classify(p, counters=use_counters)
+        ctx.synchronize()
+        key = ctx.last_kernel_info().split(' grid')[0]
+        kernels[key] = kernels.get(key, 0) + 1
+        cnt = batch.read_counters() if use_counters else None
+        for t in range(n_tiles):
+            bands = [batch.read_tile(b, t) for b in _capi.BAND_NAMES]
+            fm = batch.read_tile('fmask', t)
+            kw = {m: batch.read_tile(m, t) for m in ('land', 'shad', 'ocean')} if masks else {}
+            if mode == 'cover':
+                with np.errstate(all='ignore'):
+                    e = o.classify_tile(bands, fm, o.Thresholds(**cs['thr']), landcover=kw.get('land'),
+                                        shadow=kw.get('shad'), ocean_mask=kw.get('ocean'),
+                                        mask_adjacent_to_cloud_mode='cover', apply_aerosol=cs['aerosol'],
+                                        aerosol_fmask_values=cs['lists'], clip_negative_reflectance=cs['clip'],
+                                        collapse=cs['collapse'])
+                exp = {k: e[layer] for layer, k in NAME.items()}
+                ec = e['counters']
+                exp_cnt = [ec['n_valid'], ec['n_cloud_and_valid'], ec['n_not_ocean']]
+            else:
+                exp = c_oracle.classify(p, bands, fm, **kw)
+                exp_cnt = exp['counters'].tolist()
+            layers = ['diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'] + [x for x in extra if x == 'wtr1_aerosol']
+            bad = [k for k in layers if not np.array_equal(batch.read_tile(k, t), exp[k])]
+            if use_counters and cnt[t].tolist() != exp_cnt:
+                bad.append('counters')
+            if bad:
+                print(json.dumps({'ok': False, 'iteration': it, 'tile': t, 'geom': [n_tiles, h, w, align],
+                                  'masks': masks, 'mode': mode, 'extra': extra, 'layers': bad,
+                                  'skew': os.environ['DSWX_PLANE_SKEW'], 'kernel': ctx.last_kernel_info()},
+                                 default=str))
+                return 1
+        batch.free()
+    print(json.dumps({'ok': True, 'iterations': a.iters, 'seed': a.seed, 'kernels': kernels}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=300)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--variant', default=None, help='DSWX_FUSED_VARIANT for this run')
+    ap.add_argument('--device-batch', action='store_true', help='soak the device-resident batch entry instead')
     a = ap.parse_args()
     if a.variant is not None:
         os.environ['DSWX_FUSED_VARIANT'] = a.variant
     ctx = _capi.Context(0)
     rng = np.random.default_rng(a.seed)
     kernels = {}
+    if a.device_batch:
+        return device_batch_soak(ctx, rng, a, kernels)
     for it in range(a.iters):
         cs = _random_case(rng)
         kind = it % 4
