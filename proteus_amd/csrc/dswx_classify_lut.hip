@@ -7,6 +7,7 @@
 // rebuilt on the device for every call by dswx_build_tables from the same px_w1 / px_chain
 // the scalar kernel uses and copied into LDS by every block.
 #include <cstdio>
+#include <cstring>
 
 #include "dswx_host.h"
 #include "dswx_tables.h"
@@ -91,7 +92,15 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
     Tables* tabs = static_cast<Tables*>(ctx->tables);
     LutConsts lc;
     make_lut_consts(b.P, &lc);
-    hipLaunchKernelGGL(dswx_build_tables, dim3(4), dim3(256), 0, s, b.P, tabs);
+    // the tables depend on the parameters only: rebuilt when those change (or the stream does, so
+    // that the build always precedes its first use in stream order)
+    static_assert(sizeof(DevParams) <= sizeof(ctx->tables_params), "enlarge dswx_ctx::tables_params");
+    if (!ctx->tables_valid || ctx->tables_stream != s || std::memcmp(ctx->tables_params, &b.P, sizeof(DevParams)) != 0) {
+        hipLaunchKernelGGL(dswx_build_tables, dim3(4), dim3(256), 0, s, b.P, tabs);
+        std::memcpy(ctx->tables_params, &b.P, sizeof(DevParams));
+        ctx->tables_stream = s;
+        ctx->tables_valid = true;
+    }
     // launch bound (waves per SIMD), env DSWX_TUNE_LUT_WPS; default 4: 91 VGPRs without masks, 104
     // with LAND / SHAD / OCEAN (5 and 6 spill to scratch there; without masks they give 67 VGPRs
     // and measure 0-2 % slower than 4)

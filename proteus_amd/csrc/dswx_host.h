@@ -19,6 +19,9 @@ struct dswx_ctx {
     size_t partials_bytes = 0;
     // device copy of the lookup tables of the table-driven kernel (rebuilt per call)
     void* tables = nullptr;
+    bool tables_valid = false;             // the device tables match tables_params, built on tables_stream
+    hipStream_t tables_stream = nullptr;
+    alignas(8) unsigned char tables_params[1024] = {};
     // grow-only scratch of 'cover' mode: uncollapsed WTR-2 + pre-snow CLOUD planes
     void* cover = nullptr;
     size_t cover_bytes = 0;

@@ -611,6 +611,7 @@ int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& b, bool masks, 
     if (variant == 4 || variant == 5) {
         if (!ctx->tables) HIP_TRY(hipMalloc(&ctx->tables, sizeof(Tables)));
         tabs = static_cast<Tables*>(ctx->tables);
+        ctx->tables_valid = false;            // rebuilt below on every call: drop the production kernel's cache
         make_lut_consts(b.P, &lc);
         hipLaunchKernelGGL(dswx_build_tables, dim3(4), dim3(256), 0, s, b.P, tabs);
     }
