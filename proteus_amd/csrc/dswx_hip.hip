@@ -666,9 +666,11 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     if (counters && !aligned_to(counters, 8)) return dswx_fail(DSWX_ERR_ALIGN, "counters not 8-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    if (counters && n_tiles > 0)
-        HIP_TRY(hipMemsetAsync(counters, 0, (size_t)n_tiles * 3 * sizeof(int64_t), s));
-    if (n_tiles == 0 || n_pixels == 0) { ctx->last_kernel = "none (empty input)"; return DSWX_OK; }
+    if (n_tiles == 0 || n_pixels == 0) {
+        if (counters && n_tiles > 0) HIP_TRY(hipMemsetAsync(counters, 0, (size_t)n_tiles * 3 * sizeof(int64_t), s));
+        ctx->last_kernel = "none (empty input)";
+        return DSWX_OK;
+    }
     a.in = *in;
     a.out = *out;
     a.counters = reinterpret_cast<unsigned long long*>(counters);
@@ -739,6 +741,10 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         b.px_begin = 0;
         b.partials = nullptr;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
+        // the finishing kernel of the vector path WRITES the counters; only the generic kernel
+        // alone (atomic adds) needs them zeroed first
+        if (groups == 0 && b.counters)
+            HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)nt * 3 * sizeof(int64_t), s));
         if (groups > 0) {
             // 'cover' stage 1 and the browse plane live in the direct kernel only
             const bool plain_outputs = !cover && !b.out.browse;
