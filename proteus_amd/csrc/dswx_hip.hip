@@ -49,6 +49,7 @@
 #include <vector>
 
 #include "dswx_host.h"
+#include "dswx_tables.h"     // transpose4 (byte transposes) for the quad cover kernel
 
 // ------------------------------------------------------------------------------
 // Fused kernel, direct-store variant (the default): block = 256 threads, one
@@ -273,32 +274,45 @@ __global__ __launch_bounds__(256) void dswx_cover_stage2_bits(const KArgs a) {
         s_fin[t] = o.wtr | o.bwtr << 8 | o.conf << 16 | o.cloud << 24;
         s_fbr[t] = (uint8_t)o.browse;
     }
-    // ---- phase A
-    for (int r = wave; r < CB_H; r += 4) {
-        const int y = y0 + r;
-        uint32_t bits[2] = {0u, 0u};          // snow | area << 1 | (area & water) << 2 | clear0 << 3
-        if (y >= 0 && y < H) {
+    // ---- phase A: four rows per wave and iteration, all 24 byte loads issued before the first
+    // ballot consumes one (the loop is latency-bound, not bandwidth-bound)
+    const uint8_t* __restrict__ g_fm = a.in.fmask + tile_base;
+    const uint8_t* __restrict__ g_pc = a.cover_pc + tile_base;
+    const uint8_t* __restrict__ g_w2 = a.cover_w2 + tile_base;
+    for (int r0 = wave; r0 < CB_H; r0 += 16) {
+        uint32_t fm[4][2], pc[4][2], w2[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + r0 + 4 * j;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int x = x0 + 64 * h + lane;
-                if (x >= 0 && x < W) {
-                    const long long off = tile_base + (long long)y * W + x;
-                    const uint32_t fm = a.in.fmask[off], pc = a.cover_pc[off], w2 = a.cover_w2[off];
-                    const uint32_t clear0 = pc == 0u ? 1u : 0u, area = ((fm >> 2) & 1u) & clear0;
-                    const uint32_t water = (w2 - 1u) <= 3u ? 1u : 0u;
-                    bits[h] = ((fm >> 4) & 1u) | area << 1 | (area & water) << 2 | clear0 << 3;
-                }
+                const bool in = (y >= 0) & (y < H) & (x >= 0) & (x < W);
+                const long long off = in ? (long long)y * W + x : 0;
+                fm[j][h] = in ? g_fm[off] : 0u;          // 0 / 1 / 0: no snow, not clear, no water
+                pc[j][h] = in ? g_pc[off] : 1u;
+                w2[j][h] = in ? g_w2[off] : 0u;
             }
         }
-        u64 m[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            m[2 * k] = __ballot((bits[0] >> k) & 1u);
-            m[2 * k + 1] = __ballot((bits[1] >> k) & 1u);
-        }
-        if (lane == 0) {
+        for (int j = 0; j < 4; ++j) {
+            uint32_t bits[2];                     // snow | area << 1 | (area & water) << 2 | clear0 << 3
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s_init[r][k] = m[k];
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t clear0 = pc[j][h] == 0u ? 1u : 0u, area = ((fm[j][h] >> 2) & 1u) & clear0;
+                const uint32_t water = (w2[j][h] - 1u) <= 3u ? 1u : 0u;
+                bits[h] = ((fm[j][h] >> 4) & 1u) | area << 1 | (area & water) << 2 | clear0 << 3;
+            }
+            u64 m[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m[2 * k] = __ballot((bits[0] >> k) & 1u);
+                m[2 * k + 1] = __ballot((bits[1] >> k) & 1u);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s_init[r0 + 4 * j][k] = m[k];
+            }
         }
     }
     __syncthreads();
@@ -321,24 +335,179 @@ __global__ __launch_bounds__(256) void dswx_cover_stage2_bits(const KArgs a) {
     // final snow of the row -> LDS (buffer `buf` was last written two steps ago: free)
     s_x[buf][t + 1][0] = slo & ~clo; s_x[buf][t + 1][1] = shi & ~chi;
     __syncthreads();
-    // ---- phase C
-    for (int r = CB_HALO + wave; r < CB_H - CB_HALO; r += 4) {
-        const int y = y0 + r;
-        if (y >= H) break;
+    // ---- phase C: again four rows per wave and iteration with the loads hoisted
+    for (int r0 = CB_HALO + wave; r0 < CB_H - CB_HALO; r0 += 16) {
+        uint32_t w2[4][2], pc[4][2];
+        bool on[4][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = 64 * h + lane, x = x0 + c;
-            if (c < CB_HALO || c >= CB_W - CB_HALO || x >= W) continue;
-            const uint32_t snow = (uint32_t)(s_x[buf][r + 1][h] >> lane) & 1u;
-            const long long off = tile_base + (long long)y * W + x;
-            const uint32_t w2 = a.cover_w2[off], pc = a.cover_pc[off];
-            const uint32_t idx = (w2 < 5u ? w2 : w2 - 249u) | ((pc & 1u) | ((pc >> 1) & 6u)) << 3 | snow << 6;
-            const uint32_t e = s_fin[idx];
-            if (a.out.wtr) a.out.wtr[off] = (uint8_t)e;
-            if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)(e >> 8);
-            if (a.out.conf) a.out.conf[off] = (uint8_t)(e >> 16);
-            if (a.out.cloud) a.out.cloud[off] = (uint8_t)(e >> 24);
-            if (a.out.browse) a.out.browse[off] = s_fbr[idx];
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + 4 * j, y = y0 + r;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = 64 * h + lane, x = x0 + c;
+                on[j][h] = (r < CB_H - CB_HALO) & (y < H) & (c >= CB_HALO) & (c < CB_W - CB_HALO) & (x < W);
+                const long long off = on[j][h] ? (long long)y * W + x : 0;
+                w2[j][h] = on[j][h] ? g_w2[off] : 0u;
+                pc[j][h] = on[j][h] ? g_pc[off] : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + 4 * j, y = y0 + r;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!on[j][h]) continue;
+                const uint32_t snow = (uint32_t)(s_x[buf][r + 1][h] >> lane) & 1u;
+                const long long off = tile_base + (long long)y * W + x0 + 64 * h + lane;
+                const uint32_t idx = (w2[j][h] < 5u ? w2[j][h] : w2[j][h] - 249u) |
+                                     ((pc[j][h] & 1u) | ((pc[j][h] >> 1) & 6u)) << 3 | snow << 6;
+                const uint32_t e = s_fin[idx];
+                if (a.out.wtr) a.out.wtr[off] = (uint8_t)e;
+                if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)(e >> 8);
+                if (a.out.conf) a.out.conf[off] = (uint8_t)(e >> 16);
+                if (a.out.cloud) a.out.cloud[off] = (uint8_t)(e >> 24);
+                if (a.out.browse) a.out.browse[off] = s_fbr[idx];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// 'cover' mode, stage 2, bit-packed, FOUR pixels per lane (default when rows keep 4-byte
+// alignment: width % 4 == 0, tile stride % 4 == 0, 4-byte aligned planes).  Same window scheme as
+// dswx_cover_stage2_bits (128 x 256, one thread = one window row in phase B) with a column halo
+// of 20 so that every lane's quad is dword-aligned (88 x 222 outputs per block):
+//   phase A  a wave takes TWO rows per step (half-wave each), one dword load per plane and lane,
+//            byte-parallel predicates, ballots -> the row bitmap as 4 x u32 in pixel-interleaved
+//            order: word k, bit l <-> window column 4 l + k
+//   phase B  in that order the horizontal neighbours are plain word moves:
+//            left(k) = word k-1 (k > 0), word 3 << 1 (k = 0);  right(k) = word k+1, word 0 >> 1
+//   phase C  dword loads, four table lookups, byte transpose, dword stores
+// A quarter of the memory instructions and ballots of the byte-lane version per pixel.
+// ------------------------------------------------------------------------------
+constexpr int CQ_HALO_X = 20, CQ_OUT_W = CB_W - 2 * CQ_HALO_X;
+
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {      // 0x01 in every byte of v that is 0
+    return (~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu)) >> 7;
+}
+
+__global__ __launch_bounds__(256) void dswx_cover_stage2_quads(const KArgs a) {
+    __shared__ uint32_t s_init[CB_H][16];     // per row: snow[4], area[4], area & water[4], clear0[4]
+    __shared__ uint32_t s_x[2][CB_H + 2][4];  // row exchange, double-buffered, zero guard rows
+    __shared__ uint32_t s_fin[128];           // WTR | BWTR << 8 | CONF << 16 | CLOUD << 24
+    __shared__ uint8_t s_fbr[128];            // browse
+    const int H = a.height, W = a.width;
+    const long long tile_base = (long long)blockIdx.z * a.tile_stride;
+    const int y0 = blockIdx.y * CB_OUT_H - CB_HALO, x0 = blockIdx.x * CQ_OUT_W - CQ_HALO_X;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = threadIdx.x;
+    const int l32 = lane & 31, rsel = lane >> 5;
+    if (t < 16) s_x[t >> 3][((t >> 2) & 1) ? CB_H + 1 : 0][t & 3] = 0;
+    if (t < 128) {
+        const uint32_t c = t & 7u, b = (t >> 3) & 7u;
+        PxOut o;
+        finish_px(a.P, c < 5u ? c : (c == 5u ? 254u : 255u), (b & 1u) | ((b & 6u) << 1), (t >> 6) != 0, o);
+        s_fin[t] = o.wtr | o.bwtr << 8 | o.conf << 16 | o.cloud << 24;
+        s_fbr[t] = (uint8_t)o.browse;
+    }
+    const uint8_t* __restrict__ g_fm = a.in.fmask + tile_base;
+    const uint8_t* __restrict__ g_pc = a.cover_pc + tile_base;
+    const uint8_t* __restrict__ g_w2 = a.cover_w2 + tile_base;
+    const int x = x0 + 4 * l32;
+    const bool x_in = (x >= 0) & (x < W);                 // W % 4 == 0: a quad is inside or outside as a whole
+    // ---- phase A: row pairs p = wave + 4 i (rows 2p, 2p + 1), four pairs per iteration
+    for (int p0 = wave; p0 < CB_H / 2; p0 += 16) {
+        uint32_t fm[4], pc[4], w2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + 2 * (p0 + 4 * j) + rsel;
+            const bool in = x_in & (y >= 0) & (y < H);
+            const long long off = in ? (long long)y * W + x : 0;
+            fm[j] = in ? *reinterpret_cast<const uint32_t*>(g_fm + off) : 0u;
+            pc[j] = in ? *reinterpret_cast<const uint32_t*>(g_pc + off) : 0x01010101u;   // not clear
+            w2[j] = in ? *reinterpret_cast<const uint32_t*>(g_w2 + off) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t snow4 = (fm[j] >> 4) & 0x01010101u, clear4 = zero_bytes(pc[j]);
+            const uint32_t area4 = (fm[j] >> 2) & clear4;                       // clear4 is 0 / 1 per byte
+            // WTR-2 uncollapsed is one of 0..4, 254, 255: water classes are the nonzero bytes below 8
+            const uint32_t water4 = zero_bytes(w2[j] & 0xf8f8f8f8u) & ~zero_bytes(w2[j]);
+            const uint32_t m4[4] = {snow4, area4, area4 & water4, clear4};
+            const int row = 2 * (p0 + 4 * j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long bal = __ballot((m4[q] >> (8 * k)) & 1u);
+                    if (lane == 0) s_init[row][4 * q + k] = (uint32_t)bal;
+                    if (lane == 1) s_init[row + 1][4 * q + k] = (uint32_t)(bal >> 32);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: thread t owns window row t
+    uint32_t S[4], A[4], Wm[4], C0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { S[k] = s_init[t][k]; A[k] = s_init[t][4 + k]; Wm[k] = s_init[t][8 + k]; C0[k] = s_init[t][12 + k]; }
+    int buf = 0;
+    auto step = [&](uint32_t (&X)[4], const uint32_t (&M)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_x[buf][t + 1][k] = X[k];
+        __syncthreads();
+        uint32_t n[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) n[k] = X[k] | s_x[buf][t][k] | s_x[buf][t + 2][k];
+        n[0] |= (X[3] << 1) | X[1];
+        n[1] |= X[0] | X[2];
+        n[2] |= X[1] | X[3];
+        n[3] |= X[2] | (X[0] >> 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] |= n[k] & M[k];
+        buf ^= 1;
+    };
+    for (int it = 0; it < 10; ++it) step(S, A);
+    uint32_t C[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) C[k] = ~S[k] & C0[k];
+    for (int it = 0; it < 7; ++it) step(C, Wm);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_x[buf][t + 1][k] = S[k] & ~C[k];      // final snow of the row
+    __syncthreads();
+    // ---- phase C: row pairs again; output columns 20..107 = quads 5..26
+    const bool x_out = x_in & (l32 >= CQ_HALO_X / 4) & (l32 < (CB_W - CQ_HALO_X) / 4);
+    for (int p0 = wave; p0 < CB_H / 2; p0 += 16) {
+        uint32_t w2[4], pc[4];
+        bool on[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 2 * (p0 + 4 * j) + rsel, y = y0 + r;
+            on[j] = x_out & (r >= CB_HALO) & (r < CB_H - CB_HALO) & (y < H);
+            const long long off = on[j] ? (long long)y * W + x : 0;
+            w2[j] = on[j] ? *reinterpret_cast<const uint32_t*>(g_w2 + off) : 0u;
+            pc[j] = on[j] ? *reinterpret_cast<const uint32_t*>(g_pc + off) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!on[j]) continue;
+            const int r = 2 * (p0 + 4 * j) + rsel;
+            uint32_t e[4], br = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t snow = (s_x[buf][r + 1][k] >> l32) & 1u;
+                const uint32_t w = (w2[j] >> (8 * k)) & 0xffu, c = (pc[j] >> (8 * k)) & 0xffu;
+                const uint32_t idx = (w < 5u ? w : w - 249u) | ((c & 1u) | ((c >> 1) & 6u)) << 3 | snow << 6;
+                e[k] = s_fin[idx];
+                br |= (uint32_t)s_fbr[idx] << (8 * k);
+            }
+            uint32_t planes[4];            // byte k of every e -> plane k, pixel order
+            transpose4(e, planes);
+            const long long off = tile_base + (long long)(y0 + r) * W + x;
+            if (a.out.wtr) *reinterpret_cast<uint32_t*>(a.out.wtr + off) = planes[0];
+            if (a.out.bwtr) *reinterpret_cast<uint32_t*>(a.out.bwtr + off) = planes[1];
+            if (a.out.conf) *reinterpret_cast<uint32_t*>(a.out.conf + off) = planes[2];
+            if (a.out.cloud) *reinterpret_cast<uint32_t*>(a.out.cloud + off) = planes[3];
+            if (a.out.browse) *reinterpret_cast<uint32_t*>(a.out.browse + off) = br;
         }
     }
 }
@@ -819,18 +988,29 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             if (c2.out.conf) c2.out.conf += shift;
             if (c2.out.cloud) c2.out.cloud += shift;
             if (c2.out.browse) c2.out.browse += shift;
-            const bool bitmaps = ctx->cover_kernel != 0;
-            const int tw = bitmaps ? CB_OUT_W : CV_TILE, th = bitmaps ? CB_OUT_H : CV_TILE;
+            // stage-2 kernel: 2 = bitmaps with four pixels per lane (needs dword-aligned rows),
+            // 1 = bitmaps with one pixel per lane, 0 = byte cells; env DSWX_COVER_KERNEL caps the choice
+            int ck = ctx->cover_kernel;
+            if (ck >= 2) {
+                bool quad_ok = width % 4 == 0 && (tile_stride % 4 == 0 || n_tiles == 1) && aligned_to(c2.in.fmask, 4) &&
+                               aligned_to(c2.cover_w2, 4) && aligned_to(c2.cover_pc, 4);
+                uint8_t* const outs[5] = {c2.out.wtr, c2.out.bwtr, c2.out.conf, c2.out.cloud, c2.out.browse};
+                for (uint8_t* o : outs) quad_ok = quad_ok && (!o || aligned_to(o, 4));
+                ck = quad_ok ? 2 : 1;
+            }
+            const int tw = ck == 2 ? CQ_OUT_W : (ck == 1 ? CB_OUT_W : CV_TILE), th = ck ? CB_OUT_H : CV_TILE;
             dim3 grid((unsigned)((width + tw - 1) / tw), (unsigned)((height + th - 1) / th), (unsigned)nt);
             if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
             if (c2.out.wtr || c2.out.bwtr || c2.out.conf || c2.out.cloud || c2.out.browse) {
-                if (bitmaps) hipLaunchKernelGGL(dswx_cover_stage2_bits, grid, dim3(256), 0, s, c2);
+                if (ck == 2) hipLaunchKernelGGL(dswx_cover_stage2_quads, grid, dim3(256), 0, s, c2);
+                else if (ck == 1) hipLaunchKernelGGL(dswx_cover_stage2_bits, grid, dim3(256), 0, s, c2);
                 else hipLaunchKernelGGL(dswx_cover_stage2, grid, dim3(256), 0, s, c2);
                 HIP_TRY(hipGetLastError());
             }
             const size_t len = strlen(info);
             snprintf(info + len, sizeof info - len, " + %s grid=(%u,%u,%u)",
-                     bitmaps ? "dswx_cover_stage2_bits" : "dswx_cover_stage2", grid.x, grid.y, grid.z);
+                     ck == 2 ? "dswx_cover_stage2_quads" : (ck == 1 ? "dswx_cover_stage2_bits" : "dswx_cover_stage2"),
+                     grid.x, grid.y, grid.z);
         }
         if (any_index) {
             dim3 grid((unsigned)((n_pixels + 255) / 256), (unsigned)nt), block(256);

@@ -31,7 +31,8 @@ struct dswx_ctx {
                pipe_out[3] = {nullptr, nullptr, nullptr};
     int64_t* pipe_counters = nullptr;      // hipHostMalloc, [pipe_counters_cap][3]
     size_t pipe_counters_cap = 0;
-    int cover_kernel = 1;                  // 'cover' stage 2: 1 bit-packed (default), 0 byte cells (env DSWX_COVER_KERNEL)
+    int cover_kernel = 2;                  // 'cover' stage 2: 2 bitmaps, 4 px per lane where rows are dword-aligned (default),
+                                           // 1 bitmaps, 1 px per lane, 0 byte cells (env DSWX_COVER_KERNEL)
     int host_pipeline = 1;                 // env DSWX_HOST_PIPELINE=0 forces the synchronous path
     int host_chunks = 8;                   // env DSWX_HOST_CHUNKS: pieces per tile of the pipelined path
     std::string last_kernel;

@@ -459,29 +459,33 @@ def blobby_fmask(fmask, seed):
 
 
 @pytest.fixture(scope='module')
-def ctx_cover_bytes():
-    """Context running the byte-cell 'cover' stage 2 (the bit-packed kernel is the default)."""
+def cover_contexts():
+    """Contexts pinned to each 'cover' stage-2 kernel: 2 = bitmaps, four pixels per lane (default where
+    rows are dword-aligned), 1 = bitmaps, one pixel per lane, 0 = byte cells."""
     import os
+    made = {}
     old = os.environ.get('DSWX_COVER_KERNEL')
-    os.environ['DSWX_COVER_KERNEL'] = '0'
     try:
-        c = _capi.Context(0)
+        for k in ('2', '1', '0'):
+            os.environ['DSWX_COVER_KERNEL'] = k
+            made[k] = _capi.Context(0)
     finally:
         if old is None:
             os.environ.pop('DSWX_COVER_KERNEL')
         else:
             os.environ['DSWX_COVER_KERNEL'] = old
-    yield c
-    c.close()
+    yield made
+    for c in made.values():
+        c.close()
 
 
-# window of the bit-packed kernel: 94 x 222 outputs per block -> sizes on and around its seams
-@pytest.mark.parametrize('shape', [(1, 1), (7, 9), (64, 64), (65, 63), (100, 37), (160, 160),
-                                   (333, 517), (222, 94), (223, 95), (445, 189), (500, 300)])
+# windows: 94 x 222 outputs per block (one pixel per lane), 88 x 222 (four) -> sizes on and around the seams
+@pytest.mark.parametrize('shape', [(1, 1), (7, 9), (64, 64), (65, 63), (100, 37), (160, 160), (333, 517),
+                                   (222, 94), (223, 95), (445, 189), (500, 300), (222, 88), (223, 92), (450, 180)])
 @pytest.mark.parametrize('masks', [False, True])
-@pytest.mark.parametrize('kernel', ['bits', 'bytes'])
-def test_cover_mode_vs_numpy_oracle(ctx, ctx_cover_bytes, shape, masks, kernel):
-    ctx = ctx if kernel == 'bits' else ctx_cover_bytes
+@pytest.mark.parametrize('kernel', ['2', '1', '0'])
+def test_cover_mode_vs_numpy_oracle(cover_contexts, shape, masks, kernel):
+    ctx = cover_contexts[kernel]
     h, w = shape
     s = synth_tile(900 + h, h, w, with_masks=True)
     fmask = blobby_fmask(s['fmask'], h * 1000 + w)
@@ -489,8 +493,9 @@ def test_cover_mode_vs_numpy_oracle(ctx, ctx_cover_bytes, shape, masks, kernel):
     for collapse in (True, False):
         p = _capi.make_params(mask_adjacent_to_cloud_mode='cover', collapse_wtr_classes=collapse)
         got = ctx.classify_host(s['bands'], fmask, p, land=land, shad=shad, ocean=ocean)
-        assert ('dswx_cover_stage2_bits' in ctx.last_kernel_info()) == (kernel == 'bits')
-        assert 'dswx_cover_stage2' in ctx.last_kernel_info()
+        want = {'2': 'dswx_cover_stage2_quads' if w % 4 == 0 else 'dswx_cover_stage2_bits',
+                '1': 'dswx_cover_stage2_bits', '0': 'dswx_cover_stage2 '}[kernel]
+        assert want in ctx.last_kernel_info(), ctx.last_kernel_info()
         exp = o.classify_tile(s['bands'], fmask, landcover=land, shadow=shad, ocean_mask=ocean,
                               mask_adjacent_to_cloud_mode='cover', collapse=collapse)
         for layer, key in NAME.items():
