@@ -34,6 +34,8 @@ def parse_args():
                     help='also stream LAND/SHAD/OCEAN planes (BASELINE config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-single-tile', action='store_true',
+                    help='skip the configs[1] leg (profiling runs: keeps the kernel statistics to the batch launches)')
     ap.add_argument('--cpu-parallel-worker', type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -262,7 +264,7 @@ def main():
                          'traffic_source': pmc_note},
             'parity_check': parity,
         }
-        if world == 1:
+        if world == 1 and not args.no_single_tile:
             try:
                 out['single_tile'] = single_tile_leg(ctx, params, args.masks)
             except Exception as e:

@@ -46,12 +46,22 @@ def main():
     stats = one(os.path.join(a.src, 'trace', '**', '*kernel_stats.csv'))
     shutil.copy(stats, os.path.join(out, f'{tag}_kernel_stats.csv'))
     krow = next(r for r in csv.DictReader(open(stats)) if a.kernel in r['Name'])
+    # the bench also launches the kernel on ONE tile (single_tile leg): keep only the dispatches of the
+    # full batch, i.e. those with the largest grid, taken from the per-dispatch trace
+    trace = one(os.path.join(a.src, 'trace', '**', '*kernel_trace.csv'))
+    disp = [r for r in csv.DictReader(open(trace)) if a.kernel in r['Kernel_Name']]
+    gmax = max(int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) for r in disp)
+    durs = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in disp
+            if int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) == gmax]
+    krow = dict(krow, Calls=len(durs), AverageNs=sum(durs) / len(durs), MinNs=min(durs), MaxNs=max(durs))
     rows = []
     vals = {}
     for ctr, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
         f = one(os.path.join(a.src, sub, '**', '*counter_collection.csv'))
         sel = [r for r in csv.DictReader(open(f))
                if a.kernel in r['Kernel_Name'] and r['Counter_Name'] == ctr]
+        big = max(int(r['Grid_Size']) for r in sel)
+        sel = [r for r in sel if int(r['Grid_Size']) == big]          # full-batch dispatches only
         rows += sel
         vals[ctr] = [float(r['Counter_Value']) for r in sel]
     keep = ['Dispatch_Id', 'Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'LDS_Block_Size',
@@ -89,8 +99,10 @@ def main():
                       key=os.path.getmtime)
     if sq_files:
         acc = {}
-        for r in csv.DictReader(open(sq_files[-1])):
-            if a.kernel in r['Kernel_Name']:
+        rows_sq = [r for r in csv.DictReader(open(sq_files[-1])) if a.kernel in r['Kernel_Name']]
+        big = max(int(r['Grid_Size']) for r in rows_sq)
+        for r in rows_sq:
+            if int(r['Grid_Size']) == big:
                 acc.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
         sq = {k: sum(v) / len(v) for k, v in acc.items()}
         wc = sq.get('SQ_WAVE_CYCLES')
