@@ -12,15 +12,19 @@
 #include "dswx_host.h"
 #include "dswx_tables.h"
 
-// LUT_CHUNKS: 2048-px chunks per block (amortises the table load); WPS: launch bound
-template <bool MASKS, int LUT_CHUNKS, int WPS>
+// WPS: launch bound.  EXTRAS: also the browse plane and the stage-1 planes of 'cover' mode
+// (uncollapsed WTR-2, CLOUD before the snow step), looked up in Tables::extra.
+template <bool MASKS, bool EXTRAS, int WPS>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
                                                              const Tables* __restrict__ tabs) {
+    constexpr int LUT_CHUNKS = 1;
     constexpr int N_CHAIN = MASKS ? 1024 : 128;
     __shared__ uint32_t s_lut1[128];
     __shared__ uint16_t s_fm16[256];
     __shared__ uint8_t s_land8[MASKS ? 256 : 4];
     __shared__ uint2 s_chain[N_CHAIN];
+    __shared__ uint32_t s_extra[EXTRAS ? N_CHAIN : 1];
+    if (EXTRAS) for (int i = threadIdx.x; i < N_CHAIN; i += 256) s_extra[i] = tabs->extra[i];
     for (int i = threadIdx.x; i < 128; i += 256) s_lut1[i] = tabs->lut1[i];
     for (int i = threadIdx.x; i < 128; i += 256) reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
     if (MASKS) for (int i = threadIdx.x; i < 64; i += 256) reinterpret_cast<uint32_t*>(s_land8)[i] = reinterpret_cast<const uint32_t*>(tabs->land8)[i];
@@ -53,7 +57,20 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
             }
         }
         uint32_t w1w[8], chx[8], chy[8];      // per-pixel table words
-        lut_group<MASKS>(P, C, s_lut1, s_fm16, s_land8, s_chain, v, vf, vl, vs, vo, has_l, in_range, w1w, chx, chy, cnt);
+        uint32_t idx2[EXTRAS ? 8 : 1];
+        lut_group<MASKS, EXTRAS>(P, C, s_lut1, s_fm16, s_land8, s_chain, v, vf, vl, vs, vo, has_l, in_range, w1w, chx,
+                                 chy, cnt, idx2);
+        if (EXTRAS && in_range) {
+            uint32_t ex[8], pa[4], pb[4];     // byte 0 WTR-2 uncollapsed, 1 CLOUD pre-snow, 2 browse
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ex[j] = s_extra[idx2[j]];
+            transpose4(ex, pa); transpose4(ex + 4, pb);
+            if (a.cover_w2) {
+                stg<u32x2, false>(a.cover_w2 + off, u32x2{pa[0], pb[0]});     // re-read by stage 2: cacheable
+                stg<u32x2, false>(a.cover_pc + off, u32x2{pa[1], pb[1]});
+            }
+            if (a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{pa[2], pb[2]});
+        }
         if (in_range) {
             GroupPlanes gp;
             lut_pack(w1w, chx, chy, gp);
@@ -79,15 +96,13 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
 }
 
 void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, int* threads, long long* gx) {
-    const int lut_chunks = (ctx->tune_chunks == 1 || ctx->tune_chunks == 4) ? ctx->tune_chunks : 1;
+    (void)ctx;
     *threads = 256;
-    const long long per_block = 256LL * lut_chunks;
-    *gx = (groups + per_block - 1) / per_block;
+    *gx = (groups + 255) / 256;
 }
 
 int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 block, hipStream_t s, char* info,
                     size_t info_len) {
-    const int lut_chunks = (ctx->tune_chunks == 1 || ctx->tune_chunks == 4) ? ctx->tune_chunks : 1;
     if (!ctx->tables) HIP_TRY(hipMalloc(&ctx->tables, sizeof(Tables)));
     Tables* tabs = static_cast<Tables*>(ctx->tables);
     LutConsts lc;
@@ -105,11 +120,13 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
     // with LAND / SHAD / OCEAN (5 and 6 spill to scratch there; without masks they give 67 VGPRs
     // and measure 0-2 % slower than 4)
     const int wps = ctx->tune_lut_wps > 0 ? ctx->tune_lut_wps : 4;
-#define LUT_LAUNCH(M, CH, W) hipLaunchKernelGGL((dswx_classify_lut<M, CH, W>), grid, block, 0, s, b, lc, tabs)
-#define LUT_SEL_W(M, CH) do { if (wps >= 6) LUT_LAUNCH(M, CH, 6); else if (wps == 5) LUT_LAUNCH(M, CH, 5); else LUT_LAUNCH(M, CH, 4); } while (0)
-#define LUT_SEL_C(M) do { if (lut_chunks == 4) LUT_SEL_W(M, 4); else LUT_SEL_W(M, 1); } while (0)
-    if (masks) LUT_SEL_C(true); else LUT_SEL_C(false);
-    snprintf(info, info_len, "dswx_classify_lut<%s> (table-driven) grid=(%lld,%lld) block=256 chunks=%d wps=%d",
-             masks ? "true" : "false", (long long)grid.x, (long long)grid.y, lut_chunks, wps);
+    const bool extras = b.out.browse || b.cover_w2;
+#define LUT_LAUNCH(M, E, W) hipLaunchKernelGGL((dswx_classify_lut<M, E, W>), grid, block, 0, s, b, lc, tabs)
+#define LUT_SEL_W(M, E) do { if (wps >= 6) LUT_LAUNCH(M, E, 6); else if (wps == 5) LUT_LAUNCH(M, E, 5); else LUT_LAUNCH(M, E, 4); } while (0)
+    if (extras) { if (masks) LUT_LAUNCH(true, true, 4); else LUT_LAUNCH(false, true, 4); }
+    else if (masks) LUT_SEL_W(true, false);
+    else LUT_SEL_W(false, false);
+    snprintf(info, info_len, "dswx_classify_lut<%s%s> (table-driven) grid=(%lld,%lld) block=256 wps=%d",
+             masks ? "true" : "false", extras ? ",extras" : "", (long long)grid.x, (long long)grid.y, extras ? 4 : wps);
     return DSWX_OK;
 }

@@ -772,7 +772,6 @@ int dswx_ctx_create(int device, dswx_ctx_t** out) {
         c->fused_variant = (v >= 0 && v <= 5) ? v : -1;
     }
     if (const char* e = std::getenv("DSWX_TUNE_WPS")) c->tune_wps = std::atoi(e);
-    if (const char* e = std::getenv("DSWX_TUNE_CHUNKS")) c->tune_chunks = std::atoi(e);
     if (const char* e = std::getenv("DSWX_TUNE_ABLATE")) c->tune_ablate = std::atoi(e);
     if (const char* e = std::getenv("DSWX_TUNE_PIPE_BLOCKS")) c->tune_pipe_blocks = std::atoi(e);
     if (const char* e = std::getenv("DSWX_TUNE_LUT_WPS")) c->tune_lut_wps = std::atoi(e);
@@ -915,15 +914,16 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         if (groups == 0 && b.counters)
             HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)nt * 3 * sizeof(int64_t), s));
         if (groups > 0) {
-            // 'cover' stage 1 and the browse plane live in the direct kernel only
+            // 'cover' stage 1 and the browse plane: the direct kernel or the table-driven one (3), not
+            // the experimental structures
             const bool plain_outputs = !cover && !b.out.browse;
             // automatic choice: the table-driven kernel when every tile of every plane starts on
             // a 256-byte boundary (6.1 vs 5.5 TB/s there), the direct kernel otherwise (5.4 vs 5.1)
             int vsel = ctx->fused_variant;
-            if (vsel < 0) vsel = (aligned256 && plain_outputs) ? 3 : 0;
+            if (vsel < 0) vsel = aligned256 ? 3 : 0;
             // the LDS-DMA variants (2, 4, 5) move 16 pixels per lane of the u8 planes
             const bool dma16_ok = (n_pixels & 15) == 0 || vsel == 1 || vsel == 3;
-            const bool variant = vsel != 0 && plain_outputs && dma16_ok;
+            const bool variant = vsel != 0 && (plain_outputs || vsel == 3) && dma16_ok;
             int threads = 256;
             long long gx_ll = (groups + 255) / 256;
             if (variant && vsel == 3) dswx_lut_geometry(ctx, groups, &threads, &gx_ll);

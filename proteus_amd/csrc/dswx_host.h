@@ -44,7 +44,6 @@ struct dswx_ctx {
                              // 5: persistent double-buffered pipeline of 4
     int tune_pipe_blocks = 512;   // persistent pipeline: total blocks (env DSWX_TUNE_PIPE_BLOCKS)
     int tune_ablate = 0;     // diagnostic ablation level of variant 4 (env DSWX_TUNE_ABLATE; outputs invalid)
-    int tune_chunks = 1;     // table-driven kernel: chunks per block (env DSWX_TUNE_CHUNKS: 1, 4)
     int tune_lut_wps = 0;    // table-driven kernel: launch bound (env DSWX_TUNE_LUT_WPS: 4, 5, 6; 0 = automatic)
     int tune_wps = 6;        // launch-bound variant of the plain kernel (env DSWX_TUNE_WPS: 4, 6, 8)
 };

@@ -26,6 +26,8 @@ struct Tables {
     uint2 chain[1024];     // [code | remap<<3 | shadow<<4 | cloud<<5 | snow<<6 | shadrule<<7 |
                            //  lcpsw<<8 | lchigh<<9] -> x = WTR-1-AEROSOL | WTR-2<<8 | WTR<<16 | BWTR<<24,
                            //                           y = CONF | CLOUD<<8 | valid<<16 | cloud_and_valid<<24
+    uint32_t extra[1024];  // same index -> WTR-2 uncollapsed | CLOUD before the snow step << 8 (stage 1 of
+                           //               'cover' mode) | browse << 16; read only by the EXTRAS kernels
 };
 // WTR-1 "code": 0..4 = class, 5 = ocean masked (254), 6 = fill (255)
 
@@ -56,6 +58,7 @@ static __global__ __launch_bounds__(256) void dswx_build_tables(const DevParams 
         const uint32_t valid = code < 5u ? 1u : 0u, pc_nz = ((i >> 4) | (i >> 5)) & 1u;
         t->chain[i] = make_uint2(o.wtr1a | o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24,
                                  o.conf | o.cloud << 8 | valid << 16 | (valid & pc_nz) << 24);
+        t->extra[i] = o.w2_raw | o.pc << 8 | o.browse << 16;
     }
 }
 
@@ -99,12 +102,13 @@ __device__ __forceinline__ void transpose4(const uint32_t a[4], uint32_t out[4])
 // The table-driven classification of one 8-pixel group held in registers.  Leaves, per
 // pixel j, the three table words (w1w: DIAG | code | WTR-1; chx: WTR-1-AEROSOL, WTR-2, WTR,
 // BWTR; chy: CONF, CLOUD) and adds the group's coverage counts to `cnt`.
-template <bool MASKS>
+template <bool MASKS, bool WANT_IDX = false>
 __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C, const uint32_t* __restrict__ s_lut1,
                                           const uint16_t* __restrict__ s_fm16, const uint8_t* __restrict__ s_land8,
                                           const uint2* __restrict__ s_chain, const u32x4 (&v)[6], const u32x2 vf,
                                           const u32x2 vl, const u32x2 vs, const u32x2 vo, bool has_l, bool in_range,
-                                          uint32_t (&w1w)[8], uint32_t (&chx)[8], uint32_t (&chy)[8], uint32_t& cnt) {
+                                          uint32_t (&w1w)[8], uint32_t (&chx)[8], uint32_t (&chy)[8], uint32_t& cnt,
+                                          uint32_t* idx_out = nullptr) {
         uint32_t gsum = 0;
 #pragma unroll
         for (int wd = 0; wd < 4; ++wd) {
@@ -168,6 +172,7 @@ __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C
                 }
                 const uint2 ch = s_chain[idx2];
                 w1w[j] = word1; chx[j] = ch.x; chy[j] = ch.y;
+                if (WANT_IDX) idx_out[j] = idx2;             // chain index, for Tables::extra
                 gsum += ch.y >> 16;                  // A3: valid | cloud_and_valid << 8, from the table
             }
         }
