@@ -3,9 +3,9 @@
 //
 // Block = 256 threads = 2048 consecutive pixels of one tile (grid.y = tile); each thread owns one
 // 8-pixel group: 6 x 16-B + 1 x 8-B non-temporal loads (+ 3 x 8 B with LAND / SHAD / OCEAN),
-// 1 x 16-B + 6 x 8-B non-temporal stores.  The tables (2.3 KiB; 9.5 KiB with masks) are
-// rebuilt on the device for every call by dswx_build_tables from the same px_w1 / px_chain
-// the scalar kernel uses and copied into LDS by every block.
+// 1 x 16-B + 6 x 8-B non-temporal stores.  The tables (2 KiB; 2.5 KiB with masks) are built on
+// the device by dswx_build_tables from the same px_w1 / px_chain / finish_px the scalar kernel
+// uses (rebuilt when the parameters change) and copied into LDS by every block.
 #include <cstdio>
 #include <cstring>
 
@@ -18,17 +18,25 @@ template <bool MASKS, bool EXTRAS, int WPS>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
                                                              const Tables* __restrict__ tabs) {
     constexpr int LUT_CHUNKS = 1;
-    constexpr int N_CHAIN = MASKS ? 1024 : 128;
     __shared__ uint32_t s_lut1[128];
     __shared__ uint16_t s_fm16[256];
     __shared__ uint8_t s_land8[MASKS ? 256 : 4];
-    __shared__ uint2 s_chain[N_CHAIN];
-    __shared__ uint32_t s_extra[EXTRAS ? N_CHAIN : 1];
-    if (EXTRAS) for (int i = threadIdx.x; i < N_CHAIN; i += 256) s_extra[i] = tabs->extra[i];
-    for (int i = threadIdx.x; i < 128; i += 256) s_lut1[i] = tabs->lut1[i];
-    for (int i = threadIdx.x; i < 128; i += 256) reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
-    if (MASKS) for (int i = threadIdx.x; i < 64; i += 256) reinterpret_cast<uint32_t*>(s_land8)[i] = reinterpret_cast<const uint32_t*>(tabs->land8)[i];
-    for (int i = threadIdx.x; i < N_CHAIN; i += 256) s_chain[i] = tabs->chain[i];
+    __shared__ uint16_t s_pre16[MASKS ? 128 : 2];
+    __shared__ uint2 s_chain[128];
+    __shared__ uint32_t s_extra[EXTRAS ? 128 : 1];
+    {   // 2 KiB of tables (2.5 KiB with masks) per block: one element per thread and table
+        const int i = threadIdx.x;
+        if (i < 128) {
+            s_lut1[i] = tabs->lut1[i];
+            reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
+            s_chain[i] = MASKS ? tabs->chainm[i] : tabs->chain[i];
+            if (EXTRAS) s_extra[i] = MASKS ? tabs->extram[i] : tabs->extra[i];
+        } else if (MASKS) {
+            const int k = i - 128;
+            if (k < 64) reinterpret_cast<uint32_t*>(s_land8)[k] = reinterpret_cast<const uint32_t*>(tabs->land8)[k];
+            else reinterpret_cast<uint32_t*>(s_pre16)[k - 64] = reinterpret_cast<const uint32_t*>(tabs->pre16)[k - 64];
+        }
+    }
     __syncthreads();
 
     const DevParams& P = a.P;
@@ -58,8 +66,8 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         }
         uint32_t w1w[8], chx[8], chy[8];      // per-pixel table words
         uint32_t idx2[EXTRAS ? 8 : 1];
-        lut_group<MASKS, EXTRAS>(P, C, s_lut1, s_fm16, s_land8, s_chain, v, vf, vl, vs, vo, has_l, in_range, w1w, chx,
-                                 chy, cnt, idx2);
+        lut_group<MASKS, EXTRAS>(P, C, s_lut1, s_fm16, s_land8, s_chain, s_pre16, v, vf, vl, vs, vo, has_l, in_range,
+                                 w1w, chx, chy, cnt, idx2);
         if (EXTRAS && in_range) {
             uint32_t ex[8], pa[4], pb[4];     // byte 0 WTR-2 uncollapsed, 1 CLOUD pre-snow, 2 browse
 #pragma unroll

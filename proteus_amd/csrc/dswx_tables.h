@@ -23,23 +23,51 @@ struct Tables {
     uint16_t fm16[256];    // Fmask byte -> aerosol class bits(5) | shadow<<5 | cloud<<6 | snow<<7
                            //   | is_fill<<8 | prelim_cloud_nonzero<<9
     uint8_t land8[256];    // LAND byte -> is_water(200) | psw_rule_class(201 or <100)<<1 | high_dev<<2
-    uint2 chain[1024];     // [code | remap<<3 | shadow<<4 | cloud<<5 | snow<<6 | shadrule<<7 |
-                           //  lcpsw<<8 | lchigh<<9] -> x = WTR-1-AEROSOL | WTR-2<<8 | WTR<<16 | BWTR<<24,
-                           //                           y = CONF | CLOUD<<8 | valid<<16 | cloud_and_valid<<24
-    uint32_t extra[1024];  // same index -> WTR-2 uncollapsed | CLOUD before the snow step << 8 (stage 1 of
-                           //               'cover' mode) | browse << 16; read only by the EXTRAS kernels
+    // without LAND / SHAD planes (WTR-2 = WTR-1-AEROSOL): one lookup
+    uint2 chain[128];      // [code | remap<<3 | shadow<<4 | cloud<<5 | snow<<6]
+                           //   -> x = WTR-1-AEROSOL | WTR-2<<8 | WTR<<16 | BWTR<<24,
+                           //      y = CONF | CLOUD<<8 | valid<<16 | cloud_and_valid<<24
+    uint32_t extra[128];   // same index -> WTR-2 uncollapsed | CLOUD before the snow step << 8 (stage 1 of
+                           //   'cover' mode) | browse << 16; read only by the EXTRAS kernels
+    // with LAND / SHAD planes the chain factors at WTR-2 into two 128-entry lookups (2.5 KiB of
+    // tables per block instead of the 9.5 KiB of a flat 1024-entry table, whose per-block load
+    // cost 5 % of the kernel):
+    uint16_t pre16[128];   // [code | remap<<3 | shadrule<<4 | lcpsw<<5 | lchigh<<6]
+                           //   -> WTR-1-AEROSOL as saved | WTR-2 code << 8
+    uint2 chainm[128];     // [WTR-2 code | remap<<3 | shadow<<4 | cloud<<5 | snow<<6] -> x, y as `chain`
+                           //   (byte 0 of x unused: WTR-1-AEROSOL comes from pre16)
+    uint32_t extram[128];  // same index as chainm, content as `extra`
 };
-// WTR-1 "code": 0..4 = class, 5 = ocean masked (254), 6 = fill (255)
+// WTR-1 / WTR-2 "code": 0..4 = class, 5 = ocean masked (254), 6 = fill (255)
 
 static __global__ __launch_bounds__(256) void dswx_build_tables(const DevParams P, Tables* __restrict__ t) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t cc = (uint32_t)P.collapse;
+    auto class_of = [](uint32_t code) { return code <= 4u ? code : (code == 5u ? 254u : 255u); };
+    auto code_of = [](uint32_t cls) { return cls <= 4u ? cls : (cls == 254u ? 5u : 6u); };
     if (i < 128) {
         const uint32_t dd = (uint32_t)(i & 3) | ((((uint32_t)i >> 2) & 1u) ^ 1u) << 2 | (((uint32_t)i >> 3) & 3u) << 3;
         uint32_t diag, w1;
         px_w1(dd, (i >> 5) & 1, (i >> 6) & 1, diag, w1);
-        const uint32_t code = w1 <= 4u ? w1 : (w1 == 254u ? 5u : 6u);
-        t->lut1[i] = diag | (code << 16) | (collapse_class(w1, cc) << 24);
+        t->lut1[i] = diag | (code_of(w1) << 16) | (collapse_class(w1, cc) << 24);
+        // y bits 16 / 24: the pixel's contributions to n_valid and n_cloud_and_valid (A3)
+        const uint32_t code = i & 7, remap = (i >> 3) & 1, shadow = (i >> 4) & 1, cloud = (i >> 5) & 1, snow = (i >> 6) & 1;
+        const uint32_t valid = code < 5u ? 1u : 0u, pc_nz = shadow | cloud;
+        PxOut o;
+        px_chain(P, class_of(code), remap, shadow + 4u * cloud, snow, false, false, false, o);
+        t->chain[i] = make_uint2(o.wtr1a | o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24,
+                                 o.conf | o.cloud << 8 | valid << 16 | (valid & pc_nz) << 24);
+        t->extra[i] = o.w2_raw | o.pc << 8 | o.browse << 16;
+        // first factor: here bits 4..6 of i are the three LAND / SHAD rule hits
+        px_chain(P, class_of(code), remap, 0u, false, (i >> 4) & 1, (i >> 5) & 1, (i >> 6) & 1, o);
+        t->pre16[i] = (uint16_t)(o.wtr1a | code_of(o.w2_raw) << 8);
+        // second factor: `code` is now the WTR-2 code; the aerosol flag of CLOUD (bit 3) needs the
+        // remap bit again (do_remap = remap & class <= 4, and A10 never leaves or enters 0..4)
+        const uint32_t w2 = class_of(code), pc = (shadow + 4u * cloud) | ((remap && code < 5u) ? 8u : 0u);
+        finish_px(P, w2, pc, snow, o);
+        t->chainm[i] = make_uint2(o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24,
+                                  o.conf | o.cloud << 8 | valid << 16 | (valid & pc_nz) << 24);
+        t->extram[i] = w2 | pc << 8 | o.browse << 16;
     }
     if (i < 256) {
         const uint32_t aer = (P.aer_lut[i >> 2] >> (8 * (i & 3))) & 0x1fu;
@@ -47,18 +75,6 @@ static __global__ __launch_bounds__(256) void dswx_build_tables(const DevParams 
         t->fm16[i] = (uint16_t)(aer | shadow << 5 | cloud << 6 | snow << 7 | (i == P.fmask_fill ? 1u : 0u) << 8 |
                                 (shadow | cloud) << 9);
         t->land8[i] = (uint8_t)((i == 200 ? 1 : 0) | ((i == 201 || i < 100) ? 2 : 0) | ((i >= 100 && i < 200) ? 4 : 0));
-    }
-    if (i < 1024) {
-        const uint32_t code = i & 7;
-        const uint32_t w1 = code <= 4u ? code : (code == 5u ? 254u : 255u);
-        const uint32_t pc = ((i >> 4) & 1u) + 4u * ((i >> 5) & 1u);
-        PxOut o;
-        px_chain(P, w1, (i >> 3) & 1, pc, (i >> 6) & 1, (i >> 7) & 1, (i >> 8) & 1, (i >> 9) & 1, o);
-        // y bits 16 / 24: the pixel's contributions to n_valid and n_cloud_and_valid (A3)
-        const uint32_t valid = code < 5u ? 1u : 0u, pc_nz = ((i >> 4) | (i >> 5)) & 1u;
-        t->chain[i] = make_uint2(o.wtr1a | o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24,
-                                 o.conf | o.cloud << 8 | valid << 16 | (valid & pc_nz) << 24);
-        t->extra[i] = o.w2_raw | o.pc << 8 | o.browse << 16;
     }
 }
 
@@ -105,7 +121,8 @@ __device__ __forceinline__ void transpose4(const uint32_t a[4], uint32_t out[4])
 template <bool MASKS, bool WANT_IDX = false>
 __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C, const uint32_t* __restrict__ s_lut1,
                                           const uint16_t* __restrict__ s_fm16, const uint8_t* __restrict__ s_land8,
-                                          const uint2* __restrict__ s_chain, const u32x4 (&v)[6], const u32x2 vf,
+                                          const uint2* __restrict__ s_chain, const uint16_t* __restrict__ s_pre16,
+                                          const u32x4 (&v)[6], const u32x2 vf,
                                           const u32x2 vl, const u32x2 vs, const u32x2 vo, bool has_l, bool in_range,
                                           uint32_t (&w1w)[8], uint32_t (&chx)[8], uint32_t (&chy)[8], uint32_t& cnt,
                                           uint32_t* idx_out = nullptr) {
@@ -165,13 +182,17 @@ __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C
                 const uint32_t code = (word1 >> 16) & 7u;
                 const uint32_t remap = (F >> code) & ~(noaer >> (15 + sh)) & 1u;
                 uint32_t idx2 = code | remap << 3 | ((F >> 5) & 7u) << 4;
+                uint32_t w1a = 0;
                 if (MASKS) {
+                    // first factor (LAND / SHAD rules): WTR-1-AEROSOL and the WTR-2 code that indexes the second
                     const uint32_t shadrule = (shad_nz ^ 1u) & ~lbits & 1u;
                     const uint32_t lcpsw = (lbits >> 1) & ~(dark >> (15 + sh)) & 1u;
-                    idx2 |= shadrule << 7 | lcpsw << 8 | ((lbits >> 2) & 1u) << 9;
+                    const uint32_t pre = s_pre16[code | remap << 3 | shadrule << 4 | lcpsw << 5 | ((lbits >> 2) & 1u) << 6];
+                    w1a = pre & 0xffu;
+                    idx2 = (pre >> 8) | remap << 3 | ((F >> 5) & 7u) << 4;
                 }
                 const uint2 ch = s_chain[idx2];
-                w1w[j] = word1; chx[j] = ch.x; chy[j] = ch.y;
+                w1w[j] = word1; chx[j] = MASKS ? (ch.x | w1a) : ch.x; chy[j] = ch.y;
                 if (WANT_IDX) idx_out[j] = idx2;             // chain index, for Tables::extra
                 gsum += ch.y >> 16;                  // A3: valid | cloud_and_valid << 8, from the table
             }

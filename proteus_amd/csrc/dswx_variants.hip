@@ -323,12 +323,13 @@ __global__ __launch_bounds__(256, MASKS ? 4 : 5) void dswx_classify_ws(const KAr
 template <bool MASKS, int WPS, int ABLATE = 0>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_wslut(const KArgs a, const LutConsts C,
                                                                const Tables* __restrict__ tabs) {
-    constexpr int N_CHAIN = MASKS ? 1024 : 128;
+    constexpr int N_CHAIN = 128;
     __shared__ __attribute__((aligned(16))) uint8_t lds[WS_IN_MASKS + (MASKS ? 3 * WS_U8_BYTES : 0)];
     __shared__ uint32_t s_lut1[128];
     __shared__ uint16_t s_fm16[256];
     __shared__ uint8_t s_land8[MASKS ? 256 : 4];
     __shared__ uint2 s_chain[N_CHAIN];
+    __shared__ uint16_t s_pre16[MASKS ? 128 : 2];
     const DevParams& P = a.P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long tile_base = (long long)blockIdx.y * a.tile_stride;
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_wslut(const KArgs a, c
     for (int i = threadIdx.x; i < 128; i += 256) s_lut1[i] = tabs->lut1[i];
     for (int i = threadIdx.x; i < 128; i += 256) reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
     if (MASKS) for (int i = threadIdx.x; i < 64; i += 256) reinterpret_cast<uint32_t*>(s_land8)[i] = reinterpret_cast<const uint32_t*>(tabs->land8)[i];
-    for (int i = threadIdx.x; i < N_CHAIN; i += 256) s_chain[i] = tabs->chain[i];
+    for (int i = threadIdx.x; i < N_CHAIN; i += 256) s_chain[i] = MASKS ? tabs->chainm[i] : tabs->chain[i];
+    if (MASKS) for (int i = threadIdx.x; i < 64; i += 256) reinterpret_cast<uint32_t*>(s_pre16)[i] = reinterpret_cast<const uint32_t*>(tabs->pre16)[i];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_wslut(const KArgs a, c
     if (ABLATE < 3) __syncthreads();                     // the input images are dead from here on
     uint32_t w1w[8], chx[8], chy[8];
     if (ABLATE == 0) {
-        lut_group<MASKS>(P, C, s_lut1, s_fm16, s_land8, s_chain, v, vf, vl, vs, vo, has_l, in_range, w1w, chx, chy, cnt);
+        lut_group<MASKS>(P, C, s_lut1, s_fm16, s_land8, s_chain, s_pre16, v, vf, vl, vs, vo, has_l, in_range, w1w, chx, chy, cnt);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -492,13 +494,14 @@ __device__ __forceinline__ void ws_issue_dma(const KArgs& a, uint8_t* image, lon
 template <bool MASKS, int WPS>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_pipe(const KArgs a, const LutConsts C,
                                                               const Tables* __restrict__ tabs) {
-    constexpr int N_CHAIN = MASKS ? 1024 : 128;
+    constexpr int N_CHAIN = 128;
     constexpr int IMG = WS_IN_MASKS + (MASKS ? 3 * WS_U8_BYTES : 0);
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * IMG];
     __shared__ uint32_t s_lut1[128];
     __shared__ uint16_t s_fm16[256];
     __shared__ uint8_t s_land8[MASKS ? 256 : 4];
     __shared__ uint2 s_chain[N_CHAIN];
+    __shared__ uint16_t s_pre16[MASKS ? 128 : 2];
     const DevParams& P = a.P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long tile_base = (long long)blockIdx.y * a.tile_stride;
@@ -516,7 +519,8 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_pipe(const KArgs a, co
     for (int i = threadIdx.x; i < 128; i += 256) s_lut1[i] = tabs->lut1[i];
     for (int i = threadIdx.x; i < 128; i += 256) reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
     if (MASKS) for (int i = threadIdx.x; i < 64; i += 256) reinterpret_cast<uint32_t*>(s_land8)[i] = reinterpret_cast<const uint32_t*>(tabs->land8)[i];
-    for (int i = threadIdx.x; i < N_CHAIN; i += 256) s_chain[i] = tabs->chain[i];
+    for (int i = threadIdx.x; i < N_CHAIN; i += 256) s_chain[i] = MASKS ? tabs->chainm[i] : tabs->chain[i];
+    if (MASKS) for (int i = threadIdx.x; i < 64; i += 256) reinterpret_cast<uint32_t*>(s_pre16)[i] = reinterpret_cast<const uint32_t*>(tabs->pre16)[i];
 
     uint32_t cnt = 0, t_ocean = 0;
     int buf = 0;
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_pipe(const KArgs a, co
         }
         __syncthreads();                                                            // B2
         uint32_t w1w[8], chx[8], chy[8];
-        lut_group<MASKS>(P, C, s_lut1, s_fm16, s_land8, s_chain, v, vf, vl, vs, vo, has_l, in_range, w1w, chx, chy, cnt);
+        lut_group<MASKS>(P, C, s_lut1, s_fm16, s_land8, s_chain, s_pre16, v, vf, vl, vs, vo, has_l, in_range, w1w, chx, chy, cnt);
         GroupPlanes gp;
         lut_pack(w1w, chx, chy, gp);
         *reinterpret_cast<u32x4*>(X + threadIdx.x * 16) = u32x4{gp.diag[0], gp.diag[1], gp.diag[2], gp.diag[3]};
