@@ -502,6 +502,41 @@ __global__ __launch_bounds__(1024) void dswx_ws_thin_probe_k(const KArgs a) {
     }
 }
 
+// "Thin-4" access shape: 4 pixels per thread, a wave = 256 pixels, and every wave-level memory
+// instruction moves 1 KiB in 16-byte lanes by giving different lane ranges different planes:
+//   loads   3 x [lanes 0-31: 512 B of int16 plane 2i | lanes 32-63: 512 B of plane 2i+1]
+//           + 1 x [lanes 0-15: 256 B of Fmask]                       -> 3.25 loads per wave
+//   stores  1 x [lanes 0-31: DIAG 512 B | 32-47: WTR-1 | 48-63: WTR-2]
+//           1 x [0-15: WTR | 16-31: BWTR | 32-47: CONF | 48-63: CLOUD] -> 2 stores per wave
+// (the fused kernel has 6.5 loads and 7 stores in flight per wave of 512 pixels).  Probe only:
+// the lane <-> pixel redistribution a real kernel would need (ds_bpermute) is not done.
+template <bool NT>
+__global__ __launch_bounds__(256) void dswx_thin4_probe_k(const KArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
+    const long long px0 = (long long)blockIdx.x * 1024 + wave * 256;      // first pixel of this wave
+    if (px0 + 256 > a.n_pixels) return;
+    const int half = lane >> 5, l32 = lane & 31;
+    u32x4 x = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int16_t* plane = half ? a.in.band[2 * i + 1] : a.in.band[2 * i];
+        x ^= ldg<u32x4, NT>(reinterpret_cast<const uint8_t*>(plane + tile_base + px0) + l32 * 16);
+    }
+    if (lane < 16) x ^= ldg<u32x4, NT>(a.in.fmask + tile_base + px0 + lane * 16);
+    // stores
+    {
+        uint8_t* dst;
+        if (lane < 32) dst = reinterpret_cast<uint8_t*>(a.out.diag + tile_base + px0) + lane * 16;
+        else if (lane < 48) dst = a.out.wtr1 + tile_base + px0 + (lane - 32) * 16;
+        else dst = a.out.wtr2 + tile_base + px0 + (lane - 48) * 16;
+        stg<u32x4, NT>(dst, x);
+        uint8_t* const p4[4] = {a.out.wtr, a.out.bwtr, a.out.conf, a.out.cloud};
+        uint8_t* d2 = p4[lane >> 4] + tile_base + px0 + (lane & 15) * 16;
+        stg<u32x4, NT>(d2, x + 1u);
+    }
+}
+
 // Write-shape grid: every wave writes R consecutive 1 KiB pieces (16 B per lane) to each of P
 // of the six u8 output planes, plane after plane; the grid covers all six planes.  Tells
 // run length per plane (R KiB) from planes-per-wave (P) in the store efficiency.
@@ -680,6 +715,13 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, int64_
 #define WG(PP, RR) do { if (wnt) hipLaunchKernelGGL((dswx_write_grid_k<PP, RR, true>), grid, block, 0, s, a, total); else hipLaunchKernelGGL((dswx_write_grid_k<PP, RR, false>), grid, block, 0, s, a, total); } while (0)
 #define WG_R(PP) do { if (ri == 0) WG(PP, 1); else if (ri == 1) WG(PP, 2); else if (ri == 2) WG(PP, 4); else WG(PP, 8); } while (0)
         if (pi == 0) WG_R(1); else if (pi == 1) WG_R(2); else if (pi == 2) WG_R(3); else WG_R(6);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if ((variant & 524288) && (variant & 8)) {  // thin-4 shape: 4 px per thread, multi-plane 1-KiB instructions
+        dim3 grid((unsigned)(n_pixels / 1024), (unsigned)n_tiles), block(256);
+        if (variant & 2) hipLaunchKernelGGL(dswx_thin4_probe_k<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(dswx_thin4_probe_k<false>, grid, block, 0, s, a);
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }

@@ -103,6 +103,8 @@ def main():
             for nt in (0, 2):
                 run(f'record layout CHPX={ch} nt={nt >> 1}', (1 << 22) | (sel << 2) | nt, 21)
         run('fused shape ppt=8 nt=1 (as is)', 2, 21)
+        run('thin-4 shape (4 px/thread, 3.25 loads + 2 stores per wave) nt=0', 524288 | 8, 21)
+        run('thin-4 shape (4 px/thread, 3.25 loads + 2 stores per wave) nt=1', 524288 | 8 | 2, 21)
         run('warp-specialised (4 fat waves) nt=1', 524288 | 2, 21)
         run('warp-specialised THIN (16 waves, <= 2 loads + 1 store each) nt=0', 524288 | 4, 21)
         run('warp-specialised THIN (16 waves, <= 2 loads + 1 store each) nt=1', 524288 | 4 | 2, 21)
