@@ -40,19 +40,21 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline_sample():
-    """The numpy restatement of the reference path (oracle, kind 'port') on ONE
-    synthetic 3660x3660 tile, single thread as the reference runs."""
+def cpu_baseline_sample(n_tiles=4):
+    """The numpy restatement of the reference path (oracle, kind 'port') on a bounded sample of
+    the workload: `n_tiles` synthetic 3660x3660 tiles (~10 s), single thread as the reference runs."""
     import numpy as np
     from oracle import dswx_oracle as o
     from proteus_amd.synth import synth_tile
-    s = synth_tile(0, TILE, TILE)
-    t0 = time.perf_counter()
-    o.classify_tile(s['bands'], s['fmask'])
-    dt = time.perf_counter() - t0
-    return {'value': round(TILE * TILE / dt / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1,
+    dt = 0.0
+    for t in range(n_tiles):
+        s = synth_tile(t, TILE, TILE)
+        t0 = time.perf_counter()
+        o.classify_tile(s['bands'], s['fmask'])
+        dt += time.perf_counter() - t0
+    return {'value': round(n_tiles * TILE * TILE / dt / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1,
             'kind': 'port',
-            'sample': f'1 synthetic {TILE}x{TILE} L30 tile, numpy {np.__version__} '
+            'sample': f'{n_tiles} synthetic {TILE}x{TILE} L30 tiles, numpy {np.__version__} '
                       f'oracle/dswx_oracle.py classify_tile, {dt:.2f} s, '
                       f'host has {os.cpu_count()} logical cores'}
 
