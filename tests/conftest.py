@@ -10,3 +10,12 @@ GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+def pytest_sessionstart(session):
+    """The HIP library is a build artefact (git-ignored).  A fresh checkout has none: build it once
+    (hipcc cross-compiles gfx950 without a GPU, ~20 s) so that the suite does not depend on someone
+    having run __graft_entry__.build() first.  An existing library is used as it is."""
+    from proteus_amd import build
+    if not os.path.exists(build.LIB_PATH):
+        build.build()
