@@ -170,6 +170,10 @@ def main():
         raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
 
     import torch
+    from proteus_amd import build as _build
+    if not os.path.exists(_build.LIB_PATH):     # fresh checkout: compile the HIP library (never a CPU fallback)
+        if rank == 0 or world == 1:
+            _build.build()
     from proteus_amd import _capi, shard
     from proteus_amd.synth import SEED
 
