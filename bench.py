@@ -172,8 +172,13 @@ def main():
     import torch
     from proteus_amd import build as _build
     if not os.path.exists(_build.LIB_PATH):     # fresh checkout: compile the HIP library (never a CPU fallback)
-        if rank == 0 or world == 1:
-            _build.build()
+        if local_rank == 0:
+            _build.build()                      # os.replace at the end: the file appears complete or not at all
+        else:
+            for _ in range(600):
+                if os.path.exists(_build.LIB_PATH):
+                    break
+                time.sleep(0.5)
     from proteus_amd import _capi, shard
     from proteus_amd.synth import SEED
 
