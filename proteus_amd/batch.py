@@ -20,12 +20,15 @@ from . import shard
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def plan(runconfigs, n_gpus):
-    """[(gpu, [runconfig, ...]), ...] -- contiguous, sizes differ by at most one."""
+def plan(runconfigs, n_gpus, workers_per_gpu=1):
+    """[(gpu, [runconfig, ...]), ...] -- contiguous, sizes differ by at most one.  With
+    `workers_per_gpu` > 1 every GPU gets that many worker processes (the GPU part of a product run
+    is milliseconds, the GeoTIFF codec on the host is what takes time: extra workers overlap it)."""
     out = []
-    for g in range(n_gpus):
-        lo, hi = shard.tile_range(len(runconfigs), g, n_gpus)
-        out.append((g, list(runconfigs[lo:hi])))
+    n = n_gpus * workers_per_gpu
+    for w in range(n):
+        lo, hi = shard.tile_range(len(runconfigs), w, n)
+        out.append((w // workers_per_gpu, list(runconfigs[lo:hi])))
     return out
 
 
@@ -64,10 +67,10 @@ def _worker(device, runconfigs):
     return rc
 
 
-def run_batch(runconfigs, n_gpus, python=sys.executable):
-    """Launch one worker per GPU; returns (all_ok, [per-tile result dicts in input order])."""
+def run_batch(runconfigs, n_gpus, python=sys.executable, workers_per_gpu=1):
+    """Launch the workers; returns (all_ok, [per-tile result dicts in input order])."""
     procs = []
-    for gpu, chunk in plan(runconfigs, n_gpus):
+    for gpu, chunk in plan(runconfigs, n_gpus, workers_per_gpu):
         if not chunk:
             continue
         cmd = [python, '-m', 'proteus_amd.batch', '--worker', '--device', str(gpu)] + chunk
@@ -92,13 +95,15 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
     ap.add_argument('runconfigs', nargs='+')
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--workers-per-gpu', type=int, default=1,
+                    help='worker processes per GPU (overlaps the host-side GeoTIFF codec of several tiles)')
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--device', type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     if a.worker:
         return _worker(a.device, a.runconfigs)
     t0 = time.perf_counter()
-    ok, results = run_batch(a.runconfigs, a.gpus)
+    ok, results = run_batch(a.runconfigs, a.gpus, workers_per_gpu=max(1, a.workers_per_gpu))
     for r in results:
         print(json.dumps(r))
     print(json.dumps({'tiles': len(results), 'gpus': a.gpus, 'ok': ok,

@@ -260,6 +260,9 @@ def test_batch_driver_single_gpu(tmp_path):
         arr, _ = geotiff.read_geotiff(str(tmp_path / f'tile{t}' / 'output' / f'T{t}_v1.0_B01_WTR.tif'))
         s = synth_hls.synth_tile(20 + t, 128, 128)
         assert np.array_equal(arr, o.classify_tile(s['bands'], s['fmask'])['WTR'])
+    # several workers on the one GPU (overlapping the host-side codec of different tiles)
+    ok, results = batch.run_batch(rcs, 1, workers_per_gpu=3)
+    assert ok and [r['runconfig'] for r in results] == rcs and all(r['device'] == 0 for r in results)
     # a broken runconfig is reported, the others still run
     ok, results = batch.run_batch([rcs[0], str(tmp_path / 'missing.yaml')], 1)
     assert not ok and results[0]['ok'] and not results[1]['ok']

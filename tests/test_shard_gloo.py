@@ -99,3 +99,12 @@ def test_batch_plan():
     assert {len(c) for _, c in p} <= {2, 3}
     few = batch.plan(rcs[:2], 8)
     assert sum((c for _, c in few), []) == rcs[:2] and max(len(c) for _, c in few) == 1
+
+
+def test_batch_plan_several_workers_per_gpu():
+    from proteus_amd import batch
+    rcs = [f'rc_{i}.yaml' for i in range(11)]
+    p = batch.plan(rcs, 2, workers_per_gpu=3)
+    assert [g for g, _ in p] == [0, 0, 0, 1, 1, 1]
+    assert [x for _, chunk in p for x in chunk] == rcs               # contiguous, complete, in order
+    assert max(len(c) for _, c in p) - min(len(c) for _, c in p) <= 1

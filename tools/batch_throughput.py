@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Product throughput of the node-level driver on ONE GPU: N full-size synthetic tiles (GeoTIFFs in,
+cloud-optimized layers out) with 1 and with several worker processes per GPU.  Prints one JSON object."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import make_synthetic_hls as synth_hls          # noqa: E402
+from proteus_amd import batch                   # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 3660
+    out = {'tiles': n, 'size': size}
+    with tempfile.TemporaryDirectory() as d:
+        rcs = [synth_hls.make(os.path.join(d, f't{i}'), sensor=('L30', 'S30')[i % 2], size=size, tile=i,
+                              product_id=f'P{i}')[0] for i in range(n)]
+        for wpg in (1, 2, 4, 8):
+            t0 = time.perf_counter()
+            ok, res = batch.run_batch(rcs, 1, workers_per_gpu=wpg)
+            dt = time.perf_counter() - t0
+            assert ok, res
+            out[f'workers_per_gpu_{wpg}'] = {'seconds': round(dt, 2), 'tiles_per_s': round(n / dt, 2),
+                                             'Mpix_per_s': round(n * size * size / dt / 1e6, 1)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
