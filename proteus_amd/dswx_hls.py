@@ -710,11 +710,14 @@ def _save_output_rgb_file(red, green, blue, output_file, offset_dict, scale_dict
             arr[invalid_mask] = np.nan
         planes.append(np.asarray(arr, dtype=np.float32))
     _makedirs(output_file)
-    geotiff.write_geotiff(output_file, np.stack(planes), geo_tags=geo_tags,
-                          metadata=dswx_metadata_dict)
+    stack = np.stack(planes)
+
+    def job():
+        geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict)
+        logger.info(f'file saved: {output_file}')
     if output_files_list is not None:
         output_files_list.append(output_file)
-    logger.info(f'file saved: {output_file}')
+    _run_or_defer(job)
 
 
 def _get_binary_water_ctable():
@@ -763,17 +766,57 @@ def _makedirs(path):
         os.makedirs(d, exist_ok=True)
 
 
+class _DeferredWrites:
+    """Collects the GeoTIFF writes of one product run and executes them side by side.  Every write
+    already spreads its DEFLATE blocks over the codec's thread pool; running a few writes
+    concurrently hides their serial parts (block assembly, overviews, file output).  File lists
+    keep the order of the calls; the files exist once flush() / the `with` block returns."""
+    active = None
+
+    def __init__(self, workers=4):
+        self.jobs, self.workers = [], workers
+
+    def __enter__(self):
+        _DeferredWrites.active = self
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _DeferredWrites.active = None
+        if exc_type is None:
+            self.flush()
+
+    def flush(self):
+        jobs, self.jobs = self.jobs, []
+        if len(jobs) < 2 or self.workers < 2:
+            for job in jobs:
+                job()
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(self.workers, thread_name_prefix='dswx-write') as ex:
+            list(ex.map(lambda job: job(), jobs))      # re-raises the first failure
+
+
+def _run_or_defer(job):
+    if _DeferredWrites.active is not None:
+        _DeferredWrites.active.jobs.append(job)
+    else:
+        job()
+
+
 def _save_array(input_array, output_file, dswx_metadata_dict, geo_tags, description=None,
                 output_files_list=None, ctable=None, no_data_value=None):
     _makedirs(output_file)
     integer = np.asarray(input_array).dtype.kind in 'uib'
-    geotiff.write_geotiff(output_file, input_array, geo_tags=geo_tags,
-                          metadata=dswx_metadata_dict, nodata=no_data_value,
-                          descriptions=[description] if description else None, colormap=ctable,
-                          overviews=geotiff.COG_OVERVIEW_FACTORS if integer else None)
+
+    def job():
+        geotiff.write_geotiff(output_file, input_array, geo_tags=geo_tags,
+                              metadata=dswx_metadata_dict, nodata=no_data_value,
+                              descriptions=[description] if description else None, colormap=ctable,
+                              overviews=geotiff.COG_OVERVIEW_FACTORS if integer else None)
+        logger.info(f'file saved: {output_file}')
     if output_files_list is not None:
         output_files_list.append(output_file)
-    logger.info(f'file saved: {output_file}')
+    _run_or_defer(job)
 
 
 def save_dswx_product(layers, output_file, dswx_metadata_dict, geo_tags,
@@ -785,13 +828,16 @@ def save_dswx_product(layers, output_file, dswx_metadata_dict, geo_tags,
              and np.asarray(layers[n]).dtype in (np.uint8, np.bool_)]
     stack = np.stack([np.asarray(layers[n], dtype=np.uint8) for n in names])
     _makedirs(output_file)
-    geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict,
-                          nodata=UINT8_FILL_VALUE,
-                          descriptions=[band_description_dict[n] for n in names],
-                          overviews=geotiff.COG_OVERVIEW_FACTORS)
+
+    def job():
+        geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict,
+                              nodata=UINT8_FILL_VALUE,
+                              descriptions=[band_description_dict[n] for n in names],
+                              overviews=geotiff.COG_OVERVIEW_FACTORS)
+        logger.info(f'file saved: {output_file}')
     if output_files_list is not None:
         output_files_list.append(output_file)
-    logger.info(f'file saved: {output_file}')
+    _run_or_defer(job)
 
 
 def _as_plane(value, shape, name, dtype=np.uint8):
@@ -959,6 +1005,7 @@ def generate_dswx_layers(input_list,
     reference (:4610-4657) plus four keyword-only extensions (pre-gridded LAND / SHAD /
     ocean planes, and the GPU to use).  Returns True, or False after logging 'ERROR ...'
     when the input cannot be read (:4988-4990)."""
+    _DeferredWrites.active = None          # a previous run that raised must not leave writes deferred
     local = locals()
     needs_defaults = [hls_thresholds, check_ancillary_inputs_coverage, apply_ocean_masking,
                       apply_aerosol_class_remapping, shadow_masking_algorithm, min_slope_angle,
@@ -1163,6 +1210,7 @@ def generate_dswx_layers(input_list,
 
     build_list, output_files_list = early_list, []
     collapse = FLAG_COLLAPSE_WTR_CLASSES
+    writes = _DeferredWrites().__enter__()       # flushed before the browse PNG and at the end
     if shadow_layer is not None and output_shadow_layer:
         _save_array(shadow_layer, output_shadow_layer, md, geo_tags,
                     description=band_description_dict['SHAD'], output_files_list=build_list,
@@ -1217,6 +1265,7 @@ def generate_dswx_layers(input_list,
                     ctable=_get_browse_ctable(collapse, pick(not_water_in_browse, 'not_water_in_browse'),
                                               pick(cloud_in_browse, 'cloud_in_browse'),
                                               pick(snow_in_browse, 'snow_in_browse')))
+        writes.flush()                                # the PNG is rendered from the browse GeoTIFF
         geotiff2png(browse_tif, output_browse_image,
                     output_height=pick(browse_image_height, 'browse_image_height'),
                     output_width=pick(browse_image_width, 'browse_image_width'), logger=logger)
@@ -1229,6 +1278,7 @@ def generate_dswx_layers(input_list,
                           output_file, md, geo_tags, output_files_list=output_files_list)
     elif output_file:
         logger.warning(f'VRT output "{output_file}" skipped: needs GDAL')
+    writes.__exit__(None, None, None)
     logger.info('output files:')
     for f in build_list + output_files_list:
         logger.info(f'    {f}')

@@ -297,7 +297,7 @@ def _io_pool():
     DEFLATE -- which dominates the wall time of a product run -- scales over host cores.  The
     encoded bytes do not depend on the thread count.  DSWX_IO_THREADS overrides (1 = serial)."""
     global _pool
-    n = int(os.environ.get('DSWX_IO_THREADS', '0')) or min(16, os.cpu_count() or 1)
+    n = int(os.environ.get('DSWX_IO_THREADS', '0')) or min(32, os.cpu_count() or 1)
     if n <= 1:
         return None
     if _pool is None or _pool._max_workers != n:

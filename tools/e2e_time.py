@@ -44,7 +44,7 @@ def main():
                 assert ok
                 best = dt if best is None else min(best, dt)
             out[f'generate_dswx_layers_s_io_threads_{"default" if threads == "0" else threads}'] = round(best, 2)
-        out['io_threads_default'] = min(16, os.cpu_count() or 1)
+        out['io_threads_default'] = min(32, os.cpu_count() or 1)
         out['kernel'] = D.get_context().last_kernel_info()
     print(json.dumps(out, indent=1))
 
