@@ -502,18 +502,40 @@ def _load_hls_product_v2(file_list, image, md, flag_debug=False, alloc=None):
         key = min(missing(l30_v2_band_dict), missing(s30_v2_band_dict), key=len)[0]
         logger.info(f'ERROR band {key} not found within list of input file(s)')
         return False
-    for key in l30_v2_band_dict:
+    def read(path):
+        return geotiff.read_geotiff(path, window=(0, 0, 1000, 1000) if flag_debug else None, alloc=alloc)
+
+    # the first band's metadata decide the sensor, hence the file names of the other six, which
+    # are then decoded side by side
+    from concurrent.futures import ThreadPoolExecutor
+    pending, pool = {}, ThreadPoolExecutor(6, thread_name_prefix='dswx-read')
+    try:
+        return _load_bands(file_list, image, md, flag_debug, find, read, pending, pool)
+    finally:
+        pool.shutdown(wait=True)
+
+
+def _load_bands(file_list, image, md, flag_debug, find, read, pending, pool):
+    keys = list(l30_v2_band_dict)
+    for n_done, key in enumerate(keys):
         logger.info(f'    {key}')
         suffix, path = find(key)
         if path is None:
             logger.info(f'ERROR band {key} not found within list of input file(s)')
             return False
         try:
-            arr, info = geotiff.read_geotiff(
-                path, window=(0, 0, 1000, 1000) if flag_debug else None, alloc=alloc)
+            arr, info = pending.pop(path).result() if path in pending else read(path)
         except (OSError, geotiff.GeoTiffError) as e:
             logger.info(f'ERROR could not open {path}: {e}')
             return False
+        if n_done == 0:
+            # harvested below for reflectance bands; needed now to name the remaining files
+            if 'SPACECRAFT_NAME' not in md and not _harvest_hls_metadata(info.metadata, md):
+                return False
+            for other in keys[1:]:
+                p = find(other)[1]
+                if p is not None and p not in pending:
+                    pending[p] = pool.submit(read, p)
         if flag_debug:
             logger.info('reading in debug mode')
         if 'hls_dataset_name' not in image:
