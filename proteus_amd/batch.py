@@ -32,8 +32,9 @@ def plan(runconfigs, n_gpus, workers_per_gpu=1):
     return out
 
 
-def _worker(device, runconfigs):
-    """Runs inside the per-GPU process."""
+def _worker(device, runconfigs, skip_existing=False):
+    """Runs inside the per-GPU process.  `skip_existing`: a tile whose requested output files all
+    exist is not recomputed (tiles are idempotent: this is the driver's resume)."""
     import logging
     from . import dswx_hls as D
     logging.getLogger('dswx_hls').setLevel(logging.WARNING)
@@ -55,6 +56,12 @@ def _worker(device, runconfigs):
                       'shoreline_shapefile', 'shoreline_shapefile_description',
                       'flag_offset_and_scale_inputs', 'landcover_mask', 'shadow_layer', 'ocean_mask'):
                 kw[k] = getattr(args, k)
+            wanted = [kw[k] for k in kw if k.startswith('output_') and kw[k]] + \
+                ([args.output_file] if args.output_file else [])
+            if skip_existing and wanted and all(os.path.exists(f) for f in wanted):
+                print(json.dumps({'runconfig': path, 'device': device, 'ok': True, 'error': None,
+                                  'skipped': True, 'seconds': 0.0}), flush=True)
+                continue
             ok = D.generate_dswx_layers(args.input_list, args.output_file,
                                         hls_thresholds=consts.hls_thresholds, device=device, **kw)
             err = None
@@ -67,13 +74,14 @@ def _worker(device, runconfigs):
     return rc
 
 
-def run_batch(runconfigs, n_gpus, python=sys.executable, workers_per_gpu=1):
+def run_batch(runconfigs, n_gpus, python=sys.executable, workers_per_gpu=1, skip_existing=False):
     """Launch the workers; returns (all_ok, [per-tile result dicts in input order])."""
     procs = []
     for gpu, chunk in plan(runconfigs, n_gpus, workers_per_gpu):
         if not chunk:
             continue
-        cmd = [python, '-m', 'proteus_amd.batch', '--worker', '--device', str(gpu)] + chunk
+        cmd = [python, '-m', 'proteus_amd.batch', '--worker', '--device', str(gpu)] + \
+            (['--skip-existing'] if skip_existing else []) + chunk
         procs.append(subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True))
     results, all_ok = {}, True
@@ -97,13 +105,16 @@ def main(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--workers-per-gpu', type=int, default=1,
                     help='worker processes per GPU (overlaps the host-side GeoTIFF codec of several tiles)')
+    ap.add_argument('--skip-existing', action='store_true',
+                    help='resume: do not recompute tiles whose requested output files all exist')
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--device', type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     if a.worker:
-        return _worker(a.device, a.runconfigs)
+        return _worker(a.device, a.runconfigs, a.skip_existing)
     t0 = time.perf_counter()
-    ok, results = run_batch(a.runconfigs, a.gpus, workers_per_gpu=max(1, a.workers_per_gpu))
+    ok, results = run_batch(a.runconfigs, a.gpus, workers_per_gpu=max(1, a.workers_per_gpu),
+                            skip_existing=a.skip_existing)
     for r in results:
         print(json.dumps(r))
     print(json.dumps({'tiles': len(results), 'gpus': a.gpus, 'ok': ok,

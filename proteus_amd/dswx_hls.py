@@ -1212,10 +1212,15 @@ def generate_dswx_layers(input_list,
         p = ctx.pinned_empty(a.shape, np.uint8)
         np.copyto(p, a, casting='unsafe')
         return p
+    import time as _time
+    t_gpu = _time.perf_counter()
     res = ctx.classify_host(bands, image['fmask'], params, land=like_bands(landcover_mask),
                             shad=like_bands(shadow_layer), ocean=like_bands(ocean_mask),
                             layers=tuple(wanted))
+    t_gpu = _time.perf_counter() - t_gpu
     logger.info(f'    per-pixel chain on GPU: {ctx.last_kernel_info()}')
+    logger.info(f'    per-pixel chain incl. host <-> device copies: {t_gpu * 1e3:.1f} ms'
+                f' ({length * width / t_gpu / 1e6:.0f} Mpixels/s)')
     n_valid, n_cloud_and_valid, n_not_ocean = (int(v) for v in res['counters'][0])
 
     # coverage metadata, floor percentages (:5113-5136)

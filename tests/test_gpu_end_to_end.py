@@ -263,6 +263,13 @@ def test_batch_driver_single_gpu(tmp_path):
     # several workers on the one GPU (overlapping the host-side codec of different tiles)
     ok, results = batch.run_batch(rcs, 1, workers_per_gpu=3)
     assert ok and [r['runconfig'] for r in results] == rcs and all(r['device'] == 0 for r in results)
+    # resume: nothing is recomputed when every requested output exists; a deleted layer is
+    ok, results = batch.run_batch(rcs, 1, skip_existing=True)
+    assert ok and all(r.get('skipped') for r in results)
+    os.remove(str(tmp_path / 'tile1' / 'output' / 'T1_v1.0_B03_CONF.tif'))
+    ok, results = batch.run_batch(rcs, 1, skip_existing=True)
+    assert ok and [bool(r.get('skipped')) for r in results] == [True, False, True]
+    assert (tmp_path / 'tile1' / 'output' / 'T1_v1.0_B03_CONF.tif').exists()
     # a broken runconfig is reported, the others still run
     ok, results = batch.run_batch([rcs[0], str(tmp_path / 'missing.yaml')], 1)
     assert not ok and results[0]['ok'] and not results[1]['ok']
