@@ -59,6 +59,29 @@ def cpu_baseline_sample(n_tiles=4):
                       f'host has {os.cpu_count()} logical cores'}
 
 
+def cpu_baseline_next_rows(dem, worldcover_up3, copernicus, forest_classes, sample=1500):
+    """CPU-baseline leg of tools/next_rows_bench.py (kept here because only bench.py's CPU baseline may
+    use the oracle outside tests/): the numpy oracle's shadow layer, LAND aggregation and 'cover'-mode
+    chain on a sample x sample window, one core, scaled by area to a 3660 x 3660 tile."""
+    from oracle import dswx_oracle as o
+    from proteus_amd.synth import synth_tile
+    S = sample
+    scale = (TILE * TILE) / (S * S)
+    t0 = time.perf_counter()
+    o.compute_opera_shadow_layer(dem[:S + 100, :S + 100], 141.0, 35.0, -5.0, 40.0)
+    t_shadow = (time.perf_counter() - t0) * scale
+    t0 = time.perf_counter()
+    o.landcover_mask_from_warped(worldcover_up3[:3 * S, :3 * S], copernicus[:S, :S], forest_classes)
+    t_land = (time.perf_counter() - t0) * scale
+    s = synth_tile(0, S, S, with_masks=True)
+    t0 = time.perf_counter()
+    o.classify_tile(s['bands'], s['fmask'], landcover=s['land'], shadow=s['shad'], ocean_mask=s['ocean'],
+                    mask_adjacent_to_cloud_mode='cover')
+    t_cover = (time.perf_counter() - t0) * scale
+    return {'shadow_s_per_tile': t_shadow, 'landcover_s_per_tile': t_land, 'cover_s_per_tile': t_cover,
+            'note': f'numpy oracle on one core, {S}x{S} sample scaled by area to {TILE}x{TILE}'}
+
+
 _WORKER_TILE = None
 
 

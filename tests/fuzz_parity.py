@@ -3,7 +3,10 @@
 hugging the thresholds) through dswx_classify_host, every layer and the counters compared with
 the scalar C oracle.  Exit code 1 and a JSON description of the first mismatch on failure.
 
-    python tools/fuzz_parity.py [--iters 300] [--seed 1] [--variant N]
+    python tests/fuzz_parity.py [--iters 300] [--seed 1] [--variant N] [--device-batch]
+
+(Lives under tests/ because it uses the oracle, which only tests/, smoke() and bench.py's CPU baseline may do;
+its name keeps pytest from collecting it.)
 """
 import argparse
 import json

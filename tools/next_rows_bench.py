@@ -96,21 +96,14 @@ def main():
     batch.free()
 
     if not a.no_cpu:
-        from oracle import dswx_oracle as o
-        S = 1500                                  # bounded sample, scaled to a full tile below
-        scale = (T * T) / (S * S)
-        t0 = time.perf_counter()
-        o.compute_opera_shadow_layer(dem[:S + 100, :S + 100], 141.0, 35.0, -5.0, 40.0)
-        out['f1_shadow']['cpu_oracle_s_per_tile'] = (time.perf_counter() - t0) * scale
-        t0 = time.perf_counter()
-        o.landcover_mask_from_warped(wc[:3 * S, :3 * S], cg[:S, :S], forest)
-        out['f3_landcover']['cpu_oracle_s_per_tile'] = (time.perf_counter() - t0) * scale
-        s = synth_tile(0, S, S, with_masks=True)
-        t0 = time.perf_counter()
-        o.classify_tile(s['bands'], s['fmask'], landcover=s['land'], shadow=s['shad'], ocean_mask=s['ocean'],
-                        mask_adjacent_to_cloud_mode='cover')
-        out['f2_cover_mode']['cpu_oracle_s_per_tile'] = (time.perf_counter() - t0) * scale
-        out['cpu_note'] = f'numpy oracle on one core, {S}x{S} sample scaled by area to 3660x3660'
+        # the oracle is only reachable through bench.py's CPU-baseline leg
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        cpu = bench.cpu_baseline_next_rows(dem, wc, cg, forest)
+        out['f1_shadow']['cpu_oracle_s_per_tile'] = cpu['shadow_s_per_tile']
+        out['f3_landcover']['cpu_oracle_s_per_tile'] = cpu['landcover_s_per_tile']
+        out['f2_cover_mode']['cpu_oracle_s_per_tile'] = cpu['cover_s_per_tile']
+        out['cpu_note'] = cpu['note']
     print(json.dumps(out, indent=1))
 
 
