@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the DSWx-HLS per-pixel hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--tiles T] [--masks]
+    python bench.py --gpus N --steps K --warmup W [--tiles T] [--total-tiles M] [--masks]
 
-One "step" = one pass of the fused classify kernel over a device-resident batch of
-T synthetic 3660x3660 HLS.L30 tiles (6 int16 bands + Fmask; `--masks` adds
-LAND/SHAD/OCEAN) per GPU.  Inputs are generated in HBM before the timed region.
-For N > 1 launch with torch.distributed.run (one rank per GPU); tiles are sharded
-by rank, there is no data-path collective (weak scaling: T tiles per GPU).
+One "step" = one pass of the fused classify kernel over the tiles a GPU owns: synthetic
+3660x3660 HLS.L30 tiles (6 int16 bands + Fmask; `--masks` adds LAND/SHAD/OCEAN), generated
+in HBM before the timed region.
+  default (weak scaling)        every GPU owns T = 256 resident tiles: BASELINE configs[2] at N = 1
+  --total-tiles M (strong)      BASELINE configs[3]: M (e.g. 4096) tiles split contiguously over the
+                                N ranks (proteus_amd.shard.tile_range); a rank walks its share in
+                                resident chunks of <= T tiles, so N = 1 works too
+Tiles are independent: there is no data-path collective.  RCCL (torch.distributed 'nccl') carries
+only the barrier around the timed region and the MAX over ranks of the elapsed time.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches its own N ranks
+(torch.distributed.run as a child process, BEFORE this process touches the GPU) and relays
+rank 0's line.  Under torchrun (RANK / WORLD_SIZE set) it is a rank.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for every field).
 """
 import argparse
 import json
@@ -27,9 +35,20 @@ TILE = 3660
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--tiles', type=int, default=256, help='tiles per GPU per step')
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--tiles', type=int, default=256,
+                    help='resident tiles per GPU (weak scaling: the work of a step; strong: the chunk size)')
+    ap.add_argument('--total-tiles', type=int, default=0,
+                    help='strong scaling: tiles of the whole job, split over the ranks (BASELINE configs[3]: 4096)')
+    ap.add_argument('--allow-gloo', action='store_true',
+                    help='let the control plane fall back to gloo if RCCL cannot initialise (default: fail)')
+    ap.add_argument('--realloc-repeats', type=int, default=5,
+                    help='N = 1: after the timed region, re-allocate the batch this many times and report the '
+                         'spread of the kernel rate (it depends on where the arena lands, DESIGN.md section 5)')
+    ap.add_argument('--plan-only', action='store_true',
+                    help='no GPU work: bring the ranks up (gloo), print the sharding plan of this command line as '
+                         'JSON and exit (tests/test_shard_gloo.py drives the launcher path with it)')
     ap.add_argument('--masks', action='store_true',
                     help='also stream LAND/SHAD/OCEAN planes (BASELINE config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -42,7 +61,10 @@ def parse_args():
 
 def cpu_baseline_sample(n_tiles=4):
     """The numpy restatement of the reference path (oracle, kind 'port') on a bounded sample of
-    the workload: `n_tiles` synthetic 3660x3660 tiles (~10 s), single thread as the reference runs."""
+    the workload: `n_tiles` synthetic 3660x3660 tiles (~10 s), single thread as the reference runs.
+    The port makes the same whole-array passes as the reference's functions; timed stage by stage
+    against them in the build container it takes 0.975x their time (3.94 s vs 4.04 s per tile,
+    profiles/r02_cpu_port_vs_reference.json), so this figure is the reference's own speed to ~3 %."""
     import numpy as np
     from oracle import dswx_oracle as o
     from proteus_amd.synth import synth_tile
@@ -55,8 +77,9 @@ def cpu_baseline_sample(n_tiles=4):
     return {'value': round(n_tiles * TILE * TILE / dt / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1,
             'kind': 'port',
             'sample': f'{n_tiles} synthetic {TILE}x{TILE} L30 tiles, numpy {np.__version__} '
-                      f'oracle/dswx_oracle.py classify_tile, {dt:.2f} s, '
-                      f'host has {os.cpu_count()} logical cores'}
+                      f'oracle/dswx_oracle.py classify_tile (same array passes as the reference functions: '
+                      f'0.975x their time stage by stage, profiles/r02_cpu_port_vs_reference.json), '
+                      f'{dt:.2f} s, host has {os.cpu_count()} logical cores'}
 
 
 def cpu_baseline_next_rows(dem, worldcover_up3, copernicus, forest_classes, sample=1500):
@@ -160,52 +183,156 @@ def single_tile_leg(ctx, params, masks, reps=50):
                     'working set 281 MB (Infinity-Cache assisted), launch-latency bound'}
 
 
-def parity_spot_check(ctx, batch, params, tile):
-    """Not timed: one tile of the batch against the scalar C oracle."""
+def parity_spot_check(ctx, batch, params, tiles):
+    """Not timed: tiles of the timed batch against the scalar C oracle -- the first, the middle and the
+    LAST one (at 256 tiles the last sits past 2^31 pixels / 2^32 bytes into every plane)."""
     import numpy as np
     from oracle import c_oracle
     from proteus_amd import _capi
-    bands = [batch.read_tile(b, tile) for b in _capi.BAND_NAMES]
-    kw = {}
-    if batch.masks:
-        kw = {m: batch.read_tile(m, tile) for m in ('land', 'shad', 'ocean')}
-    exp = c_oracle.classify(params, bands, batch.read_tile('fmask', tile), **kw)
-    for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
-        if not np.array_equal(batch.read_tile(key, tile), exp[key]):
-            return f'MISMATCH in {key}'
-    if batch.read_counters()[tile].tolist() != exp['counters'].tolist():
-        return 'MISMATCH in counters'
-    return 'bit-exact'
+    cnt = batch.read_counters()
+    for tile in tiles:
+        bands = [batch.read_tile(b, tile) for b in _capi.BAND_NAMES]
+        kw = {}
+        if batch.masks:
+            kw = {m: batch.read_tile(m, tile) for m in ('land', 'shad', 'ocean')}
+        exp = c_oracle.classify(params, bands, batch.read_tile('fmask', tile), **kw)
+        for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+            if not np.array_equal(batch.read_tile(key, tile), exp[key]):
+                return {'tiles': list(tiles), 'result': f'MISMATCH in {key} of tile {tile}'}
+        if cnt[tile].tolist() != exp['counters'].tolist():
+            return {'tiles': list(tiles), 'result': f'MISMATCH in counters of tile {tile}'}
+    return {'tiles': list(tiles), 'result': 'bit-exact'}
+
+
+def pmc_traffic(masks, n_tiles):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes -- only if they were taken on THIS
+    kernel (source hash of dswx_classify_lut.hip + dswx_tables.h + dswx_device.h) and tile count."""
+    from proteus_amd import build as _build
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.exists(path):
+        return None, 'profiles/pmc_traffic.json absent'
+    pmc = json.load(open(path))
+    entry = pmc.get('masks' if masks else 'plain')
+    if not entry:
+        return None, 'no PMC pass for this plane set'
+    if entry.get('tiles') != n_tiles:
+        return None, f"PMC pass was taken at {entry.get('tiles')} tiles per launch, this run has {n_tiles}"
+    now = _build.hot_kernel_hash()
+    if entry.get('kernel_source_hash') != now:
+        return None, (f"stale: PMC pass taken on kernel sources {entry.get('kernel_source_hash')}, "
+                      f'this build is {now} -- re-run tools/run_profiles.sh')
+    return entry['hbm_bytes_per_launch'], entry.get('source')
+
+
+def realloc_spread(ctx, params, n_tiles, masks, repeats, launches=5):
+    """The kernel rate depends on where hipMalloc puts the 14 streams: re-allocate
+    the batch `repeats` times, time `launches` launches in each, report min / median / max."""
+    from proteus_amd import _capi
+    from proteus_amd.synth import SEED
+    bpp = 24 if masks else 21
+    rates = []
+    for r in range(repeats):
+        b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks)
+        b.synth(SEED)
+        b.classify(params)
+        ctx.synchronize()
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0)
+        for _ in range(launches):
+            b.classify(params)
+        ctx.record(e1)
+        ctx.synchronize()
+        ms = ctx.elapsed_ms(e0, e1) / launches
+        ctx.destroy_event(e0)
+        ctx.destroy_event(e1)
+        b.free()
+        rates.append(n_tiles * TILE * TILE * bpp / (ms * 1e-3) / 1e9)
+    rates.sort()
+    return {'allocations': repeats, 'launches_each': launches,
+            'frac_min': round(rates[0] / HBM_PEAK_GBS, 4),
+            'frac_median': round(rates[len(rates) // 2] / HBM_PEAK_GBS, 4),
+            'frac_max': round(rates[-1] / HBM_PEAK_GBS, 4)}
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as a child
+    (torch.distributed.run) and relay its output.  Nothing in this process touches the GPU -- no torch
+    import, no HIP call -- so the child ranks are the only GPU users (and nothing here exec()s)."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rank_plan(args, rank, world):
+    """What `rank` of `world` does in one step: (tiles it owns, first tile index, resident tiles,
+    launches as a list of tile counts).  Shared by the measurement and --plan-only."""
+    from proteus_amd import shard
+    if args.total_tiles > 0:
+        lo, hi = shard.tile_range(args.total_tiles, rank, world)       # this rank's share of the job
+        my_tiles = hi - lo
+        n_tiles = max(1, min(args.tiles, my_tiles))                    # resident chunk
+        return my_tiles, lo, n_tiles, shard.chunk_sizes(my_tiles, n_tiles)
+    lo, _ = shard.weak_tile_range(args.tiles, rank)                    # rank r owns tiles [r*T, (r+1)*T)
+    return args.tiles, lo, args.tiles, [args.tiles]
+
+
+def plan_only(args, rank, world):
+    from proteus_amd import shard
+    cp = shard.ControlPlane(backend='gloo', device=None)
+    my_tiles, tile0, n_tiles, chunks = rank_plan(args, rank, world)
+    cp.barrier()
+    total = cp.sum_over_ranks(my_tiles)
+    plans = cp.gather_objects({'rank': rank, 'first_tile': tile0, 'tiles': my_tiles, 'resident_tiles': n_tiles,
+                               'launches': chunks})
+    if rank == 0:
+        print(json.dumps({'plan_only': True, 'n_gpus': world, 'scaling': 'strong' if args.total_tiles else 'weak',
+                          'tiles_per_step_all_ranks': total, 'control_plane': cp.backend, 'ranks': plans}), flush=True)
+    cp.close()
+    return 0
 
 
 def main():
     args = parse_args()
     if args.cpu_parallel_worker:
         cpu_parallel_main(args.cpu_parallel_worker)
-        return
+        return 0
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run '
-                             '--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...')
         raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
+
+    if args.plan_only:
+        return plan_only(args, rank, world)
 
     import torch
     from proteus_amd import build as _build
-    if not os.path.exists(_build.LIB_PATH):     # fresh checkout: compile the HIP library (never a CPU fallback)
-        if local_rank == 0:
-            _build.build()                      # os.replace at the end: the file appears complete or not at all
-        else:
-            for _ in range(600):
-                if os.path.exists(_build.LIB_PATH):
-                    break
-                time.sleep(0.5)
+    # compile when missing or stale (never a CPU fallback, never an old binary); one rank builds
+    if local_rank == 0:
+        _build.build()                      # os.replace at the end: the file appears complete or not at all
+    else:
+        for _ in range(1200):
+            if not _build.is_stale():
+                break
+            time.sleep(0.5)
     from proteus_amd import _capi, shard
     from proteus_amd.synth import SEED
 
-    if os.environ.get('DSWX_BENCH_SHARE_DEVICE') == '1':
+    share_device = os.environ.get('DSWX_BENCH_SHARE_DEVICE') == '1'
+    if share_device:
         # functional test of the N > 1 code path on a 1-GPU box: every rank on device 0, gloo as
         # the control plane (RCCL refuses two ranks on one GPU).  Not a measurement.
         local_rank = 0
@@ -213,19 +340,26 @@ def main():
         cp = shard.ControlPlane(backend='gloo', device=None)
     else:
         torch.cuda.set_device(local_rank)
-        cp = shard.ControlPlane(backend='nccl', device=torch.device('cuda', local_rank))
+        cp = shard.ControlPlane(backend='nccl', device=torch.device('cuda', local_rank),
+                                allow_fallback=args.allow_gloo)
 
     ctx = _capi.Context(local_rank)        # raises if the HIP extension / GPU is missing
     params = _capi.default_params()
-    n_tiles = args.tiles
+    strong = args.total_tiles > 0
+    my_tiles, tile0, n_tiles, chunks = rank_plan(args, rank, world)
     batch = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=args.masks)
-    tile0, _ = shard.weak_tile_range(n_tiles, rank)     # rank r owns tiles [r*T, (r+1)*T)
     batch.synth(SEED, tile0=tile0)
     ctx.synchronize()
     barrier = cp.barrier
+    # a partial last chunk classifies the first `c` tiles of the resident batch
+    geoms = {c: _capi.BatchGeom(c, TILE, TILE, batch.tile_stride) for c in set(chunks)}
+
+    def one_step():
+        for c in chunks:
+            ctx.classify_batch(params, geoms[c], batch.pin, batch.pout, batch.counters_ptr)
 
     for _ in range(args.warmup):
-        batch.classify(params)
+        one_step()
     ctx.synchronize()
     kernel_info = ctx.last_kernel_info()
 
@@ -237,52 +371,60 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ctx.record(starts[k])
-        batch.classify(params)
+        one_step()
         ctx.record(stops[k])
     ctx.synchronize()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
 
-    launch_ms = [ctx.elapsed_ms(a, b) for a, b in zip(starts, stops)]
+    step_ms = [ctx.elapsed_ms(a, b) for a, b in zip(starts, stops)]
     for e in starts + stops:
         ctx.destroy_event(e)
     elapsed = cp.max_over_ranks(elapsed)
+    total_px_per_step = cp.sum_over_ranks(my_tiles) * TILE * TILE
 
     parity = None
     if rank == 0 and not args.no_parity:
         try:
-            parity = parity_spot_check(ctx, batch, params, n_tiles // 2)
+            if len(chunks) > 1:                 # leave the full resident batch classified
+                batch.classify(params)
+                ctx.synchronize()
+            parity = parity_spot_check(ctx, batch, params, sorted({0, n_tiles // 2, n_tiles - 1}))
         except Exception as e:          # the checker failing is reported, not fatal to the measurement
-            parity = f'not checked ({type(e).__name__}: {e})'[:300]
+            parity = {'result': f'not checked ({type(e).__name__}: {e})'[:300]}
 
     if rank == 0:
-        px_per_launch = n_tiles * TILE * TILE
         bytes_per_px = 24 if args.masks else 21      # 13+8 (16+8 with masks)
-        avg_ms = sum(launch_ms) / len(launch_ms)
-        achieved = px_per_launch * bytes_per_px / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        pmc_note = None
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            key = 'masks' if args.masks else 'plain'
-            if key in pmc and pmc[key].get('tiles') == n_tiles:
-                traffic = pmc[key]['hbm_bytes_per_launch']
-                pmc_note = pmc[key].get('source')
+        # dominant kernel: one launch = one resident chunk; a step is len(chunks) launches
+        px_per_launch = n_tiles * TILE * TILE
+        my_px_per_step = my_tiles * TILE * TILE
+        avg_step_ms = sum(step_ms) / len(step_ms)
+        achieved = my_px_per_step * bytes_per_px / (avg_step_ms * 1e-3) / 1e9
+        avg_launch_ms = avg_step_ms * px_per_launch / my_px_per_step
+        traffic, pmc_note = pmc_traffic(args.masks, n_tiles)
+        if strong:
+            workload = (f'BASELINE configs[3]: {args.total_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles in all, split '
+                        f'contiguously over {world} rank(s); a rank walks its share ({my_tiles} tiles on rank 0) in '
+                        f'{len(chunks)} launch(es) over a resident chunk of {n_tiles} tiles (chunks after the first '
+                        f're-use the resident planes: same bytes streamed, the generator stays outside the timed region)')
+        else:
+            workload = (f'BASELINE configs[2]: {n_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles per GPU per step, '
+                        f'device-resident band-planar batch')
+        workload += (f' (tile stride {batch.tile_stride} px = 256-byte aligned tile starts)'
+                     + (', LAND+SHAD+OCEAN planes' if args.masks else ''))
         out = {
             'metric': 'Mpixels/sec DSWx classify (3660^2 7-band HLS tiles)',
-            'value': round(world * px_per_launch * args.steps / elapsed / 1e6, 1),
+            'value': round(total_px_per_step * args.steps / elapsed / 1e6, 1),
             'unit': 'Mpixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'int16+f64', 'data': 'synthetic',
-            'config': {'workload': f'{n_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles per GPU '
-                                   f'per step, device-resident band-planar batch '
-                                   f'(tile stride {batch.tile_stride} px = 256-byte aligned tile starts)'
-                                   + (', LAND+SHAD+OCEAN planes' if args.masks else ''),
-                       'tiles_per_gpu': n_tiles, 'tile': [TILE, TILE], 'tile_stride_px': batch.tile_stride,
+            'config': {'workload': workload,
+                       'tiles_per_step_all_ranks': total_px_per_step // (TILE * TILE),
+                       'tiles_per_gpu_resident': n_tiles, 'launches_per_step': len(chunks),
+                       'tile': [TILE, TILE], 'tile_stride_px': batch.tile_stride,
                        'planes_in': 10 if args.masks else 7, 'planes_out': 7,
                        'sharding': f'tiles by rank x{world}, no collective',
                        'control_plane': cp.backend,
@@ -292,12 +434,24 @@ def main():
                          'traffic': traffic,
                          'algorithmic_bytes_per_pixel': bytes_per_px,
                          'pixels_per_launch': px_per_launch,
-                         'launch_ms_avg': round(avg_ms, 4), 'launch_ms_min': round(min(launch_ms), 4),
+                         'launch_ms_avg': round(avg_launch_ms, 4),
+                         'launch_ms_min': round(min(step_ms) * px_per_launch / my_px_per_step, 4),
+                         'launch_ms_max': round(max(step_ms) * px_per_launch / my_px_per_step, 4),
+                         'launches_timed': args.steps * len(chunks),
                          'read_frac_of_peak': round(achieved * (bytes_per_px - 8) / bytes_per_px
                                                     / HBM_PEAK_GBS, 4),
-                         'traffic_source': pmc_note},
+                         'traffic_source': pmc_note,
+                         'kernel_source_hash': _build.hot_kernel_hash()},
             'parity_check': parity,
         }
+        if world == 1 and args.realloc_repeats > 0:
+            try:
+                batch.free()
+                batch = None
+                out['roofline']['realloc_spread'] = realloc_spread(ctx, params, n_tiles, args.masks,
+                                                                   args.realloc_repeats)
+            except Exception as e:
+                out['roofline']['realloc_spread'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         if world == 1 and not args.no_single_tile:
             try:
                 out['single_tile'] = single_tile_leg(ctx, params, args.masks)
@@ -312,10 +466,12 @@ def main():
             except Exception as e:      # a reported baseline must never cost the bench line
                 out['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         print(json.dumps(out), flush=True)
-    batch.free()
+    if batch is not None:
+        batch.free()
     ctx.close()
     cp.close()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -273,15 +273,6 @@ int dswx_synth_fill(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0, int64_t n_til
 int dswx_synth_batch(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0,
                      const dswx_batch_geom_t* geom, const dswx_planes_in_t* in, void* stream);
 
-/* Roofline probe: streams exactly the bytes dswx_classify_device streams for the
- * same arguments (7 planes in, 7 planes out, no LAND/SHAD/OCEAN) with trivial
- * arithmetic, to measure the HBM rate that access pattern can reach.  The output
- * planes receive meaningless values.  variant = ppt16 | nt << 1 | log2(iters) << 2:
- * 8 or 16 pixels per thread, non-temporal accesses, chunks per block. */
-int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels,
-                      int64_t tile_stride, const dswx_planes_in_t* in,
-                      const dswx_planes_out_t* out, int variant, void* stream);
-
 /* ---- device plumbing for hosts without another HIP binding ------------------- */
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_device_free(dswx_ctx_t* ctx, void* ptr);

@@ -4,6 +4,7 @@ There is exactly one compute path: the HIP library.  If it is missing, or no
 MI355X is visible, every entry point here raises -- nothing falls back to numpy.
 """
 import ctypes
+import threading
 import weakref
 import os
 
@@ -25,7 +26,7 @@ EXPORTED_SYMBOLS = (
     'dswx_abi_version', 'dswx_last_error', 'dswx_device_count', 'dswx_ctx_create',
     'dswx_ctx_destroy', 'dswx_params_default', 'dswx_classify_host',
     'dswx_classify_device', 'dswx_classify_device_2d', 'dswx_classify_batch', 'dswx_synth_batch', 'dswx_interpret_layer_host', 'dswx_shadow_layer_host', 'dswx_shadow_layer_device', 'dswx_shadow_thresholds', 'dswx_shadow_layer_host_q', 'dswx_shadow_layer_device_q', 'dswx_shadow_layer_host_q32', 'dswx_shadow_layer_device_q32', 'dswx_landcover_mask_host', 'dswx_landcover_mask_device',
-    'dswx_stream_probe', 'dswx_synth_fill', 'dswx_device_malloc',
+    'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_host_alloc', 'dswx_host_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info')
@@ -91,6 +92,8 @@ def load_library(path=None):
     if path is not None and path in _alt_libs:
         return _alt_libs[path]
     alt = path is not None
+    if not alt:
+        _build.build()        # no-op unless a source is newer than the library (never a stale binary)
     path = path or library_path()
     if not os.path.exists(path):
         raise RuntimeError(
@@ -149,8 +152,6 @@ def load_library(path=None):
                                                     ctypes.c_int32, vp]),
         'dswx_landcover_mask_device': (ctypes.c_int, [vp, vp, vp, i64, i64, i64, vp, ctypes.c_int32,
                                                       vp, ctypes.c_int32, vp, vp]),
-        'dswx_stream_probe': (ctypes.c_int, [vp, i64, i64, i64, ctypes.POINTER(PlanesIn),
-                                             ctypes.POINTER(PlanesOut), ctypes.c_int, vp]),
         'dswx_synth_fill': (ctypes.c_int, [vp, ctypes.c_uint64, i64, i64, i64, i64,
                                            ctypes.POINTER(PlanesIn), vp]),
         'dswx_device_malloc': (ctypes.c_int, [vp, ctypes.c_size_t, pp]),
@@ -181,6 +182,32 @@ def load_library(path=None):
     else:
         _lib = lib
     return lib
+
+
+_lab = None
+# every symbol csrc/lab/dswx_lab.h declares
+LAB_SYMBOLS = ('dswx_lab_attach', 'dswx_lab_configure', 'dswx_stream_probe')
+
+
+def load_lab():
+    """dlopen libdswx_lab.so (experiments: kernel structures that lost, roofline probes, A/B switches).
+    Only tools/ and the variant tests call this; nothing in the product path does."""
+    global _lab
+    if _lab is not None:
+        return _lab
+    load_library()
+    path = _build.build_lab()
+    lab = ctypes.CDLL(path)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lab.dswx_lab_attach.restype = ctypes.c_int
+    lab.dswx_lab_attach.argtypes = [vp]
+    lab.dswx_lab_configure.restype = ctypes.c_int
+    lab.dswx_lab_configure.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
+    lab.dswx_stream_probe.restype = ctypes.c_int
+    lab.dswx_stream_probe.argtypes = [vp, i64, i64, i64, ctypes.POINTER(PlanesIn), ctypes.POINTER(PlanesOut),
+                                      ctypes.c_int, vp]
+    _lab = lab
+    return lab
 
 
 def _check(rc):
@@ -366,6 +393,7 @@ class Context:
         self._pinned = {}          # page-locked host spans: address -> bytes
         self._pinned_pool = {}     # released spans by size
         self._pinned_pool_bytes = 0
+        self._pinned_lock = threading.Lock()   # reader threads allocate, finalizers release on any thread
 
     def close(self):
         if self.handle:
@@ -388,14 +416,18 @@ class Context:
         slow (~0.1 ms per MB), so released spans go to a per-context pool and are reused."""
         dtype = np.dtype(dtype)
         nbytes = max(int(np.prod(shape, dtype=np.int64)) * dtype.itemsize, 1)
-        if self._pinned_pool.get(nbytes):
-            addr = self._pinned_pool[nbytes].pop()
-            self._pinned_pool_bytes -= nbytes
-        else:
+        addr = None
+        with self._pinned_lock:
+            spans = self._pinned_pool.get(nbytes)
+            if spans:
+                addr = spans.pop()
+                self._pinned_pool_bytes -= nbytes
+        if addr is None:
             ptr = ctypes.c_void_p()
             _check(self.lib.dswx_host_alloc(self.handle, nbytes, ctypes.byref(ptr)))
             addr = ptr.value
-            self._pinned[addr] = nbytes
+            with self._pinned_lock:
+                self._pinned[addr] = nbytes
         raw = (ctypes.c_char * nbytes).from_address(addr)
         arr = np.frombuffer(raw, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape) \
             if int(np.prod(shape, dtype=np.int64)) else np.empty(shape, dtype)
@@ -404,18 +436,23 @@ class Context:
             ctx = ctx_ref()
             if ctx is None or not ctx.handle:
                 return
-            if ctx._pinned_pool_bytes + nbytes <= ctx.PINNED_POOL_CAP:
-                ctx._pinned_pool.setdefault(nbytes, []).append(addr)
-                ctx._pinned_pool_bytes += nbytes
-            else:
-                ctx._pinned.pop(addr, None)
+            with ctx._pinned_lock:
+                keep = ctx._pinned_pool_bytes + nbytes <= ctx.PINNED_POOL_CAP
+                if keep:
+                    ctx._pinned_pool.setdefault(nbytes, []).append(addr)
+                    ctx._pinned_pool_bytes += nbytes
+                else:
+                    ctx._pinned.pop(addr, None)
+            if not keep:
                 ctx.lib.dswx_host_free(ctx.handle, ctypes.c_void_p(addr))
         weakref.finalize(raw, release)
         return arr
 
     def is_pinned(self, arr):
         a = arr.ctypes.data
-        return any(base <= a and a + arr.nbytes <= base + size for base, size in self._pinned.items())
+        with self._pinned_lock:
+            spans = list(self._pinned.items())
+        return any(base <= a and a + arr.nbytes <= base + size for base, size in spans)
 
     # ---- host-pointer path ----------------------------------------------------
     def classify_host(self, bands, fmask, params, *, land=None, shad=None, ocean=None,
@@ -540,18 +577,31 @@ class Context:
 
     def shadow_layer_device(self, dem_ptr, n_tiles, height, width, margin, sun_vector, sin_azimuth,
                             cos_azimuth, min_slope_angle, max_sun_local_inc_angle, out_ptr,
-                            pixel_spacing_x=30, pixel_spacing_y=30, stream=None):
-        """Device-pointer form: [n_tiles][H][W] float32 DEMs -> [n_tiles][H-2m][W-2m] u8, asynchronous."""
+                            pixel_spacing_x=30, pixel_spacing_y=30, stream=None, float32=False):
+        """Device-pointer form: [n_tiles][H][W] float32 DEMs -> [n_tiles][H-2m][W-2m] u8, asynchronous.
+        float32=True: numpy < 2 value-based casting (the _q32 entry point)."""
         vec = (ctypes.c_double * 3)(*[float(v) for v in sun_vector])
-        slope_arg_max, inc_q_min = shadow_thresholds(min_slope_angle, max_sun_local_inc_angle)
-        _check(self.lib.dswx_shadow_layer_device_q(
+        slope_arg_max, inc_q_min = shadow_thresholds(min_slope_angle, max_sun_local_inc_angle, float32)
+        fn = self.lib.dswx_shadow_layer_device_q32 if float32 else self.lib.dswx_shadow_layer_device_q
+        _check(fn(
             self.handle, ctypes.c_void_p(dem_ptr), int(n_tiles), int(height), int(width), int(margin),
             ctypes.byref(vec), float(sin_azimuth), float(cos_azimuth), slope_arg_max, inc_q_min,
             float(pixel_spacing_x), float(pixel_spacing_y),
             ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream) if stream else None))
 
+    # ---- libdswx_lab.so (experiments; tools/ and the variant tests only) -----------
+    def lab_configure(self, **settings):
+        """A/B switches of this context, e.g. lab_configure(fused_variant=2) or (host_chunks=3);
+        loads libdswx_lab.so and attaches its kernel structures on first use."""
+        lab = load_lab()
+        if not getattr(self, '_lab_attached', False):
+            _check(lab.dswx_lab_attach(self.handle))
+            self._lab_attached = True
+        for key, value in settings.items():
+            _check(lab.dswx_lab_configure(self.handle, key.encode(), int(value)))
+
     def stream_probe(self, n_tiles, n_pixels, pin, pout, variant=0, stream=None, tile_stride=0):
-        _check(self.lib.dswx_stream_probe(
+        _check(load_lab().dswx_stream_probe(
             self.handle, int(n_tiles), int(n_pixels), int(tile_stride), ctypes.byref(pin),
             ctypes.byref(pout), int(variant), ctypes.c_void_p(stream) if stream else None))
 
@@ -619,7 +669,7 @@ class DeviceBatch:
     Used by bench.py, the multi-GPU driver and the device-path parity tests.
     """
 
-    def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=(), tile_align=256):
+    def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=(), tile_align=256, plane_skew=0):
         self.ctx, self.n_tiles, self.height, self.width = ctx, n_tiles, height, width
         self.n_pixels = height * width
         self.tile_stride = -(-self.n_pixels // tile_align) * tile_align
@@ -629,7 +679,7 @@ class DeviceBatch:
         off = 0
         self.offsets = {}
 
-        skew = int(os.environ.get('DSWX_PLANE_SKEW', '0'))
+        skew = int(plane_skew)
 
         def take(name, nbytes):
             # optional skew: plane k starts k*skew bytes later than plain packing,

@@ -13,7 +13,7 @@
 #include "dswx_tables.h"
 
 // WPS: launch bound.  EXTRAS: also the browse plane and the stage-1 planes of 'cover' mode
-// (uncollapsed WTR-2, CLOUD before the snow step), looked up in Tables::extra.
+// (the cover state byte), looked up in Tables::extra.
 template <bool MASKS, bool EXTRAS, int WPS>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
                                                              const Tables* __restrict__ tabs) {
@@ -69,14 +69,11 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         lut_group<MASKS, EXTRAS>(P, C, s_lut1, s_fm16, s_land8, s_chain, s_pre16, v, vf, vl, vs, vo, has_l, in_range,
                                  w1w, chx, chy, cnt, idx2);
         if (EXTRAS && in_range) {
-            uint32_t ex[8], pa[4], pb[4];     // byte 0 WTR-2 uncollapsed, 1 CLOUD pre-snow, 2 browse
+            uint32_t ex[8], pa[4], pb[4];     // byte 0 cover state (+ adjacent bit), byte 2 browse
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ex[j] = s_extra[idx2[j]];
+            for (int j = 0; j < 8; ++j) ex[j] = s_extra[idx2[j] & 127u] | (idx2[j] & 128u);
             transpose4(ex, pa); transpose4(ex + 4, pb);
-            if (a.cover_w2) {
-                stg<u32x2, false>(a.cover_w2 + off, u32x2{pa[0], pb[0]});     // re-read by stage 2: cacheable
-                stg<u32x2, false>(a.cover_pc + off, u32x2{pa[1], pb[1]});
-            }
+            if (a.cover_state) stg<u32x2, false>(a.cover_state + off, u32x2{pa[0], pb[0]});   // re-read by stage 2: cacheable
             if (a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{pa[2], pb[2]});
         }
         if (in_range) {
@@ -128,7 +125,7 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
     // with LAND / SHAD / OCEAN (5 and 6 spill to scratch there; without masks they give 67 VGPRs
     // and measure 0-2 % slower than 4)
     const int wps = ctx->tune_lut_wps > 0 ? ctx->tune_lut_wps : 4;
-    const bool extras = b.out.browse || b.cover_w2;
+    const bool extras = b.out.browse || b.cover_state;
 #define LUT_LAUNCH(M, E, W) hipLaunchKernelGGL((dswx_classify_lut<M, E, W>), grid, block, 0, s, b, lc, tabs)
 #define LUT_SEL_W(M, E) do { if (wps >= 6) LUT_LAUNCH(M, E, 6); else if (wps == 5) LUT_LAUNCH(M, E, 5); else LUT_LAUNCH(M, E, 4); } while (0)
     if (extras) { if (masks) LUT_LAUNCH(true, true, 4); else LUT_LAUNCH(false, true, 4); }

@@ -43,8 +43,8 @@ struct KArgs {
     int u8_region[7];               //   and the LDS staging region each one lives in
     int n_u8_out;
     int n_diag_pieces;              // 8 if DIAG is wanted, else 0
-    uint8_t* cover_w2;              // 'cover' mode: stage 1 parks the uncollapsed WTR-2 and
-    uint8_t* cover_pc;              //   the pre-snow CLOUD here; stage 2 reads them back
+    uint8_t* cover_state;           // 'cover' mode: stage 1 parks one state byte per pixel here
+                                    //   (cover_state_of); stage 2 (dswx_cover.hip) reads it back
     int height, width;              // 'cover' stage 2 only
     unsigned long long* counters;   // [n_tiles][3] or nullptr
     long long n_pixels;             // per tile
@@ -72,7 +72,8 @@ static constexpr uint32_t CLS_B2 = class_bit_mask(2);
 
 struct PxOut {
     uint32_t diag, wtr1, wtr1a, wtr2, wtr, bwtr, conf, cloud;
-    uint32_t w2_raw, pc;   // uncollapsed WTR-2 and pre-snow CLOUD ('cover' stage 1)
+    uint32_t w2_raw, pc;   // uncollapsed WTR-2 and pre-snow CLOUD
+    uint32_t state;        // 'cover' stage 1: cover_state_of(w2_raw, pc, snow) (without the adjacent bit)
     uint32_t browse;       // _compute_browse_array of the uncollapsed WTR
 };
 
@@ -91,6 +92,14 @@ __device__ __forceinline__ uint32_t collapse_class(uint32_t v, uint32_t c) {
     // _collapse_wtr_classes :2578-2598 on the value set {0..4, 252..255};
     // c = 1 collapses (0,1,1,2,2), c = 0 is the identity
     return v <= 4u ? (v + c) >> c : v;
+}
+
+// 'cover' mode: what stage 2 needs of a pixel, in one byte.  bits 0-2: WTR-2 code (0..4 class, 5 ocean
+// masked, 6 fill); bits 3-5: bits 0, 2, 3 of CLOUD before the snow step; bit 6: Fmask snow (bit 4);
+// bit 7 (added by the caller): Fmask adjacent-to-cloud (bit 2).
+__device__ __forceinline__ uint32_t cover_state_of(uint32_t w2, uint32_t pc, bool snow) {
+    const uint32_t code = w2 <= 4u ? w2 : (w2 == 254u ? 5u : 6u);
+    return code | (pc & 1u) << 3 | ((pc >> 2) & 3u) << 4 | (snow ? 64u : 0u);
 }
 
 // A11-A15 of one pixel, given the uncollapsed WTR-2 class, the CLOUD value before the
@@ -151,6 +160,7 @@ __device__ __forceinline__ void px_chain(const DevParams& P, uint32_t w1, bool r
     const uint32_t cc = (uint32_t)P.collapse;
     o.wtr1 = collapse_class(w1, cc); o.wtr1a = collapse_class(w1a, cc);
     o.w2_raw = w2; o.pc = pc;
+    o.state = cover_state_of(w2, pc, snow);
     finish_px(P, w2, pc, snow, o);
 }
 

@@ -1,11 +1,11 @@
 // dswx_hip.hip -- MI355X (gfx950 / CDNA4) DSWx-HLS per-pixel classifier: the direct fused kernel,
-// the 'cover' stage-2 kernels, the generic kernel, kernel dispatch and the core of the C-ABI
+// the generic kernel, kernel dispatch and the core of the C-ABI
 // (context, parameters, device-pointer entry points, device plumbing).  Elsewhere:
 //   dswx_device.h         per-pixel device functions (single source of truth of the chain)
 //   dswx_classify_lut.hip table-driven production kernel (+ dswx_tables.h)
 //   dswx_host_path.hip    dswx_classify_host (synchronous and pipelined), page-locked memory
 //   dswx_layers.hip       shadow layer, LAND aggregation, interpret-alone, synthetic tiles
-//   dswx_variants.hip     experimental data-movement structures;  dswx_probes.hip  roofline probes
+//   (experimental data-movement structures and roofline probes: libdswx_lab.so, csrc/lab/)
 //
 // One fused streaming kernel computes, per pixel, everything the reference does
 // in ~100 whole-array numpy passes between src/proteus/dswx_hls.py:5088 and :5369:
@@ -49,7 +49,6 @@
 #include <vector>
 
 #include "dswx_host.h"
-#include "dswx_tables.h"     // transpose4 (byte transposes) for the quad cover kernel
 
 // ------------------------------------------------------------------------------
 // Fused kernel, direct-store variant (the default): block = 256 threads, one
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
         }
         uint32_t q_diag[4] = {0, 0, 0, 0};
         uint32_t q_w1[2] = {0, 0}, q_w1a[2] = {0, 0}, q_w2[2] = {0, 0}, q_w[2] = {0, 0},
-                 q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0}, q_w2r[2] = {0, 0}, q_pc[2] = {0, 0}, q_br[2] = {0, 0};
+                 q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0}, q_st[2] = {0, 0}, q_br[2] = {0, 0};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int wd = j >> 1, hf = j & 1;
@@ -126,8 +125,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
             q_cf[bw] |= o.conf << (8 * bk);
             q_cl[bw] |= o.cloud << (8 * bk);
             if (EXTRAS) {
-                q_w2r[bw] |= o.w2_raw << (8 * bk);
-                q_pc[bw] |= o.pc << (8 * bk);
+                q_st[bw] |= (o.state | ((uint32_t)fm & 4u) << 5) << (8 * bk);
                 q_br[bw] |= o.browse << (8 * bk);
             }
         }
@@ -141,10 +139,8 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
         if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{q_cf[0], q_cf[1]});
         if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{q_cl[0], q_cl[1]});
         if (EXTRAS && a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{q_br[0], q_br[1]});
-        if (EXTRAS && a.cover_w2) {   // 'cover' stage 1 (wave-uniform)
-            *reinterpret_cast<u32x2*>(a.cover_w2 + off) = u32x2{q_w2r[0], q_w2r[1]};
-            *reinterpret_cast<u32x2*>(a.cover_pc + off) = u32x2{q_pc[0], q_pc[1]};
-        }
+        if (EXTRAS && a.cover_state)   // 'cover' stage 1 (wave-uniform)
+            *reinterpret_cast<u32x2*>(a.cover_state + off) = u32x2{q_st[0], q_st[1]};
         }
     }
     if (a.partials) {
@@ -155,359 +151,6 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
         if ((threadIdx.x & 63) == 0) {
             const long long slot = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
             a.partials[slot] = make_uint2(w_valid | (w_cloud << 16), t_ocean);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------
-// 'cover' mode, stage 2 (_add_snow_to_cloud_layer :2055-2078, then A11-A15).
-//   snow  = dilate^10(Fmask bit 4)            restricted to  area = adjacent & (CLOUD == 0)
-//   clear = dilate^7(~snow & (CLOUD == 0))    restricted to  area & (WTR-2 in 1..4)
-//   snow &= ~clear
-// with scipy.ndimage.binary_dilation semantics: 4-neighbour cross, synchronous
-// iterations, cells outside the mask keep their value, outside the raster = False.
-// k iterations reach k pixels, so a 64 x 64 output tile is exact from a 98 x 98
-// window (halo 10 + 7) held in LDS; the two masked dilations ping-pong between
-// two byte arrays there.  One block = 256 threads; grid = (tiles_x, tiles_y, n_tiles).
-// ------------------------------------------------------------------------------
-constexpr int CV_TILE = 64, CV_HALO = 17, CV_DIM = CV_TILE + 2 * CV_HALO, CV_CELLS = CV_DIM * CV_DIM;
-enum : uint8_t { CV_SNOW = 1, CV_AREA = 2, CV_WATER = 4, CV_CLEAR0 = 8 };
-
-__global__ __launch_bounds__(256) void dswx_cover_stage2(const KArgs a) {
-    __shared__ uint8_t flags[CV_CELLS];      // static per-cell bits (CV_AREA, CV_WATER, CV_CLEAR0)
-    __shared__ uint8_t cur[CV_CELLS];        // the mask being dilated
-    __shared__ uint8_t nxt[CV_CELLS];
-    const int H = a.height, W = a.width;
-    const long long tile_base = (long long)blockIdx.z * a.tile_stride;
-    const int y0 = blockIdx.y * CV_TILE - CV_HALO, x0 = blockIdx.x * CV_TILE - CV_HALO;
-    for (int c = threadIdx.x; c < CV_CELLS; c += 256) {
-        const int y = y0 + c / CV_DIM, x = x0 + c % CV_DIM;
-        uint8_t f = 0, snow = 0;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            const long long off = tile_base + (long long)y * W + x;
-            const uint32_t fm = a.in.fmask[off], pc = a.cover_pc[off], w2 = a.cover_w2[off];
-            snow = (fm & 16u) ? 1 : 0;
-            const bool area = (fm & 4u) && pc == 0u;
-            f = (area ? CV_AREA : 0) | ((w2 - 1u) <= 3u ? CV_WATER : 0) | (pc == 0u ? CV_CLEAR0 : 0);
-        }
-        flags[c] = f;
-        cur[c] = snow;
-    }
-    __syncthreads();
-    uint8_t* src = cur;
-    uint8_t* dst = nxt;
-    auto dilate = [&](uint8_t need) {
-        for (int c = threadIdx.x; c < CV_CELLS; c += 256) {
-            uint8_t v = src[c];
-            if (!v && (flags[c] & need) == need) {
-                const int yy = c / CV_DIM, xx = c % CV_DIM;
-                v = (yy > 0 && src[c - CV_DIM]) || (yy < CV_DIM - 1 && src[c + CV_DIM]) ||
-                    (xx > 0 && src[c - 1]) || (xx < CV_DIM - 1 && src[c + 1]);
-            }
-            dst[c] = v;
-        }
-        __syncthreads();
-        uint8_t* t = src; src = dst; dst = t;
-    };
-    for (int it = 0; it < 10; ++it) dilate(CV_AREA);
-    // src = dilated snow.  Keep it in `flags` (bit CV_SNOW) and start the second mask.
-    for (int c = threadIdx.x; c < CV_CELLS; c += 256) {
-        const uint8_t sn = src[c];
-        const uint8_t f = flags[c];
-        flags[c] = f | (sn ? CV_SNOW : 0);
-        dst[c] = (!sn && (f & CV_CLEAR0)) ? 1 : 0;
-    }
-    __syncthreads();
-    { uint8_t* t = src; src = dst; dst = t; }
-    for (int it = 0; it < 7; ++it) dilate(CV_AREA | CV_WATER);
-    // finish the interior 64 x 64
-    for (int i = threadIdx.x; i < CV_TILE * CV_TILE; i += 256) {
-        const int ly = i / CV_TILE, lx = i % CV_TILE;
-        const int y = blockIdx.y * CV_TILE + ly, x = blockIdx.x * CV_TILE + lx;
-        if (y >= H || x >= W) continue;
-        const int c = (ly + CV_HALO) * CV_DIM + lx + CV_HALO;
-        const bool snow = (flags[c] & CV_SNOW) && !src[c];
-        const long long off = tile_base + (long long)y * W + x;
-        PxOut o;
-        finish_px(a.P, a.cover_w2[off], a.cover_pc[off], snow, o);
-        if (a.out.wtr) a.out.wtr[off] = (uint8_t)o.wtr;
-        if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)o.bwtr;
-        if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
-        if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
-        if (a.out.browse) a.out.browse[off] = (uint8_t)o.browse;
-    }
-}
-
-// ------------------------------------------------------------------------------
-// 'cover' mode, stage 2, bit-packed (default).  Same semantics as dswx_cover_stage2 above, but
-// the four per-pixel predicates live as BITMAPS: one block owns a 128-column x 256-row window
-// (halo 17 on every side -> 94 x 222 output pixels), one thread owns one window row as a
-// 128-bit word pair per mask.  A masked 4-neighbour dilation step is then
-//     x |= (x | x<<1 | x>>1 | row_above | row_below) & mask
-// on 128 bits: ~30 VALU and one 16-byte LDS exchange per thread and iteration, instead of
-// one LDS byte read-modify-write per cell (9604 cells x 17 iterations per 4096 outputs).
-//   phase A  waves build the bitmaps row by row with coalesced byte loads + wave ballots
-//   phase B  17 synchronous iterations (10 on snow within `area`, 7 on clear within area & water)
-//   phase C  waves walk the output rows again (coalesced), finish A11-A15 per pixel
-// Window edges are wrong by one more row / column per iteration; after 17 iterations
-// exactly the halo is contaminated, so the output region is exact.
-// ------------------------------------------------------------------------------
-constexpr int CB_W = 128, CB_H = 256, CB_HALO = 17, CB_OUT_W = CB_W - 2 * CB_HALO, CB_OUT_H = CB_H - 2 * CB_HALO;
-
-__global__ __launch_bounds__(256) void dswx_cover_stage2_bits(const KArgs a) {
-    typedef unsigned long long u64;
-    __shared__ u64 s_init[CB_H][8];          // per row: snow, area, area & water, clear0  (lo, hi each)
-    __shared__ u64 s_x[2][CB_H + 2][2];      // row exchange, double-buffered, zero guard rows
-    const int H = a.height, W = a.width;
-    const long long tile_base = (long long)blockIdx.z * a.tile_stride;
-    const int y0 = blockIdx.y * CB_OUT_H - CB_HALO, x0 = blockIdx.x * CB_OUT_W - CB_HALO;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = threadIdx.x;
-    if (t < 4) { s_x[t >> 1][(t & 1) ? CB_H + 1 : 0][0] = 0; s_x[t >> 1][(t & 1) ? CB_H + 1 : 0][1] = 0; }
-    // A11-A15 as a table over (WTR-2 code, preliminary CLOUD bits, snow): filled once per block by
-    // finish_px itself, looked up per pixel in phase C
-    __shared__ uint32_t s_fin[128];          // WTR | BWTR << 8 | CONF << 16 | CLOUD << 24
-    __shared__ uint8_t s_fbr[128];           // browse
-    if (t < 128) {
-        const uint32_t c = t & 7u, b = (t >> 3) & 7u;
-        PxOut o;
-        finish_px(a.P, c < 5u ? c : (c == 5u ? 254u : 255u), (b & 1u) | ((b & 6u) << 1), (t >> 6) != 0, o);
-        s_fin[t] = o.wtr | o.bwtr << 8 | o.conf << 16 | o.cloud << 24;
-        s_fbr[t] = (uint8_t)o.browse;
-    }
-    // ---- phase A: four rows per wave and iteration, all 24 byte loads issued before the first
-    // ballot consumes one (the loop is latency-bound, not bandwidth-bound)
-    const uint8_t* __restrict__ g_fm = a.in.fmask + tile_base;
-    const uint8_t* __restrict__ g_pc = a.cover_pc + tile_base;
-    const uint8_t* __restrict__ g_w2 = a.cover_w2 + tile_base;
-    for (int r0 = wave; r0 < CB_H; r0 += 16) {
-        uint32_t fm[4][2], pc[4][2], w2[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int y = y0 + r0 + 4 * j;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int x = x0 + 64 * h + lane;
-                const bool in = (y >= 0) & (y < H) & (x >= 0) & (x < W);
-                const long long off = in ? (long long)y * W + x : 0;
-                fm[j][h] = in ? g_fm[off] : 0u;          // 0 / 1 / 0: no snow, not clear, no water
-                pc[j][h] = in ? g_pc[off] : 1u;
-                w2[j][h] = in ? g_w2[off] : 0u;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t bits[2];                     // snow | area << 1 | (area & water) << 2 | clear0 << 3
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t clear0 = pc[j][h] == 0u ? 1u : 0u, area = ((fm[j][h] >> 2) & 1u) & clear0;
-                const uint32_t water = (w2[j][h] - 1u) <= 3u ? 1u : 0u;
-                bits[h] = ((fm[j][h] >> 4) & 1u) | area << 1 | (area & water) << 2 | clear0 << 3;
-            }
-            u64 m[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                m[2 * k] = __ballot((bits[0] >> k) & 1u);
-                m[2 * k + 1] = __ballot((bits[1] >> k) & 1u);
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) s_init[r0 + 4 * j][k] = m[k];
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase B: thread t owns window row t
-    u64 slo = s_init[t][0], shi = s_init[t][1];
-    const u64 alo = s_init[t][2], ahi = s_init[t][3], wlo = s_init[t][4], whi = s_init[t][5];
-    const u64 c0lo = s_init[t][6], c0hi = s_init[t][7];
-    int buf = 0;
-    auto step = [&](u64& lo, u64& hi, u64 mlo, u64 mhi) {
-        s_x[buf][t + 1][0] = lo; s_x[buf][t + 1][1] = hi;
-        __syncthreads();
-        const u64 nlo = lo | s_x[buf][t][0] | s_x[buf][t + 2][0] | (lo << 1) | (lo >> 1) | (hi << 63);
-        const u64 nhi = hi | s_x[buf][t][1] | s_x[buf][t + 2][1] | (hi << 1) | (hi >> 1) | (lo >> 63);
-        lo |= nlo & mlo; hi |= nhi & mhi;
-        buf ^= 1;
-    };
-    for (int it = 0; it < 10; ++it) step(slo, shi, alo, ahi);
-    u64 clo = ~slo & c0lo, chi = ~shi & c0hi;
-    for (int it = 0; it < 7; ++it) step(clo, chi, wlo, whi);
-    // final snow of the row -> LDS (buffer `buf` was last written two steps ago: free)
-    s_x[buf][t + 1][0] = slo & ~clo; s_x[buf][t + 1][1] = shi & ~chi;
-    __syncthreads();
-    // ---- phase C: again four rows per wave and iteration with the loads hoisted
-    for (int r0 = CB_HALO + wave; r0 < CB_H - CB_HALO; r0 += 16) {
-        uint32_t w2[4][2], pc[4][2];
-        bool on[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + 4 * j, y = y0 + r;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = 64 * h + lane, x = x0 + c;
-                on[j][h] = (r < CB_H - CB_HALO) & (y < H) & (c >= CB_HALO) & (c < CB_W - CB_HALO) & (x < W);
-                const long long off = on[j][h] ? (long long)y * W + x : 0;
-                w2[j][h] = on[j][h] ? g_w2[off] : 0u;
-                pc[j][h] = on[j][h] ? g_pc[off] : 0u;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + 4 * j, y = y0 + r;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (!on[j][h]) continue;
-                const uint32_t snow = (uint32_t)(s_x[buf][r + 1][h] >> lane) & 1u;
-                const long long off = tile_base + (long long)y * W + x0 + 64 * h + lane;
-                const uint32_t idx = (w2[j][h] < 5u ? w2[j][h] : w2[j][h] - 249u) |
-                                     ((pc[j][h] & 1u) | ((pc[j][h] >> 1) & 6u)) << 3 | snow << 6;
-                const uint32_t e = s_fin[idx];
-                if (a.out.wtr) a.out.wtr[off] = (uint8_t)e;
-                if (a.out.bwtr) a.out.bwtr[off] = (uint8_t)(e >> 8);
-                if (a.out.conf) a.out.conf[off] = (uint8_t)(e >> 16);
-                if (a.out.cloud) a.out.cloud[off] = (uint8_t)(e >> 24);
-                if (a.out.browse) a.out.browse[off] = s_fbr[idx];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------
-// 'cover' mode, stage 2, bit-packed, FOUR pixels per lane (default when rows keep 4-byte
-// alignment: width % 4 == 0, tile stride % 4 == 0, 4-byte aligned planes).  Same window scheme as
-// dswx_cover_stage2_bits (128 x 256, one thread = one window row in phase B) with a column halo
-// of 20 so that every lane's quad is dword-aligned (88 x 222 outputs per block):
-//   phase A  a wave takes TWO rows per step (half-wave each), one dword load per plane and lane,
-//            byte-parallel predicates, ballots -> the row bitmap as 4 x u32 in pixel-interleaved
-//            order: word k, bit l <-> window column 4 l + k
-//   phase B  in that order the horizontal neighbours are plain word moves:
-//            left(k) = word k-1 (k > 0), word 3 << 1 (k = 0);  right(k) = word k+1, word 0 >> 1
-//   phase C  dword loads, four table lookups, byte transpose, dword stores
-// A quarter of the memory instructions and ballots of the byte-lane version per pixel.
-// ------------------------------------------------------------------------------
-constexpr int CQ_HALO_X = 20, CQ_OUT_W = CB_W - 2 * CQ_HALO_X;
-
-__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {      // 0x01 in every byte of v that is 0
-    return (~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu)) >> 7;
-}
-
-__global__ __launch_bounds__(256) void dswx_cover_stage2_quads(const KArgs a) {
-    __shared__ uint32_t s_init[CB_H][16];     // per row: snow[4], area[4], area & water[4], clear0[4]
-    __shared__ uint32_t s_x[2][CB_H + 2][4];  // row exchange, double-buffered, zero guard rows
-    __shared__ uint32_t s_fin[128];           // WTR | BWTR << 8 | CONF << 16 | CLOUD << 24
-    __shared__ uint8_t s_fbr[128];            // browse
-    const int H = a.height, W = a.width;
-    const long long tile_base = (long long)blockIdx.z * a.tile_stride;
-    const int y0 = blockIdx.y * CB_OUT_H - CB_HALO, x0 = blockIdx.x * CQ_OUT_W - CQ_HALO_X;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = threadIdx.x;
-    const int l32 = lane & 31, rsel = lane >> 5;
-    if (t < 16) s_x[t >> 3][((t >> 2) & 1) ? CB_H + 1 : 0][t & 3] = 0;
-    if (t < 128) {
-        const uint32_t c = t & 7u, b = (t >> 3) & 7u;
-        PxOut o;
-        finish_px(a.P, c < 5u ? c : (c == 5u ? 254u : 255u), (b & 1u) | ((b & 6u) << 1), (t >> 6) != 0, o);
-        s_fin[t] = o.wtr | o.bwtr << 8 | o.conf << 16 | o.cloud << 24;
-        s_fbr[t] = (uint8_t)o.browse;
-    }
-    const uint8_t* __restrict__ g_fm = a.in.fmask + tile_base;
-    const uint8_t* __restrict__ g_pc = a.cover_pc + tile_base;
-    const uint8_t* __restrict__ g_w2 = a.cover_w2 + tile_base;
-    const int x = x0 + 4 * l32;
-    const bool x_in = (x >= 0) & (x < W);                 // W % 4 == 0: a quad is inside or outside as a whole
-    // ---- phase A: row pairs p = wave + 4 i (rows 2p, 2p + 1), four pairs per iteration
-    for (int p0 = wave; p0 < CB_H / 2; p0 += 16) {
-        uint32_t fm[4], pc[4], w2[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int y = y0 + 2 * (p0 + 4 * j) + rsel;
-            const bool in = x_in & (y >= 0) & (y < H);
-            const long long off = in ? (long long)y * W + x : 0;
-            fm[j] = in ? *reinterpret_cast<const uint32_t*>(g_fm + off) : 0u;
-            pc[j] = in ? *reinterpret_cast<const uint32_t*>(g_pc + off) : 0x01010101u;   // not clear
-            w2[j] = in ? *reinterpret_cast<const uint32_t*>(g_w2 + off) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t snow4 = (fm[j] >> 4) & 0x01010101u, clear4 = zero_bytes(pc[j]);
-            const uint32_t area4 = (fm[j] >> 2) & clear4;                       // clear4 is 0 / 1 per byte
-            // WTR-2 uncollapsed is one of 0..4, 254, 255: water classes are the nonzero bytes below 8
-            const uint32_t water4 = zero_bytes(w2[j] & 0xf8f8f8f8u) & ~zero_bytes(w2[j]);
-            const uint32_t m4[4] = {snow4, area4, area4 & water4, clear4};
-            const int row = 2 * (p0 + 4 * j);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned long long bal = __ballot((m4[q] >> (8 * k)) & 1u);
-                    if (lane == 0) s_init[row][4 * q + k] = (uint32_t)bal;
-                    if (lane == 1) s_init[row + 1][4 * q + k] = (uint32_t)(bal >> 32);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase B: thread t owns window row t
-    uint32_t S[4], A[4], Wm[4], C0[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { S[k] = s_init[t][k]; A[k] = s_init[t][4 + k]; Wm[k] = s_init[t][8 + k]; C0[k] = s_init[t][12 + k]; }
-    int buf = 0;
-    auto step = [&](uint32_t (&X)[4], const uint32_t (&M)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s_x[buf][t + 1][k] = X[k];
-        __syncthreads();
-        uint32_t n[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) n[k] = X[k] | s_x[buf][t][k] | s_x[buf][t + 2][k];
-        n[0] |= (X[3] << 1) | X[1];
-        n[1] |= X[0] | X[2];
-        n[2] |= X[1] | X[3];
-        n[3] |= X[2] | (X[0] >> 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) X[k] |= n[k] & M[k];
-        buf ^= 1;
-    };
-    for (int it = 0; it < 10; ++it) step(S, A);
-    uint32_t C[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) C[k] = ~S[k] & C0[k];
-    for (int it = 0; it < 7; ++it) step(C, Wm);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s_x[buf][t + 1][k] = S[k] & ~C[k];      // final snow of the row
-    __syncthreads();
-    // ---- phase C: row pairs again; output columns 20..107 = quads 5..26
-    const bool x_out = x_in & (l32 >= CQ_HALO_X / 4) & (l32 < (CB_W - CQ_HALO_X) / 4);
-    for (int p0 = wave; p0 < CB_H / 2; p0 += 16) {
-        uint32_t w2[4], pc[4];
-        bool on[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = 2 * (p0 + 4 * j) + rsel, y = y0 + r;
-            on[j] = x_out & (r >= CB_HALO) & (r < CB_H - CB_HALO) & (y < H);
-            const long long off = on[j] ? (long long)y * W + x : 0;
-            w2[j] = on[j] ? *reinterpret_cast<const uint32_t*>(g_w2 + off) : 0u;
-            pc[j] = on[j] ? *reinterpret_cast<const uint32_t*>(g_pc + off) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!on[j]) continue;
-            const int r = 2 * (p0 + 4 * j) + rsel;
-            uint32_t e[4], br = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t snow = (s_x[buf][r + 1][k] >> l32) & 1u;
-                const uint32_t w = (w2[j] >> (8 * k)) & 0xffu, c = (pc[j] >> (8 * k)) & 0xffu;
-                const uint32_t idx = (w < 5u ? w : w - 249u) | ((c & 1u) | ((c >> 1) & 6u)) << 3 | snow << 6;
-                e[k] = s_fin[idx];
-                br |= (uint32_t)s_fbr[idx] << (8 * k);
-            }
-            uint32_t planes[4];            // byte k of every e -> plane k, pixel order
-            transpose4(e, planes);
-            const long long off = tile_base + (long long)(y0 + r) * W + x;
-            if (a.out.wtr) *reinterpret_cast<uint32_t*>(a.out.wtr + off) = planes[0];
-            if (a.out.bwtr) *reinterpret_cast<uint32_t*>(a.out.bwtr + off) = planes[1];
-            if (a.out.conf) *reinterpret_cast<uint32_t*>(a.out.conf + off) = planes[2];
-            if (a.out.cloud) *reinterpret_cast<uint32_t*>(a.out.cloud + off) = planes[3];
-            if (a.out.browse) *reinterpret_cast<uint32_t*>(a.out.browse + off) = br;
         }
     }
 }
@@ -585,7 +228,7 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
         if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
         if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
         if (a.out.browse) a.out.browse[off] = (uint8_t)o.browse;
-        if (a.cover_w2) { a.cover_w2[off] = (uint8_t)o.w2_raw; a.cover_pc[off] = (uint8_t)o.pc; }
+        if (a.cover_state) a.cover_state[off] = (uint8_t)(o.state | ((uint32_t)fm & 4u) << 5);
     }
     if (a.counters) reduce_counters(a.counters + (long long)blockIdx.y * 3, red, c0, c1, c2);
 }
@@ -767,17 +410,6 @@ int dswx_ctx_create(int device, dswx_ctx_t** out) {
     HIP_TRY(hipSetDevice(device));
     dswx_ctx* c = new dswx_ctx();
     c->device = device;
-    if (const char* e = std::getenv("DSWX_FUSED_VARIANT")) {
-        const int v = std::atoi(e);
-        c->fused_variant = (v >= 0 && v <= 5) ? v : -1;
-    }
-    if (const char* e = std::getenv("DSWX_TUNE_WPS")) c->tune_wps = std::atoi(e);
-    if (const char* e = std::getenv("DSWX_TUNE_ABLATE")) c->tune_ablate = std::atoi(e);
-    if (const char* e = std::getenv("DSWX_TUNE_PIPE_BLOCKS")) c->tune_pipe_blocks = std::atoi(e);
-    if (const char* e = std::getenv("DSWX_TUNE_LUT_WPS")) c->tune_lut_wps = std::atoi(e);
-    if (const char* e = std::getenv("DSWX_COVER_KERNEL")) c->cover_kernel = std::atoi(e);
-    if (const char* e = std::getenv("DSWX_HOST_PIPELINE")) c->host_pipeline = std::atoi(e);
-    if (const char* e = std::getenv("DSWX_HOST_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) c->host_chunks = v; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -844,11 +476,11 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     a.counters = reinterpret_cast<unsigned long long*>(counters);
     a.n_pixels = n_pixels;
     a.tile_stride = tile_stride;
-    a.cover_w2 = a.cover_pc = nullptr;
+    a.cover_state = nullptr;
     a.height = (int)height; a.width = (int)width;
     dswx_planes_out_t final_out = *out;     // what stage 2 of 'cover' writes
     if (cover) {
-        const size_t need = 2 * (size_t)n_tiles * (size_t)tile_stride;
+        const size_t need = (size_t)n_tiles * (size_t)tile_stride;
         if (need > ctx->cover_bytes) {
             HIP_TRY(hipStreamSynchronize(s));
             if (ctx->cover) HIP_TRY(hipFree(ctx->cover));
@@ -856,8 +488,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             HIP_TRY(hipMalloc(&ctx->cover, need));
             ctx->cover_bytes = need;
         }
-        a.cover_w2 = static_cast<uint8_t*>(ctx->cover);
-        a.cover_pc = a.cover_w2 + (size_t)n_tiles * (size_t)tile_stride;
+        a.cover_state = static_cast<uint8_t*>(ctx->cover);
         // stage 1 stops before the snow step: these four layers come from stage 2
         a.out.wtr = a.out.bwtr = a.out.conf = a.out.cloud = a.out.browse = nullptr;
     }
@@ -905,7 +536,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         if (b.out.ndvi) b.out.ndvi += shift;
         if (b.out.awesh) b.out.awesh += shift;
         if (b.counters) b.counters += t0 * 3;
-        if (b.cover_w2) { b.cover_w2 += shift; b.cover_pc += shift; }
+        if (b.cover_state) b.cover_state += shift;
         b.px_begin = 0;
         b.partials = nullptr;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
@@ -919,15 +550,15 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             const bool plain_outputs = !cover && !b.out.browse;
             // automatic choice: the table-driven kernel when every tile of every plane starts on
             // a 256-byte boundary (6.1 vs 5.5 TB/s there), the direct kernel otherwise (5.4 vs 5.1)
-            int vsel = ctx->fused_variant;
-            if (vsel < 0) vsel = aligned256 ? 3 : 0;
+            int vsel = ctx->lab.fused_variant;
+            if (vsel < 0 || (vsel != 0 && vsel != 3 && !ctx->lab.launch)) vsel = aligned256 ? 3 : 0;
             // the LDS-DMA variants (2, 4, 5) move 16 pixels per lane of the u8 planes
             const bool dma16_ok = (n_pixels & 15) == 0 || vsel == 1 || vsel == 3;
             const bool variant = vsel != 0 && (plain_outputs || vsel == 3) && dma16_ok;
             int threads = 256;
             long long gx_ll = (groups + 255) / 256;
             if (variant && vsel == 3) dswx_lut_geometry(ctx, groups, &threads, &gx_ll);
-            else if (variant) dswx_variant_geometry(ctx, vsel, groups, nt, &threads, &gx_ll);
+            else if (variant) ctx->lab.geometry(ctx, vsel, groups, nt, &threads, &gx_ll);
             const int64_t gx = gx_ll;
             const int waves = threads / 64;
             dim3 grid((unsigned)gx, (unsigned)nt), block(threads);
@@ -949,10 +580,10 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             b.n_diag_pieces = b.out.diag ? 8 : 0;
             if (variant) {
                 const int vrc = vsel == 3 ? dswx_lut_launch(ctx, b, masks, grid, block, s, info, sizeof info)
-                                          : dswx_variant_launch(ctx, vsel, b, masks, grid, block, s, info, sizeof info);
+                                          : ctx->lab.launch(ctx, vsel, b, masks, grid, block, s, info, sizeof info);
                 if (vrc) return vrc;
             } else {
-                const bool extras = b.out.browse || b.cover_w2;
+                const bool extras = b.out.browse || b.cover_state;
                 if (masks && extras) hipLaunchKernelGGL((dswx_classify_v8<true, true>), grid, block, 0, s, b);
                 else if (masks) hipLaunchKernelGGL((dswx_classify_v8<true, false>), grid, block, 0, s, b);
                 else if (extras) hipLaunchKernelGGL((dswx_classify_v8<false, true>), grid, block, 0, s, b);
@@ -988,29 +619,9 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             if (c2.out.conf) c2.out.conf += shift;
             if (c2.out.cloud) c2.out.cloud += shift;
             if (c2.out.browse) c2.out.browse += shift;
-            // stage-2 kernel: 2 = bitmaps with four pixels per lane (needs dword-aligned rows),
-            // 1 = bitmaps with one pixel per lane, 0 = byte cells; env DSWX_COVER_KERNEL caps the choice
-            int ck = ctx->cover_kernel;
-            if (ck >= 2) {
-                bool quad_ok = width % 4 == 0 && (tile_stride % 4 == 0 || n_tiles == 1) && aligned_to(c2.in.fmask, 4) &&
-                               aligned_to(c2.cover_w2, 4) && aligned_to(c2.cover_pc, 4);
-                uint8_t* const outs[5] = {c2.out.wtr, c2.out.bwtr, c2.out.conf, c2.out.cloud, c2.out.browse};
-                for (uint8_t* o : outs) quad_ok = quad_ok && (!o || aligned_to(o, 4));
-                ck = quad_ok ? 2 : 1;
-            }
-            const int tw = ck == 2 ? CQ_OUT_W : (ck == 1 ? CB_OUT_W : CV_TILE), th = ck ? CB_OUT_H : CV_TILE;
-            dim3 grid((unsigned)((width + tw - 1) / tw), (unsigned)((height + th - 1) / th), (unsigned)nt);
-            if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
-            if (c2.out.wtr || c2.out.bwtr || c2.out.conf || c2.out.cloud || c2.out.browse) {
-                if (ck == 2) hipLaunchKernelGGL(dswx_cover_stage2_quads, grid, dim3(256), 0, s, c2);
-                else if (ck == 1) hipLaunchKernelGGL(dswx_cover_stage2_bits, grid, dim3(256), 0, s, c2);
-                else hipLaunchKernelGGL(dswx_cover_stage2, grid, dim3(256), 0, s, c2);
-                HIP_TRY(hipGetLastError());
-            }
             const size_t len = strlen(info);
-            snprintf(info + len, sizeof info - len, " + %s grid=(%u,%u,%u)",
-                     ck == 2 ? "dswx_cover_stage2_quads" : (ck == 1 ? "dswx_cover_stage2_bits" : "dswx_cover_stage2"),
-                     grid.x, grid.y, grid.z);
+            const int crc = dswx_cover_stage2_launch(ctx, c2, nt, tile_stride, s, info + len, sizeof info - len);
+            if (crc) return crc;
         }
         if (any_index) {
             dim3 grid((unsigned)((n_pixels + 255) / 256), (unsigned)nt), block(256);
@@ -1048,13 +659,6 @@ int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out) {
     if (!ctx || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
-    // DSWX_MALLOC_FLAGS (experiments): hipExtMallocWithFlags flags, e.g. 4 = hipDeviceMallocContiguous
-    static const int flags = [] { const char* e = std::getenv("DSWX_MALLOC_FLAGS"); return e ? std::atoi(e) : 0; }();
-    if (flags) {
-        const hipError_t e = hipExtMallocWithFlags(out, bytes ? bytes : 1, (unsigned)flags);
-        if (e == hipSuccess) return DSWX_OK;
-        (void)hipGetLastError();          // fall back to the default allocator
-    }
     HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
     return DSWX_OK;
 }

@@ -22,7 +22,7 @@ struct dswx_ctx {
     bool tables_valid = false;             // the device tables match tables_params, built on tables_stream
     hipStream_t tables_stream = nullptr;
     alignas(8) unsigned char tables_params[1024] = {};
-    // grow-only scratch of 'cover' mode: uncollapsed WTR-2 + pre-snow CLOUD planes
+    // grow-only scratch of 'cover' mode: one state byte per pixel (cover_state_of)
     void* cover = nullptr;
     size_t cover_bytes = 0;
     // pipelined host path (pinned host buffers): copy streams, per-slot events, pinned counter scratch
@@ -31,21 +31,28 @@ struct dswx_ctx {
                pipe_out[3] = {nullptr, nullptr, nullptr};
     int64_t* pipe_counters = nullptr;      // hipHostMalloc, [pipe_counters_cap][3]
     size_t pipe_counters_cap = 0;
-    int cover_kernel = 2;                  // 'cover' stage 2: 2 bitmaps, 4 px per lane where rows are dword-aligned (default),
-                                           // 1 bitmaps, 1 px per lane, 0 byte cells (env DSWX_COVER_KERNEL)
-    int host_pipeline = 1;                 // env DSWX_HOST_PIPELINE=0 forces the synchronous path
-    int host_chunks = 8;                   // env DSWX_HOST_CHUNKS: pieces per tile of the pipelined path
+    // Fixed in production; libdswx_lab.so (experiments, A/B tools, variant tests) changes them through
+    // dswx_lab_configure -- the product library reads no environment variable.
+    int cover_kernel = 2;                  // 'cover' stage 2: 2 bitmaps, 4 px per lane where rows are dword-aligned,
+                                           // 1 bitmaps, 1 px per lane
+    int host_pipeline = 1;                 // 0 forces the synchronous host path
+    int host_chunks = 8;                   // pieces per tile of the pipelined host path
     std::string last_kernel;
-    int fused_variant = -1;  // env DSWX_FUSED_VARIANT -- unset (-1): automatic = 3 when every tile starts on a
-                             // 256-byte boundary in every plane, else 0;  0: direct stores; 1: LDS-staged
-                             // stores; 2: warp-specialised (LDS-DMA in, plane-run stores out);
-                             // 3: table-driven (packed int16 + LDS tables + v_perm packing);
-                             // 4: warp-specialised data movement + table-driven compute;
-                             // 5: persistent double-buffered pipeline of 4
-    int tune_pipe_blocks = 512;   // persistent pipeline: total blocks (env DSWX_TUNE_PIPE_BLOCKS)
-    int tune_ablate = 0;     // diagnostic ablation level of variant 4 (env DSWX_TUNE_ABLATE; outputs invalid)
-    int tune_lut_wps = 0;    // table-driven kernel: launch bound (env DSWX_TUNE_LUT_WPS: 4, 5, 6; 0 = automatic)
-    int tune_wps = 6;        // launch-bound variant of the plain kernel (env DSWX_TUNE_WPS: 4, 6, 8)
+    int tune_lut_wps = 0;    // table-driven kernel: launch bound (4, 5, 6; 0 = automatic)
+    int tune_wps = 6;        // launch bound of the direct kernel without masks (4, 6, 8)
+    // Experiment hook, empty in production: libdswx_lab.so installs its fused-kernel structures here
+    // (dswx_lab_attach) so that A/B tools can run them through the same entry points.
+    struct lab_hooks {
+        int fused_variant = -1;  // -1 automatic (table-driven kernel when every tile starts on a 256-byte
+                                 // boundary in every plane, else the direct kernel); 0 / 3 force those two;
+                                 // 1, 2, 4, 5 = the lab's LDS-staged / warp-specialised / pipelined structures
+        int tune_pipe_blocks = 512;   // persistent pipeline: total blocks
+        int tune_ablate = 0;          // diagnostic ablation level of variant 4 (outputs invalid)
+        void (*geometry)(const dswx_ctx* ctx, int variant, long long groups, long long n_tiles, int* threads,
+                         long long* gx) = nullptr;
+        int (*launch)(dswx_ctx* ctx, int variant, const KArgs& args, bool masks, dim3 grid, dim3 block,
+                      hipStream_t stream, char* info, size_t info_len) = nullptr;
+    } lab;
 };
 
 // records a printf-style message for dswx_last_error() and returns `code`
@@ -69,10 +76,6 @@ void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, int* threads, long
 int dswx_lut_launch(dswx_ctx* ctx, const KArgs& args, bool masks, dim3 grid, dim3 block, hipStream_t stream,
                     char* info, size_t info_len);
 
-// ---- experimental fused-kernel variants (dswx_variants.hip), DSWX_FUSED_VARIANT = 1, 2, 4, 5
-// block size and grid.x the selected variant wants for `groups` 8-pixel groups per tile
-void dswx_variant_geometry(const dswx_ctx* ctx, int variant, long long groups, long long n_tiles, int* threads,
-                           long long* gx);
-// launches the selected variant; `info` receives its description
-int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& args, bool masks, dim3 grid, dim3 block,
-                        hipStream_t stream, char* info, size_t info_len);
+// ---- 'cover' mode stage 2 (dswx_cover.hip): appends its description to `info`
+int dswx_cover_stage2_launch(dswx_ctx* ctx, const KArgs& c2, long long n_tiles, long long tile_stride,
+                             hipStream_t stream, char* info, size_t info_len);

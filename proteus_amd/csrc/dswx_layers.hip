@@ -59,23 +59,14 @@ struct ShadowArgs {
     double inc_q_min, slope_arg_max;
 };
 
+// The arithmetic of one pixel exactly as the reference orders it, given the two finite differences
+// and their np.gradient scale factors (0.5 inside, 1 on a border).
 // F32: the value-based casting of numpy < 2 (what the reference pins: numpy 1.23.5), where the
 // float64 sun scalars do NOT upcast the float32 arrays -- every product, sum, quotient, arccos,
 // arctan, degrees and comparison of :4264-4281 is float32, the scalars rounded to float32 first.
 template <bool F32>
-__global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
-    const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
-    const int ow = W - 2 * margin, oh = H - 2 * margin;
-    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ox >= ow || oy >= oh) return;
-    const int x = ox + margin, y = oy + margin;
-    const float* __restrict__ d = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W;
-    // np.gradient, edge_order 1, unit spacing: central differences inside ((f[i+1] - f[i-1]) / 2,
-    // and x / 2 == x * 0.5f exactly), one-sided first differences at the borders; branch-free
-    const int c = y * W + x;                       // H * W < 2^31 is checked on the host
-    const bool x_in = (x > 0) & (x < W - 1), y_in = (y > 0) & (y < H - 1);
-    const float gx = (d[x < W - 1 ? c + 1 : c] - d[x > 0 ? c - 1 : c]) * (x_in ? 0.5f : 1.0f);
-    const float gy = (d[y < H - 1 ? c + W : c] - d[y > 0 ? c - W : c]) * (y_in ? 0.5f : 1.0f);
+__device__ __forceinline__ bool shadow_px_exact(const ShadowArgs& a, float dx, float sx, float dy, float sy) {
+    const float gx = dx * sx, gy = dy * sy;
     const float n0 = -gx / a.spacing_x;
     const float n1 = -gy / a.neg_abs_spacing_y;
     const float norm = sqrtf(n0 * n0 + n1 * n1 + 1.0f);
@@ -92,7 +83,115 @@ __global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
         low_inc = (q >= a.inc_q_min) & (q <= 1.0);                // arccos(q > 1) is NaN: the test fails
         backslope = t <= a.slope_arg_max;
     }
-    a.shadow[(size_t)blockIdx.z * (size_t)oh * (size_t)ow + (size_t)(oy * ow + ox)] = (low_inc | !backslope) ? 1 : 0;
+    return low_inc | !backslope;
+}
+
+// General form: one thread per output pixel, any margin / width / alignment (also the borders of a
+// margin-free call, where np.gradient falls back to one-sided differences).
+template <bool F32>
+__global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
+    const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
+    const int ow = W - 2 * margin, oh = H - 2 * margin;
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= ow || oy >= oh) return;
+    const int x = ox + margin, y = oy + margin;
+    const float* __restrict__ d = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W;
+    // np.gradient, edge_order 1, unit spacing: central differences inside ((f[i+1] - f[i-1]) / 2,
+    // and x / 2 == x * 0.5f exactly), one-sided first differences at the borders; branch-free
+    const int c = y * W + x;                       // H * W < 2^31 is checked on the host
+    const bool x_in = (x > 0) & (x < W - 1), y_in = (y > 0) & (y < H - 1);
+    const float dx = d[x < W - 1 ? c + 1 : c] - d[x > 0 ? c - 1 : c];
+    const float dy = d[y < H - 1 ? c + W : c] - d[y > 0 ? c - W : c];
+    const bool v = shadow_px_exact<F32>(a, dx, x_in ? 0.5f : 1.0f, dy, y_in ? 0.5f : 1.0f);
+    a.shadow[(size_t)blockIdx.z * (size_t)oh * (size_t)ow + (size_t)(oy * ow + ox)] = v ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------
+// Production form (margin >= 2 and even, even DEM width, output width % 4 == 0 -- the reference's
+// 3760 x 3760 DEM with its 50-pixel margin): FOUR output pixels per thread, 8-byte DEM loads, one
+// dword store, and a floating-point FILTER in front of the exact arithmetic.
+//
+// The exact chain costs ~106 VALU per pixel (two correctly rounded float32 divisions, a correctly
+// rounded sqrtf, a float64 division) and made the one-pixel kernel issue-bound at 0.2 of the HBM
+// rate.  But the result is two threshold tests, and all but a handful of pixels sit far from both
+// thresholds.  So every pixel is first evaluated approximately in packed float32 (reciprocal
+// multiplies, v_rsq_f32: ~25 VALU) with a rigorous error bound:
+//     |q~ - q_ref| <= K  = 2^-18 (|sun_x| + |sun_y| + |sun_z|)           (q = arccos argument)
+//     |t~ - t_ref| <= Et = 2^-19 (|n0 sin_az| + |n1 cos_az|) (+ 2^-120)  (t = arctan argument)
+// (derivation in DESIGN.md section 3: both chains are within ~20 float32 half-ulps of the real-number
+// value, the bound has 3x slack, thresholds are rounded outwards to float32 on the host).  A test
+// whose approximate value clears its threshold by more than the bound is DECIDED; otherwise -- or
+// when anything is non-finite / huge -- the pixel is recomputed with shadow_px_exact, the very
+// arithmetic of the general kernel.  Bit-exact by construction, and the uncertain band is ~4e-6 wide.
+// ------------------------------------------------------------------------------
+struct ShadowFilter {
+    float inv_x, inv_y;                  // RN(1 / (-2 sx)), RN(1 / (2 |sy|)):  n0 ~ (d[x+1] - d[x-1]) * inv_x
+    float s0, s1, s2, sin_az, cos_az;    // the five sun scalars rounded to float32
+    float q_lo_in, q_hi_in;              // low_inc decided TRUE  if q_lo_in <= q~ <= q_hi_in
+    float q_lo_out, q_hi_out;            // low_inc decided FALSE if q~ < q_lo_out or q~ > q_hi_out
+    float t_lo, t_hi;                    // backslope decided TRUE if t~ + Et <= t_lo, FALSE if t~ - Et > t_hi
+    float et_rel;                        // 2^-19
+    int t_tiny;                          // |slope_arg_max| < 2^-100: add the absolute term to Et
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool F32>
+__global__ __launch_bounds__(256) void dswx_shadow_v3(const ShadowArgs a, const ShadowFilter f) {
+    const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
+    const int ow = W - 2 * margin, oh = H - 2 * margin;
+    const int oq = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (4 * oq >= ow || oy >= oh) return;
+    const float* __restrict__ row = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W +
+                                    (size_t)(oy + margin) * (size_t)W + (size_t)(4 * oq + margin);
+    // centre row d[x-2 .. x+5], rows above / below d[x .. x+3]; x is even, rows are 8-byte aligned
+    const f32x2 c0 = *reinterpret_cast<const f32x2*>(row - 2), c1 = *reinterpret_cast<const f32x2*>(row),
+                c2 = *reinterpret_cast<const f32x2*>(row + 2), c3 = *reinterpret_cast<const f32x2*>(row + 4);
+    const f32x2 u0 = *reinterpret_cast<const f32x2*>(row - W), u1 = *reinterpret_cast<const f32x2*>(row - W + 2);
+    const f32x2 b0 = *reinterpret_cast<const f32x2*>(row + W), b1 = *reinterpret_cast<const f32x2*>(row + W + 2);
+    // finite differences of the four pixels as two packed pairs (every output pixel is interior)
+    const f32x2 dx[2] = {f32x2{c1.y, c2.x} - f32x2{c0.y, c1.x}, f32x2{c2.y, c3.x} - f32x2{c1.y, c2.x}};
+    const f32x2 dy[2] = {b0 - u0, b1 - u1};
+    uint32_t out = 0, unsure = 0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2 n0 = dx[p] * f.inv_x, n1 = dy[p] * f.inv_y;
+        const f32x2 S = __builtin_elementwise_fma(n0, n0, __builtin_elementwise_fma(n1, n1, f32x2{1.0f, 1.0f}));
+        const f32x2 dot = __builtin_elementwise_fma(n0, f32x2{f.s0, f.s0},
+                                                    __builtin_elementwise_fma(n1, f32x2{f.s1, f.s1}, f32x2{f.s2, f.s2}));
+        const f32x2 t = __builtin_elementwise_fma(n0, f32x2{f.sin_az, f.sin_az}, n1 * f.cos_az);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float q = dot[h] * __builtin_amdgcn_rsqf(S[h]);
+            float et = f.et_rel * __builtin_fmaf(__builtin_fabsf(n0[h]), __builtin_fabsf(f.sin_az),
+                                                 __builtin_fabsf(n1[h]) * __builtin_fabsf(f.cos_az));
+            if (f.t_tiny)     // exact zero differences give an exact t = 0; anything else gets the absolute term
+                et += __builtin_fminf((__builtin_fabsf(dx[p][h]) + __builtin_fabsf(dy[p][h])) * 0x1p100f, 0x1p-120f);
+            const bool sane = S[h] < 0x1p60f;                                     // false for NaN / inf / huge
+            const bool inc_yes = (q >= f.q_lo_in) & (q <= f.q_hi_in);
+            const bool inc_no = (q < f.q_lo_out) | (q > f.q_hi_out);
+            const bool back_yes = t[h] + et <= f.t_lo;
+            const bool back_no = t[h] - et > f.t_hi;
+            // result = low_inc | !backslope: known 1 if either says so, known 0 if both deny
+            const bool one = sane & (inc_yes | back_no);
+            const bool zero = sane & inc_no & back_yes;
+            const int k = 2 * p + h;
+            out |= (one ? 1u : 0u) << (8 * k);
+            unsure |= ((one | zero) ? 0u : 1u) << k;
+        }
+    }
+    if (unsure) {                       // rare: within the error bound of a threshold, or not finite
+        const float cx[6] = {c0.y, c1.x, c1.y, c2.x, c2.y, c3.x};
+        const float up[4] = {u0.x, u0.y, u1.x, u1.y}, dn[4] = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((unsure >> k) & 1u)) continue;
+            const bool v = shadow_px_exact<F32>(a, cx[k + 2] - cx[k], 0.5f, dn[k] - up[k], 0.5f);
+            out = (out & ~(0xffu << (8 * k))) | ((v ? 1u : 0u) << (8 * k));
+        }
+    }
+    *reinterpret_cast<uint32_t*>(a.shadow + (size_t)blockIdx.z * (size_t)oh * (size_t)ow +
+                                 (size_t)oy * (size_t)ow + (size_t)(4 * oq)) = out;
 }
 
 // ------------------------------------------------------------------------------
@@ -341,6 +440,40 @@ static int shadow_args(ShadowArgs* a, int64_t height, int64_t width, int64_t mar
     return DSWX_OK;
 }
 
+// largest float <= v / smallest float >= v (v may be +-inf; NaN never reaches here)
+static float float_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+static float float_up(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
+// Constants of the approximate evaluation in front of the exact one (dswx_shadow_v3).  In float32
+// mode the thresholds the exact path compares against are the float32 roundings of a.inc_q_min /
+// a.slope_arg_max (already float32 values when they come through the _q32 entry points).
+static void shadow_filter(const ShadowArgs& a, bool f32, ShadowFilter* f) {
+    const double q_min = f32 ? (double)(float)a.inc_q_min : a.inc_q_min;
+    const double t_max = f32 ? (double)(float)a.slope_arg_max : a.slope_arg_max;
+    f->inv_x = (float)(1.0 / (-2.0 * (double)a.spacing_x));
+    f->inv_y = (float)(1.0 / (-2.0 * (double)a.neg_abs_spacing_y));
+    f->s0 = (float)a.sun[0]; f->s1 = (float)a.sun[1]; f->s2 = (float)a.sun[2];
+    f->sin_az = (float)a.sin_az; f->cos_az = (float)a.cos_az;
+    const double K = std::ldexp(std::fabs(a.sun[0]) + std::fabs(a.sun[1]) + std::fabs(a.sun[2]), -18) + 1e-30;
+    f->q_lo_in = float_up(q_min + K);   f->q_hi_in = float_down(1.0 - K);
+    f->q_lo_out = float_down(q_min - K); f->q_hi_out = float_up(1.0 + K);
+    f->et_rel = 0x1p-19f;
+    // absolute float32-denormal rounding noise (< 2^-140) is folded into the threshold by widening it
+    // relatively; a threshold too close to zero for that gets the explicit absolute term instead
+    f->t_tiny = std::fabs(t_max) < 0x1p-100 ? 1 : 0;
+    const double widen = (f->t_tiny || std::isinf(t_max)) ? 0.0 : std::fabs(t_max) * 0x1p-20;
+    f->t_lo = float_down(t_max - widen);
+    f->t_hi = float_up(t_max + widen);
+}
+
 static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
                               int64_t margin, const double sun_vector[3], double sin_azimuth,
                               double cos_azimuth, double slope_arg_max, double inc_q_min,
@@ -357,10 +490,21 @@ static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const long long ow = width - 2 * margin, oh = height - 2 * margin;
-    dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
-    if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
-    if (f32) hipLaunchKernelGGL(dswx_shadow_v2<true>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(dswx_shadow_v2<false>, grid, block, 0, s, a);
+    if ((oh + 3) / 4 > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
+    // four pixels per thread behind the filter where the geometry allows 8-byte loads and dword stores
+    const bool quads = margin >= 2 && margin % 2 == 0 && width % 2 == 0 && ow % 4 == 0 && aligned_to(dem, 8) &&
+                       aligned_to(shadow, 4);
+    if (quads) {
+        ShadowFilter f;
+        shadow_filter(a, f32, &f);
+        dim3 grid((unsigned)((ow / 4 + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
+        if (f32) hipLaunchKernelGGL(dswx_shadow_v3<true>, grid, block, 0, s, a, f);
+        else hipLaunchKernelGGL(dswx_shadow_v3<false>, grid, block, 0, s, a, f);
+    } else {
+        dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
+        if (f32) hipLaunchKernelGGL(dswx_shadow_v2<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(dswx_shadow_v2<false>, grid, block, 0, s, a);
+    }
     HIP_TRY(hipGetLastError());
     return DSWX_OK;
 }

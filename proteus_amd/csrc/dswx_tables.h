@@ -21,14 +21,14 @@ struct Tables {
     uint32_t lut1[128];    // [T1 | T2<<1 | !T3<<2 | T4<<3 | T5<<4 | invalid<<5 | ocean0<<6]
                            //   -> DIAG(16) | WTR-1 code(8) << 16 | WTR-1 as saved(8) << 24
     uint16_t fm16[256];    // Fmask byte -> aerosol class bits(5) | shadow<<5 | cloud<<6 | snow<<7
-                           //   | is_fill<<8 | prelim_cloud_nonzero<<9
+                           //   | is_fill<<8 | prelim_cloud_nonzero<<9 | adjacent(bit 2)<<10
     uint8_t land8[256];    // LAND byte -> is_water(200) | psw_rule_class(201 or <100)<<1 | high_dev<<2
     // without LAND / SHAD planes (WTR-2 = WTR-1-AEROSOL): one lookup
     uint2 chain[128];      // [code | remap<<3 | shadow<<4 | cloud<<5 | snow<<6]
                            //   -> x = WTR-1-AEROSOL | WTR-2<<8 | WTR<<16 | BWTR<<24,
                            //      y = CONF | CLOUD<<8 | valid<<16 | cloud_and_valid<<24
-    uint32_t extra[128];   // same index -> WTR-2 uncollapsed | CLOUD before the snow step << 8 (stage 1 of
-                           //   'cover' mode) | browse << 16; read only by the EXTRAS kernels
+    uint32_t extra[128];   // same index -> cover state byte (cover_state_of: stage 1 of 'cover' mode)
+                           //   | browse << 16; read only by the EXTRAS kernels
     // with LAND / SHAD planes the chain factors at WTR-2 into two 128-entry lookups (2.5 KiB of
     // tables per block instead of the 9.5 KiB of a flat 1024-entry table, whose per-block load
     // cost 5 % of the kernel):
@@ -57,7 +57,7 @@ static __global__ __launch_bounds__(256) void dswx_build_tables(const DevParams 
         px_chain(P, class_of(code), remap, shadow + 4u * cloud, snow, false, false, false, o);
         t->chain[i] = make_uint2(o.wtr1a | o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24,
                                  o.conf | o.cloud << 8 | valid << 16 | (valid & pc_nz) << 24);
-        t->extra[i] = o.w2_raw | o.pc << 8 | o.browse << 16;
+        t->extra[i] = o.state | o.browse << 16;
         // first factor: here bits 4..6 of i are the three LAND / SHAD rule hits
         px_chain(P, class_of(code), remap, 0u, false, (i >> 4) & 1, (i >> 5) & 1, (i >> 6) & 1, o);
         t->pre16[i] = (uint16_t)(o.wtr1a | code_of(o.w2_raw) << 8);
@@ -67,13 +67,13 @@ static __global__ __launch_bounds__(256) void dswx_build_tables(const DevParams 
         finish_px(P, w2, pc, snow, o);
         t->chainm[i] = make_uint2(o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24,
                                   o.conf | o.cloud << 8 | valid << 16 | (valid & pc_nz) << 24);
-        t->extram[i] = w2 | pc << 8 | o.browse << 16;
+        t->extram[i] = cover_state_of(w2, pc, snow != 0u) | o.browse << 16;
     }
     if (i < 256) {
         const uint32_t aer = (P.aer_lut[i >> 2] >> (8 * (i & 3))) & 0x1fu;
         const uint32_t shadow = (i & P.shadow_bits) ? 1u : 0u, cloud = (i >> 1) & 1u, snow = (i >> 4) & 1u;
         t->fm16[i] = (uint16_t)(aer | shadow << 5 | cloud << 6 | snow << 7 | (i == P.fmask_fill ? 1u : 0u) << 8 |
-                                (shadow | cloud) << 9);
+                                (shadow | cloud) << 9 | (((uint32_t)i >> 2) & 1u) << 10);
         t->land8[i] = (uint8_t)((i == 200 ? 1 : 0) | ((i == 201 || i < 100) ? 2 : 0) | ((i >= 100 && i < 200) ? 4 : 0));
     }
 }
@@ -193,7 +193,7 @@ __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C
                 }
                 const uint2 ch = s_chain[idx2];
                 w1w[j] = word1; chx[j] = MASKS ? (ch.x | w1a) : ch.x; chy[j] = ch.y;
-                if (WANT_IDX) idx_out[j] = idx2;             // chain index, for Tables::extra
+                if (WANT_IDX) idx_out[j] = idx2 | ((F >> 10) & 1u) << 7;   // chain index for Tables::extra | adjacent << 7
                 gsum += ch.y >> 16;                  // A3: valid | cloud_and_valid << 8, from the table
             }
         }

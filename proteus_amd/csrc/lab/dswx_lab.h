@@ -1,0 +1,38 @@
+/*
+ * dswx_lab.h -- C ABI of libdswx_lab.so: experiments, calibration probes and A/B switches around
+ * the DSWx-HLS classifier.  NOT part of the drop-in boundary (include/dswx_hip.h): nothing here is
+ * needed to run the product, and the product library (libdswx_hip.so) carries none of these kernels.
+ * libdswx_lab.so links against libdswx_hip.so and works on the same dswx_ctx_t.  Users:
+ * tools/roofline_probe.py, tools/ab_variants.py, tests/test_gpu_parity.py (variant parity),
+ * tests/fuzz_parity.py.
+ */
+#ifndef DSWX_LAB_H
+#define DSWX_LAB_H
+
+#include "dswx_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Installs the lab's fused-kernel structures (1 LDS-staged stores, 2 warp-specialised LDS-DMA,
+ * 4 warp-specialised + table-driven, 5 persistent pipeline) as candidates of this context's
+ * dispatch; they run only after dswx_lab_configure(ctx, "fused_variant", v). */
+int dswx_lab_attach(dswx_ctx_t* ctx);
+
+/* A/B switches (what round 1 read from DSWX_* environment variables): "fused_variant" (-1 automatic,
+ * 0 direct kernel, 3 table-driven kernel, 1/2/4/5 lab structures), "tune_wps", "tune_lut_wps",
+ * "tune_ablate", "tune_pipe_blocks", "cover_kernel", "host_pipeline", "host_chunks". */
+int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value);
+
+/* Roofline probe: streams exactly the bytes dswx_classify_device streams for the same arguments
+ * (7 planes in, 7 planes out, no LAND/SHAD/OCEAN) with trivial arithmetic, to measure the HBM rate
+ * that access pattern can reach.  The output planes receive meaningless values.
+ * variant = ppt16 | nt << 1 | log2(iters) << 2 | ... (see dswx_probes.hip). */
+int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, int64_t tile_stride,
+                      const dswx_planes_in_t* in, const dswx_planes_out_t* out, int variant, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSWX_LAB_H */

@@ -1,9 +1,10 @@
-// dswx_probes.hip -- roofline calibration kernels behind dswx_stream_probe(): they move the
+// dswx_probes.hip (libdswx_lab.so, NOT part of the product library) -- roofline calibration kernels behind dswx_stream_probe(): they move the
 // fused kernel's bytes in many access shapes with trivial arithmetic (DESIGN.md section 5,
 // tools/roofline_probe.py).  Outputs are meaningless by design.
 #include <cstring>
 
 #include "dswx_host.h"
+#include "dswx_lab.h"
 
 // ------------------------------------------------------------------------------
 // Roofline probe: the fused kernel's plane traffic (six int16 planes + one u8 plane

@@ -1,5 +1,6 @@
-// dswx_variants.hip -- experimental data-movement structures of the fused kernel, selected per
-// context with DSWX_FUSED_VARIANT = 1, 2, 4, 5.  All are bit-exact (tests/test_gpu_parity.py::
+// dswx_variants.hip (libdswx_lab.so, NOT part of the product library) -- experimental data-movement
+// structures of the fused kernel, selected per context with dswx_lab_configure(ctx, "fused_variant",
+// 1 | 2 | 4 | 5).  All are bit-exact (tests/test_gpu_parity.py::
 // test_kernel_variants_parity) and all are slower than the production kernels (0: dswx_classify_v8
 // in dswx_hip.hip, 3: dswx_classify_lut in dswx_classify_lut.hip); they are kept because each
 // isolates one structural idea measured in DESIGN.md section 5.
@@ -595,18 +596,18 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_pipe(const KArgs a, co
 
 
 
-void dswx_variant_geometry(const dswx_ctx* ctx, int variant, long long groups, long long n_tiles, int* threads,
+static void dswx_variant_geometry(const dswx_ctx* ctx, int variant, long long groups, long long n_tiles, int* threads,
                            long long* gx) {
     *threads = variant == 1 ? FUSED_THREADS : 256;
     *gx = (groups + *threads - 1) / *threads;
     if (variant == 5) {
         // persistent grid: ~tune_pipe_blocks blocks in all, spread evenly over the tiles
-        const long long want = (ctx->tune_pipe_blocks + n_tiles - 1) / n_tiles;
+        const long long want = (ctx->lab.tune_pipe_blocks + n_tiles - 1) / n_tiles;
         if (want < *gx) *gx = want < 1 ? 1 : want;
     }
 }
 
-int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& b, bool masks, dim3 grid, dim3 block, hipStream_t s,
+static int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& b, bool masks, dim3 grid, dim3 block, hipStream_t s,
                         char* info, size_t info_len) {
     const long long gx = grid.x, nt = grid.y;
     const char* m = masks ? "true" : "false";
@@ -635,9 +636,9 @@ int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& b, bool masks, 
         const int wps = ctx->tune_lut_wps > 0 ? ctx->tune_lut_wps : 4;
 #define WSLUT_LAUNCH(M, W) hipLaunchKernelGGL((dswx_classify_wslut<M, W>), grid, block, 0, s, b, lc, tabs)
         if (masks) { if (wps >= 5) WSLUT_LAUNCH(true, 5); else if (wps == 4) WSLUT_LAUNCH(true, 4); else WSLUT_LAUNCH(true, 3); }
-        else if (ctx->tune_ablate == 1) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 1>), grid, block, 0, s, b, lc, tabs);
-        else if (ctx->tune_ablate == 2) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 2>), grid, block, 0, s, b, lc, tabs);
-        else if (ctx->tune_ablate == 3) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 3>), grid, block, 0, s, b, lc, tabs);
+        else if (ctx->lab.tune_ablate == 1) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 1>), grid, block, 0, s, b, lc, tabs);
+        else if (ctx->lab.tune_ablate == 2) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 2>), grid, block, 0, s, b, lc, tabs);
+        else if (ctx->lab.tune_ablate == 3) hipLaunchKernelGGL((dswx_classify_wslut<false, 4, 3>), grid, block, 0, s, b, lc, tabs);
         else { if (wps >= 5) WSLUT_LAUNCH(false, 5); else if (wps == 4) WSLUT_LAUNCH(false, 4); else WSLUT_LAUNCH(false, 3); }
         snprintf(info, info_len, "dswx_classify_wslut<%s> (warp-specialised + table-driven) grid=(%lld,%lld) block=256 wps=%d",
                  m, gx, nt, wps);
@@ -654,3 +655,39 @@ int dswx_variant_launch(dswx_ctx* ctx, int variant, const KArgs& b, bool masks, 
     }
     return DSWX_OK;
 }
+
+
+// ==============================================================================
+// lab C-ABI (csrc/lab/dswx_lab.h)
+// ==============================================================================
+#include "dswx_lab.h"
+
+extern "C" {
+
+int dswx_lab_attach(dswx_ctx_t* ctx) {
+    if (!ctx) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    ctx->lab.geometry = dswx_variant_geometry;
+    ctx->lab.launch = dswx_variant_launch;
+    return DSWX_OK;
+}
+
+int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value) {
+    if (!ctx || !key) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    const std::string k = key;
+    if (k == "fused_variant") {
+        if (value < -1 || value > 5) return dswx_fail(DSWX_ERR_ARG, "fused_variant out of range");
+        ctx->lab.fused_variant = value;
+    } else if (k == "tune_wps") ctx->tune_wps = value;
+    else if (k == "tune_lut_wps") ctx->tune_lut_wps = value;
+    else if (k == "tune_ablate") ctx->lab.tune_ablate = value;
+    else if (k == "tune_pipe_blocks") ctx->lab.tune_pipe_blocks = value;
+    else if (k == "cover_kernel") ctx->cover_kernel = value;
+    else if (k == "host_pipeline") ctx->host_pipeline = value;
+    else if (k == "host_chunks") {
+        if (value < 1 || value > 256) return dswx_fail(DSWX_ERR_ARG, "host_chunks out of range");
+        ctx->host_chunks = value;
+    } else return dswx_fail(DSWX_ERR_ARG, "unknown lab key '%s'", key);
+    return DSWX_OK;
+}
+
+}  // extern "C"

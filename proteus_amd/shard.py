@@ -26,6 +26,14 @@ def weak_tile_range(tiles_per_rank, rank):
     return rank * tiles_per_rank, (rank + 1) * tiles_per_rank
 
 
+def chunk_sizes(n_tiles, chunk):
+    """A rank's share walked in resident chunks: [chunk, chunk, ..., remainder]; sums to n_tiles."""
+    if chunk <= 0:
+        raise ValueError('chunk must be positive')
+    full, rest = divmod(max(n_tiles, 0), chunk)
+    return [chunk] * full + ([rest] if rest else [])
+
+
 def env_rank():
     """(rank, local_rank, world) from the torch.distributed.run environment."""
     return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
@@ -35,7 +43,7 @@ def env_rank():
 class ControlPlane:
     """Barrier + max-over-ranks; a no-op object for world == 1."""
 
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, allow_fallback=False):
         self.rank, self.local_rank, self.world = env_rank()
         self.dist = None
         self.device = device
@@ -51,10 +59,11 @@ class ControlPlane:
                     dist.init_process_group(backend, **kw)
                     self.backend = backend
                 except Exception as e:                      # noqa: BLE001
-                    # The control plane only carries a barrier and a MAX of one double: if RCCL
-                    # cannot come up on this node, gloo does the same job and the measurement
-                    # stays valid (there is no data-path collective to lose).
-                    if backend == 'gloo':
+                    # RCCL could not come up.  A measurement must not quietly change its control plane:
+                    # fail unless the caller opted in (bench.py --allow-gloo).  With the opt-in, gloo
+                    # carries the same barrier and MAX of one double (there is no data-path collective
+                    # to lose) and the backend string records what happened.
+                    if backend == 'gloo' or not allow_fallback:
                         raise
                     if dist.is_initialized():
                         dist.destroy_process_group()
@@ -77,6 +86,24 @@ class ControlPlane:
                          device=self.device if self.device is not None else 'cpu')
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def sum_over_ranks(self, value):
+        """Integer sum over ranks (e.g. tiles processed per step by the whole job)."""
+        if self.dist is None:
+            return int(value)
+        import torch
+        t = torch.tensor([int(value)], dtype=torch.int64,
+                         device=self.device if self.device is not None else 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
+    def gather_objects(self, obj):
+        """Every rank's small Python object, in rank order, on every rank."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def gather_counters(self, local):
         """All ranks' per-tile counters ([t_r, 3] int64 each) on every rank, in tile order.

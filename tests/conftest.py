@@ -13,9 +13,9 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """The HIP library is a build artefact (git-ignored).  A fresh checkout has none: build it once
-    (hipcc cross-compiles gfx950 without a GPU, ~20 s) so that the suite does not depend on someone
-    having run __graft_entry__.build() first.  An existing library is used as it is."""
+    """The HIP libraries are build artefacts (git-ignored).  build() compiles them when they are missing
+    OR older than any of their sources (hipcc cross-compiles gfx950 without a GPU, ~20 s; a no-op when
+    fresh), so the suite can never pass against a stale binary after an edit to csrc/ or include/."""
     from proteus_amd import build
-    if not os.path.exists(build.LIB_PATH):
-        build.build()
+    build.build()
+    build.build_lab()

@@ -35,9 +35,10 @@ def device_batch_soak(ctx, rng, a, kernels):
         h, w = int(rng.integers(1, 120)), int(rng.integers(1, 150))
         align = int(rng.choice([1, 8, 16, 64, 256]))
         masks = bool(rng.integers(2))
-        os.environ['DSWX_PLANE_SKEW'] = str(int(rng.choice([0, 0, 16, 48, 272])))
+        skew = int(rng.choice([0, 0, 16, 48, 272]))
         extra = tuple(x for x in ('wtr1_aerosol', 'browse') if rng.integers(2))
-        batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=masks, extra_layers=extra, tile_align=align)
+        batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=masks, extra_layers=extra, tile_align=align,
+                                  plane_skew=skew)
         batch.synth(777 + it, tile0=it)
         mode = str(rng.choice(['mask', 'ignore', 'cover']))
         p = _capi.make_params(
@@ -75,7 +76,7 @@ def device_batch_soak(ctx, rng, a, kernels):
             if bad:
                 print(json.dumps({'ok': False, 'iteration': it, 'tile': t, 'geom': [n_tiles, h, w, align],
                                   'masks': masks, 'mode': mode, 'extra': extra, 'layers': bad,
-                                  'skew': os.environ['DSWX_PLANE_SKEW'], 'kernel': ctx.last_kernel_info()},
+                                  'skew': skew, 'kernel': ctx.last_kernel_info()},
                                  default=str))
                 return 1
         batch.free()
@@ -87,12 +88,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=300)
     ap.add_argument('--seed', type=int, default=1)
-    ap.add_argument('--variant', default=None, help='DSWX_FUSED_VARIANT for this run')
+    ap.add_argument('--variant', default=None, help='fused-kernel structure for this run (libdswx_lab.so switch: 0..5)')
     ap.add_argument('--device-batch', action='store_true', help='soak the device-resident batch entry instead')
     a = ap.parse_args()
-    if a.variant is not None:
-        os.environ['DSWX_FUSED_VARIANT'] = a.variant
     ctx = _capi.Context(0)
+    if a.variant is not None:
+        ctx.lab_configure(fused_variant=int(a.variant))
     rng = np.random.default_rng(a.seed)
     kernels = {}
     if a.device_batch:

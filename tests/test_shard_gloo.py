@@ -90,6 +90,90 @@ def test_two_rank_gloo_control_plane(tmp_path):
     assert out['counters'] == exp
 
 
+@pytest.mark.parametrize('n,chunk', [(0, 4), (1, 4), (4, 4), (9, 4), (512, 512), (513, 512)])
+def test_chunk_sizes(n, chunk):
+    c = shard.chunk_sizes(n, chunk)
+    assert sum(c) == n and all(0 < x <= chunk for x in c) and c[:-1] == [chunk] * (len(c) - 1)
+
+
+def _bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), capture_output=True,
+                          text=True, timeout=300, cwd=ROOT, env=e)
+
+
+def test_bench_self_launches_its_ranks_strong_scaling():
+    """`python bench.py --gpus 2 --total-tiles 13` with no torchrun environment: the parent starts the two
+    ranks itself (torch.distributed.run as a child) and relays rank 0's line.  --plan-only stops before any
+    GPU work, so this runs here: BASELINE configs[3]'s split, chunked walk and control plane."""
+    import json
+    res = _bench('--gpus', '2', '--total-tiles', '13', '--tiles', '4', '--plan-only')
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['tiles_per_step_all_ranks'] == 13
+    r0, r1 = out['ranks']
+    assert (r0['first_tile'], r0['tiles'], r0['launches']) == (0, 6, [4, 2])
+    assert (r1['first_tile'], r1['tiles'], r1['launches']) == (6, 7, [4, 3])
+
+
+def test_bench_self_launch_weak_scaling_and_single_rank_plan():
+    import json
+    res = _bench('--gpus', '2', '--tiles', '3', '--plan-only')
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['scaling'] == 'weak' and out['tiles_per_step_all_ranks'] == 6
+    assert [r['first_tile'] for r in out['ranks']] == [0, 3]
+    # N = 1 walks configs[3] alone, in resident chunks
+    res = _bench('--total-tiles', '4096', '--tiles', '512', '--plan-only')
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['ranks'][0]['launches'] == [512] * 8 and out['tiles_per_step_all_ranks'] == 4096
+
+
+def test_bench_rank_without_a_gpu_fails_loudly():
+    """A real (not --plan-only) run on a box without a GPU must fail, not fall back to anything."""
+    from proteus_amd import _capi
+    if _capi.device_count() > 0:
+        pytest.skip('a GPU is present')
+    res = _bench('--steps', '1', '--warmup', '0', '--tiles', '1', '--no-cpu-baseline')
+    assert res.returncode != 0
+    assert '{"metric"' not in res.stdout
+
+
+def test_control_plane_does_not_fall_back_to_gloo_silently(tmp_path):
+    """RCCL cannot come up here (no GPU): without allow_fallback the control plane raises; with it the
+    backend string says what happened."""
+    script = tmp_path / 'cp.py'
+    script.write_text(textwrap.dedent('''
+        import sys
+        sys.path.insert(0, %r)
+        from proteus_amd import shard
+        allow = sys.argv[1] == '1'
+        try:
+            cp = shard.ControlPlane(backend='nccl', device=None, allow_fallback=allow)
+        except Exception as e:
+            print('RAISED', type(e).__name__)
+            raise SystemExit(3)
+        if cp.rank == 0:
+            print('BACKEND', cp.backend)
+        cp.close()
+    ''') % ROOT)
+    for allow, rc in (('0', 3), ('1', 0)):
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), allow]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        if rc:
+            assert res.returncode != 0 and 'RAISED' in res.stdout
+        else:
+            assert res.returncode == 0, res.stderr[-2000:]
+            assert 'BACKEND gloo (fallback: nccl init failed' in res.stdout
+
+
 def test_batch_plan():
     from proteus_amd import batch
     rcs = [f'rc{i}.yaml' for i in range(10)]

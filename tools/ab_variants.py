@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of kernel variants in ONE process on ONE device (contexts created with
-different DSWX_* environment knobs), as cdna_hip_programming.md rule 24 asks.
+"""Interleaved A/B of kernel variants in ONE process on ONE device (one context per variant, each
+configured through libdswx_lab.so's switches), as cdna_hip_programming.md rule 24 asks.
 
-    python tools/ab_variants.py --tiles 64 --rounds 7 DSWX_TUNE_WPS=4 DSWX_TUNE_WPS=6 ...
-    python tools/ab_variants.py DSWX_TUNE_WPS=4 LIB=proteus_amd/_lib/ab/libdswx_prev.so   # two builds
+    python tools/ab_variants.py --tiles 64 --rounds 7 fused_variant=3 fused_variant=0 fused_variant=2 ...
+    python tools/ab_variants.py tune_lut_wps=4 tune_lut_wps=5,fused_variant=3
+    python tools/ab_variants.py auto LIB=proteus_amd/_lib/ab/libdswx_prev.so   # two builds of the product library
 """
 import argparse
 import json
@@ -18,7 +19,7 @@ from proteus_amd.synth import SEED       # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('variants', nargs='+', help='ENV=VALUE[,ENV=VALUE] per variant')
+    ap.add_argument('variants', nargs='+', help='key=value[,key=value] per variant (lab switches), or auto')
     ap.add_argument('--tiles', type=int, default=64)
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--reps', type=int, default=5)
@@ -27,21 +28,19 @@ def main():
     a = ap.parse_args()
     ctxs = []
     for v in a.variants:
-        saved = {}
-        lib_path = None
+        lib_path, settings = None, {}
         for kv in v.split(','):
-            k, val = kv.split('=')
-            if k == 'LIB':              # another build of the library (same ABI), e.g. the previous commit
-                lib_path = os.path.abspath(val)
+            if kv == 'auto':
                 continue
-            saved[k] = os.environ.get(k)
-            os.environ[k] = val
-        ctxs.append(_capi.Context(0, lib_path=lib_path))
-        for k, old in saved.items():
-            if old is None:
-                os.environ.pop(k, None)
+            k, val = kv.split('=')
+            if k == 'LIB':              # another build of the product library (same ABI), e.g. the previous commit
+                lib_path = os.path.abspath(val)
             else:
-                os.environ[k] = old
+                settings[k] = int(val)
+        ctx = _capi.Context(0, lib_path=lib_path)
+        if settings:
+            ctx.lab_configure(**settings)
+        ctxs.append(ctx)
     base = ctxs[0]
     batch = _capi.DeviceBatch(base, a.tiles, 3660, 3660, masks=a.masks, tile_align=a.tile_align)
     batch.synth(SEED)

@@ -2,7 +2,7 @@
 """Measurement of the SURVEY 8(f) rows next to the hot path, device-resident, HIP events:
 terrain shadow layer (f1), 'cover' mode (f2), LAND 3x3 aggregation (f3).  For each: time per
 3660^2 tile, achieved GB/s of the algorithmic bytes, and the numpy oracle on one host core on a
-bounded sample.  Prints one JSON object (profiles/r01_next_rows.json).
+bounded sample.  Prints one JSON object (profiles/rNN_next_rows.json).
 
     python tools/next_rows_bench.py [--tiles 8] [--reps 5] [--no-cpu]
 """
@@ -47,23 +47,29 @@ def main():
     out = {'tiles_per_launch': n, 'tile': [T, T]}
 
     # ---- f1 terrain shadow: [n][3760][3760] float32 -> [n][3660][3660] u8
-    H = W = T + 2 * MARGIN
-    dem = synth_dem(3, H, W)
-    d_dem = ctx.malloc(n * dem.nbytes)
-    d_sh = ctx.malloc(n * T * T)
-    for t in range(n):
-        d_dem.upload(dem, t * dem.nbytes)
     az, el = np.radians(141.0), 35.0
     zen = np.radians(90 - el)
     sun = [np.sin(az) * np.sin(zen), np.cos(az) * np.sin(zen), np.cos(zen)]
-    avg, mn = timed(ctx, lambda: ctx.shadow_layer_device(d_dem.ptr, n, H, W, MARGIN, sun, np.sin(az), np.cos(az),
-                                                         -5.0, 40.0, d_sh.ptr), a.reps)
-    nbytes = n * (H * W * 4 + T * T)
-    out['f1_shadow'] = {'kernel': 'dswx_shadow', 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n,
-                        'algorithmic_bytes_per_tile': nbytes // n, 'GBps': nbytes / avg / 1e6,
-                        'Mpix_s': n * T * T / avg / 1e3}
-    d_dem.free()
-    d_sh.free()
+    out['f1_shadow'] = {}
+    # margin 50 (the reference's) -> dswx_shadow_v3 (four pixels per thread behind the filter);
+    # margin 51 on a 3762^2 DEM -> the general one-pixel kernel dswx_shadow_v2 on the same 3660^2 outputs
+    for tag, margin in (('quads_filter_v3', MARGIN), ('general_v2', MARGIN + 1)):
+        H = W = T + 2 * margin
+        dem = synth_dem(3, H, W)
+        d_dem = ctx.malloc(n * dem.nbytes)
+        d_sh = ctx.malloc(n * T * T)
+        for t in range(n):
+            d_dem.upload(dem, t * dem.nbytes)
+        nbytes = n * (H * W * 4 + T * T)
+        for mode, f32 in (('nep50', False), ('legacy_f32', True)):
+            avg, mn = timed(ctx, lambda: ctx.shadow_layer_device(d_dem.ptr, n, H, W, margin, sun, np.sin(az), np.cos(az),
+                                                                 -5.0, 40.0, d_sh.ptr, float32=f32), a.reps)
+            out['f1_shadow'][f'{tag}_{mode}'] = {
+                'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n, 'algorithmic_bytes_per_tile': nbytes // n,
+                'GBps': nbytes / avg / 1e6, 'frac_of_8TBps': nbytes / avg / 1e6 / 8000, 'Mpix_s': n * T * T / avg / 1e3}
+        d_dem.free()
+        d_sh.free()
+    dem = synth_dem(3, T + 2 * MARGIN, T + 2 * MARGIN)
 
     # ---- f3 LAND aggregation: [n][10980][10980] u8 + [n][3660][3660] u8 -> [n][3660][3660] u8
     wc, cg = synth_landcover_inputs(2, T, T)
@@ -74,8 +80,9 @@ def main():
     forest = [111, 113, 115, 116, 121, 123, 125, 126]
     avg, mn = timed(ctx, lambda: ctx.landcover_mask_device(d_wc.ptr, d_cg.ptr, n, T, T, forest, d_land.ptr), a.reps)
     nbytes = n * T * T * 11
-    out['f3_landcover'] = {'kernel': 'dswx_landcover_v2', 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n,
+    out['f3_landcover'] = {'kernel': 'dswx_landcover', 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n,
                            'algorithmic_bytes_per_tile': T * T * 11, 'GBps': nbytes / avg / 1e6,
+                           'frac_of_8TBps': nbytes / avg / 1e6 / 8000,
                            'Mpix_s': n * T * T / avg / 1e3}
     for b in (d_wc, d_cg, d_land):
         b.free()
@@ -92,6 +99,7 @@ def main():
     out['f2_cover_mode'] = {'kernel': info, 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n,
                             'fused_mask_mode_ms_per_tile': avg_m / n,
                             'algorithmic_bytes_per_tile': T * T * 24, 'GBps_of_24B_per_px': n * T * T * 24 / avg / 1e6,
+                            'frac_of_8TBps': n * T * T * 24 / avg / 1e6 / 8000,
                             'Mpix_s': n * T * T / avg / 1e3}
     batch.free()
 

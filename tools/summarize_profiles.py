@@ -32,16 +32,79 @@ def one(pattern):
     return hits[-1]
 
 
+def counter_rows(src, sub):
+    hits = sorted(glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True),
+                  key=os.path.getmtime)
+    return list(csv.DictReader(open(hits[-1]))) if hits else []
+
+
+def short(name):
+    return name.split('(')[0].replace('void ', '')
+
+
+def summarize_next_rows(a, out):
+    """Every kernel of tools/next_rows_bench.py (shadow, cover stage 2, land cover, and the fused stage 1):
+    kernel-trace average, HBM bytes per launch (FETCH doubled, KiB units, separate passes) and the SQ
+    wave-cycle breakdown -> profiles/rNN_next_rows_pmc.json + the kernel-stats csv."""
+    tag = f'r{int(a.round):02d}_next_rows'
+    stats = one(os.path.join(a.src, 'trace', '**', '*kernel_stats.csv'))
+    shutil.copy(stats, os.path.join(out, f'{tag}_kernel_stats.csv'))
+    log = os.path.join(a.src, 'next_rows.log')
+    if os.path.exists(log):
+        txt = open(log).read()
+        if '{' in txt:
+            open(os.path.join(out, f'{tag}.json'), 'w').write(txt[txt.index('{'):txt.rindex('}') + 1] + '\n')
+    trace = list(csv.DictReader(open(one(os.path.join(a.src, 'trace', '**', '*kernel_trace.csv')))))
+    res = {}
+    for r in trace:
+        k = short(r['Kernel_Name'])
+        if 'synth' in k or 'build_tables' in k or 'counters_finish' in k:
+            continue
+        res.setdefault(k, {'durs': []})['durs'].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    for ctr, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+        for r in counter_rows(a.src, sub):
+            k = short(r['Kernel_Name'])
+            if k in res and r['Counter_Name'] == ctr:
+                res[k].setdefault(ctr, []).append(float(r['Counter_Value']))
+    for r in counter_rows(a.src, 'pmc_sq'):
+        k = short(r['Kernel_Name'])
+        if k in res:
+            res[k].setdefault('sq', {}).setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+    summary = {}
+    for k, v in res.items():
+        avg = lambda x: sum(x) / len(x)                      # noqa: E731
+        e = {'launches_traced': len(v['durs']), 'avg_ns': avg(v['durs']), 'min_ns': min(v['durs'])}
+        if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+            rd, wr = 2.0 * avg(v['FETCH_SIZE']) * 1024.0, avg(v['WRITE_SIZE']) * 1024.0
+            e.update(read_bytes_corrected=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr,
+                     hbm_GBps_at_trace_avg=(rd + wr) / e['avg_ns'])
+        if 'sq' in v:
+            sq = {c: avg(x) for c, x in v['sq'].items()}
+            wc = sq.get('SQ_WAVE_CYCLES')
+            if wc:
+                e['sq_fraction_of_wave_cycles'] = {c: round(x / wc, 4) for c, x in sq.items()
+                                                   if c not in ('SQ_WAVE_CYCLES', 'SQ_WAVES')}
+            e['sq_per_launch_avg'] = sq
+        summary[k] = e
+    json.dump(summary, open(os.path.join(out, f'{tag}_pmc.json'), 'w'), indent=1)
+    print(json.dumps(summary, indent=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('round')
     ap.add_argument('tiles', type=int)
     ap.add_argument('--masks', action='store_true')
-    ap.add_argument('--src', default=os.path.join(ROOT, 'gpurun_out', 'prof'))
+    ap.add_argument('--next-rows', action='store_true', help='digest gpurun_out/prof_next instead of the hot kernel')
+    ap.add_argument('--src', default=None)
     ap.add_argument('--kernel', default='dswx_classify')
     a = ap.parse_args()
     out = os.path.join(ROOT, 'profiles')
     os.makedirs(out, exist_ok=True)
+    if a.src is None:
+        a.src = os.path.join(ROOT, 'gpurun_out', 'prof_next' if a.next_rows else ('prof_masks' if a.masks else 'prof'))
+    if a.next_rows:
+        return summarize_next_rows(a, out)
     tag = f'r{int(a.round):02d}' + ('_masks' if a.masks else '')
     stats = one(os.path.join(a.src, 'trace', '**', '*kernel_stats.csv'))
     shutil.copy(stats, os.path.join(out, f'{tag}_kernel_stats.csv'))
@@ -115,8 +178,17 @@ def main():
     json.dump(summary, open(os.path.join(out, f'{tag}_summary.json'), 'w'), indent=1)
     tpath = os.path.join(out, 'pmc_traffic.json')
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    # the hash of the kernel sources the profiled run was built from: bench.py prints it in its line
+    khash = None
+    blog = os.path.join(a.src, 'bench_trace.log')
+    if os.path.exists(blog):
+        shutil.copy(blog, os.path.join(out, f'{tag}_bench_under_rocprof.log'))
+        for line in open(blog):
+            if line.startswith('{"metric"'):
+                khash = json.loads(line)['roofline'].get('kernel_source_hash')
     traffic['masks' if a.masks else 'plain'] = {
         'tiles': a.tiles, 'hbm_bytes_per_launch': round(read_bytes + write_bytes),
+        'kernel_source_hash': khash,
         'source': f'profiles/{tag}_pmc_counters.csv: rocprofv3 --pmc FETCH_SIZE and --pmc '
                   f'WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950), KiB units'}
     json.dump(traffic, open(tpath, 'w'), indent=1)
