@@ -218,35 +218,45 @@ __device__ __forceinline__ int land_class(const LandArgs& a, int water, int urba
     return v;
 }
 
-// Four HLS pixels per thread (width % 4 == 0): three 12-byte row pieces of the WorldCover map as
-// dword loads (a wave reads 768 contiguous bytes per row), one dword of CGLS, one dword stored.
+// Four HLS pixels per thread (width % 4 == 0): three 12-byte row pieces of the WorldCover map per
+// thread (a wave reads 768 contiguous bytes per row), one dword of CGLS, one dword stored.
 // blockIdx.z = tile.  HBM-bound: 10 B read + 1 B written per pixel.
-__global__ __launch_bounds__(256) void dswx_landcover_v2(const LandArgs a) {
+// The nine class tests per pixel (is the byte 80 / 90 / 95, 50, 10?) are ONE 256-entry LDS table
+// lookup per WorldCover byte -- water | urban << 4 | tree << 8, so that the sum of nine entries IS the
+// three 3x3 counts (each <= 9 fits its 4-bit field).  Round 1 compared every byte against the five
+// codes in registers: 116 VALU per pixel, issue-bound at 0.43 of the HBM rate; this form needs ~38.
+__global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
+    __shared__ uint16_t s_code[256];
+    {
+        const int v = threadIdx.x;
+        s_code[v] = (uint16_t)(((v == 80) | (v == 90) | (v == 95) ? 1 : 0) | (v == 50 ? 16 : 0) | (v == 10 ? 256 : 0));
+    }
+    __syncthreads();
     const long long xq = (long long)blockIdx.x * 64 + (threadIdx.x & 63);      // quad index
     const long long y = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
     if (xq * 4 >= a.width || y >= a.height) return;
     const long long W3 = 3 * a.width, tile = blockIdx.z;
     const uint8_t* wc = a.wc3 + tile * 9 * a.height * a.width;
-    uint32_t cnt[4] = {0u, 0u, 0u, 0u};      // per pixel: water | urban << 8 | tree << 16
+    uint32_t w[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const uint32_t* row = reinterpret_cast<const uint32_t*>(wc + (3 * y + i) * W3 + 12 * xq);
-        const uint32_t w[3] = {__builtin_nontemporal_load(row), __builtin_nontemporal_load(row + 1),
-                               __builtin_nontemporal_load(row + 2)};
 #pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            const uint32_t v = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
-            cnt[j / 3] += (uint32_t)((v == 80u) | (v == 90u) | (v == 95u)) + ((uint32_t)(v == 50u) << 8) +
-                          ((uint32_t)(v == 10u) << 16);
-        }
+        for (int k = 0; k < 3; ++k) w[i][k] = __builtin_nontemporal_load(row + k);
     }
     const long long o = tile * a.height * a.width + y * a.width + 4 * xq;
-    const uint32_t cg = *reinterpret_cast<const uint32_t*>(a.cgls + o);
+    const uint32_t cg = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.cgls + o));
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};      // per pixel: water | urban << 4 | tree << 8
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) cnt[j / 3] += s_code[(w[i][j >> 2] >> (8 * (j & 3))) & 0xffu];
+    }
     uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        out |= (uint32_t)land_class(a, cnt[k] & 0xff, (cnt[k] >> 8) & 0xff, cnt[k] >> 16, (cg >> (8 * k)) & 0xff) << (8 * k);
-    *reinterpret_cast<uint32_t*>(a.land + o) = out;
+        out |= (uint32_t)land_class(a, cnt[k] & 15u, (cnt[k] >> 4) & 15u, cnt[k] >> 8, (cg >> (8 * k)) & 0xff) << (8 * k);
+    __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(a.land + o));
 }
 
 __global__ __launch_bounds__(256) void dswx_landcover_v1(const LandArgs a) {
@@ -632,7 +642,7 @@ int dswx_landcover_mask_device(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, c
     if (quad) {
         dim3 grid((unsigned)((width / 4 + 63) / 64), (unsigned)((height + 3) / 4), (unsigned)n_tiles), block(256);
         if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
-        hipLaunchKernelGGL(dswx_landcover_v2, grid, block, 0, s, a);
+        hipLaunchKernelGGL(dswx_landcover_v3, grid, block, 0, s, a);
     } else {
         dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4), (unsigned)n_tiles), block(256);
         if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
