@@ -12,8 +12,8 @@
 #include "dswx_host.h"
 #include "dswx_tables.h"
 
-// WPS: launch bound.  EXTRAS: also the browse plane and the stage-1 planes of 'cover' mode
-// (the cover state byte), looked up in Tables::extra.
+// WPS: launch bound.  EXTRAS: also the browse plane and the stage-1 scratch of 'cover' mode (the cover
+// state byte, looked up in Tables::extra, and the bitmaps of the four dilation predicates).
 template <bool MASKS, bool EXTRAS, int WPS>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
                                                              const Tables* __restrict__ tabs) {
@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
 #pragma unroll
             for (int j = 0; j < 8; ++j) ex[j] = s_extra[idx2[j] & 127u] | (idx2[j] & 128u);
             transpose4(ex, pa); transpose4(ex + 4, pb);
-            if (a.cover_state) stg<u32x2, false>(a.cover_state + off, u32x2{pa[0], pb[0]});   // re-read by stage 2: cacheable
+            if (a.cover_state) {              // re-read by stage 2: cacheable stores
+                stg<u32x2, false>(a.cover_state + off, u32x2{pa[0], pb[0]});
+                a.cover_bits[(long long)blockIdx.y * a.cover_bits_stride + grp] = cover_nibbles(pa[0]) | cover_nibbles(pb[0]) << 4;
+            }
             if (a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{pa[2], pb[2]});
         }
         if (in_range) {
@@ -128,10 +131,12 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
     const bool extras = b.out.browse || b.cover_state;
 #define LUT_LAUNCH(M, E, W) hipLaunchKernelGGL((dswx_classify_lut<M, E, W>), grid, block, 0, s, b, lc, tabs)
 #define LUT_SEL_W(M, E) do { if (wps >= 6) LUT_LAUNCH(M, E, 6); else if (wps == 5) LUT_LAUNCH(M, E, 5); else LUT_LAUNCH(M, E, 4); } while (0)
-    if (extras) { if (masks) LUT_LAUNCH(true, true, 4); else LUT_LAUNCH(false, true, 4); }
+    const bool ex4 = ctx->tune_lut_wps == 4;      // lab A/B: masks + extras at 4 waves per SIMD (128 VGPRs: 5 dwords spill)
+    if (extras) { if (masks && ex4) LUT_LAUNCH(true, true, 4); else if (masks) LUT_LAUNCH(true, true, 3); else LUT_LAUNCH(false, true, 4); }
     else if (masks) LUT_SEL_W(true, false);
     else LUT_SEL_W(false, false);
     snprintf(info, info_len, "dswx_classify_lut<%s%s> (table-driven) grid=(%lld,%lld) block=256 wps=%d",
-             masks ? "true" : "false", extras ? ",extras" : "", (long long)grid.x, (long long)grid.y, extras ? 4 : wps);
+             masks ? "true" : "false", extras ? ",extras" : "", (long long)grid.x, (long long)grid.y,
+             extras ? (masks && !ex4 ? 3 : 4) : wps);
     return DSWX_OK;
 }

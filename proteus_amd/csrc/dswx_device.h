@@ -44,7 +44,12 @@ struct KArgs {
     int n_u8_out;
     int n_diag_pieces;              // 8 if DIAG is wanted, else 0
     uint8_t* cover_state;           // 'cover' mode: stage 1 parks one state byte per pixel here
-                                    //   (cover_state_of); stage 2 (dswx_cover.hip) reads it back
+                                    //   (cover_state_of) ...
+    uint32_t* cover_bits;           //   ... and the four dilation predicates of every 8-pixel group as one
+                                    //   dword of bitmaps (cover_bits_of), [tile][cover_bits_stride];
+    long long cover_bits_stride;    //   stage 2 (dswx_cover.hip) reads the bitmaps and leaves
+    uint32_t* cover_snow;           //   the final snow decision, one bit per pixel, [tile][cover_snow_stride]
+    long long cover_snow_stride;    //   dwords; stage 3 finishes the layers from state + snow
     int height, width;              // 'cover' stage 2 only
     unsigned long long* counters;   // [n_tiles][3] or nullptr
     long long n_pixels;             // per tile
@@ -100,6 +105,26 @@ __device__ __forceinline__ uint32_t collapse_class(uint32_t v, uint32_t c) {
 __device__ __forceinline__ uint32_t cover_state_of(uint32_t w2, uint32_t pc, bool snow) {
     const uint32_t code = w2 <= 4u ? w2 : (w2 == 254u ? 5u : 6u);
     return code | (pc & 1u) << 3 | ((pc >> 2) & 3u) << 4 | (snow ? 64u : 0u);
+}
+
+// The four predicates of the masked dilations (_add_snow_to_cloud_layer :2055-2078) of one pixel from
+// its state byte (adjacent bit included), as bits 0-3: snow seed, area = adjacent & (CLOUD == 0),
+// area & (WTR-2 in 1..4), CLOUD == 0.
+__device__ __forceinline__ uint32_t cover_flags_of(uint32_t state) {
+    const uint32_t clear0 = (state & 0x38u) == 0u ? 1u : 0u;
+    const uint32_t area = clear0 & (state >> 7);
+    const uint32_t water = ((state & 7u) - 1u) <= 3u ? 1u : 0u;
+    return ((state >> 6) & 1u) | area << 1 | (area & water) << 2 | clear0 << 3;
+}
+// Eight pixels' flags -> the bitmap dword stage 1 stores per 8-pixel group: byte q = bit q of the flags
+// of pixels 0..7 (pixel j = bit j): [snow8, area8, area-and-water8, clear8].
+__device__ __forceinline__ uint32_t cover_bits_of(const uint32_t (&flags)[8]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m |= ((flags[j] >> q) & 1u) << (8 * q + j);
+    return m;
 }
 
 // A11-A15 of one pixel, given the uncollapsed WTR-2 class, the CLOUD value before the

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
             }
         }
         uint32_t q_diag[4] = {0, 0, 0, 0};
+        uint32_t cflags[EXTRAS ? 8 : 1] = {};
         uint32_t q_w1[2] = {0, 0}, q_w1a[2] = {0, 0}, q_w2[2] = {0, 0}, q_w[2] = {0, 0},
                  q_bw[2] = {0, 0}, q_cf[2] = {0, 0}, q_cl[2] = {0, 0}, q_st[2] = {0, 0}, q_br[2] = {0, 0};
 #pragma unroll
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
             q_cl[bw] |= o.cloud << (8 * bk);
             if (EXTRAS) {
                 q_st[bw] |= (o.state | ((uint32_t)fm & 4u) << 5) << (8 * bk);
+                cflags[j] = cover_flags_of(o.state | ((uint32_t)fm & 4u) << 5);
                 q_br[bw] |= o.browse << (8 * bk);
             }
         }
@@ -139,8 +141,13 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
         if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{q_cf[0], q_cf[1]});
         if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{q_cl[0], q_cl[1]});
         if (EXTRAS && a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{q_br[0], q_br[1]});
-        if (EXTRAS && a.cover_state)   // 'cover' stage 1 (wave-uniform)
+        if (EXTRAS && a.cover_state) {   // 'cover' stage 1 (wave-uniform)
             *reinterpret_cast<u32x2*>(a.cover_state + off) = u32x2{q_st[0], q_st[1]};
+            uint32_t fl[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fl[j] = cflags[EXTRAS ? j : 0];
+            a.cover_bits[(long long)blockIdx.y * a.cover_bits_stride + grp] = cover_bits_of(fl);
+        }
         }
     }
     if (a.partials) {
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
     if (threadIdx.x < 64) lut32[threadIdx.x] = a.P.aer_lut[threadIdx.x];
     __syncthreads();
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
-    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, cstate = 0, cflags = 0;
     const long long px = a.px_begin + (long long)blockIdx.x * 256 + threadIdx.x;
     if (px < a.n_pixels) {
         const long long off = (long long)blockIdx.y * a.tile_stride + px;
@@ -228,7 +235,26 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
         if (a.out.conf) a.out.conf[off] = (uint8_t)o.conf;
         if (a.out.cloud) a.out.cloud[off] = (uint8_t)o.cloud;
         if (a.out.browse) a.out.browse[off] = (uint8_t)o.browse;
-        if (a.cover_state) a.cover_state[off] = (uint8_t)(o.state | ((uint32_t)fm & 4u) << 5);
+        if (a.cover_state) {
+            cstate = o.state | ((uint32_t)fm & 4u) << 5;
+            a.cover_state[off] = (uint8_t)cstate;
+            cflags = cover_flags_of(cstate);
+        }
+    }
+    if (a.cover_state) {
+        // the wave's 64 consecutive pixels start on a multiple of 8 (px_begin is one): four ballots are the
+        // bitmaps of its eight 8-pixel groups; lane k stores group k's dword (pixels past the tile's end: 0)
+        unsigned long long bal[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bal[q] = __ballot((cflags >> q) & 1u);
+        const int lane = threadIdx.x & 63;
+        const long long g = ((px - lane) >> 3) + lane;
+        if (lane < 8 && (px - lane) + 8 * lane < a.n_pixels) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m |= (uint32_t)((bal[q] >> (8 * lane)) & 0xffull) << (8 * q);
+            a.cover_bits[(long long)blockIdx.y * a.cover_bits_stride + g] = m;
+        }
     }
     if (a.counters) reduce_counters(a.counters + (long long)blockIdx.y * 3, red, c0, c1, c2);
 }
@@ -476,11 +502,19 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     a.counters = reinterpret_cast<unsigned long long*>(counters);
     a.n_pixels = n_pixels;
     a.tile_stride = tile_stride;
-    a.cover_state = nullptr;
+    a.cover_state = nullptr; a.cover_bits = nullptr; a.cover_bits_stride = 0;
+    a.cover_snow = nullptr; a.cover_snow_stride = 0;
+    dswx_planes_out_t final_out = *out;     // what stages 2 + 3 of 'cover' write
     a.height = (int)height; a.width = (int)width;
-    dswx_planes_out_t final_out = *out;     // what stage 2 of 'cover' writes
     if (cover) {
-        const size_t need = (size_t)n_tiles * (size_t)tile_stride;
+        // scratch: one state byte per pixel (>= 256 bytes, it doubles as the slack IN FRONT of the bitmaps) +
+        // one bitmap dword per 8-pixel group + 64 dwords of slack behind them (the unconditional 16-byte row
+        // loads of stage 2) + the final snow bit plane
+        const size_t groups_per_tile = ((size_t)n_pixels + 7) / 8;
+        const size_t snow_dw_per_tile = ((size_t)n_pixels + 31) / 32 + 1;
+        const size_t state_bytes = (((size_t)n_tiles * (size_t)tile_stride + 255) & ~(size_t)255) + 256;
+        const size_t bits_bytes = ((size_t)n_tiles * groups_per_tile + 64) * 4;
+        const size_t need = state_bytes + bits_bytes + (size_t)n_tiles * snow_dw_per_tile * 4;
         if (need > ctx->cover_bytes) {
             HIP_TRY(hipStreamSynchronize(s));
             if (ctx->cover) HIP_TRY(hipFree(ctx->cover));
@@ -489,7 +523,11 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             ctx->cover_bytes = need;
         }
         a.cover_state = static_cast<uint8_t*>(ctx->cover);
-        // stage 1 stops before the snow step: these four layers come from stage 2
+        a.cover_bits = reinterpret_cast<uint32_t*>(a.cover_state + state_bytes);
+        a.cover_bits_stride = (long long)groups_per_tile;
+        a.cover_snow = reinterpret_cast<uint32_t*>(a.cover_state + state_bytes + bits_bytes);
+        a.cover_snow_stride = (long long)snow_dw_per_tile;
+        // stage 1 stops before the snow step: these layers come from stages 2 + 3
         a.out.wtr = a.out.bwtr = a.out.conf = a.out.cloud = a.out.browse = nullptr;
     }
 
@@ -536,7 +574,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         if (b.out.ndvi) b.out.ndvi += shift;
         if (b.out.awesh) b.out.awesh += shift;
         if (b.counters) b.counters += t0 * 3;
-        if (b.cover_state) b.cover_state += shift;
+        if (b.cover_state) { b.cover_state += shift; b.cover_bits += t0 * b.cover_bits_stride; b.cover_snow += t0 * b.cover_snow_stride; }
         b.px_begin = 0;
         b.partials = nullptr;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
@@ -620,7 +658,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             if (c2.out.cloud) c2.out.cloud += shift;
             if (c2.out.browse) c2.out.browse += shift;
             const size_t len = strlen(info);
-            const int crc = dswx_cover_stage2_launch(ctx, c2, nt, tile_stride, s, info + len, sizeof info - len);
+            const int crc = dswx_cover_stage2_launch(ctx, c2, nt, s, info + len, sizeof info - len);
             if (crc) return crc;
         }
         if (any_index) {

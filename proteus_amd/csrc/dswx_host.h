@@ -22,7 +22,7 @@ struct dswx_ctx {
     bool tables_valid = false;             // the device tables match tables_params, built on tables_stream
     hipStream_t tables_stream = nullptr;
     alignas(8) unsigned char tables_params[1024] = {};
-    // grow-only scratch of 'cover' mode: one state byte per pixel (cover_state_of)
+    // grow-only scratch of 'cover' mode: state byte per pixel + bitmap dword per 8-pixel group + final snow bits
     void* cover = nullptr;
     size_t cover_bytes = 0;
     // pipelined host path (pinned host buffers): copy streams, per-slot events, pinned counter scratch
@@ -33,8 +33,7 @@ struct dswx_ctx {
     size_t pipe_counters_cap = 0;
     // Fixed in production; libdswx_lab.so (experiments, A/B tools, variant tests) changes them through
     // dswx_lab_configure -- the product library reads no environment variable.
-    int cover_kernel = 2;                  // 'cover' stage 2: 2 bitmaps, 4 px per lane where rows are dword-aligned,
-                                           // 1 bitmaps, 1 px per lane
+    int cover_kernel = 8;                  // 'cover' stage 2: words per window row (8 = 256-column windows, 4 = 128)
     int host_pipeline = 1;                 // 0 forces the synchronous host path
     int host_chunks = 8;                   // pieces per tile of the pipelined host path
     std::string last_kernel;
@@ -77,5 +76,5 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& args, bool masks, dim3 grid, dim
                     char* info, size_t info_len);
 
 // ---- 'cover' mode stage 2 (dswx_cover.hip): appends its description to `info`
-int dswx_cover_stage2_launch(dswx_ctx* ctx, const KArgs& c2, long long n_tiles, long long tile_stride,
-                             hipStream_t stream, char* info, size_t info_len);
+int dswx_cover_stage2_launch(dswx_ctx* ctx, const KArgs& c2, long long n_tiles, hipStream_t stream, char* info,
+                             size_t info_len);

@@ -107,6 +107,19 @@ struct LutConsts {
     int32_t awesh_init;                 // -awesh4_min
 };
 
+// 'cover' stage 1, byte-parallel: four state bytes (adjacent bit included) -> the four predicate nibbles,
+// one per byte: snow | area << 8 | (area & water) << 16 | clear << 24, pixel p = bit p of its nibble.
+__device__ __forceinline__ uint32_t cover_nibbles(uint32_t s) {
+    auto zero_bytes = [](uint32_t v) { return (~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu)) >> 7; };
+    auto gather = [](uint32_t x) { return (x | x >> 7 | x >> 14 | x >> 21) & 0xfu; };     // 0/1 per byte -> nibble
+    const uint32_t snow4 = (s >> 6) & 0x01010101u, clear4 = zero_bytes(s & 0x38383838u);
+    const uint32_t area4 = (s >> 7) & clear4;
+    const uint32_t code4 = s & 0x07070707u;
+    // water classes: code 1..4  <=>  nonzero and (code + 3) has bit 3 clear
+    const uint32_t water4 = ~zero_bytes(code4) & ~((code4 + 0x03030303u) >> 3) & 0x01010101u;
+    return gather(snow4) | gather(area4) << 8 | gather(area4 & water4) << 16 | gather(clear4) << 24;
+}
+
 // 4 pixels' table words -> 4 plane dwords (byte k of every word -> plane k)
 __device__ __forceinline__ void transpose4(const uint32_t a[4], uint32_t out[4]) {
     const uint32_t t01l = perm_b32(a[1], a[0], 0x05010400u), t01h = perm_b32(a[1], a[0], 0x07030602u);

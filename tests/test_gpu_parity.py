@@ -500,20 +500,23 @@ def blobby_fmask(fmask, seed):
 
 @pytest.fixture(scope='module')
 def cover_contexts():
-    """Contexts pinned to each 'cover' stage-2 kernel: 2 = bitmaps, four pixels per lane (the product's
-    choice where rows are dword-aligned), 1 = bitmaps, one pixel per lane (forced through the lab switch)."""
-    made = {'2': _capi.Context(0), '1': _capi.Context(0)}
-    made['1'].lab_configure(cover_kernel=1)
+    """Contexts pinned to each window width of the 'cover' stage-2 kernel: 8 words per row (256-column
+    windows, the product's choice) and 4 (128 columns, forced through the lab switch)."""
+    made = {'8': _capi.Context(0)}
+    for name, switch in (('4', 4), ('8,direct', 8 + 16), ('4,direct', 4 + 16)):   # lab switch: words | 16 = no LDS staging
+        made[name] = _capi.Context(0)
+        made[name].lab_configure(cover_kernel=switch)
     yield made
     for c in made.values():
         c.close()
 
 
-# windows: 94 x 222 outputs per block (one pixel per lane), 88 x 222 (four) -> sizes on and around the seams
+# windows: 222 x 222 outputs per block (8 words per row), 94 x 222 (4 words) -> sizes on and around the seams
 @pytest.mark.parametrize('shape', [(1, 1), (7, 9), (64, 64), (65, 63), (100, 37), (160, 160), (333, 517),
-                                   (222, 94), (223, 95), (445, 189), (500, 300), (222, 88), (223, 92), (450, 180)])
+                                   (222, 94), (223, 95), (445, 189), (500, 300), (222, 222), (223, 223), (450, 445),
+                                   (3, 700), (700, 5)])
 @pytest.mark.parametrize('masks', [False, True])
-@pytest.mark.parametrize('kernel', ['2', '1'])
+@pytest.mark.parametrize('kernel', ['8', '4', '8,direct', '4,direct'])
 def test_cover_mode_vs_numpy_oracle(cover_contexts, shape, masks, kernel):
     ctx = cover_contexts[kernel]
     h, w = shape
@@ -523,9 +526,7 @@ def test_cover_mode_vs_numpy_oracle(cover_contexts, shape, masks, kernel):
     for collapse in (True, False):
         p = _capi.make_params(mask_adjacent_to_cloud_mode='cover', collapse_wtr_classes=collapse)
         got = ctx.classify_host(s['bands'], fmask, p, land=land, shad=shad, ocean=ocean)
-        want = {'2': 'dswx_cover_stage2_quads' if w % 4 == 0 else 'dswx_cover_stage2_bits',
-                '1': 'dswx_cover_stage2_bits'}[kernel]
-        assert want in ctx.last_kernel_info(), ctx.last_kernel_info()
+        assert f'dswx_cover_dilate<{kernel}>' in ctx.last_kernel_info(), ctx.last_kernel_info()
         exp = o.classify_tile(s['bands'], fmask, landcover=land, shadow=shad, ocean_mask=ocean,
                               mask_adjacent_to_cloud_mode='cover', collapse=collapse)
         for layer, key in NAME.items():

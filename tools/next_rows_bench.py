@@ -41,6 +41,7 @@ def main():
     ap.add_argument('--tiles', type=int, default=8)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--lab', action='store_true', help='also time lab A/B switches (libdswx_lab.so)')
     a = ap.parse_args()
     n = a.tiles
     ctx = _capi.Context(0)
@@ -101,6 +102,16 @@ def main():
                             'algorithmic_bytes_per_tile': T * T * 24, 'GBps_of_24B_per_px': n * T * T * 24 / avg / 1e6,
                             'frac_of_8TBps': n * T * T * 24 / avg / 1e6 / 8000,
                             'Mpix_s': n * T * T / avg / 1e3}
+    if a.lab:
+        # window width A/B of the stage-2 kernel through the lab switch (libdswx_lab.so)
+        for name, switch in (('window_4_words', {'cover_kernel': 4}), ('window_8_words_direct', {'cover_kernel': 24}),
+                             ('stage1_4_waves_per_simd', {'tune_lut_wps': 4})):
+            c4 = _capi.Context(0)
+            c4.lab_configure(**switch)
+            avg4, mn4 = timed(c4, lambda: c4.classify_batch(pc, batch.geom, batch.pin, batch.pout, batch.counters_ptr), a.reps)
+            out['f2_cover_mode']['ab_' + name] = {'kernel': c4.last_kernel_info(), 'ms_per_tile': avg4 / n,
+                                                  'ms_min_per_tile': mn4 / n}
+            c4.close()
     batch.free()
 
     if not a.no_cpu:
