@@ -127,28 +127,20 @@ __global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
 struct ShadowFilter {
     float inv_x, inv_y;                  // RN(1 / (-2 sx)), RN(1 / (2 |sy|)):  n0 ~ (d[x+1] - d[x-1]) * inv_x
     float s0, s1, s2, sin_az, cos_az;    // the five sun scalars rounded to float32
-    float q_lo_in, q_hi_in;              // low_inc decided TRUE  if q_lo_in <= q~ <= q_hi_in
-    float q_lo_out, q_hi_out;            // low_inc decided FALSE if q~ < q_lo_out or q~ > q_hi_out
-    float t_lo, t_hi;                    // backslope decided TRUE if t~ + Et <= t_lo, FALSE if t~ - Et > t_hi
-    float et_rel;                        // 2^-19
-    int t_tiny;                          // |slope_arg_max| < 2^-100: add the absolute term to Et
+    float q_c, q_h_in, q_h_out;          // u = q~ - q_c:  low_inc decided TRUE if |u| <= q_h_in, FALSE if |u| > q_h_out
+    float t_c;                           // v = t~ - t_c:  backslope decided if |v| > e (TRUE if v < 0, FALSE if v > 0)
+    float e_rel, e_abs;                  // e = e_rel sqrt(S) + e_abs   (sqrt(S) >= |n0 sin| + |n1 cos| up to |(sin, cos)|)
+    float et_rel;                        // t_tiny only: e = et_rel (|n0 sin| + |n1 cos|) + (2^-120 unless both differences are 0)
+    int t_tiny;                          // |slope_arg_max| < 2^-100: the threshold is too close to 0 for a relative bound
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool F32>
-__global__ __launch_bounds__(256) void dswx_shadow_v3(const ShadowArgs a, const ShadowFilter f) {
-    const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
-    const int ow = W - 2 * margin, oh = H - 2 * margin;
-    const int oq = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (4 * oq >= ow || oy >= oh) return;
-    const float* __restrict__ row = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W +
-                                    (size_t)(oy + margin) * (size_t)W + (size_t)(4 * oq + margin);
-    // centre row d[x-2 .. x+5], rows above / below d[x .. x+3]; x is even, rows are 8-byte aligned
-    const f32x2 c0 = *reinterpret_cast<const f32x2*>(row - 2), c1 = *reinterpret_cast<const f32x2*>(row),
-                c2 = *reinterpret_cast<const f32x2*>(row + 2), c3 = *reinterpret_cast<const f32x2*>(row + 4);
-    const f32x2 u0 = *reinterpret_cast<const f32x2*>(row - W), u1 = *reinterpret_cast<const f32x2*>(row - W + 2);
-    const f32x2 b0 = *reinterpret_cast<const f32x2*>(row + W), b1 = *reinterpret_cast<const f32x2*>(row + W + 2);
+// One quad (four horizontally adjacent output pixels) from the three DEM rows around it: c0..c3 = centre
+// row d[x-2 .. x+5], u0 u1 / b0 b1 = rows above / below d[x .. x+3].  Returns the four 0 / 1 bytes.
+template <bool F32, bool TINY>
+__device__ __forceinline__ uint32_t shadow_quad(const ShadowArgs& a, const ShadowFilter& f, f32x2 c0, f32x2 c1, f32x2 c2,
+                                                f32x2 c3, f32x2 u0, f32x2 u1, f32x2 b0, f32x2 b1) {
     // finite differences of the four pixels as two packed pairs (every output pixel is interior)
     const f32x2 dx[2] = {f32x2{c1.y, c2.x} - f32x2{c0.y, c1.x}, f32x2{c2.y, c3.x} - f32x2{c1.y, c2.x}};
     const f32x2 dy[2] = {b0 - u0, b1 - u1};
@@ -159,19 +151,27 @@ __global__ __launch_bounds__(256) void dswx_shadow_v3(const ShadowArgs a, const 
         const f32x2 S = __builtin_elementwise_fma(n0, n0, __builtin_elementwise_fma(n1, n1, f32x2{1.0f, 1.0f}));
         const f32x2 dot = __builtin_elementwise_fma(n0, f32x2{f.s0, f.s0},
                                                     __builtin_elementwise_fma(n1, f32x2{f.s1, f.s1}, f32x2{f.s2, f.s2}));
-        const f32x2 t = __builtin_elementwise_fma(n0, f32x2{f.sin_az, f.sin_az}, n1 * f.cos_az);
+        const f32x2 v = __builtin_elementwise_fma(n0, f32x2{f.sin_az, f.sin_az},
+                                                  __builtin_elementwise_fma(n1, f32x2{f.cos_az, f.cos_az}, f32x2{-f.t_c, -f.t_c}));
+        const f32x2 r = {__builtin_amdgcn_rsqf(S.x), __builtin_amdgcn_rsqf(S.y)};
+        const f32x2 u = __builtin_elementwise_fma(dot, r, f32x2{-f.q_c, -f.q_c});
+        f32x2 e = __builtin_elementwise_fma(S * r, f32x2{f.e_rel, f.e_rel}, f32x2{f.e_abs, f.e_abs});
+        if (TINY) {       // exact zero differences give an exact t = 0; anything else gets an absolute term
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                e[h] = f.et_rel * __builtin_fmaf(__builtin_fabsf(n0[h]), __builtin_fabsf(f.sin_az),
+                                                 __builtin_fabsf(n1[h]) * __builtin_fabsf(f.cos_az)) +
+                       __builtin_fminf((__builtin_fabsf(dx[p][h]) + __builtin_fabsf(dy[p][h])) * 0x1p100f, 0x1p-120f);
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float q = dot[h] * __builtin_amdgcn_rsqf(S[h]);
-            float et = f.et_rel * __builtin_fmaf(__builtin_fabsf(n0[h]), __builtin_fabsf(f.sin_az),
-                                                 __builtin_fabsf(n1[h]) * __builtin_fabsf(f.cos_az));
-            if (f.t_tiny)     // exact zero differences give an exact t = 0; anything else gets the absolute term
-                et += __builtin_fminf((__builtin_fabsf(dx[p][h]) + __builtin_fabsf(dy[p][h])) * 0x1p100f, 0x1p-120f);
             const bool sane = S[h] < 0x1p60f;                                     // false for NaN / inf / huge
-            const bool inc_yes = (q >= f.q_lo_in) & (q <= f.q_hi_in);
-            const bool inc_no = (q < f.q_lo_out) | (q > f.q_hi_out);
-            const bool back_yes = t[h] + et <= f.t_lo;
-            const bool back_no = t[h] - et > f.t_hi;
+            const float au = __builtin_fabsf(u[h]), av = __builtin_fabsf(v[h]);
+            const bool inc_yes = au <= f.q_h_in, inc_no = au > f.q_h_out;
+            const bool back_known = av > e[h], back_no = back_known & (v[h] > 0.0f);
+            // t_tiny: |v| > e never holds for an exact zero (e = 0, v = 0): decide that case by v <= 0 directly
+            const bool back_yes = TINY ? ((back_known & (v[h] < 0.0f)) | ((e[h] == 0.0f) & (v[h] <= 0.0f)))
+                                           : (back_known & !(v[h] > 0.0f));
             // result = low_inc | !backslope: known 1 if either says so, known 0 if both deny
             const bool one = sane & (inc_yes | back_no);
             const bool zero = sane & inc_no & back_yes;
@@ -190,8 +190,44 @@ __global__ __launch_bounds__(256) void dswx_shadow_v3(const ShadowArgs a, const 
             out = (out & ~(0xffu << (8 * k))) | ((v ? 1u : 0u) << (8 * k));
         }
     }
-    *reinterpret_cast<uint32_t*>(a.shadow + (size_t)blockIdx.z * (size_t)oh * (size_t)ow +
-                                 (size_t)oy * (size_t)ow + (size_t)(4 * oq)) = out;
+    return out;
+}
+
+// One wave = 64 quads x SHADOW_ROWS consecutive output rows: every DEM row is loaded once per wave (eight
+// floats per lane, 8-byte aligned) and serves as the row below, the centre row and the row above of three
+// successive output rows -- a block of 4 x SHADOW_ROWS output rows reads 4 x SHADOW_ROWS + 2 DEM rows.  (With one
+// output row per wave a block read 6 DEM rows for 4 output rows and the halo rows were NOT served by a cache --
+// vertically adjacent blocks run on different XCDs: PMC showed 1.54 x the DEM's bytes fetched from HBM.)
+constexpr int SHADOW_ROWS = 8;
+
+// TINY: the slope threshold is (almost) zero -- see ShadowFilter::t_tiny
+template <bool F32, bool TINY>
+__global__ __launch_bounds__(256) void dswx_shadow_v3(const ShadowArgs a, const ShadowFilter f) {
+    const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
+    const int ow = W - 2 * margin, oh = H - 2 * margin;
+    const int oq = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * SHADOW_ROWS;
+    if (4 * oq >= ow || oy0 >= oh) return;
+    const float* __restrict__ col = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W + (size_t)(4 * oq + margin);
+    uint8_t* __restrict__ dst = a.shadow + (size_t)blockIdx.z * (size_t)oh * (size_t)ow + (size_t)(4 * oq);
+    struct Row { f32x2 v[4]; };         // d[x-2 .. x+5]; x is even, rows are 8-byte aligned
+    auto load_row = [&](int y) {
+        const float* r = col + (size_t)(y < H ? y : H - 1) * (size_t)W;        // rows past the last output row: clamped, unused
+        return Row{{*reinterpret_cast<const f32x2*>(r - 2), *reinterpret_cast<const f32x2*>(r),
+                    *reinterpret_cast<const f32x2*>(r + 2), *reinterpret_cast<const f32x2*>(r + 4)}};
+    };
+    const int y0 = oy0 + margin;
+    Row up = load_row(y0 - 1), ce = load_row(y0);
+#pragma unroll
+    for (int i = 0; i < SHADOW_ROWS; ++i) {
+        const Row dn = load_row(y0 + i + 1);
+        if (oy0 + i < oh) {
+            const uint32_t out = shadow_quad<F32, TINY>(a, f, ce.v[0], ce.v[1], ce.v[2], ce.v[3], up.v[1], up.v[2], dn.v[1], dn.v[2]);
+            *reinterpret_cast<uint32_t*>(dst + (size_t)(oy0 + i) * (size_t)ow) = out;
+        }
+        up = ce;
+        ce = dn;
+    }
 }
 
 // ------------------------------------------------------------------------------
@@ -225,6 +261,8 @@ __device__ __forceinline__ int land_class(const LandArgs& a, int water, int urba
 // lookup per WorldCover byte -- water | urban << 4 | tree << 8, so that the sum of nine entries IS the
 // three 3x3 counts (each <= 9 fits its 4-bit field).  Round 1 compared every byte against the five
 // codes in registers: 116 VALU per pixel, issue-bound at 0.43 of the HBM rate; this form needs ~38.
+constexpr int LAND_ROWS = 2;
+
 __global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
     __shared__ uint16_t s_code[256];
     {
@@ -233,30 +271,38 @@ __global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
     }
     __syncthreads();
     const long long xq = (long long)blockIdx.x * 64 + (threadIdx.x & 63);      // quad index
-    const long long y = (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (xq * 4 >= a.width || y >= a.height) return;
+    const long long y0 = ((long long)blockIdx.y * 4 + (threadIdx.x >> 6)) * LAND_ROWS;
+    if (xq * 4 >= a.width || y0 >= a.height) return;
     const long long W3 = 3 * a.width, tile = blockIdx.z;
     const uint8_t* wc = a.wc3 + tile * 9 * a.height * a.width;
-    uint32_t w[3][3];
+    // LAND_ROWS HLS rows per thread, all loads issued before the first lookup (more bytes in flight per wave)
+    uint32_t w[LAND_ROWS][3][3], cg[LAND_ROWS];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(wc + (3 * y + i) * W3 + 12 * xq);
+    for (int r = 0; r < LAND_ROWS; ++r) {
+        const long long y = y0 + r < a.height ? y0 + r : a.height - 1;          // past the last row: clamped, unused
 #pragma unroll
-        for (int k = 0; k < 3; ++k) w[i][k] = __builtin_nontemporal_load(row + k);
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(wc + (3 * y + i) * W3 + 12 * xq);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[r][i][k] = __builtin_nontemporal_load(row + k);
+        }
+        cg[r] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.cgls + tile * a.height * a.width + y * a.width + 4 * xq));
     }
-    const long long o = tile * a.height * a.width + y * a.width + 4 * xq;
-    const uint32_t cg = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.cgls + o));
-    uint32_t cnt[4] = {0u, 0u, 0u, 0u};      // per pixel: water | urban << 4 | tree << 8
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int r = 0; r < LAND_ROWS; ++r) {
+        if (y0 + r >= a.height) break;
+        uint32_t cnt[4] = {0u, 0u, 0u, 0u};      // per pixel: water | urban << 4 | tree << 8
 #pragma unroll
-        for (int j = 0; j < 12; ++j) cnt[j / 3] += s_code[(w[i][j >> 2] >> (8 * (j & 3))) & 0xffu];
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) cnt[j / 3] += s_code[(w[r][i][j >> 2] >> (8 * (j & 3))) & 0xffu];
+        }
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            out |= (uint32_t)land_class(a, cnt[k] & 15u, (cnt[k] >> 4) & 15u, cnt[k] >> 8, (cg[r] >> (8 * k)) & 0xff) << (8 * k);
+        __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(a.land + tile * a.height * a.width + (y0 + r) * a.width + 4 * xq));
     }
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        out |= (uint32_t)land_class(a, cnt[k] & 15u, (cnt[k] >> 4) & 15u, cnt[k] >> 8, (cg >> (8 * k)) & 0xff) << (8 * k);
-    __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(a.land + o));
 }
 
 __global__ __launch_bounds__(256) void dswx_landcover_v1(const LandArgs a) {
@@ -472,16 +518,29 @@ static void shadow_filter(const ShadowArgs& a, bool f32, ShadowFilter* f) {
     f->inv_y = (float)(1.0 / (-2.0 * (double)a.neg_abs_spacing_y));
     f->s0 = (float)a.sun[0]; f->s1 = (float)a.sun[1]; f->s2 = (float)a.sun[2];
     f->sin_az = (float)a.sin_az; f->cos_az = (float)a.cos_az;
-    const double K = std::ldexp(std::fabs(a.sun[0]) + std::fabs(a.sun[1]) + std::fabs(a.sun[2]), -18) + 1e-30;
-    f->q_lo_in = float_up(q_min + K);   f->q_hi_in = float_down(1.0 - K);
-    f->q_lo_out = float_down(q_min - K); f->q_hi_out = float_up(1.0 + K);
+    // low_inc <=> q_min <= q <= 1, tested as |q - c| against half the interval: |q~ - q_ref| <= K (see the
+    // kernel comment), + the float32 roundings of the centre and of the subtraction
+    const double sum_abs = std::fabs(a.sun[0]) + std::fabs(a.sun[1]) + std::fabs(a.sun[2]);
+    const double K = std::ldexp(sum_abs, -18) + std::ldexp(sum_abs + 2.0, -22) + 1e-30;
+    f->q_c = (float)(0.5 * (q_min + 1.0));
+    const double hw_lo = (double)f->q_c - q_min, hw_hi = 1.0 - (double)f->q_c;
+    f->q_h_in = float_down((hw_lo < hw_hi ? hw_lo : hw_hi) - K);
+    f->q_h_out = float_up((hw_lo > hw_hi ? hw_lo : hw_hi) + K);
+    // backslope <=> t <= t_max, tested as v = t~ - t_c against e >= |t~ - t_ref| + |t_c - t_max|:
+    // 2^-19 (|n0 sin| + |n1 cos|) covers the arithmetic (7 half-ulps of float32 needed, 4 x slack, which
+    // also pays for the rounding of the subtraction), and |n0 sin| + |n1 cos| <= sqrt(S) |(sin, cos)|
+    const double hyp = std::sqrt(a.sin_az * a.sin_az + a.cos_az * a.cos_az);
+    f->e_rel = float_up(std::ldexp(hyp, -19));
     f->et_rel = 0x1p-19f;
-    // absolute float32-denormal rounding noise (< 2^-140) is folded into the threshold by widening it
-    // relatively; a threshold too close to zero for that gets the explicit absolute term instead
     f->t_tiny = std::fabs(t_max) < 0x1p-100 ? 1 : 0;
-    const double widen = (f->t_tiny || std::isinf(t_max)) ? 0.0 : std::fabs(t_max) * 0x1p-20;
-    f->t_lo = float_down(t_max - widen);
-    f->t_hi = float_up(t_max + widen);
+    if (std::isinf(t_max) || std::fabs(t_max) > 3e38) {
+        f->t_c = t_max > 0 ? std::numeric_limits<float>::infinity() : -std::numeric_limits<float>::infinity();
+        f->e_abs = 0.0f;                 // v = -+inf (or NaN): decided by its sign, NaN falls to the exact path
+    } else {
+        f->t_c = (float)t_max;
+        // float32 rounding of the threshold + of the subtraction's threshold share + denormal noise (< 2^-140)
+        f->e_abs = f->t_tiny ? 0.0f : float_up(std::fabs((double)f->t_c - t_max) + std::fabs(t_max) * 0x1p-20 + 1e-40);
+    }
 }
 
 static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
@@ -507,9 +566,11 @@ static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles
     if (quads) {
         ShadowFilter f;
         shadow_filter(a, f32, &f);
-        dim3 grid((unsigned)((ow / 4 + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
-        if (f32) hipLaunchKernelGGL(dswx_shadow_v3<true>, grid, block, 0, s, a, f);
-        else hipLaunchKernelGGL(dswx_shadow_v3<false>, grid, block, 0, s, a, f);
+        dim3 grid((unsigned)((ow / 4 + 63) / 64), (unsigned)((oh + 4 * SHADOW_ROWS - 1) / (4 * SHADOW_ROWS)), (unsigned)n_tiles), block(256);
+        if (f32 && f.t_tiny) hipLaunchKernelGGL((dswx_shadow_v3<true, true>), grid, block, 0, s, a, f);
+        else if (f32) hipLaunchKernelGGL((dswx_shadow_v3<true, false>), grid, block, 0, s, a, f);
+        else if (f.t_tiny) hipLaunchKernelGGL((dswx_shadow_v3<false, true>), grid, block, 0, s, a, f);
+        else hipLaunchKernelGGL((dswx_shadow_v3<false, false>), grid, block, 0, s, a, f);
     } else {
         dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
         if (f32) hipLaunchKernelGGL(dswx_shadow_v2<true>, grid, block, 0, s, a);
@@ -640,7 +701,7 @@ int dswx_landcover_mask_device(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, c
     // four pixels per thread with dword loads when rows keep 4-byte alignment
     const bool quad = width % 4 == 0 && aligned_to(worldcover_up3, 4) && aligned_to(copernicus, 4) && aligned_to(land, 4);
     if (quad) {
-        dim3 grid((unsigned)((width / 4 + 63) / 64), (unsigned)((height + 3) / 4), (unsigned)n_tiles), block(256);
+        dim3 grid((unsigned)((width / 4 + 63) / 64), (unsigned)((height + 4 * LAND_ROWS - 1) / (4 * LAND_ROWS)), (unsigned)n_tiles), block(256);
         if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
         hipLaunchKernelGGL(dswx_landcover_v3, grid, block, 0, s, a);
     } else {

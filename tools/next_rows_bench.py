@@ -21,16 +21,19 @@ from proteus_amd.synth import SEED, synth_dem, synth_landcover_inputs, synth_til
 T, MARGIN = 3660, 50
 
 
-def timed(ctx, fn, reps):
+def timed(ctx, fn, reps, inner=10):
+    """Average over `reps` timings of `inner` back-to-back launches each (HIP events on the kernel's stream):
+    a single ~0.1 ms launch between two events also measures ~10 us of dispatch gap."""
     fn()
     ctx.synchronize()
     ms = []
     for _ in range(reps):
         a, b = ctx.event(), ctx.event()
         ctx.record(a)
-        fn()
+        for _ in range(inner):
+            fn()
         ctx.record(b)
-        ms.append(ctx.elapsed_ms(a, b))
+        ms.append(ctx.elapsed_ms(a, b) / inner)
         ctx.destroy_event(a)
         ctx.destroy_event(b)
     return sum(ms) / len(ms), min(ms)
