@@ -421,10 +421,12 @@ def _compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
     if dem.ndim != 2 or min(dem.shape) < 2:
         raise ValueError('Shape of array too small to calculate a numerical gradient, '
                          'at least 2 elements are required.')
-    # which numpy does the caller want to agree with?  'nep50' (numpy >= 2, default: what the
-    # reference computes when run under a current numpy) or 'legacy' (numpy < 2 value-based
-    # casting, what it computes under the numpy 1.23.5 it pins): env DSWX_NUMPY_PROMOTION
-    mode = (numpy_promotion or os.environ.get('DSWX_NUMPY_PROMOTION', 'nep50')).lower()
+    # which numpy does the caller want to agree with?  'legacy' (DEFAULT: numpy < 2 value-based casting,
+    # what the reference computes in its supported environment -- it pins numpy==1.23.5, setup.py:78 --
+    # where the float64 sun scalars do not upcast the float32 DEM arrays) or 'nep50' (numpy >= 2: what
+    # the same source computes under a current numpy; the committed shadow_s_*.npz goldens were generated
+    # by importing the reference under numpy 2.2 and pin this mode).  env DSWX_NUMPY_PROMOTION overrides.
+    mode = (numpy_promotion or os.environ.get('DSWX_NUMPY_PROMOTION', 'legacy')).lower()
     if mode not in ('nep50', 'legacy'):
         raise ValueError(f"numpy_promotion must be 'nep50' or 'legacy', not {mode!r}")
     return get_context().shadow_layer(
@@ -841,20 +843,49 @@ def _save_array(input_array, output_file, dswx_metadata_dict, geo_tags, descript
     _run_or_defer(job)
 
 
+def _gdal_byte(band_array):
+    """What `gdal_band.WriteArray(array)` stores in a GDT_Byte band (GDALCopyWords): integers are clamped
+    to 0..255; floating point is rounded half up after clamping, NaN becomes 0.  (GDAL is not installed
+    here: the clamp / round rule is GDAL's documented conversion, unpinned by execution.)"""
+    a = np.asarray(band_array)
+    if a.dtype == np.uint8:
+        return a
+    if a.dtype == np.bool_:
+        return a.astype(np.uint8)
+    if a.dtype.kind in 'iu':
+        return np.clip(a, 0, 255).astype(np.uint8)
+    with np.errstate(invalid='ignore'):
+        v = np.floor(np.clip(np.nan_to_num(a.astype(np.float64), nan=0.0), 0.0, 255.0) + 0.5)
+    return np.minimum(v, 255.0).astype(np.uint8)
+
+
 def save_dswx_product(layers, output_file, dswx_metadata_dict, geo_tags,
                       output_files_list=None):
-    """Multi-band product in band_description_dict order (:2655-2707): every band of the
-    ten that was produced; Byte bands, nodata 255.  DIAG (UInt16) and DEM (Float32) do not
-    fit a Byte file and are skipped here, as gdal.GDT_Byte would truncate them there."""
-    names = [n for n in band_description_dict if layers.get(n) is not None
-             and np.asarray(layers[n]).dtype in (np.uint8, np.bool_)]
-    stack = np.stack([np.asarray(layers[n], dtype=np.uint8) for n in names])
+    """Multi-band product (:2601-2707): ALWAYS the ten Byte bands of band_description_dict, in its order
+    (WTR, BWTR, CONF, DIAG, WTR-1, WTR-2, LAND, SHAD, CLOUD, DEM), nodata 255 -- band k of this file is
+    band k of a reference-made product.  As there:
+      * DIAG (UInt16 decimal digits) and DEM (Float32) go through GDAL's Byte conversion (`_gdal_byte`),
+        i.e. they saturate at 255 (:2666 creates every band as GDT_Byte);
+      * every band carries the description of the FIRST band: `description` is assigned once from
+        band_description_dict inside the loop and never reset (:2686-2687);
+      * WTR, WTR-1, WTR-2 arrive collapsed (the kernel applied _collapse_wtr_classes, :2688-2689).
+    A layer that was not produced (LAND / SHAD / DEM without their ancillary inputs; the reference
+    would raise on WriteArray(None)) is a plane of nodata."""
+    names = list(band_description_dict)
+    first = next((np.asarray(v) for v in layers.values() if v is not None), None)
+    if first is None:
+        raise ValueError('save_dswx_product: no layer to save')
+    shape = first.shape
+    stack = np.full((len(names),) + shape, UINT8_FILL_VALUE, dtype=np.uint8)
+    for i, n in enumerate(names):
+        if layers.get(n) is not None:
+            stack[i] = _gdal_byte(layers[n])
+    description = band_description_dict[names[0]]
     _makedirs(output_file)
 
     def job():
         geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict,
-                              nodata=UINT8_FILL_VALUE,
-                              descriptions=[band_description_dict[n] for n in names],
+                              nodata=UINT8_FILL_VALUE, descriptions=[description] * len(names),
                               overviews=geotiff.COG_OVERVIEW_FACTORS)
         logger.info(f'file saved: {output_file}')
     if output_files_list is not None:
@@ -1299,9 +1330,9 @@ def generate_dswx_layers(input_list,
         output_files_list.append(output_browse_image)
     if output_file and not output_file.endswith('.vrt'):
         # the multi-band file carries the post-aerosol WTR-1 (in-place remap, :5260 -> :5389)
-        save_dswx_product({'WTR': res['wtr'], 'BWTR': res['bwtr'], 'CONF': res['conf'],
+        save_dswx_product({'WTR': res['wtr'], 'BWTR': res['bwtr'], 'CONF': res['conf'], 'DIAG': res['diag'],
                            'WTR-1': res['wtr1_aerosol'], 'WTR-2': res['wtr2'],
-                           'LAND': landcover_mask, 'SHAD': shadow_layer, 'CLOUD': res['cloud']},
+                           'LAND': landcover_mask, 'SHAD': shadow_layer, 'CLOUD': res['cloud'], 'DEM': dem},
                           output_file, md, geo_tags, output_files_list=output_files_list)
     elif output_file:
         logger.warning(f'VRT output "{output_file}" skipped: needs GDAL')

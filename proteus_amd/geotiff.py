@@ -7,13 +7,15 @@ the drop-in carries this small classic-TIFF implementation of exactly what that
 path touches:
 
  read   little/big-endian classic TIFF, strips or tiles, compression none / DEFLATE
-        (with horizontal predictor), 1..N samples (chunky or planar), u8/i8/u16/i16/
-        u32/i32/f32/f64, GDAL_METADATA (42112), GDAL_NODATA (42113), colour map and
-        the GeoTIFF tags (33550, 33922, 34264, 34735-34737).
- write  little-endian classic TIFF, 512x512 tiles, DEFLATE + predictor 2 for the
-        integer layers (the reference's COG creation options, core.py:60-75, minus
-        overviews), planar multi-band, nodata, per-band descriptions, colour table,
-        metadata, and the GeoTIFF tags copied from the input HLS file.
+        (horizontal predictor 2, floating-point predictor 3), 1..N samples (chunky or
+        planar), u8/i8/u16/i16/u32/i32/f32/f64, GDAL_METADATA (42112), GDAL_NODATA (42113),
+        colour map and the GeoTIFF tags (33550, 33922, 34264, 34735-34737).
+ write  little-endian classic TIFF, 512x512 tiles, DEFLATE + PREDICTOR=2 for the integer
+        layers and PREDICTOR=3 for the Float32 ones (the reference's COG creation options,
+        core.py:60-75), internal overviews 4 / 16 / 64 / 128 (NEAREST for integer layers,
+        CUBICSPLINE for floating point, core.py:37-46), planar multi-band, nodata,
+        per-band descriptions, colour table, metadata, and the GeoTIFF tags copied from the
+        input HLS file.  Files appear under their final name only when complete.
 
 The georeferencing is carried opaquely: the projection of the output product is the
 set of GeoKey tags of the input (the reference copies `GetProjection()` the same
@@ -178,7 +180,7 @@ def read_geotiff(path, window=None, overview=None, alloc=None):
         raise GeoTiffError(f'{path}: compression {comp} is not supported')
     predictor = one(TAG_PREDICTOR, 1)
     planar = one(TAG_PLANAR, 1)
-    if predictor not in (1, 2):
+    if predictor not in (1, 2, 3) or (predictor == 3 and fmt != 3):
         raise GeoTiffError(f'{path}: predictor {predictor} is not supported')
     dt = info.dtype.newbyteorder(e)
     H, W = info.height, info.width
@@ -205,7 +207,11 @@ def read_geotiff(path, window=None, overview=None, alloc=None):
             raw = zlib.decompress(raw)
         rows = bh if tiled else min(bh, H - by * bh)
         need = rows * bw * chunk_spp * dt.itemsize
-        blk = np.frombuffer(raw[:need], dtype=dt).reshape(rows, bw, chunk_spp)
+        if predictor == 3:
+            blk = _fp_predictor_decode(np.frombuffer(raw[:need], dtype=np.uint8), rows, bw * chunk_spp,
+                                       chunk_spp, info.dtype).reshape(rows, bw, chunk_spp)
+        else:
+            blk = np.frombuffer(raw[:need], dtype=dt).reshape(rows, bw, chunk_spp)
         if predictor == 2:
             blk = np.cumsum(blk.astype(info.dtype), axis=1, dtype=info.dtype)
         y0, x0 = by * bh, bx * bw
@@ -276,6 +282,80 @@ def geo_tags_from_geotransform(geotransform, epsg=None):
 COG_OVERVIEW_FACTORS = (4, 16, 64, 128)      # reference core.py:37
 
 
+def _fp_predictor_encode(blk):
+    """TIFF floating-point predictor (PREDICTOR=3, Adobe TIFF Technical Note 3; libtiff fpDiff): per row,
+    the bytes of the samples are regrouped into byte planes, most significant byte first whatever the
+    file's byte order, and the whole row of bytes is differenced horizontally.  blk: [rows, n] float32 /
+    float64 (one sample per pixel: planar configuration) -> bytes."""
+    rows, n = blk.shape
+    bps = blk.dtype.itemsize
+    be = np.ascontiguousarray(blk.astype(blk.dtype.newbyteorder('>')))          # byte 0 = most significant
+    planes = be.view(np.uint8).reshape(rows, n, bps).transpose(0, 2, 1).reshape(rows, bps * n)
+    out = planes.copy()
+    out[:, 1:] = planes[:, 1:] - planes[:, :-1]                                  # uint8 arithmetic wraps
+    return out.tobytes()
+
+
+def _fp_predictor_decode(raw, rows, n, stride, dtype):
+    """Inverse of _fp_predictor_encode (libtiff fpAcc).  `stride` = samples per pixel of the block (the
+    byte differencing runs with that stride; 1 for planar files)."""
+    bps = np.dtype(dtype).itemsize
+    acc = raw.reshape(rows, bps * n).copy()
+    for s0 in range(stride):                              # cumulative sum per interleaved sample
+        acc[:, s0::stride] = np.cumsum(acc[:, s0::stride], axis=1, dtype=np.uint8)
+    be = np.ascontiguousarray(acc.reshape(rows, bps, n).transpose(0, 2, 1))      # [rows, n, bps] big-endian
+    return be.view(np.dtype(dtype).newbyteorder('>')).reshape(rows, n).astype(np.dtype(dtype))
+
+
+def _bspline(x):
+    """Cubic B-spline kernel of GDAL's CUBICSPLINE resampling (GWKBSpline, support |x| < 2)."""
+    x = np.abs(x)
+    return np.where(x <= 1.0, 2.0 / 3.0 + x * x * (0.5 * x - 1.0),
+                    np.where(x < 2.0, (2.0 - x) ** 3 / 6.0, 0.0))
+
+
+def _convolve_axis(a, n_out, axis):
+    """One separable pass of GDAL's overview convolution (GDALResampleChunk_Convolution, overview.cpp) along
+    `axis`: destination pixel i is centred on source coordinate (i + 0.5) * ratio; the kernel is stretched
+    by the decimation ratio (radius 2 * ratio source pixels), evaluated at source pixel centres, and the
+    weights are normalised over the pixels that exist and are not NaN (a destination whose whole support is
+    NaN / outside is NaN).  float64 accumulation."""
+    n_in = a.shape[axis]
+    ratio = n_in / n_out
+    scale = min(1.0, 1.0 / ratio)                       # < 1 when decimating
+    radius = 2.0 / scale
+    centre = (np.arange(n_out) + 0.5) * ratio
+    first = np.floor(centre - radius + 0.5).astype(np.int64)
+    taps = int(np.ceil(2 * radius)) + 1
+    idx = first[:, None] + np.arange(taps)[None, :]                       # [n_out, taps]
+    w = _bspline((idx + 0.5 - centre[:, None]) * scale)
+    w = np.where((idx >= 0) & (idx < n_in), w, 0.0)
+    idx = np.clip(idx, 0, n_in - 1)
+    a = np.moveaxis(a, axis, -1).astype(np.float64)
+    g = a[..., idx]                                                       # [..., n_out, taps]
+    ok = ~np.isnan(g)
+    ww = np.where(ok, w, 0.0)
+    with np.errstate(invalid='ignore'):
+        num = np.sum(np.where(ww > 0.0, g, 0.0) * ww, axis=-1)          # inf stays inf; zero-weight taps contribute nothing
+    den = np.sum(ww, axis=-1)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        out = np.where(den > 0.0, num / den, np.nan)
+    return np.moveaxis(out, -1, axis)
+
+
+def overview_cubicspline(arr, factor):
+    """One CUBICSPLINE overview level (`gdal.BuildOverviews('CUBICSPLINE', ...)`, what `save_as_cog` asks for
+    on non-integer layers, reference core.py:41-46): overview size ceil(N / factor), separable cubic B-spline
+    convolution with the kernel stretched by the decimation ratio, horizontal pass then vertical pass.
+    GDAL builds the levels of a non-NEAREST pyramid in cascade (each from the previous one); the caller
+    does the same.  GDAL is not in the reference tree: the weights follow GDAL's published algorithm, the
+    last-ulp agreement of the float32 results is UNPINNED."""
+    h, w = arr.shape[-2:]
+    oh, ow = (h + factor - 1) // factor, (w + factor - 1) // factor
+    tmp = _convolve_axis(np.asarray(arr), ow, arr.ndim - 1)
+    return np.ascontiguousarray(_convolve_axis(tmp, oh, arr.ndim - 2).astype(arr.dtype))
+
+
 def overview_nearest(arr, factor):
     """One NEAREST overview level the way `gdal.BuildOverviews('NEAREST', ...)` picks source
     pixels from the full-resolution band (GDALResampleChunk_Near): overview size
@@ -323,7 +403,7 @@ def _encode_blocks(arr, tile, compress, predictor):
             d = blk.copy()
             d[:, 1:] = blk[:, 1:] - blk[:, :-1]
             blk = d
-        raw = blk.tobytes()
+        raw = _fp_predictor_encode(blk) if predictor == 3 else blk.tobytes()
         return zlib.compress(raw, 6) if compress else raw
 
     n = B * across * down
@@ -337,10 +417,13 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
     [256][3] (single-band u8 only).  NaN nodata is written as 'nan' like GDAL does.
 
     `overviews`: decimation factors (e.g. COG_OVERVIEW_FACTORS) -> internal reduced-resolution
-    IFDs (NEAREST) in cloud-optimized order, as `save_as_cog` (reference core.py:7-91) leaves the
-    file: all IFDs first (main, then overviews by descending size), then the block data of
-    the smallest overview ... the largest overview, the full-resolution image last; 512 x 512
-    tiles, DEFLATE, PREDICTOR=2 for integer types."""
+    IFDs in cloud-optimized order, as `save_as_cog` (reference core.py:7-91) leaves the file:
+    all IFDs first (main, then overviews by descending size), then the block data of the
+    smallest overview ... the largest overview, the full-resolution image last; 512 x 512 tiles,
+    DEFLATE; integer types: NEAREST overviews + PREDICTOR=2, floating point: CUBICSPLINE
+    overviews (cascaded, as GDAL builds them) + PREDICTOR=3 (core.py:37-46, :66-69).
+    The file is written under a temporary name and renamed when complete, so a reader (or the
+    batch driver's --skip-existing) never sees a truncated product."""
     arr = np.asarray(array)
     if arr.ndim == 2:
         arr = arr[None]
@@ -352,7 +435,7 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
     kind = {'u': 1, 'i': 2, 'f': 3}.get(arr.dtype.kind)
     if kind is None or arr.dtype.itemsize not in (1, 2, 4, 8):
         raise GeoTiffError(f'unsupported dtype {arr.dtype}')
-    predictor = 2 if (compress and kind != 3) else 1
+    predictor = (3 if (kind == 3 and arr.dtype.itemsize in (4, 8)) else 2) if compress else 1
     palette = colormap is not None and B == 1 and arr.dtype == np.uint8
     cm_values = None
     if palette:
@@ -370,9 +453,21 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
 
     # level 0 = full resolution, then the overviews by descending size
     levels = [arr]
+    prev_f = 1
     for f in (overviews or ()):
         if f > 1 and (arr.shape[1] > 1 or arr.shape[2] > 1):
-            levels.append(overview_nearest(arr, int(f)))
+            if kind == 3:
+                # cascade: level f from the previous level when it divides evenly (GDAL's
+                # GDALRegenerateCascadingOverviews), else from the full-resolution image
+                lv = overview_cubicspline(levels[-1], int(f) // prev_f) if (prev_f > 1 and int(f) % prev_f == 0) \
+                    else overview_cubicspline(arr, int(f))
+                want = ((arr.shape[1] + int(f) - 1) // int(f), (arr.shape[2] + int(f) - 1) // int(f))
+                if lv.shape[1:] != want:          # ceil of a ceil can differ by one: take it from the full image
+                    lv = overview_cubicspline(arr, int(f))
+                levels.append(lv)
+                prev_f = int(f)
+            else:
+                levels.append(overview_nearest(arr, int(f)))
     level_blocks = [_encode_blocks(lv, tile, compress, predictor) for lv in levels]
 
     def entries_of(k):
@@ -385,8 +480,8 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
                 (TAG_COMPRESSION, 3, [8 if compress else 1]),
                 (TAG_PHOTOMETRIC, 3, [3 if palette else 1]),
                 (TAG_SAMPLES, 3, [B]), (TAG_PLANAR, 3, [2 if B > 1 else 1])]
-        if predictor == 2:
-            ent.append((TAG_PREDICTOR, 3, [2]))
+        if predictor != 1:
+            ent.append((TAG_PREDICTOR, 3, [predictor]))
         if palette:
             ent.append((TAG_COLORMAP, 3, cm_values))
         ent += [(TAG_TILE_W, 3, [tile]), (TAG_TILE_L, 3, [tile]),
@@ -433,7 +528,8 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
         block_offs[k] = offs
     if cursor >= 2 ** 32:
         raise GeoTiffError('file would exceed 4 GiB (BigTIFF not supported)')
-    with open(path, 'wb') as fh:
+    tmp_path = f'{path}.{os.getpid()}.{id(arr):x}.tmp'
+    with open(tmp_path, 'wb') as fh:
         fh.write(struct.pack('<2sHI', b'II', 42, ifd_offs[0]))
         for k, ent in enumerate(all_entries):
             fh.write(struct.pack('<H', len(ent)))
@@ -456,6 +552,7 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
                 fh.write(x)
                 if len(x) & 1:
                     fh.write(b'\x00')
+    os.replace(tmp_path, path)
 
 
 def cog_layout(path):
@@ -546,8 +643,10 @@ def write_png_palette(path, indices, colormap, transparent_index=None):
         out.append(chunk(b'tRNS', bytes(alpha)))
     out.append(chunk(b'IDAT', zlib.compress(raw.tobytes(), 6)))
     out.append(chunk(b'IEND', b''))
-    with open(path, 'wb') as fh:
+    tmp_path = f'{path}.{os.getpid()}.{id(idx):x}.tmp'
+    with open(tmp_path, 'wb') as fh:
         fh.write(b''.join(out))
+    os.replace(tmp_path, path)
 
 
 def resample_nearest(arr, out_height, out_width):

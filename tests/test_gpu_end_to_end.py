@@ -184,12 +184,15 @@ def test_api_with_masks_and_multiband(tmp_path):
     conf, _ = geotiff.read_geotiff(str(tmp_path / 'conf.tif'))
     assert np.array_equal(conf, exp['CONF'])
     stack, info = geotiff.read_geotiff(out)
-    # bands in band_description_dict order, Byte layers only; WTR-1 is the post-aerosol one
-    names = ['WTR', 'BWTR', 'CONF', 'WTR-1', 'WTR-2', 'LAND', 'SHAD', 'CLOUD']
-    assert info.descriptions == [D.band_description_dict[n] for n in names]
+    # the reference's fixed ten-band Byte layout (:2658-2667), band_description_dict order; WTR-1 is the
+    # post-aerosol one; DIAG saturates like GDT_Byte; no DEM here -> nodata plane; every band carries the
+    # first band's description (the reference never resets `description`, :2686-2687)
+    names = list(D.band_description_dict)
+    assert info.bands == 10 and info.descriptions == [D.band_description_dict['WTR']] * 10
     want = {'WTR': exp['WTR'], 'BWTR': exp['BWTR'], 'CONF': exp['CONF'],
+            'DIAG': np.minimum(exp['DIAG'], 255).astype(np.uint8),
             'WTR-1': exp['WTR-1-AEROSOL'], 'WTR-2': exp['WTR-2'], 'LAND': s['land'],
-            'SHAD': s['shad'], 'CLOUD': exp['CLOUD']}
+            'SHAD': s['shad'], 'CLOUD': exp['CLOUD'], 'DEM': np.full(exp['WTR'].shape, 255, np.uint8)}
     for i, n in enumerate(names):
         assert np.array_equal(stack[i], want[n]), n
     assert info.metadata['OCEAN_MASKING_ENABLED'] == 'TRUE'
@@ -294,7 +297,8 @@ def test_mixed_stream_with_terrain_shadow_and_landcover(tmp_path):
         s = synth_hls.synth_tile(40 + t, size, size)
         dem = synth_dem(40 + t, size + 100, size + 100)
         # sun angles of the synthetic product: azimuth 143.2, zenith 34.5 (tools/make_synthetic_hls.py)
-        shad = o.compute_opera_shadow_layer(dem, 143.2, 90 - 34.5, -5, 40)[50:-50, 50:-50]
+        # the host mirror defaults to the promotion of the numpy the reference pins (1.23.5: value-based casting)
+        shad = o.compute_opera_shadow_layer(dem, 143.2, 90 - 34.5, -5, 40, legacy_promotion=True)[50:-50, 50:-50]
         wc, cg = synth_landcover_inputs(40 + t, size, size)
         land = o.landcover_mask_from_warped(wc, cg, forest, year=2021)
         exp = o.classify_tile(s['bands'], s['fmask'], landcover=land, shadow=shad, collapse=True)

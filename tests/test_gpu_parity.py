@@ -571,17 +571,17 @@ def test_cover_mode_device_batch(ctx):
 @pytest.mark.parametrize('name', ['s_default', 's_low_sun', 's_noon_north',
                                   's_other_thresholds', 's_thin'])
 def test_shadow_layer_golden(ctx, name):
-    """Against the reference's own output (numpy 2.x promotion).  The float32 part is
-    bit-exact by construction; arccos/arctan are float64 on both sides and only a pixel
-    whose angle sits within an ulp or two of the threshold could differ: none does."""
+    """Against the reference's own output.  The goldens were generated by importing the reference under
+    numpy 2.2 (oracle/gen_golden.py), i.e. they pin numpy_promotion='nep50'; the host mirror's DEFAULT is
+    'legacy' (the numpy 1.23.5 the reference pins), covered by test_shadow_layer_legacy_float32_promotion."""
     from proteus_amd import dswx_hls as D
     z = G.load(f'shadow_{name}.npz')
     args = (float(z['az']), float(z['el']), float(z['mn']), float(z['mx']))
-    full = D._compute_opera_shadow_layer(z['dem'], *args)
+    full = D._compute_opera_shadow_layer(z['dem'], *args, numpy_promotion='nep50')
     assert full.dtype == np.bool_ and full.shape == z['dem'].shape
     assert np.array_equal(full, z['full'])
     m = int(z['margin'])
-    assert np.array_equal(D._compute_opera_shadow_layer(z['dem'], *args, margin=m), z['cropped'])
+    assert np.array_equal(D._compute_opera_shadow_layer(z['dem'], *args, margin=m, numpy_promotion='nep50'), z['cropped'])
     assert np.array_equal(D._crop_2d_array_all_sides(full, m), z['cropped'])
 
 
@@ -591,12 +591,13 @@ def test_shadow_layer_full_size(ctx):
     from proteus_amd import dswx_hls as D
     from proteus_amd.synth import synth_dem
     dem = synth_dem(7, 2100, 2100)
-    got = D._compute_opera_shadow_layer(dem, 143.2, 55.5, -5, 40, margin=50)
-    exp = o.crop_2d_array_all_sides(o.compute_opera_shadow_layer(dem, 143.2, 55.5, -5, 40), 50)
-    assert got.shape == (2000, 2000)
-    # no device transcendental any more: the thresholds are pulled back through numpy's own
-    # arccos / arctan, so the layer is bit-exact, not "within a budget"
-    assert np.array_equal(got, exp)
+    # no device transcendental: the thresholds are pulled back through numpy's own arccos / arctan, so
+    # the layer is bit-exact, not "within a budget" -- in both promotion modes (the default is 'legacy')
+    for mode, legacy in (('nep50', False), (None, True)):
+        got = D._compute_opera_shadow_layer(dem, 143.2, 55.5, -5, 40, margin=50, numpy_promotion=mode)
+        exp = o.crop_2d_array_all_sides(o.compute_opera_shadow_layer(dem, 143.2, 55.5, -5, 40, legacy_promotion=legacy), 50)
+        assert got.shape == (2000, 2000)
+        assert np.array_equal(got, exp), mode
     with pytest.raises(ValueError, match='too small'):
         D._compute_opera_shadow_layer(np.zeros((1, 5), np.float32), 10, 10, -5, 40)
 

