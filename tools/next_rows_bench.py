@@ -41,7 +41,8 @@ def timed(ctx, fn, reps, inner=10):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--tiles', type=int, default=8)
+    ap.add_argument('--tiles', type=int, default=32,
+                    help='tiles per launch (8 tiles = 0.1 ms launches whose ramp / tail cost ~10 %%)')
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--lab', action='store_true', help='also time lab A/B switches (libdswx_lab.so)')
