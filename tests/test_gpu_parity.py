@@ -699,6 +699,38 @@ def test_shadow_layer_filter_adversarial(ctx, legacy):
         assert np.array_equal(got1[1:-1, 1:-1], exp), k
 
 
+@pytest.mark.parametrize('legacy', [False, True])
+def test_shadow_layer_thresholds_inside_the_data(ctx, legacy):
+    """Thresholds placed at QUANTILES of the tile's own arccos / arctan arguments, so that the densest part
+    of the distribution sits on the decision boundary and thousands of pixels land inside the filter's
+    uncertainty band (and must come out of the exact path identical to numpy)."""
+    from proteus_amd import dswx_hls as D
+    from proteus_amd.synth import synth_dem
+    rng = np.random.default_rng(4242)
+    n_checked = 0
+    for k in range(10):
+        dem = synth_dem(30 + k, 900, 1100)
+        if k % 2:
+            dem = (dem * np.float32(0.05)).astype(np.float32)          # gentle terrain: q clusters near cos(zenith)
+        az, el = float(rng.uniform(0, 360)), float(rng.uniform(15, 80))
+        azr, zen = np.radians(az), np.radians(90 - el)
+        gy, gx = np.gradient(dem)
+        n0, n1 = -gx / 30, -gy / -30
+        q = (n0 * (np.sin(azr) * np.sin(zen)) + n1 * (np.cos(azr) * np.sin(zen)) + np.cos(zen)) / np.sqrt(n0 ** 2 + n1 ** 2 + 1)
+        t = n0 * np.sin(azr) + n1 * np.cos(azr)
+        qq, tq = float(rng.choice([0.3, 0.5, 0.7])), float(rng.choice([0.3, 0.5, 0.7]))
+        max_inc = float(np.degrees(np.arccos(np.clip(np.quantile(q, 1 - qq), -1, 1))))
+        min_slope = float(np.degrees(np.arctan(np.quantile(t, tq))))
+        got = D._compute_opera_shadow_layer(dem, az, el, min_slope, max_inc, margin=50,
+                                            numpy_promotion='legacy' if legacy else 'nep50')
+        with np.errstate(all='ignore'):
+            exp = o.compute_opera_shadow_layer(dem, az, el, min_slope, max_inc, legacy_promotion=legacy)[50:-50, 50:-50]
+        assert np.array_equal(got, exp), (k, az, el, min_slope, max_inc, int(np.count_nonzero(got != exp)))
+        assert 0.02 < exp.mean() < 0.98, (k, exp.mean())              # the thresholds really cut through the data
+        n_checked += exp.size
+    assert n_checked == 10 * 800 * 1000
+
+
 def _sun(az_deg, el_deg):
     """(sun vector, sin az, cos az) formed exactly as the reference forms them (:4246-4253, :4276-4277)."""
     az, zen = np.radians(az_deg), np.radians(90 - el_deg)
