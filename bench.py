@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument('--realloc-repeats', type=int, default=5,
                     help='N = 1: after the timed region, re-allocate the batch this many times and report the '
                          'spread of the kernel rate (it depends on where the arena lands, DESIGN.md section 5)')
+    ap.add_argument('--placement-trials', type=int, default=3,
+                    help='allocate this many candidate arenas and keep the one the kernel runs fastest on (1 = first)')
     ap.add_argument('--plan-only', action='store_true',
                     help='no GPU work: bring the ranks up (gloo), print the sharding plan of this command line as '
                          'JSON and exit (tests/test_shard_gloo.py drives the launcher path with it)')
@@ -254,6 +256,39 @@ def realloc_spread(ctx, params, n_tiles, masks, repeats, launches=5):
             'frac_max': round(rates[-1] / HBM_PEAK_GBS, 4)}
 
 
+def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
+    """Allocate the resident batch.  The kernel's rate depends on where hipMalloc lands the arena (a property of
+    the physical placement of the 14 streams that persists for the arena's lifetime: DESIGN.md section 5,
+    `roofline.realloc_spread`), so a long-lived arena is worth choosing: allocate up to `trials` arenas -- the next
+    one while the previous is still held, so the allocator cannot hand the same range back -- time `launches`
+    launches on each and keep the fastest.  Outside the timed region; `--placement-trials 1` takes the first."""
+    from proteus_amd import _capi
+    from proteus_amd.synth import SEED
+    best, best_ms, seen = None, None, []
+    for _ in range(max(1, trials)):
+        b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks)
+        b.synth(SEED, tile0=tile0)
+        b.classify(params)
+        ctx.synchronize()
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0)
+        for _ in range(launches):
+            b.classify(params)
+        ctx.record(e1)
+        ctx.synchronize()
+        ms = ctx.elapsed_ms(e0, e1) / launches
+        ctx.destroy_event(e0)
+        ctx.destroy_event(e1)
+        seen.append(round(ms, 4))
+        if best is None or ms < best_ms:
+            if best is not None:
+                best.free()
+            best, best_ms = b, ms
+        else:
+            b.free()
+    return best, {'trials': max(1, trials), 'probe_launch_ms': seen, 'kept_ms': round(best_ms, 4)}
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -347,9 +382,7 @@ def main():
     params = _capi.default_params()
     strong = args.total_tiles > 0
     my_tiles, tile0, n_tiles, chunks = rank_plan(args, rank, world)
-    batch = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=args.masks)
-    batch.synth(SEED, tile0=tile0)
-    ctx.synchronize()
+    batch, placement = place_batch(ctx, params, n_tiles, tile0, args.masks, args.placement_trials)
     barrier = cp.barrier
     # a partial last chunk classifies the first `c` tiles of the resident batch
     geoms = {c: _capi.BatchGeom(c, TILE, TILE, batch.tile_stride) for c in set(chunks)}
@@ -428,6 +461,9 @@ def main():
                        'planes_in': 10 if args.masks else 7, 'planes_out': 7,
                        'sharding': f'tiles by rank x{world}, no collective',
                        'control_plane': cp.backend,
+                       'arena_placement': dict(placement, note='fastest of `trials` hipMalloc placements of the resident '
+                                               'batch, chosen before warm-up (the rate is a property of the placement; '
+                                               'roofline.realloc_spread shows what an arbitrary one gives)'),
                        'kernel': kernel_info},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
