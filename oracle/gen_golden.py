@@ -284,12 +284,22 @@ TILE_CASES = [
     dict(name='t17x16', tile=16, H=17, W=16, land=1, shad=1, ocean=1),
     dict(name='t160_cover', tile=17, H=160, W=160, land=1, shad=1, ocean=1,
          mode='cover'),
+    # round 2: more of the reference's own 'cover' outputs -- rasters wider / taller than one 222-pixel window
+    # of the dilation kernel in both directions, large coherent snow fields that the 10 + 7 steps really travel
+    # through, other plane sets / aerosol settings
+    dict(name='t300x470_cover_plain', tile=18, H=300, W=470, mode='cover', blobs='discs'),
+    dict(name='t250x230_cover_land_custom', tile=19, H=250, W=230, land=1, mode='cover', blobs='discs',
+         lists='custom'),
+    dict(name='t96x120_cover_no_aerosol', tile=20, H=96, W=120, shad=1, ocean=1, mode='cover', aerosol=False),
 ]
 
 
 def gen_tiles(ref):
     rng = np.random.default_rng(7)
+    only = os.environ.get('GOLDEN_ONLY_TILES')           # e.g. 'cover': regenerate a subset, leave the rest untouched
     for case in TILE_CASES:
+        if only and only not in case['name']:
+            continue
         H, W = case['H'], case['W']
         s = synth_tile(case['tile'], H, W, with_masks=True)
         bands = [b.copy() for b in s['bands']]
@@ -310,6 +320,20 @@ def gen_tiles(ref):
             blob = ((yy // 9 + xx // 11) % 5 == 0)
             fmask = np.where(blob & (fmask != 255), fmask | 4, fmask & ~np.uint8(4)).astype(np.uint8)
             snowb = ((yy // 7 + 2 * (xx // 5)) % 9 == 0)
+            if case.get('blobs') == 'discs':
+                # wide adjacent-to-cloud rings with cloud-free interiors and snow fields touching them
+                crng = np.random.default_rng(1000 + case['tile'])
+                blob = np.zeros((H, W), bool)
+                snowb = np.zeros((H, W), bool)
+                for _ in range(max(4, H * W // 9000)):
+                    cy, cx, r = crng.integers(0, H), crng.integers(0, W), crng.integers(8, 40)
+                    d2 = (yy - cy) ** 2 + (xx - cx) ** 2
+                    blob |= (d2 < r * r) & (d2 >= (r - crng.integers(3, 16)) ** 2)
+                    cy2, cx2 = cy + crng.integers(-r, r + 1), cx + crng.integers(-r, r + 1)
+                    snowb |= (yy - cy2) ** 2 + (xx - cx2) ** 2 < crng.integers(2, 9) ** 2
+                # adjacent pixels are cloud / shadow free in Fmask (so that CLOUD == 0 there)
+                fmask = np.where(blob & (fmask != 255), fmask & ~np.uint8(2 | 8), fmask).astype(np.uint8)
+                fmask = np.where(blob & (fmask != 255), fmask | 4, fmask & ~np.uint8(4)).astype(np.uint8)
             fmask = np.where(snowb & (fmask != 255), fmask | 16, fmask).astype(np.uint8)
         land = s['land'] if case.get('land') else None
         shad = s['shad'].astype(bool) if case.get('shad') else None
