@@ -73,9 +73,10 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
 #pragma unroll
             for (int j = 0; j < 8; ++j) ex[j] = s_extra[idx2[j] & 127u] | (idx2[j] & 128u);
             transpose4(ex, pa); transpose4(ex + 4, pb);
-            if (a.cover_state) {              // re-read by stage 2: cacheable stores
-                stg<u32x2, false>(a.cover_state + off, u32x2{pa[0], pb[0]});
-                a.cover_bits[(long long)blockIdx.y * a.cover_bits_stride + grp] = cover_nibbles(pa[0]) | cover_nibbles(pb[0]) << 4;
+            if (a.cover_state) {              // read back by stages 2 / 3 only after the whole batch: stream them out
+                stg<u32x2, true>(a.cover_state + off, u32x2{pa[0], pb[0]});
+                __builtin_nontemporal_store(cover_nibbles(pa[0]) | cover_nibbles(pb[0]) << 4,
+                                            a.cover_bits + (long long)blockIdx.y * a.cover_bits_stride + grp);
             }
             if (a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{pa[2], pb[2]});
         }

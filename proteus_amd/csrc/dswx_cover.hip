@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void dswx_cover_finish(const KArgs a) {
     const int n = a.n_pixels - px0 < 8 ? (int)(a.n_pixels - px0) : 8;
     uint32_t st[2] = {0u, 0u};
     if (VEC && n == 8) {
-        const u32x2 v = *reinterpret_cast<const u32x2*>(a.cover_state + off);
+        const u32x2 v = ldg<u32x2, true>(a.cover_state + off);
         st[0] = v.x; st[1] = v.y;
     } else {
         for (int j = 0; j < n; ++j) st[j >> 2] |= (uint32_t)a.cover_state[off + j] << (8 * (j & 3));

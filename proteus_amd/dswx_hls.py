@@ -1127,10 +1127,17 @@ def generate_dswx_layers(input_list,
             'reflectance (:2300-2302) and runs the whole chain on those floats; this library '
             'implements the int16 path the production configuration uses (the flag defaults to False)')
     if shoreline_shapefile is not None:
-        raise NotImplementedError(
-            'shoreline_shapefile: rasterising the shoreline needs GDAL/OGR, which stays on the host '
-            'and is outside this drop-in (SURVEY.md section 2); pass the ocean mask already on the '
-            'HLS grid with ocean_mask=')
+        if str(shoreline_shapefile).lower().endswith(('.tif', '.tiff')):
+            # the same rule as for the DEM and the land-cover maps: an ancillary input that is ALREADY a raster
+            # on the product grid is taken as it is -- here the ocean mask the reference would get by rasterising
+            # the shoreline polygons (0 = ocean beyond the shoreline distance, :5243-5245)
+            if ocean_mask is None:
+                ocean_mask = os.fspath(shoreline_shapefile)
+        else:
+            raise NotImplementedError(
+                'shoreline_shapefile: rasterising the shoreline needs GDAL/OGR, which stays on the host '
+                'and is outside this drop-in (SURVEY.md section 2); pass the ocean mask already on the '
+                'HLS grid with ocean_mask= (or give a GeoTIFF of it as shoreline_shapefile)')
     if dem_file is not None and shadow_masking_algorithm == 'otsu':
         raise NotImplementedError(
             "shadow_masking_algorithm 'otsu' thresholds GDAL's hillshade (gdal.DEMProcessing, "
@@ -1151,7 +1158,8 @@ def generate_dswx_layers(input_list,
     version = '2.0'
     _populate_dswx_metadata_datasets(md, image['hls_dataset_name'], dem_file, dem_file_description,
                                      landcover_file, landcover_file_description,
-                                     worldcover_file, worldcover_file_description)
+                                     worldcover_file, worldcover_file_description,
+                                     shoreline_shapefile, shoreline_shapefile_description)
     _populate_dswx_metadata_processing_parameters(
         md, apply_ocean_masking, apply_aerosol_class_remapping, aerosol_lists,
         shadow_masking_algorithm, min_slope_angle, max_sun_local_inc_angle,

@@ -280,28 +280,29 @@ def test_batch_driver_single_gpu(tmp_path):
 
 def test_mixed_stream_with_terrain_shadow_and_landcover(tmp_path):
     """BASELINE.json configs[4] on one GPU: a mixed HLS.L30 / HLS.S30 stream through the node-level
-    driver with the terrain-shadow layer computed from a DEM and the LAND layer from CGLS +
-    WorldCover (both GPU kernels, rasters already on the product grid), WTR-2 / CONF / SHAD / LAND
-    / DEM validated against the oracle."""
+    driver, from runconfigs alone, with terrain shadow + ocean masking + land cover enabled: SHAD computed
+    from a DEM and LAND from CGLS + WorldCover (both GPU kernels), the ocean mask from the shoreline input
+    (rasters already on the product grid); WTR-2 / CONF / WTR / DIAG / SHAD / LAND / DEM validated against
+    the oracle.  512 x 512 tiles: more than one dilation / shadow block in each direction."""
     from proteus_amd import batch
     from proteus_amd.synth import synth_dem, synth_landcover_inputs
-    size, rcs = 240, []
+    size, rcs = 512, []
     for t in range(4):
         rcfile, _, _, _ = synth_hls.make(str(tmp_path / f'tile{t}'), sensor=('L30', 'S30')[t % 2], size=size,
-                                         tile=40 + t, product_id=f'M{t}', ancillary=True)
+                                         tile=40 + t, product_id=f'M{t}', ancillary=True, ocean=True)
         rcs.append(rcfile)
     ok, results = batch.run_batch(rcs, 1)
     assert ok, results
     forest = [20, 50, 111, 113, 115, 116, 121, 123, 125, 126]     # defaults/dswx_hls.yaml
     for t in range(4):
-        s = synth_hls.synth_tile(40 + t, size, size)
+        s = synth_hls.synth_tile(40 + t, size, size, with_masks=True)
         dem = synth_dem(40 + t, size + 100, size + 100)
         # sun angles of the synthetic product: azimuth 143.2, zenith 34.5 (tools/make_synthetic_hls.py)
         # the host mirror defaults to the promotion of the numpy the reference pins (1.23.5: value-based casting)
         shad = o.compute_opera_shadow_layer(dem, 143.2, 90 - 34.5, -5, 40, legacy_promotion=True)[50:-50, 50:-50]
         wc, cg = synth_landcover_inputs(40 + t, size, size)
         land = o.landcover_mask_from_warped(wc, cg, forest, year=2021)
-        exp = o.classify_tile(s['bands'], s['fmask'], landcover=land, shadow=shad, collapse=True)
+        exp = o.classify_tile(s['bands'], s['fmask'], landcover=land, shadow=shad, ocean_mask=s['ocean'], collapse=True)
         out = tmp_path / f'tile{t}' / 'output'
         read = lambda stem: geotiff.read_geotiff(str(out / f'M{t}_v1.0_{stem}.tif'))   # noqa: E731
         assert np.array_equal(read('B08_SHAD')[0], shad.astype(np.uint8))
@@ -314,9 +315,11 @@ def test_mixed_stream_with_terrain_shadow_and_landcover(tmp_path):
         md = info.metadata
         assert md['DEM_SOURCE'] == 'Synthetic DEM' and md['WORLDCOVER_SOURCE'] == 'Synthetic ESA WorldCover 10m 2021'
         assert md['SPACECRAFT_NAME'] == ('Landsat-8', 'Sentinel-2A')[t % 2]
-        # the shadow and land-cover rules did change pixels, or the test is vacuous
+        assert md['OCEAN_MASKING_ENABLED'] == 'TRUE' and md['SHORELINE_SOURCE'] == 'Synthetic shoreline raster'
+        # the shadow, land-cover and ocean rules did change pixels, or the test is vacuous
         plain = o.classify_tile(s['bands'], s['fmask'], collapse=True)
         assert not np.array_equal(plain['WTR-2'], exp['WTR-2'])
+        assert (exp['WTR'] == 254).any() and not (plain['WTR'] == 254).any()
 
 
 def test_ancillary_files_off_grid_are_refused(tmp_path):

@@ -24,7 +24,7 @@ S30 = {'blue': 'B02', 'green': 'B03', 'red': 'B04', 'nir': 'B8A', 'swir1': 'B11'
 
 
 def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx_hls_synth',
-         ancillary=False, dem_margin=50):
+         ancillary=False, dem_margin=50, ocean=False):
     in_dir = os.path.join(out_dir, 'input')
     os.makedirs(in_dir, exist_ok=True)
     s = synth_tile(tile, size, size, with_masks=masks)
@@ -81,6 +81,13 @@ def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx
         geotiff.write_geotiff(anc['worldcover_file'], wc, geo_tags=geotiff.geo_tags_from_geotransform(gt3, 32615),
                               metadata={'time_start': '2021-01-01T00:00:00Z', 'time_end': '2021-12-31T23:59:59Z'})
         anc['worldcover_file_description'] = 'Synthetic ESA WorldCover 10m 2021'
+        if ocean:
+            # the shoreline input already rasterised on the product grid (0 = ocean), as the DEM / land-cover
+            # inputs above are already warped
+            anc['shoreline_shapefile'] = os.path.join(adir, 'ocean_mask.tif')
+            geotiff.write_geotiff(anc['shoreline_shapefile'], synth_tile(tile, size, size, with_masks=True)['ocean'],
+                                  geo_tags=geo)
+            anc['shoreline_shapefile_description'] = 'Synthetic shoreline raster'
     rc = {'runconfig': {'name': 'dswx_hls_workflow_synthetic', 'groups': {
         'pge_name_group': {'pge_name': 'DSWX_HLS_PGE'},
         'input_file_group': {'input_file_path': [in_dir]},
@@ -90,7 +97,8 @@ def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx
                                'scratch_path': os.path.join(out_dir, 'scratch'),
                                'output_dir': os.path.join(out_dir, 'output'),
                                'product_id': product_id, 'product_version': 1.0},
-        'processing': {'check_ancillary_inputs_coverage': False, 'save_land': bool(ancillary),
+        'processing': {'check_ancillary_inputs_coverage': False, 'apply_ocean_masking': bool(ancillary and ocean),
+                       'save_land': bool(ancillary),
                        'save_shad': bool(ancillary), 'save_dem': bool(ancillary)},
         'browse_image_group': {'save_browse': False}}}}
     rc_path = os.path.join(out_dir, 'runconfig.yaml')
