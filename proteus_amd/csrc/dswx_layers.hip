@@ -194,11 +194,12 @@ __device__ __forceinline__ uint32_t shadow_quad(const ShadowArgs& a, const Shado
 }
 
 // One wave = 64 quads x SHADOW_ROWS consecutive output rows: every DEM row is loaded once per wave (eight
-// floats per lane, 8-byte aligned) and serves as the row below, the centre row and the row above of three
-// successive output rows -- a block of 4 x SHADOW_ROWS output rows reads 4 x SHADOW_ROWS + 2 DEM rows.  (With one
-// output row per wave a block read 6 DEM rows for 4 output rows and the halo rows were NOT served by a cache --
-// vertically adjacent blocks run on different XCDs: PMC showed 1.54 x the DEM's bytes fetched from HBM.)
-constexpr int SHADOW_ROWS = 8;
+// floats per lane, 8-byte aligned) and serves as the row below, the centre row and the row above of successive
+// output rows.  Measured on MI355X (ms per 3660^2 tile, +-4 % between boxes): SHADOW_ROWS 1: 0.0149, 2: 0.0125-0.0131,
+// 3: 0.0127-0.0131, 4: 0.0133-0.0138, 6: 0.0135, 8: 0.0139, 16: 0.0157 -- short waves with all their loads in
+// flight beat long ones, although a block then re-reads more halo rows (vertically adjacent blocks run on
+// different XCDs, so the halo comes from the Infinity Cache / HBM, not from an L2).
+constexpr int SHADOW_ROWS = 2, SHADOW_WARM = 2;
 
 // TINY: the slope threshold is (almost) zero -- see ShadowFilter::t_tiny
 template <bool F32, bool TINY>
@@ -219,16 +220,23 @@ __global__ __launch_bounds__(256) void dswx_shadow_v3(const ShadowArgs a, const 
                     *reinterpret_cast<const f32x2*>(r + 2), *reinterpret_cast<const f32x2*>(r + 4)}};
     };
     const int y0 = oy0 + margin;
-    Row up = load_row(y0 - 1), ce = load_row(y0);
+    // software pipeline: the rows of output row i + 2 are requested before output row i is computed, so a
+    // wave always has two DEM rows in flight (left to the compiler, every row's load sat directly in front of
+    // its first use -- behind the branch of the exact path -- and the wave stalled a full latency per row)
+    Row up = load_row(y0 - 1), ce = load_row(y0), dn = load_row(y0 + 1), nx = SHADOW_ROWS > 1 ? load_row(y0 + 2) : dn;
 #pragma unroll
     for (int i = 0; i < SHADOW_ROWS; ++i) {
-        const Row dn = load_row(y0 + i + 1);
+        // rows past the wave's own need (i + 3 > SHADOW_ROWS) are the first rows of the wave BELOW: requesting
+        // SHADOW_WARM of them here warms the L2 for it (measured: 0.0131 -> 0.0125 ms per tile with 2)
+        const Row nn = i + 3 <= SHADOW_ROWS + SHADOW_WARM ? load_row(y0 + i + 3) : nx;
         if (oy0 + i < oh) {
             const uint32_t out = shadow_quad<F32, TINY>(a, f, ce.v[0], ce.v[1], ce.v[2], ce.v[3], up.v[1], up.v[2], dn.v[1], dn.v[2]);
             __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(dst + (size_t)(oy0 + i) * (size_t)ow));
         }
         up = ce;
         ce = dn;
+        dn = nx;
+        nx = nn;
     }
 }
 
@@ -246,8 +254,9 @@ struct LandArgs {
     int low_class, high_class;   // year_offset, 100 + year_offset (as uint8)
 };
 
-__device__ __forceinline__ int land_class(const LandArgs& a, int water, int urban, int tree, int c) {
-    if (!((a.forest_bits[c >> 5] >> (c & 31)) & 1u)) tree = 0;
+// `is_forest`: the CGLS class of the pixel is one of forest_mask_landcover_classes
+__device__ __forceinline__ int land_class(const LandArgs& a, int water, int urban, int tree, bool is_forest) {
+    if (!is_forest) tree = 0;
     int v = 255;
     if (tree >= a.thr_tree) v = 201;
     if (urban >= a.thr_low) v = a.low_class;
@@ -256,20 +265,24 @@ __device__ __forceinline__ int land_class(const LandArgs& a, int water, int urba
     return v;
 }
 
-// Four HLS pixels per thread (width % 4 == 0): three 12-byte row pieces of the WorldCover map per
-// thread (a wave reads 768 contiguous bytes per row), one dword of CGLS, one dword stored.
-// blockIdx.z = tile.  HBM-bound: 10 B read + 1 B written per pixel.
 // The nine class tests per pixel (is the byte 80 / 90 / 95, 50, 10?) are ONE 256-entry LDS table
 // lookup per WorldCover byte -- water | urban << 4 | tree << 8, so that the sum of nine entries IS the
 // three 3x3 counts (each <= 9 fits its 4-bit field).  Round 1 compared every byte against the five
-// codes in registers: 116 VALU per pixel, issue-bound at 0.43 of the HBM rate; this form needs ~38.
-constexpr int LAND_ROWS = 2;
+// codes in registers: 116 VALU per pixel, issue-bound at 0.43 of the HBM rate; this form needs ~40.
+// blockIdx.z = tile.  HBM-bound: 10 B read + 1 B written per pixel.
+constexpr int LAND_ROWS = 1;
 
+// Four HLS pixels x LAND_ROWS rows per thread: three 12-byte row pieces of the WorldCover map per row (a wave
+// reads 768 contiguous bytes per row), one dword of CGLS, one dword stored.  width % 4 == 0.
+// (Eight pixels per thread -- 1536-byte pieces, 72 VGPRs -- measured 9 % slower.)
 __global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
     __shared__ uint16_t s_code[256];
+    __shared__ uint8_t s_forest[256];     // CGLS class -> is a forest class (a dynamic index into the kernel
+                                          // argument's bit set is a global load in the middle of the pixel loop)
     {
         const int v = threadIdx.x;
         s_code[v] = (uint16_t)(((v == 80) | (v == 90) | (v == 95) ? 1 : 0) | (v == 50 ? 16 : 0) | (v == 10 ? 256 : 0));
+        s_forest[v] = (uint8_t)((a.forest_bits[v >> 5] >> (v & 31)) & 1u);
     }
     __syncthreads();
     const long long xq = (long long)blockIdx.x * 64 + (threadIdx.x & 63);      // quad index
@@ -277,7 +290,8 @@ __global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
     if (xq * 4 >= a.width || y0 >= a.height) return;
     const long long W3 = 3 * a.width, tile = blockIdx.z;
     const uint8_t* wc = a.wc3 + tile * 9 * a.height * a.width;
-    // LAND_ROWS HLS rows per thread, all loads issued before the first lookup (more bytes in flight per wave)
+    // all loads issued before the first lookup (more bytes in flight per wave); cacheable: neighbouring waves
+    // share the cache lines at the ends of their pieces (non-temporal loads fetched them twice: 10 % slower)
     uint32_t w[LAND_ROWS][3][3], cg[LAND_ROWS];
 #pragma unroll
     for (int r = 0; r < LAND_ROWS; ++r) {
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
         for (int i = 0; i < 3; ++i) {
             const uint32_t* row = reinterpret_cast<const uint32_t*>(wc + (3 * y + i) * W3 + 12 * xq);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) w[r][i][k] = __builtin_nontemporal_load(row + k);
+            for (int k = 0; k < 3; ++k) w[r][i][k] = row[k];
         }
         cg[r] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.cgls + tile * a.height * a.width + y * a.width + 4 * xq));
     }
@@ -302,7 +316,8 @@ __global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            out |= (uint32_t)land_class(a, cnt[k] & 15u, (cnt[k] >> 4) & 15u, cnt[k] >> 8, (cg[r] >> (8 * k)) & 0xff) << (8 * k);
+            out |= (uint32_t)land_class(a, cnt[k] & 15u, (cnt[k] >> 4) & 15u, cnt[k] >> 8,
+                                        s_forest[(cg[r] >> (8 * k)) & 0xffu] != 0) << (8 * k);
         __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(a.land + tile * a.height * a.width + (y0 + r) * a.width + 4 * xq));
     }
 }
@@ -326,7 +341,8 @@ __global__ __launch_bounds__(256) void dswx_landcover_v1(const LandArgs a) {
         }
     }
     const long long o = tile * a.height * a.width + y * a.width + x;
-    a.land[o] = (uint8_t)land_class(a, water, urban, tree, a.cgls[o]);
+    const int c = a.cgls[o];
+    a.land[o] = (uint8_t)land_class(a, water, urban, tree, ((a.forest_bits[c >> 5] >> (c & 31)) & 1u) != 0);
 }
 
 // ------------------------------------------------------------------------------
