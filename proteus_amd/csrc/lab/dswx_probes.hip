@@ -100,6 +100,27 @@ __global__ __launch_bounds__(BLOCK) void dswx_stream_probe_k(const KArgs a, int 
     }
 }
 
+// Four pixels per thread, plain one-group-per-thread shape (round 2): 6 x 8-B + 1 x 4-B loads,
+// 1 x 8-B + 6 x 4-B stores -- half the requests in flight per thread of the 8-pixel shape, twice the waves.
+template <bool NT>
+__global__ __launch_bounds__(256) void dswx_ppt4_probe_k(const KArgs a) {
+    const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (grp >= (a.n_pixels >> 2)) return;
+    const long long off = (long long)blockIdx.y * a.tile_stride + grp * 4;
+    u32x2 x = ldg<u32x2, NT>(a.in.band[0] + off);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) x ^= ldg<u32x2, NT>(a.in.band[k] + off);
+    const uint32_t f = ldg<uint32_t, NT>(a.in.fmask + off);
+    const uint32_t y = x.x ^ x.y ^ f;
+    stg<u32x2, NT>(a.out.diag + off, x);
+    stg<uint32_t, NT>(a.out.wtr1 + off, y);
+    stg<uint32_t, NT>(a.out.wtr2 + off, y + 1u);
+    stg<uint32_t, NT>(a.out.wtr + off, y + 2u);
+    stg<uint32_t, NT>(a.out.bwtr + off, y + 3u);
+    stg<uint32_t, NT>(a.out.conf + off, ~y);
+    stg<uint32_t, NT>(a.out.cloud + off, y + 5u);
+}
+
 // Staged probe: the fused kernel's data movement (register loads, LDS-transposed
 // plane-run stores) with trivial math.  BLOCK threads x 8 px; each wave stores
 // consecutive 1 KiB pieces.
@@ -703,6 +724,13 @@ int dswx_stream_probe(dswx_ctx_t* ctx, int64_t n_tiles, int64_t n_pixels, int64_
         dim3 grid((unsigned)((n16_in + 255) / 256)), block(256);
         if (variant & 2) hipLaunchKernelGGL(dswx_flat_copy_k<true>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
         else hipLaunchKernelGGL(dswx_flat_copy_k<false>, grid, block, 0, s, (const u32x4*)in->band[0], (u32x4*)out->diag, n16_in, n16_out);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (variant & (1 << 26)) {  // four pixels per thread, bit 1 = nt
+        dim3 grid((unsigned)(((n_pixels >> 2) + 255) / 256), (unsigned)n_tiles), block(256);
+        if (variant & 2) hipLaunchKernelGGL(dswx_ppt4_probe_k<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(dswx_ppt4_probe_k<false>, grid, block, 0, s, a);
         HIP_TRY(hipGetLastError());
         return DSWX_OK;
     }
