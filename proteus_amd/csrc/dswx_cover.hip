@@ -213,6 +213,8 @@ __global__ __launch_bounds__(256) void dswx_cover_dilate(const KArgs a) {
 // one 8-byte state load + one byte of the snow plane in, four (five) 8-byte stores out.  VEC = the planes
 // allow 8-byte accesses (tile starts and pointers 8-byte aligned); otherwise the same with byte accesses.
 // ------------------------------------------------------------------------------
+constexpr int FIN_GROUPS = 4;     // 8-pixel groups per thread, 256 groups apart: four loads in flight per thread
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void dswx_cover_finish(const KArgs a) {
     __shared__ uint32_t s_fin[128];             // WTR | BWTR << 8 | CONF << 16 | CLOUD << 24
@@ -226,38 +228,62 @@ __global__ __launch_bounds__(256) void dswx_cover_finish(const KArgs a) {
         s_fbr[t] = o.browse;
     }
     __syncthreads();
-    const long long grp = (long long)blockIdx.x * 256 + t;
-    const long long px0 = grp * 8;
-    if (px0 >= a.n_pixels) return;
-    const long long off = (long long)blockIdx.y * a.tile_stride + px0;
-    const uint32_t snow8 = reinterpret_cast<const uint8_t*>(a.cover_snow + (long long)blockIdx.y * a.cover_snow_stride)[grp];
-    const int n = a.n_pixels - px0 < 8 ? (int)(a.n_pixels - px0) : 8;
-    uint32_t st[2] = {0u, 0u};
-    if (VEC && n == 8) {
-        const u32x2 v = ldg<u32x2, true>(a.cover_state + off);
-        st[0] = v.x; st[1] = v.y;
-    } else {
-        for (int j = 0; j < n; ++j) st[j >> 2] |= (uint32_t)a.cover_state[off + j] << (8 * (j & 3));
-    }
-    uint32_t e[8], br[2] = {0u, 0u};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t idx = ((st[j >> 2] >> (8 * (j & 3))) & 0x3fu) | ((snow8 >> j) & 1u) << 6;
-        e[j] = s_fin[idx];
-        br[j >> 2] |= s_fbr[idx] << (8 * (j & 3));
-    }
-    uint32_t lo[4], hi[4];              // byte k of every e -> plane k, pixel order
-    transpose4(e, lo);
-    transpose4(e + 4, hi);
+    const uint8_t* __restrict__ snow_plane = reinterpret_cast<const uint8_t*>(a.cover_snow + (long long)blockIdx.y * a.cover_snow_stride);
+    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
+    // a thread's state bytes carry ~8 bytes per wave lane: with one group per thread the kernel is bound by
+    // waves-in-flight x bytes-per-wave / latency (5.4 TB/s measured); all FIN_GROUPS loads go out first
     uint8_t* const planes[5] = {a.out.wtr, a.out.bwtr, a.out.conf, a.out.cloud, a.out.browse};
+    auto finish_group = [&](const uint32_t (&st)[2], uint32_t snow8, uint32_t (&lo)[5], uint32_t (&hi)[5]) {
+        uint32_t e[8], br[2] = {0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        if (!planes[k]) continue;
-        const uint32_t v0 = k < 4 ? lo[k] : br[0], v1 = k < 4 ? hi[k] : br[1];
-        if (VEC && n == 8) {
-            stg<u32x2, true>(planes[k] + off, u32x2{v0, v1});
-        } else {
-            for (int j = 0; j < n; ++j) planes[k][off + j] = (uint8_t)((j < 4 ? v0 : v1) >> (8 * (j & 3)));
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t idx = ((st[j >> 2] >> (8 * (j & 3))) & 0x3fu) | ((snow8 >> j) & 1u) << 6;
+            e[j] = s_fin[idx];
+            br[j >> 2] |= s_fbr[idx] << (8 * (j & 3));
+        }
+        uint32_t l4[4], h4[4];              // byte k of every e -> plane k, pixel order
+        transpose4(e, l4);
+        transpose4(e + 4, h4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo[k] = l4[k]; hi[k] = h4[k]; }
+        lo[4] = br[0]; hi[4] = br[1];
+    };
+    const long long grp0 = (long long)blockIdx.x * FIN_GROUPS * 256 + t;
+    if (VEC && (grp0 + (FIN_GROUPS - 1) * 256) * 8 + 8 <= a.n_pixels) {
+        // every group of this thread is complete: straight-line code, all loads before the first use
+        u32x2 st[FIN_GROUPS];
+        uint32_t snow8[FIN_GROUPS];
+#pragma unroll
+        for (int u = 0; u < FIN_GROUPS; ++u) {
+            st[u] = ldg<u32x2, true>(a.cover_state + tile_base + (grp0 + u * 256) * 8);
+            snow8[u] = snow_plane[grp0 + u * 256];
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_GROUPS; ++u) {
+            const uint32_t s2[2] = {st[u].x, st[u].y};
+            uint32_t lo[5], hi[5];
+            finish_group(s2, snow8[u], lo, hi);
+            const long long off = tile_base + (grp0 + u * 256) * 8;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (planes[k]) stg<u32x2, true>(planes[k] + off, u32x2{lo[k], hi[k]});
+        }
+        return;
+    }
+    // the tile's last groups, or planes without 8-byte alignment: byte accesses
+    for (int u = 0; u < FIN_GROUPS; ++u) {
+        const long long px0 = (grp0 + u * 256) * 8;
+        const long long left = a.n_pixels - px0;
+        if (left <= 0) break;
+        const int n = left >= 8 ? 8 : (int)left;
+        const long long off = tile_base + px0;
+        uint32_t st[2] = {0u, 0u};
+        for (int j = 0; j < n; ++j) st[j >> 2] |= (uint32_t)a.cover_state[off + j] << (8 * (j & 3));
+        uint32_t lo[5], hi[5];
+        finish_group(st, snow_plane[grp0 + u * 256], lo, hi);
+        for (int k = 0; k < 5; ++k) {
+            if (!planes[k]) continue;
+            for (int j = 0; j < n; ++j) planes[k][off + j] = (uint8_t)((j < 4 ? lo[k] : hi[k]) >> (8 * (j & 3)));
         }
     }
 }
@@ -283,7 +309,7 @@ int dswx_cover_stage2_launch(dswx_ctx* ctx, const KArgs& c2, long long n_tiles, 
         uint8_t* const outs[5] = {c2.out.wtr, c2.out.bwtr, c2.out.conf, c2.out.cloud, c2.out.browse};
         for (uint8_t* o : outs) vec = vec && (!o || aligned_to(o, 8));
         const long long groups = (c2.n_pixels + 7) / 8;
-        dim3 fgrid((unsigned)((groups + 255) / 256), (unsigned)n_tiles);
+        dim3 fgrid((unsigned)((groups + 256 * FIN_GROUPS - 1) / (256 * FIN_GROUPS)), (unsigned)n_tiles);
         if (vec) hipLaunchKernelGGL(dswx_cover_finish<true>, fgrid, dim3(256), 0, s, c2);
         else hipLaunchKernelGGL(dswx_cover_finish<false>, fgrid, dim3(256), 0, s, c2);
         HIP_TRY(hipGetLastError());
