@@ -198,7 +198,10 @@ __device__ __forceinline__ uint32_t shadow_quad(const ShadowArgs& a, const Shado
 // output rows.  Measured on MI355X (ms per 3660^2 tile, +-4 % between boxes): SHADOW_ROWS 1: 0.0149, 2: 0.0125-0.0131,
 // 3: 0.0127-0.0131, 4: 0.0133-0.0138, 6: 0.0135, 8: 0.0139, 16: 0.0157 -- short waves with all their loads in
 // flight beat long ones, although a block then re-reads more halo rows (vertically adjacent blocks run on
-// different XCDs, so the halo comes from the Infinity Cache / HBM, not from an L2).
+// different XCDs, so the halo comes from the Infinity Cache / HBM, not from an L2).  An XCD-contiguous block order
+// (guide T1: each XCD walks a run of row-blocks down a column strip, so halos meet in one L2) was measured too:
+// 0.0141 -> 0.0157 ms per tile (0.0149 with the remap per tile instead of per launch) -- slower, as for the
+// fused kernel in round 1; the plain order stays.
 constexpr int SHADOW_ROWS = 2, SHADOW_WARM = 2;
 
 // TINY: the slope threshold is (almost) zero -- see ShadowFilter::t_tiny
