@@ -183,7 +183,8 @@ __device__ __forceinline__ uint32_t shadow_quad(const ShadowArgs& a, const Shado
     if (unsure) {                       // rare: within the error bound of a threshold, or not finite
         const float cx[6] = {c0.y, c1.x, c1.y, c2.x, c2.y, c3.x};
         const float up[4] = {u0.x, u0.y, u1.x, u1.y}, dn[4] = {b0.x, b0.y, b1.x, b1.y};
-#pragma unroll
+        // one copy of the ~100-instruction exact path per quad, not four: it is cold code
+#pragma unroll 1
         for (int k = 0; k < 4; ++k) {
             if (!((unsure >> k) & 1u)) continue;
             const bool v = shadow_px_exact<F32>(a, cx[k + 2] - cx[k], 0.5f, dn[k] - up[k], 0.5f);
@@ -202,7 +203,7 @@ __device__ __forceinline__ uint32_t shadow_quad(const ShadowArgs& a, const Shado
 // (guide T1: each XCD walks a run of row-blocks down a column strip, so halos meet in one L2) was measured too:
 // 0.0141 -> 0.0157 ms per tile (0.0149 with the remap per tile instead of per launch) -- slower, as for the
 // fused kernel in round 1; the plain order stays.
-constexpr int SHADOW_ROWS = 2, SHADOW_WARM = 2;
+constexpr int SHADOW_ROWS = 2;
 
 // TINY: the slope threshold is (almost) zero -- see ShadowFilter::t_tiny
 template <bool F32, bool TINY>
@@ -229,9 +230,7 @@ __global__ __launch_bounds__(256) void dswx_shadow_v3(const ShadowArgs a, const 
     Row up = load_row(y0 - 1), ce = load_row(y0), dn = load_row(y0 + 1), nx = SHADOW_ROWS > 1 ? load_row(y0 + 2) : dn;
 #pragma unroll
     for (int i = 0; i < SHADOW_ROWS; ++i) {
-        // rows past the wave's own need (i + 3 > SHADOW_ROWS) are the first rows of the wave BELOW: requesting
-        // SHADOW_WARM of them here warms the L2 for it (measured: 0.0131 -> 0.0125 ms per tile with 2)
-        const Row nn = i + 3 <= SHADOW_ROWS + SHADOW_WARM ? load_row(y0 + i + 3) : nx;
+        const Row nn = i + 3 <= SHADOW_ROWS ? load_row(y0 + i + 3) : nx;       // only rows an output row of this wave needs
         if (oy0 + i < oh) {
             const uint32_t out = shadow_quad<F32, TINY>(a, f, ce.v[0], ce.v[1], ce.v[2], ce.v[3], up.v[1], up.v[2], dn.v[1], dn.v[2]);
             __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(dst + (size_t)(oy0 + i) * (size_t)ow));
