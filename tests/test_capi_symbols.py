@@ -78,6 +78,82 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.BatchGeom) == 4 * 8
 
 
+def test_make_params_field_by_field_against_the_reference_defaults():
+    """VERDICT r01 'weak' 3: the C oracle receives its parameters through _capi.make_params, so a wrong
+    mapping there would be shared by both sides of every C-oracle comparison.  Here every field of the
+    struct make_params builds is checked against values written out by hand from the reference's default
+    runconfig (defaults/dswx_hls.yaml:73-101, :176-212) and constants (dswx_hls.py:26, :31, :45-46), for the
+    default call and for a call that moves every knob."""
+    p = _capi.make_params()
+    want = dict(wigt=0.124, awgt=0.0, pswt_1_mndwi=-0.44, pswt_1_nir=1500.0, pswt_1_swir1=900.0, pswt_1_ndvi=0.7,
+                pswt_2_mndwi=-0.5, pswt_2_blue=1000.0, pswt_2_nir=2500.0, pswt_2_swir1=3000.0, pswt_2_swir2=1000.0,
+                lcmask_nir=1200.0)
+    for k, v in want.items():
+        assert getattr(p, k) == v, k
+    assert list(p.band_fill) == [-9999.0] * 6 and p.fmask_fill == 255.0 and p.aerosol_max_nir == 1000.0
+    assert (p.clip_negative_reflectance, p.mask_adjacent_to_cloud_mode, p.apply_aerosol_class_remapping,
+            p.collapse_wtr_classes) == (1, 0, 1, 1)
+    assert (p.browse_exclude_psw_aggressive, p.browse_not_water_to_nodata, p.browse_cloud_to_nodata,
+            p.browse_snow_to_nodata, p.browse_ocean_masked_to_nodata) == (1, 0, 0, 0, 1)
+    lut = np.array([list(r) for r in p.aerosol_fmask_lut])
+    assert lut.sum() == 3 + 3 + 5 + 5
+    # every knob moved
+    thr = {k: float(i) + 0.5 for i, k in enumerate(_capi.THRESHOLD_NAMES)}
+    q = _capi.make_params(thr, band_fills=[1.0, None, -3.0, 4.5, 0.0, 32767.0], fmask_fill=None,
+                          clip_negative_reflectance=False, mask_adjacent_to_cloud_mode='cover',
+                          apply_aerosol_class_remapping=False,
+                          aerosol_fmask_values={0: [1, 2], 2: [], 3: [255, 0, 300, 7.5], 4: [64]},
+                          collapse_wtr_classes=False, aerosol_max_nir=123.25,
+                          exclude_psw_aggressive_in_browse=False, not_water_in_browse='nodata',
+                          cloud_in_browse='nodata', snow_in_browse='nodata', set_ocean_masked_to_nodata=False)
+    for i, k in enumerate(_capi.THRESHOLD_NAMES):
+        assert getattr(q, k) == i + 0.5, k
+    bf = list(q.band_fill)
+    assert bf[0] == 1.0 and np.isnan(bf[1]) and bf[2:] == [-3.0, 4.5, 0.0, 32767.0] and np.isnan(q.fmask_fill)
+    assert q.aerosol_max_nir == 123.25
+    assert (q.clip_negative_reflectance, q.mask_adjacent_to_cloud_mode, q.apply_aerosol_class_remapping,
+            q.collapse_wtr_classes) == (0, 2, 0, 0)
+    assert (q.browse_exclude_psw_aggressive, q.browse_not_water_to_nodata, q.browse_cloud_to_nodata,
+            q.browse_snow_to_nodata, q.browse_ocean_masked_to_nodata) == (0, 1, 1, 1, 0)
+    lut = np.array([list(r) for r in q.aerosol_fmask_lut])
+    assert np.nonzero(lut[0])[0].tolist() == [1, 2] and lut[1].sum() == 0
+    assert np.nonzero(lut[2])[0].tolist() == [0, 255]           # 300 and 7.5 are not Fmask byte values
+    assert np.nonzero(lut[3])[0].tolist() == [64]
+    assert _capi.make_params(mask_adjacent_to_cloud_mode='ignore').mask_adjacent_to_cloud_mode == 1
+    with pytest.raises(ValueError, match='is not set'):
+        _capi.make_params({k: (None if k == 'awgt' else 1.0) for k in _capi.THRESHOLD_NAMES})
+
+
+def test_struct_field_offsets_match_a_c_compiler(tmp_path):
+    """The ctypes mirrors in _capi.py against `offsetof` as gcc sees include/dswx_hip.h (sizes alone would not
+    notice two swapped fields)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    fields = {'dswx_params_t': [n for n, _ in _capi.Params._fields_],
+              'dswx_planes_in_t': [n for n, _ in _capi.PlanesIn._fields_],
+              'dswx_planes_out_t': [n for n, _ in _capi.PlanesOut._fields_],
+              'dswx_batch_geom_t': [n for n, _ in _capi.BatchGeom._fields_]}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dswx_hip.h"', 'int main(void) {']
+    for st, names in fields.items():
+        for n in names:
+            lines.append(f'  printf("{st}.{n} %zu\\n", offsetof({st}, {n}));')
+        lines.append(f'  printf("{st}.sizeof %zu\\n", sizeof({st}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'off.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'off'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    mirrors = {'dswx_params_t': _capi.Params, 'dswx_planes_in_t': _capi.PlanesIn,
+               'dswx_planes_out_t': _capi.PlanesOut, 'dswx_batch_geom_t': _capi.BatchGeom}
+    for st, cls in mirrors.items():
+        assert int(got[f'{st}.sizeof']) == ctypes.sizeof(cls), st
+        for n in fields[st]:
+            assert int(got[f'{st}.{n}']) == getattr(cls, n).offset, (st, n)
+
+
 def test_bad_mode_raises_like_reference():
     with pytest.raises(Exception, match='ERROR mask adjacent to cloud/cloud-shadow mode'):
         _capi.make_params(mask_adjacent_to_cloud_mode='bogus')
