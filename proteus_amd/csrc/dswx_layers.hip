@@ -202,16 +202,19 @@ __device__ __forceinline__ uint32_t shadow_quad(const ShadowArgs& a, const Shado
 // different XCDs, so the halo comes from the Infinity Cache / HBM, not from an L2).  An XCD-contiguous block order
 // (guide T1: each XCD walks a run of row-blocks down a column strip, so halos meet in one L2) was measured too:
 // 0.0141 -> 0.0157 ms per tile (0.0149 with the remap per tile instead of per launch) -- slower, as for the
-// fused kernel in round 1; the plain order stays.
-constexpr int SHADOW_ROWS = 2;
+// fused kernel in round 1; the plain order stays.  Waves per block (stacked in y; ms per tile, legacy promotion):
+// 1: 0.0177, 2: 0.0133, 4: 0.0126, 8: 0.0133, 16: 0.0147 -- taller blocks save halo re-reads but run slower.
+// (The waves of a block MUST be stacked in y: they share their halo rows through the CU's L1.  Numbering the
+// work items along the rows instead -- no idle lanes at the row ends -- measured 0.0173.)
+constexpr int SHADOW_ROWS = 2, SHADOW_WAVES = 4;     // waves (stacked in y) per block
 
 // TINY: the slope threshold is (almost) zero -- see ShadowFilter::t_tiny
 template <bool F32, bool TINY>
-__global__ __launch_bounds__(256) void dswx_shadow_v3(const ShadowArgs a, const ShadowFilter f) {
+__global__ __launch_bounds__(64 * SHADOW_WAVES) void dswx_shadow_v3(const ShadowArgs a, const ShadowFilter f) {
     const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
     const int ow = W - 2 * margin, oh = H - 2 * margin;
     const int oq = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int oy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * SHADOW_ROWS;
+    const int oy0 = (blockIdx.y * SHADOW_WAVES + (threadIdx.x >> 6)) * SHADOW_ROWS;
     if (4 * oq >= ow || oy0 >= oh) return;
     const float* __restrict__ col = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W + (size_t)(4 * oq + margin);
     uint8_t* __restrict__ dst = a.shadow + (size_t)blockIdx.z * (size_t)oh * (size_t)ow + (size_t)(4 * oq);
@@ -287,9 +290,13 @@ __global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
         s_forest[v] = (uint8_t)((a.forest_bits[v >> 5] >> (v & 31)) & 1u);
     }
     __syncthreads();
-    const long long xq = (long long)blockIdx.x * 64 + (threadIdx.x & 63);      // quad index
-    const long long y0 = ((long long)blockIdx.y * 4 + (threadIdx.x >> 6)) * LAND_ROWS;
-    if (xq * 4 >= a.width || y0 >= a.height) return;
+    // quads are numbered along the rows of the whole raster (LAND_ROWS = 1): consecutive waves continue along the
+    // row, so the cache lines two 768-byte pieces share are fetched by one CU, and no lane is idle at the row ends
+    const unsigned quads_per_row = (unsigned)(a.width >> 2);
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;
+    const unsigned yq = q / quads_per_row;
+    const long long xq = q - yq * quads_per_row, y0 = yq;
+    if (y0 >= a.height) return;
     const long long W3 = 3 * a.width, tile = blockIdx.z;
     const uint8_t* wc = a.wc3 + tile * 9 * a.height * a.width;
     // all loads issued before the first lookup (more bytes in flight per wave); cacheable: neighbouring waves
@@ -586,7 +593,7 @@ static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles
     if (quads) {
         ShadowFilter f;
         shadow_filter(a, f32, &f);
-        dim3 grid((unsigned)((ow / 4 + 63) / 64), (unsigned)((oh + 4 * SHADOW_ROWS - 1) / (4 * SHADOW_ROWS)), (unsigned)n_tiles), block(256);
+        dim3 grid((unsigned)((ow / 4 + 63) / 64), (unsigned)((oh + SHADOW_WAVES * SHADOW_ROWS - 1) / (SHADOW_WAVES * SHADOW_ROWS)), (unsigned)n_tiles), block(64 * SHADOW_WAVES);
         if (f32 && f.t_tiny) hipLaunchKernelGGL((dswx_shadow_v3<true, true>), grid, block, 0, s, a, f);
         else if (f32) hipLaunchKernelGGL((dswx_shadow_v3<true, false>), grid, block, 0, s, a, f);
         else if (f.t_tiny) hipLaunchKernelGGL((dswx_shadow_v3<false, true>), grid, block, 0, s, a, f);
@@ -721,8 +728,10 @@ int dswx_landcover_mask_device(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, c
     // four pixels per thread with dword loads when rows keep 4-byte alignment
     const bool quad = width % 4 == 0 && aligned_to(worldcover_up3, 4) && aligned_to(copernicus, 4) && aligned_to(land, 4);
     if (quad) {
-        dim3 grid((unsigned)((width / 4 + 63) / 64), (unsigned)((height + 4 * LAND_ROWS - 1) / (4 * LAND_ROWS)), (unsigned)n_tiles), block(256);
-        if (grid.y > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
+        static_assert(LAND_ROWS == 1, "the flat quad numbering assumes one row per thread");
+        const long long quads = (width / 4) * height;
+        if (quads > 0xffffffffLL - 256) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
+        dim3 grid((unsigned)((quads + 255) / 256), 1, (unsigned)n_tiles), block(256);
         hipLaunchKernelGGL(dswx_landcover_v3, grid, block, 0, s, a);
     } else {
         dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4), (unsigned)n_tiles), block(256);
