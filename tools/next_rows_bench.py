@@ -24,7 +24,8 @@ T, MARGIN = 3660, 50
 def timed(ctx, fn, reps, inner=10):
     """Average over `reps` timings of `inner` back-to-back launches each (HIP events on the kernel's stream):
     a single ~0.1 ms launch between two events also measures ~10 us of dispatch gap."""
-    fn()
+    for _ in range(3 * inner):          # warm-up: clocks ramp for the first tenths of a second after an idle period
+        fn()
     ctx.synchronize()
     ms = []
     for _ in range(reps):
