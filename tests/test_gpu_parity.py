@@ -731,6 +731,42 @@ def test_shadow_layer_thresholds_inside_the_data(ctx, legacy):
     assert n_checked == 10 * 800 * 1000
 
 
+@pytest.mark.parametrize('legacy', [False, True])
+def test_shadow_filter_vs_exact_kernel_soak(ctx, legacy):
+    """The filter kernel (even margin) against the general kernel (odd margin: exact arithmetic only, itself
+    pinned to numpy above) on the same pixels: 120 random DEMs x sun geometries x pixel spacings, thresholds
+    at random quantiles of each case's own arccos / arctan arguments, degenerate thresholds, rough / gentle /
+    terraced terrain.  No numpy in the loop, so the soak is wide."""
+    rng = np.random.default_rng(777)
+    c = ctx
+    n_diff_cases = 0
+    for k in range(120):
+        h, w = int(rng.integers(60, 400)), 4 * int(rng.integers(20, 110))     # even margin + width % 4 == 0: the filter kernel
+        kind = k % 4
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        z = rng.uniform(5, 400) * np.sin(xx / rng.uniform(5, 60) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(5, 60)) \
+            + rng.normal(0, (0.01, 1.0, 5.0, 0.0)[kind], size=(h, w))
+        if kind == 3:
+            z = np.round(z / 7.0) * 7.0                       # terraces: exact zero differences next to big steps
+        dem = z.astype(np.float32)
+        az, zen = rng.uniform(0, 2 * np.pi), np.radians(rng.uniform(5, 85))
+        sun = [np.sin(az) * np.sin(zen), np.cos(az) * np.sin(zen), np.cos(zen)]
+        sx, sy = (30.0, 30.0) if k % 3 else (float(rng.uniform(1, 90)), float(rng.uniform(1, 90)))
+        gy, gx = np.gradient(dem.astype(np.float64))
+        n0, n1 = -gx / sx, gy / sy
+        q = (n0 * sun[0] + n1 * sun[1] + sun[2]) / np.sqrt(n0 ** 2 + n1 ** 2 + 1)
+        t = n0 * np.sin(az) + n1 * np.cos(az)
+        max_inc = (float(np.degrees(np.arccos(np.clip(np.quantile(q, rng.uniform(0.05, 0.95)), -1, 1)))), 0.0, 180.0)[(k // 4) % 3 if k % 11 == 0 else 0]
+        min_slope = (float(np.degrees(np.arctan(np.quantile(t, rng.uniform(0.05, 0.95))))), 0.0, -90.0, 90.0)[(k // 5) % 4 if k % 7 == 0 else 0]
+        m = 2 * int(rng.integers(1, 10))
+        a = c.shadow_layer(dem, sun, np.sin(az), np.cos(az), min_slope, max_inc, sx, sy, margin=m, float32=legacy)
+        b = c.shadow_layer(dem, sun, np.sin(az), np.cos(az), min_slope, max_inc, sx, sy, margin=m - 1, float32=legacy)
+        assert a.shape == (h - 2 * m, w - 2 * m)
+        assert np.array_equal(a, b[1:-1, 1:-1]), (k, h, w, m, max_inc, min_slope, sx, sy, int(np.count_nonzero(a != b[1:-1, 1:-1])))
+        n_diff_cases += int(0.02 < a.mean() < 0.98)
+    assert n_diff_cases > 60          # most cases have the thresholds cutting through the data
+
+
 def _sun(az_deg, el_deg):
     """(sun vector, sin az, cos az) formed exactly as the reference forms them (:4246-4253, :4276-4277)."""
     az, zen = np.radians(az_deg), np.radians(90 - el_deg)
