@@ -257,19 +257,23 @@ def realloc_spread(ctx, params, n_tiles, masks, repeats, launches=5):
 
 
 def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
-    """Allocate the resident batch.  The kernel's rate depends on where hipMalloc lands the arena (a property of
-    the physical placement of the 14 streams that persists for the arena's lifetime: DESIGN.md section 5,
-    `roofline.realloc_spread`), so a long-lived arena is worth choosing: allocate up to `trials` arenas -- the next
-    one while the previous is still held, so the allocator cannot hand the same range back -- time `launches`
-    launches on each and keep the fastest.  Outside the timed region; `--placement-trials 1` takes the first."""
+    """Allocate the resident batch.  The kernel's rate depends on WHERE in HBM the arena lands: a stable property
+    of the physical range (tools/placement_probe.py and profiles/r02_placement_probe.json: the same layout runs
+    5 - 8 % faster in some allocations than in others, at every base offset and plane gap; per-range write-only
+    probes show it is the write side), so a long-lived arena is worth choosing.  Up to `trials` candidate arenas
+    are allocated SIDE BY SIDE (each covers a different physical range; a freed range would simply be handed out
+    again), `launches` launches are timed on each, the fastest is kept and the others are freed.  Outside the timed
+    region; `--placement-trials 1` takes the first."""
     from proteus_amd import _capi
     from proteus_amd.synth import SEED
-    best, best_ms, seen = None, None, []
-    if 2 * n_tiles * TILE * TILE * (24 if masks else 21) > 250e9:
-        trials = 1                      # two candidate arenas must fit the 288 GB of HBM side by side
-    for _ in range(max(1, trials)):
+    arena_bytes = n_tiles * TILE * TILE * (24 if masks else 21)
+    trials = max(1, min(trials, int(250e9 // arena_bytes)))      # all candidates must fit the 288 GB of HBM together
+    cands, seen = [], []
+    for _ in range(trials):
         b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks)
         b.synth(SEED, tile0=tile0)
+        cands.append(b)
+    for b in cands:
         b.classify(params)
         ctx.synchronize()
         e0, e1 = ctx.event(), ctx.event()
@@ -278,17 +282,14 @@ def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
             b.classify(params)
         ctx.record(e1)
         ctx.synchronize()
-        ms = ctx.elapsed_ms(e0, e1) / launches
+        seen.append(round(ctx.elapsed_ms(e0, e1) / launches, 4))
         ctx.destroy_event(e0)
         ctx.destroy_event(e1)
-        seen.append(round(ms, 4))
-        if best is None or ms < best_ms:
-            if best is not None:
-                best.free()
-            best, best_ms = b, ms
-        else:
+    keep = seen.index(min(seen))
+    for k, b in enumerate(cands):
+        if k != keep:
             b.free()
-    return best, {'trials': len(seen), 'probe_launch_ms': seen, 'kept_ms': round(best_ms, 4)}
+    return cands[keep], {'trials': len(seen), 'probe_launch_ms': seen, 'kept_ms': seen[keep]}
 
 
 def free_port():
