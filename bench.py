@@ -46,8 +46,9 @@ def parse_args():
     ap.add_argument('--realloc-repeats', type=int, default=5,
                     help='N = 1: after the timed region, re-allocate the batch this many times and report the '
                          'spread of the kernel rate (it depends on where the arena lands, DESIGN.md section 5)')
-    ap.add_argument('--placement-trials', type=int, default=3,
-                    help='allocate this many candidate arenas and keep the one the kernel runs fastest on (1 = first)')
+    ap.add_argument('--placement-trials', type=int, default=6,
+                    help='allocate this many candidate arenas for the output planes and keep the one the kernel runs '
+                         'fastest on (1 = first)')
     ap.add_argument('--plan-only', action='store_true',
                     help='no GPU work: bring the ranks up (gloo), print the sharding plan of this command line as '
                          'JSON and exit (tests/test_shard_gloo.py drives the launcher path with it)')
@@ -257,23 +258,23 @@ def realloc_spread(ctx, params, n_tiles, masks, repeats, launches=5):
 
 
 def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
-    """Allocate the resident batch.  The kernel's rate depends on WHERE in HBM the arena lands: a stable property
-    of the physical range (tools/placement_probe.py and profiles/r02_placement_probe.json: the same layout runs
-    5 - 8 % faster in some allocations than in others, at every base offset and plane gap; per-range write-only
-    probes show it is the write side), so a long-lived arena is worth choosing.  Up to `trials` candidate arenas
-    are allocated SIDE BY SIDE (each covers a different physical range; a freed range would simply be handed out
-    again), `launches` launches are timed on each, the fastest is kept and the others are freed.  Outside the timed
-    region; `--placement-trials 1` takes the first."""
+    """Allocate the resident batch.  The kernel's rate depends on WHERE in HBM its output planes land: a stable
+    property of the physical range (tools/placement_probe.py, profiles/r02_placement_probe.json: reads stream at
+    ~7.1 TB/s everywhere, writes at 5.7 - 5.9 TB/s in most ranges and 6.4 - 7.1 in a few, and the fused kernel
+    follows the write side), so a long-lived arena is worth choosing.  The inputs get one allocation; up to
+    `trials` candidate allocations for the OUTPUT planes are made side by side (each covers a different physical
+    range; a freed range would simply be handed out again), `launches` launches are timed on each, the fastest is
+    kept and the others are freed.  Outside the timed region; `--placement-trials 1` takes the first."""
     from proteus_amd import _capi
     from proteus_amd.synth import SEED
-    arena_bytes = n_tiles * TILE * TILE * (24 if masks else 21)
-    trials = max(1, min(trials, int(250e9 // arena_bytes)))      # all candidates must fit the 288 GB of HBM together
-    cands, seen = [], []
-    for _ in range(trials):
-        b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks)
-        b.synth(SEED, tile0=tile0)
-        cands.append(b)
-    for b in cands:
+    b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=True)
+    b.synth(SEED, tile0=tile0)
+    in_bytes = n_tiles * TILE * TILE * (16 if masks else 13)
+    trials = max(1, min(trials, int((235e9 - in_bytes) // b.out_bytes)))     # everything must fit the 288 GB of HBM
+    cands = [b.out_arena] + [b.new_output_arena() for _ in range(trials - 1)]
+    seen = []
+    for buf in cands:
+        b.use_output_arena(buf)
         b.classify(params)
         ctx.synchronize()
         e0, e1 = ctx.event(), ctx.event()
@@ -286,10 +287,11 @@ def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
         ctx.destroy_event(e0)
         ctx.destroy_event(e1)
     keep = seen.index(min(seen))
-    for k, b in enumerate(cands):
+    b.use_output_arena(cands[keep])
+    for k, buf in enumerate(cands):
         if k != keep:
-            b.free()
-    return cands[keep], {'trials': len(seen), 'probe_launch_ms': seen, 'kept_ms': seen[keep]}
+            buf.free()
+    return b, {'trials': len(seen), 'probe_launch_ms': seen, 'kept_ms': seen[keep]}
 
 
 def free_port():
@@ -464,9 +466,10 @@ def main():
                        'planes_in': 10 if args.masks else 7, 'planes_out': 7,
                        'sharding': f'tiles by rank x{world}, no collective',
                        'control_plane': cp.backend,
-                       'arena_placement': dict(placement, note='fastest of `trials` hipMalloc placements of the resident '
-                                               'batch, chosen before warm-up (the rate is a property of the placement; '
-                                               'roofline.realloc_spread shows what an arbitrary one gives)'),
+                       'arena_placement': dict(placement, note='output planes in the fastest of `trials` candidate '
+                                               'allocations, chosen before warm-up (the rate is a property of the physical '
+                                               'range the writes land in; roofline.realloc_spread shows what arbitrary '
+                                               'single-arena placements give)'),
                        'kernel': kernel_info},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),

@@ -662,50 +662,57 @@ class Context:
 class DeviceBatch:
     """Band-planar batch resident in HBM: every plane is [n_tiles][tile_stride].
 
-    Owns one arena; plane offsets are 256-byte aligned and, by default, the tile stride is
+    Owns one arena (two with separate_outputs); plane offsets are 256-byte aligned and, by default, the tile stride is
     H*W rounded up to a multiple of 256 pixels, so every tile starts on a 256-byte boundary
     in every plane (contiguous tiles of 3660 x 3660 do not: 13,395,600 = 144 mod 256, which
     costs ~20 % of the HBM rate).  `tile_align=1` gives contiguous tiles.
     Used by bench.py, the multi-GPU driver and the device-path parity tests.
     """
 
-    def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=(), tile_align=256, plane_skew=0):
+    def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=(), tile_align=256, plane_skew=0,
+                 separate_outputs=False):
+        """separate_outputs: the output planes get an allocation of their own (`out_arena`), so that it can
+        be chosen among several candidates (`new_output_arena` / `use_output_arena`): on MI355X the kernel's
+        rate depends on which physical range its WRITE streams land in."""
         self.ctx, self.n_tiles, self.height, self.width = ctx, n_tiles, height, width
         self.n_pixels = height * width
         self.tile_stride = -(-self.n_pixels // tile_align) * tile_align
         self.geom = BatchGeom(n_tiles, height, width, self.tile_stride)
         total = n_tiles * self.tile_stride
         self.total = total
-        off = 0
-        self.offsets = {}
-
+        self.offsets = {}          # name -> byte offset inside its arena
+        self._in_out = {}          # name -> 'in' | 'out'
+        cursor = {'in': 0, 'out': 0}
         skew = int(plane_skew)
 
-        def take(name, nbytes):
+        def take(name, nbytes, side):
             # optional skew: plane k starts k*skew bytes later than plain packing,
             # so equal pixel indices of different planes differ in their low
             # address bits (DRAM channel / bank selection)
-            nonlocal off
-            off += skew * len(self.offsets)
+            side = side if separate_outputs else 'in'
+            off = cursor[side] + skew * len(self.offsets)
             off = (off + 255) & ~255
             self.offsets[name] = off
-            off += (nbytes + 255) & ~255
+            self._in_out[name] = side
+            cursor[side] = off + ((nbytes + 255) & ~255)
 
         for b in BAND_NAMES:
-            take(b, total * 2)
-        take('fmask', total)
+            take(b, total * 2, 'in')
+        take('fmask', total, 'in')
         self.masks = masks
         if masks:
             for m in ('land', 'shad', 'ocean'):
-                take(m, total)
-        take('diag', total * 2)
+                take(m, total, 'in')
+        take('diag', total * 2, 'out')
         self.out_layers = ['wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'] + \
             [x for x in extra_layers if x in U8_LAYERS]
         for name in self.out_layers:
-            take(name, total)
-        take('counters', n_tiles * 24)
-        self.arena = ctx.malloc(off)
-        self.nbytes = off
+            take(name, total, 'out')
+        take('counters', n_tiles * 24, 'in')
+        self.arena = ctx.malloc(cursor['in'])
+        self.out_bytes = cursor['out']
+        self.out_arena = ctx.malloc(self.out_bytes) if separate_outputs else self.arena
+        self.nbytes = cursor['in'] + cursor['out']
         base = self.arena.ptr
         self.pin = PlanesIn()
         for i, b in enumerate(BAND_NAMES):
@@ -716,10 +723,28 @@ class DeviceBatch:
             self.pin.shad = base + self.offsets['shad']
             self.pin.ocean = base + self.offsets['ocean']
         self.pout = PlanesOut()
+        self._bind_outputs()
+        self.counters_ptr = base + self.offsets['counters']
+
+    def _bind_outputs(self):
+        base = self.out_arena.ptr
         self.pout.diag = base + self.offsets['diag']
         for name in self.out_layers:
             setattr(self.pout, name, base + self.offsets[name])
-        self.counters_ptr = base + self.offsets['counters']
+
+    def new_output_arena(self):
+        """Another allocation that could hold the output planes (separate_outputs only)."""
+        assert self.out_arena is not self.arena, 'DeviceBatch was built with one arena'
+        return self.ctx.malloc(self.out_bytes)
+
+    def use_output_arena(self, buf):
+        """Point the output planes at `buf` (from new_output_arena); returns the arena used before."""
+        old, self.out_arena = self.out_arena, buf
+        self._bind_outputs()
+        return old
+
+    def _arena_of(self, name):
+        return self.out_arena if self._in_out[name] == 'out' else self.arena
 
     def synth(self, seed, tile0=0, stream=None):
         self.ctx.synth_batch(seed, tile0, self.geom, self.pin, stream)
@@ -737,17 +762,19 @@ class DeviceBatch:
         else:
             dt, sz = np.uint8, 1
         off = self.offsets[name] + tile * self.tile_stride * sz
-        return self.arena.download(dt, self.n_pixels, off).reshape(self.height, self.width)
+        return self._arena_of(name).download(dt, self.n_pixels, off).reshape(self.height, self.width)
 
     def write_tile(self, name, tile, arr):
         sz = 2 if name in BAND_NAMES else 1
         dt = np.int16 if name in BAND_NAMES else np.uint8
-        self.arena.upload(np.ascontiguousarray(arr, dtype=dt).ravel(),
-                          self.offsets[name] + tile * self.tile_stride * sz)
+        self._arena_of(name).upload(np.ascontiguousarray(arr, dtype=dt).ravel(),
+                                    self.offsets[name] + tile * self.tile_stride * sz)
 
     def read_counters(self):
         return self.arena.download(np.int64, self.n_tiles * 3,
                                    self.offsets['counters']).reshape(self.n_tiles, 3)
 
     def free(self):
+        if self.out_arena is not self.arena:
+            self.out_arena.free()
         self.arena.free()
