@@ -269,9 +269,16 @@ def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
     from proteus_amd.synth import SEED
     b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=True)
     b.synth(SEED, tile0=tile0)
-    in_bytes = n_tiles * TILE * TILE * (16 if masks else 13)
-    trials = max(1, min(trials, int((235e9 - in_bytes) // b.out_bytes)))     # everything must fit the 288 GB of HBM
-    cands = [b.out_arena] + [b.new_output_arena() for _ in range(trials - 1)]
+    # every candidate must fit beside the batch: bounded by what the device reports free (8 GB kept back)
+    import torch
+    free_bytes, _ = torch.cuda.mem_get_info()
+    trials = max(1, min(trials, 1 + int(max(0, free_bytes - 8e9) // b.out_bytes)))
+    cands = [b.out_arena]
+    for _ in range(trials - 1):
+        try:
+            cands.append(b.new_output_arena())
+        except RuntimeError:          # hipMalloc refused: probe what there is
+            break
     seen = []
     for buf in cands:
         b.use_output_arena(buf)
@@ -387,7 +394,8 @@ def main():
     params = _capi.default_params()
     strong = args.total_tiles > 0
     my_tiles, tile0, n_tiles, chunks = rank_plan(args, rank, world)
-    batch, placement = place_batch(ctx, params, n_tiles, tile0, args.masks, args.placement_trials)
+    batch, placement = place_batch(ctx, params, n_tiles, tile0, args.masks,
+                                   1 if share_device else args.placement_trials)
     barrier = cp.barrier
     # a partial last chunk classifies the first `c` tiles of the resident batch
     geoms = {c: _capi.BatchGeom(c, TILE, TILE, batch.tile_stride) for c in set(chunks)}

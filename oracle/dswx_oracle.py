@@ -377,7 +377,9 @@ def compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
     scalars are float64; numpy 1.23.5, which the reference pins, keeps them float32).
     legacy_promotion=True restates the numpy < 2 behaviour under numpy >= 2 by rounding the
     five sun scalars to float32 first, which is all that value-based casting does to these
-    expressions (UNPINNED: no numpy < 2 in this image to run the reference under)."""
+    expressions.  No numpy < 2 is in this image; the restatement is pinned to fixtures made by the
+    reference's OWN function run with weak (Python float) sun scalars, which is how numpy >= 2 is made to
+    use the float32 loops of numpy 1.23.5 (oracle/gen_golden.py::gen_shadow_legacy, tests/golden/shadow_legacy_*)."""
     sun_azimuth = np.radians(sun_azimuth_angle)
     sun_zenith = np.radians(90 - sun_elevation_angle)
     to_sun = [np.sin(sun_azimuth) * np.sin(sun_zenith),

@@ -369,14 +369,29 @@ SHADOW_CASES = [
     dict(name='s_noon_north', tile=2, H=150, W=170, az=0.0, el=89.0, mn=-5, mx=40),
     dict(name='s_other_thresholds', tile=3, H=160, W=160, az=95.0, el=33.0, mn=2.5, mx=55.5),
     dict(name='s_thin', tile=4, H=102, W=140, az=310.0, el=40.0, mn=-5, mx=40),
+    # terraced DEMs (heights rounded to whole metres: few distinct slopes, many pixels each) with both
+    # thresholds ON frequent float32 angle values, so that hundreds of pixels sit where float32 and
+    # float64 arithmetic part: these are the cases on which the two promotion regimes give different layers
+    dict(name='s_terraced_flat_tie', tile=5, H=200, W=240, az=143.2, el=55.5, terraced=True,
+         mn=0.5720064043998718, mx=34.499996185302734),
+    dict(name='s_terraced_low_sun', tile=6, H=180, W=180, az=231.7, el=18.25, terraced=True,
+         mn=0.5918244123458862, mx=72.34337615966797),
+    dict(name='s_terraced_high_sun', tile=8, H=160, W=200, az=10.0, el=70.0, terraced=True,
+         mn=0.9403377175331116, mx=20.940963745117188),
 ]
+
+
+def _shadow_dem(case):
+    from proteus_amd.synth import synth_dem
+    dem = synth_dem(case['tile'], case['H'], case['W'])
+    return np.round(dem).astype(np.float32) if case.get('terraced') else dem
 
 
 def gen_shadow(ref):
     from proteus_amd.synth import synth_dem
     margin = ref.DEM_MARGIN_IN_PIXELS
     for case in SHADOW_CASES:
-        dem = synth_dem(case['tile'], case['H'], case['W'])
+        dem = _shadow_dem(case)
         full = ref._compute_opera_shadow_layer(dem, case['az'], case['el'], case['mn'], case['mx'])
         cropped = ref._crop_2d_array_all_sides(full, margin)
         np.savez_compressed(os.path.join(GOLDEN, f"shadow_{case['name']}.npz"), dem=dem,
@@ -385,6 +400,58 @@ def gen_shadow(ref):
                             margin=np.array(margin), full=full, cropped=cropped,
                             numpy_version=np.array(np.__version__))
         print('shadow', case['name'], full.dtype, float(full.mean()))
+
+
+class _WeakScalarNumpy:
+    """numpy as the reference module sees it while the 'legacy' shadow goldens are made: every
+    attribute is numpy's own, except that radians / sin / cos / sqrt of a SCALAR return a Python float
+    instead of an np.float64.
+
+    Why that reproduces numpy 1.23.5 (which the reference pins, setup.py:78) under numpy >= 2: the only
+    place the two promotion regimes part in _compute_opera_shadow_layer :4246-4281 is where a float32
+    ARRAY meets one of the float64 SCALARS derived from the sun angles.  numpy < 2 (value-based casting)
+    keeps such an operation in float32, with the scalar converted to float32 first; numpy >= 2 (NEP 50)
+    makes it float64 -- unless the scalar is a Python float, which NEP 50 treats as weak: float32 loop,
+    scalar converted to float32 first, i.e. exactly what value-based casting did.  Scalar-with-scalar
+    arithmetic is double precision in all three cases.  So the reference's OWN code runs, expression by
+    expression, with the arithmetic numpy 1.23.5 would give it; only the scalar type is swapped."""
+    _SCALAR_FUNCS = ('radians', 'sin', 'cos')
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        attr = getattr(self._real, name)
+        if name in self._SCALAR_FUNCS:
+            def weak(x, *a, **k):
+                out = attr(x, *a, **k)
+                return float(out) if np.ndim(out) == 0 else out
+            return weak
+        return attr
+
+
+def gen_shadow_legacy(ref):
+    """'legacy' fixtures: the reference's _compute_opera_shadow_layer itself, executed with
+    _WeakScalarNumpy in place of its module-level `np` (restored afterwards)."""
+    from proteus_amd.synth import synth_dem
+    margin = ref.DEM_MARGIN_IN_PIXELS
+    real = ref.np
+    ref.np = _WeakScalarNumpy(real)
+    try:
+        for case in SHADOW_CASES:
+            dem = _shadow_dem(case)
+            full = ref._compute_opera_shadow_layer(dem, case['az'], case['el'], case['mn'], case['mx'])
+            assert full.dtype == np.bool_
+            cropped = ref._crop_2d_array_all_sides(full, margin)
+            np.savez_compressed(os.path.join(GOLDEN, f"shadow_legacy_{case['name']}.npz"), dem=dem,
+                                az=np.array(case['az']), el=np.array(case['el']),
+                                mn=np.array(case['mn']), mx=np.array(case['mx']),
+                                margin=np.array(margin), full=full, cropped=cropped,
+                                numpy_version=np.array(np.__version__),
+                                promotion=np.array('numpy < 2 value-based casting, emulated by weak scalars'))
+            print('shadow legacy', case['name'], float(full.mean()))
+    finally:
+        ref.np = real
 
 
 def gen_browse(ref):
@@ -458,6 +525,7 @@ def main():
         gen_tiles(ref)
     if 'shadow' in which:
         gen_shadow(ref)
+        gen_shadow_legacy(ref)
 
 
 if __name__ == '__main__':

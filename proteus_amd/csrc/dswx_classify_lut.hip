@@ -3,7 +3,8 @@
 //
 // Block = 256 threads = 2048 consecutive pixels of one tile (grid.y = tile); each thread owns one
 // 8-pixel group: 6 x 16-B + 1 x 8-B non-temporal loads (+ 3 x 8 B with LAND / SHAD / OCEAN),
-// 1 x 16-B + 6 x 8-B non-temporal stores.  The tables (2 KiB; 2.5 KiB with masks) are built on
+// 1 x 16-B + 6 x 8-B non-temporal stores.  The tables (2 KiB; 2.5 KiB with masks; + 2 KiB in the EXTRAS
+// instantiations) are built on
 // the device by dswx_build_tables from the same px_w1 / px_chain / finish_px the scalar kernel
 // uses (rebuilt when the parameters change) and copied into LDS by every block.
 #include <cstdio>
@@ -23,20 +24,20 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
     __shared__ uint8_t s_land8[MASKS ? 256 : 4];
     __shared__ uint16_t s_pre16[MASKS ? 128 : 2];
     __shared__ uint2 s_chain[128];
-    __shared__ uint32_t s_extra[EXTRAS ? 128 : 1];
+    __shared__ uint2 s_extra[EXTRAS ? 256 : 1];
     {   // 2 KiB of tables (2.5 KiB with masks) per block: one element per thread and table
         const int i = threadIdx.x;
         if (i < 128) {
             s_lut1[i] = tabs->lut1[i];
             reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
             s_chain[i] = MASKS ? tabs->chainm[i] : tabs->chain[i];
-            if (EXTRAS) s_extra[i] = MASKS ? tabs->extram[i] : tabs->extra[i];
         } else if (MASKS) {
             const int k = i - 128;
             if (k < 64) reinterpret_cast<uint32_t*>(s_land8)[k] = reinterpret_cast<const uint32_t*>(tabs->land8)[k];
             else reinterpret_cast<uint32_t*>(s_pre16)[k - 64] = reinterpret_cast<const uint32_t*>(tabs->pre16)[k - 64];
         }
     }
+    if (EXTRAS) s_extra[threadIdx.x] = MASKS ? tabs->extram[threadIdx.x] : tabs->extra[threadIdx.x];
     __syncthreads();
 
     const DevParams& P = a.P;
@@ -69,14 +70,14 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         lut_group<MASKS, EXTRAS>(P, C, s_lut1, s_fm16, s_land8, s_chain, s_pre16, v, vf, vl, vs, vo, has_l, in_range,
                                  w1w, chx, chy, cnt, idx2);
         if (EXTRAS && in_range) {
-            uint32_t ex[8], pa[4], pb[4];     // byte 0 cover state (+ adjacent bit), byte 2 browse
+            uint32_t ex[8], pa[4], pb[4];     // byte 0 cover state (adjacent bit included), byte 2 browse
+            uint32_t bitmaps = 0;             // [snow8, area8, area-and-water8, clear8], pixel j = bit j of every byte
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ex[j] = s_extra[idx2[j] & 127u] | (idx2[j] & 128u);
+            for (int j = 0; j < 8; ++j) { const uint2 e = s_extra[idx2[j]]; ex[j] = e.x; bitmaps |= e.y << j; }
             transpose4(ex, pa); transpose4(ex + 4, pb);
             if (a.cover_state) {              // read back by stages 2 / 3 only after the whole batch: stream them out
                 stg<u32x2, true>(a.cover_state + off, u32x2{pa[0], pb[0]});
-                __builtin_nontemporal_store(cover_nibbles(pa[0]) | cover_nibbles(pb[0]) << 4,
-                                            a.cover_bits + (long long)blockIdx.y * a.cover_bits_stride + grp);
+                __builtin_nontemporal_store(bitmaps, a.cover_bits + (long long)blockIdx.y * a.cover_bits_stride + grp);
             }
             if (a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{pa[2], pb[2]});
         }
@@ -132,12 +133,13 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
     const bool extras = b.out.browse || b.cover_state;
 #define LUT_LAUNCH(M, E, W) hipLaunchKernelGGL((dswx_classify_lut<M, E, W>), grid, block, 0, s, b, lc, tabs)
 #define LUT_SEL_W(M, E) do { if (wps >= 6) LUT_LAUNCH(M, E, 6); else if (wps == 5) LUT_LAUNCH(M, E, 5); else LUT_LAUNCH(M, E, 4); } while (0)
-    const bool ex4 = ctx->tune_lut_wps == 4;      // lab A/B: masks + extras at 4 waves per SIMD (128 VGPRs: 5 dwords spill)
-    if (extras) { if (masks && ex4) LUT_LAUNCH(true, true, 4); else if (masks) LUT_LAUNCH(true, true, 3); else LUT_LAUNCH(false, true, 4); }
+    // masks + extras: 125 VGPRs at a bound of 4 (no spill) since the cover bitmaps come from the table; lab A/B: 3
+    const bool ex3 = ctx->tune_lut_wps == 3;
+    if (extras) { if (masks && ex3) LUT_LAUNCH(true, true, 3); else if (masks) LUT_LAUNCH(true, true, 4); else LUT_LAUNCH(false, true, 4); }
     else if (masks) LUT_SEL_W(true, false);
     else LUT_SEL_W(false, false);
     snprintf(info, info_len, "dswx_classify_lut<%s%s> (table-driven) grid=(%lld,%lld) block=256 wps=%d",
              masks ? "true" : "false", extras ? ",extras" : "", (long long)grid.x, (long long)grid.y,
-             extras ? (masks && !ex4 ? 3 : 4) : wps);
+             extras ? (masks && ex3 ? 3 : 4) : wps);
     return DSWX_OK;
 }

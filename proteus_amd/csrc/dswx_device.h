@@ -116,6 +116,12 @@ __device__ __forceinline__ uint32_t cover_flags_of(uint32_t state) {
     const uint32_t water = ((state & 7u) - 1u) <= 3u ? 1u : 0u;
     return ((state >> 6) & 1u) | area << 1 | (area & water) << 2 | clear0 << 3;
 }
+// The flags of one pixel spread over a dword, flag q in bit 0 of byte q: pixel j of an 8-pixel group adds
+// cover_spread_of(state) << j to the group's bitmap dword (what the table-driven stage 1 looks up per pixel).
+__device__ __forceinline__ uint32_t cover_spread_of(uint32_t state) {
+    const uint32_t f = cover_flags_of(state);
+    return (f & 1u) | ((f >> 1) & 1u) << 8 | ((f >> 2) & 1u) << 16 | ((f >> 3) & 1u) << 24;
+}
 // Eight pixels' flags -> the bitmap dword stage 1 stores per 8-pixel group: byte q = bit q of the flags
 // of pixels 0..7 (pixel j = bit j): [snow8, area8, area-and-water8, clear8].
 __device__ __forceinline__ uint32_t cover_bits_of(const uint32_t (&flags)[8]) {

@@ -27,8 +27,9 @@ struct Tables {
     uint2 chain[128];      // [code | remap<<3 | shadow<<4 | cloud<<5 | snow<<6]
                            //   -> x = WTR-1-AEROSOL | WTR-2<<8 | WTR<<16 | BWTR<<24,
                            //      y = CONF | CLOUD<<8 | valid<<16 | cloud_and_valid<<24
-    uint32_t extra[128];   // same index -> cover state byte (cover_state_of: stage 1 of 'cover' mode)
-                           //   | browse << 16; read only by the EXTRAS kernels
+    uint2 extra[256];      // chain index | Fmask adjacent << 7 -> x = cover state byte (cover_state_of | adjacent << 7:
+                           //   stage 1 of 'cover' mode) | browse << 16, y = the four dilation predicates of the
+                           //   pixel spread over the bytes (cover_spread_of); read only by the EXTRAS kernels
     // with LAND / SHAD planes the chain factors at WTR-2 into two 128-entry lookups (2.5 KiB of
     // tables per block instead of the 9.5 KiB of a flat 1024-entry table, whose per-block load
     // cost 5 % of the kernel):
@@ -36,7 +37,7 @@ struct Tables {
                            //   -> WTR-1-AEROSOL as saved | WTR-2 code << 8
     uint2 chainm[128];     // [WTR-2 code | remap<<3 | shadow<<4 | cloud<<5 | snow<<6] -> x, y as `chain`
                            //   (byte 0 of x unused: WTR-1-AEROSOL comes from pre16)
-    uint32_t extram[128];  // same index as chainm, content as `extra`
+    uint2 extram[256];     // chainm index | adjacent << 7, content as `extra`
 };
 // WTR-1 / WTR-2 "code": 0..4 = class, 5 = ocean masked (254), 6 = fill (255)
 
@@ -57,7 +58,6 @@ static __global__ __launch_bounds__(256) void dswx_build_tables(const DevParams 
         px_chain(P, class_of(code), remap, shadow + 4u * cloud, snow, false, false, false, o);
         t->chain[i] = make_uint2(o.wtr1a | o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24,
                                  o.conf | o.cloud << 8 | valid << 16 | (valid & pc_nz) << 24);
-        t->extra[i] = o.state | o.browse << 16;
         // first factor: here bits 4..6 of i are the three LAND / SHAD rule hits
         px_chain(P, class_of(code), remap, 0u, false, (i >> 4) & 1, (i >> 5) & 1, (i >> 6) & 1, o);
         t->pre16[i] = (uint16_t)(o.wtr1a | code_of(o.w2_raw) << 8);
@@ -67,9 +67,19 @@ static __global__ __launch_bounds__(256) void dswx_build_tables(const DevParams 
         finish_px(P, w2, pc, snow, o);
         t->chainm[i] = make_uint2(o.wtr2 << 8 | o.wtr << 16 | o.bwtr << 24,
                                   o.conf | o.cloud << 8 | valid << 16 | (valid & pc_nz) << 24);
-        t->extram[i] = cover_state_of(w2, pc, snow != 0u) | o.browse << 16;
     }
     if (i < 256) {
+        {   // EXTRAS tables: bits 0-6 = the chain index of the pixel, bit 7 = its Fmask adjacent bit
+            const uint32_t code = i & 7, remap = (i >> 3) & 1, shadow = (i >> 4) & 1, cloud = (i >> 5) & 1, snow = (i >> 6) & 1;
+            const uint32_t adj = ((uint32_t)i >> 7) << 7;
+            PxOut o;
+            px_chain(P, class_of(code), remap, shadow + 4u * cloud, snow, false, false, false, o);
+            t->extra[i] = make_uint2(o.state | adj | o.browse << 16, cover_spread_of(o.state | adj));
+            const uint32_t w2 = class_of(code), pc = (shadow + 4u * cloud) | ((remap && code < 5u) ? 8u : 0u);
+            finish_px(P, w2, pc, snow, o);
+            const uint32_t st = cover_state_of(w2, pc, snow != 0u) | adj;
+            t->extram[i] = make_uint2(st | o.browse << 16, cover_spread_of(st));
+        }
         const uint32_t aer = (P.aer_lut[i >> 2] >> (8 * (i & 3))) & 0x1fu;
         const uint32_t shadow = (i & P.shadow_bits) ? 1u : 0u, cloud = (i >> 1) & 1u, snow = (i >> 4) & 1u;
         t->fm16[i] = (uint16_t)(aer | shadow << 5 | cloud << 6 | snow << 7 | (i == P.fmask_fill ? 1u : 0u) << 8 |
@@ -106,19 +116,6 @@ struct LutConsts {
     uint32_t force4, force5, force_dark, force_noaer;   // 0x80008000 when a threshold lies outside int16
     int32_t awesh_init;                 // -awesh4_min
 };
-
-// 'cover' stage 1, byte-parallel: four state bytes (adjacent bit included) -> the four predicate nibbles,
-// one per byte: snow | area << 8 | (area & water) << 16 | clear << 24, pixel p = bit p of its nibble.
-__device__ __forceinline__ uint32_t cover_nibbles(uint32_t s) {
-    auto zero_bytes = [](uint32_t v) { return (~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu)) >> 7; };
-    auto gather = [](uint32_t x) { return (x | x >> 7 | x >> 14 | x >> 21) & 0xfu; };     // 0/1 per byte -> nibble
-    const uint32_t snow4 = (s >> 6) & 0x01010101u, clear4 = zero_bytes(s & 0x38383838u);
-    const uint32_t area4 = (s >> 7) & clear4;
-    const uint32_t code4 = s & 0x07070707u;
-    // water classes: code 1..4  <=>  nonzero and (code + 3) has bit 3 clear
-    const uint32_t water4 = ~zero_bytes(code4) & ~((code4 + 0x03030303u) >> 3) & 0x01010101u;
-    return gather(snow4) | gather(area4) << 8 | gather(area4 & water4) << 16 | gather(clear4) << 24;
-}
 
 // 4 pixels' table words -> 4 plane dwords (byte k of every word -> plane k)
 __device__ __forceinline__ void transpose4(const uint32_t a[4], uint32_t out[4]) {
@@ -206,7 +203,7 @@ __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C
                 }
                 const uint2 ch = s_chain[idx2];
                 w1w[j] = word1; chx[j] = MASKS ? (ch.x | w1a) : ch.x; chy[j] = ch.y;
-                if (WANT_IDX) idx_out[j] = idx2 | ((F >> 10) & 1u) << 7;   // chain index for Tables::extra | adjacent << 7
+                if (WANT_IDX) idx_out[j] = idx2 | ((F >> 3) & 128u);       // chain index | adjacent << 7: index of Tables::extra
                 gsum += ch.y >> 16;                  // A3: valid | cloud_and_valid << 8, from the table
             }
         }

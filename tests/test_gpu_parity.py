@@ -568,21 +568,29 @@ def test_cover_mode_device_batch(ctx):
 
 
 # ---- terrain shadow layer --------------------------------------------
-@pytest.mark.parametrize('name', ['s_default', 's_low_sun', 's_noon_north',
-                                  's_other_thresholds', 's_thin'])
-def test_shadow_layer_golden(ctx, name):
-    """Against the reference's own output.  The goldens were generated by importing the reference under
-    numpy 2.2 (oracle/gen_golden.py), i.e. they pin numpy_promotion='nep50'; the host mirror's DEFAULT is
-    'legacy' (the numpy 1.23.5 the reference pins), covered by test_shadow_layer_legacy_float32_promotion."""
+SHADOW_GOLDENS = ['s_default', 's_low_sun', 's_noon_north', 's_other_thresholds', 's_thin',
+                  's_terraced_flat_tie', 's_terraced_low_sun', 's_terraced_high_sun']
+
+
+@pytest.mark.parametrize('promotion', ['nep50', 'legacy'])
+@pytest.mark.parametrize('name', SHADOW_GOLDENS)
+def test_shadow_layer_golden(ctx, name, promotion):
+    """Against the reference's own output in both promotion regimes (oracle/gen_golden.py): 'nep50' fixtures =
+    the reference imported under numpy 2.2 as it is; 'legacy' fixtures (the host mirror's DEFAULT: numpy 1.23.5
+    is what the reference pins) = the reference's own function run with weak sun scalars, which gives its
+    expressions the float32 loops of value-based casting.  The terraced cases put hundreds of pixels where
+    the two regimes differ."""
     from proteus_amd import dswx_hls as D
-    z = G.load(f'shadow_{name}.npz')
+    z = G.load(f'shadow_{name}.npz' if promotion == 'nep50' else f'shadow_legacy_{name}.npz')
     args = (float(z['az']), float(z['el']), float(z['mn']), float(z['mx']))
-    full = D._compute_opera_shadow_layer(z['dem'], *args, numpy_promotion='nep50')
+    full = D._compute_opera_shadow_layer(z['dem'], *args, numpy_promotion=promotion)
     assert full.dtype == np.bool_ and full.shape == z['dem'].shape
     assert np.array_equal(full, z['full'])
     m = int(z['margin'])
-    assert np.array_equal(D._compute_opera_shadow_layer(z['dem'], *args, margin=m, numpy_promotion='nep50'), z['cropped'])
+    assert np.array_equal(D._compute_opera_shadow_layer(z['dem'], *args, margin=m, numpy_promotion=promotion), z['cropped'])
     assert np.array_equal(D._crop_2d_array_all_sides(full, m), z['cropped'])
+    if promotion == 'legacy':       # and it is the default
+        assert np.array_equal(D._compute_opera_shadow_layer(z['dem'], *args), z['full'])
 
 
 def test_shadow_layer_full_size(ctx):
@@ -632,8 +640,9 @@ def test_shadow_layer_random_geometry_sweep(ctx):
 
 def test_shadow_layer_legacy_float32_promotion(ctx):
     """numpy < 2 value-based casting (the numpy 1.23.5 the reference pins): all-float32 arithmetic.
-    UNPINNED against the reference (no numpy < 2 here); pinned against the oracle's restatement of
-    that casting, bit-exact over random geometries, and through the host mirror's switch."""
+    The oracle's restatement of that casting is pinned to reference-made fixtures by
+    test_oracle_golden.py::test_shadow_layer_legacy_promotion; here the device path follows it bit-exactly
+    over random geometries, and through the host mirror's switch."""
     from proteus_amd import dswx_hls as D
     from proteus_amd.synth import synth_dem
     rng = np.random.default_rng(7)

@@ -139,7 +139,8 @@ def test_tile_chain(name):
         assert got == c['expected']['counters'].tolist()
 
 
-SHADOW_CASES = ['s_default', 's_low_sun', 's_noon_north', 's_other_thresholds', 's_thin']
+SHADOW_CASES = ['s_default', 's_low_sun', 's_noon_north', 's_other_thresholds', 's_thin',
+                's_terraced_flat_tie', 's_terraced_low_sun', 's_terraced_high_sun']
 
 
 @pytest.mark.parametrize('name', SHADOW_CASES)
@@ -152,6 +153,25 @@ def test_shadow_layer(name):
     assert full.dtype == np.bool_ and np.array_equal(full, z['full'])
     assert np.array_equal(o.crop_2d_array_all_sides(full, int(z['margin'])), z['cropped'])
     assert 0.05 < z['cropped'].mean() < 0.95        # both classes present
+
+
+@pytest.mark.parametrize('name', SHADOW_CASES)
+def test_shadow_layer_legacy_promotion(name):
+    """numpy < 2 value-based casting (numpy 1.23.5 is what the reference pins): fixtures made by running the
+    reference's own _compute_opera_shadow_layer with weak (Python float) sun scalars, which is what makes
+    numpy >= 2 use the float32 loops numpy 1.23.5 used (oracle/gen_golden.py::_WeakScalarNumpy)."""
+    z = G.load(f'shadow_legacy_{name}.npz')
+    full = o.compute_opera_shadow_layer(z['dem'], float(z['az']), float(z['el']),
+                                        float(z['mn']), float(z['mx']), legacy_promotion=True)
+    assert full.dtype == np.bool_ and np.array_equal(full, z['full'])
+    assert np.array_equal(o.crop_2d_array_all_sides(full, int(z['margin'])), z['cropped'])
+    other = G.load(f'shadow_{name}.npz')
+    assert np.array_equal(other['dem'], z['dem'])
+    n_diff = int(np.count_nonzero(other['full'] != z['full']))
+    if 'terraced' in name:      # the cases built so that the two regimes give different layers
+        assert n_diff > 100, n_diff
+    else:
+        assert n_diff < 1e-3 * full.size
 
 
 def test_browse_tables():

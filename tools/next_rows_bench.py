@@ -110,7 +110,7 @@ def main():
     if a.lab:
         # window width A/B of the stage-2 kernel through the lab switch (libdswx_lab.so)
         for name, switch in (('window_4_words', {'cover_kernel': 4}), ('window_8_words_direct', {'cover_kernel': 24}),
-                             ('stage1_4_waves_per_simd', {'tune_lut_wps': 4})):
+                             ('stage1_3_waves_per_simd', {'tune_lut_wps': 3})):
             c4 = _capi.Context(0)
             c4.lab_configure(**switch)
             avg4, mn4 = timed(c4, lambda: c4.classify_batch(pc, batch.geom, batch.pin, batch.pout, batch.counters_ptr), a.reps)
