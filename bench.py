@@ -47,8 +47,8 @@ def parse_args():
                     help='N = 1: after the timed region, re-allocate the batch this many times and report the '
                          'spread of the kernel rate (it depends on where the arena lands, DESIGN.md section 5)')
     ap.add_argument('--placement-trials', type=int, default=6,
-                    help='allocate this many candidate arenas for the output planes and keep the one the kernel runs '
-                         'fastest on (1 = first)')
+                    help='candidate allocations per output plane; each plane keeps the one under which the kernel runs '
+                         'fastest (1 = first come)')
     ap.add_argument('--plan-only', action='store_true',
                     help='no GPU work: bring the ranks up (gloo), print the sharding plan of this command line as '
                          'JSON and exit (tests/test_shard_gloo.py drives the launcher path with it)')
@@ -258,30 +258,23 @@ def realloc_spread(ctx, params, n_tiles, masks, repeats, launches=5):
 
 
 def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
-    """Allocate the resident batch.  The kernel's rate depends on WHERE in HBM its output planes land: a stable
-    property of the physical range (tools/placement_probe.py, profiles/r02_placement_probe.json: reads stream at
-    ~7.1 TB/s everywhere, writes at 5.7 - 5.9 TB/s in most ranges and 6.4 - 7.1 in a few, and the fused kernel
-    follows the write side), so a long-lived arena is worth choosing.  The inputs get one allocation; up to
-    `trials` candidate allocations for the OUTPUT planes are made side by side (each covers a different physical
-    range; a freed range would simply be handed out again), `launches` launches are timed on each, the fastest is
-    kept and the others are freed.  Outside the timed region; `--placement-trials 1` takes the first."""
+    """Allocate the resident batch.  The kernel's rate depends on WHERE in HBM its output planes land -- a stable
+    property of the physical ranges (tools/placement_probe.py, tools/slab_probe.py, profiles/r02_placement_probe.json,
+    profiles/r02_slab_probe.json: reads stream at ~7.1 TB/s everywhere; with the seven write streams in different
+    ranges the same launch takes 11.3 - 12.0 ms, and moving ONE u8 plane changes it by up to 1.5 %, repeatably) --
+    so a long-lived batch is worth placing.  The inputs get one allocation and every output plane its own; beside
+    them `trials - 1` spare allocations per output plane are made (side by side: a freed range would simply be
+    handed out again), and one pass of coordinate descent binds each plane in turn (DIAG first) to the candidate
+    under which `launches` launches of the real kernel run fastest.  The spares are freed afterwards.  Outside the
+    timed region; `--placement-trials 1` takes what comes first."""
     from proteus_amd import _capi
     from proteus_amd.synth import SEED
+    import torch
     b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=True)
     b.synth(SEED, tile0=tile0)
-    # every candidate must fit beside the batch: bounded by what the device reports free (8 GB kept back)
-    import torch
-    free_bytes, _ = torch.cuda.mem_get_info()
-    trials = max(1, min(trials, 1 + int(max(0, free_bytes - 8e9) // b.out_bytes)))
-    cands = [b.out_arena]
-    for _ in range(trials - 1):
-        try:
-            cands.append(b.new_output_arena())
-        except RuntimeError:          # hipMalloc refused: probe what there is
-            break
-    seen = []
-    for buf in cands:
-        b.use_output_arena(buf)
+    names = ['diag'] + list(b.out_layers)
+
+    def launch_ms():
         b.classify(params)
         ctx.synchronize()
         e0, e1 = ctx.event(), ctx.event()
@@ -290,15 +283,50 @@ def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
             b.classify(params)
         ctx.record(e1)
         ctx.synchronize()
-        seen.append(round(ctx.elapsed_ms(e0, e1) / launches, 4))
+        ms = ctx.elapsed_ms(e0, e1) / launches
         ctx.destroy_event(e0)
         ctx.destroy_event(e1)
-    keep = seen.index(min(seen))
-    b.use_output_arena(cands[keep])
-    for k, buf in enumerate(cands):
-        if k != keep:
+        return ms
+
+    # spare candidates: whole sets of output planes, as many as fit beside the batch (8 GB kept back)
+    free_bytes, _ = torch.cuda.mem_get_info()
+    sets = max(0, min(trials - 1, int(max(0, free_bytes - 8e9) // b.out_bytes)))
+    pools = {}          # plane size -> spare buffers
+    try:
+        for _ in range(sets):
+            for name in names:
+                pools.setdefault(b.plane_nbytes[name], []).append(b.new_plane_buffer(name))
+    except RuntimeError:            # hipMalloc refused: search among what there is
+        pass
+    original = {name: b.out_bufs[name] for name in names}
+    everything = list(original.values()) + [buf for pool in pools.values() for buf in pool]
+    first_ms = launch_ms()
+    probes = 0
+    for name in names:
+        pool = pools.get(b.plane_nbytes[name], [])
+        if not pool:
+            continue
+        best_ms, best_k = launch_ms(), None
+        for k, buf in enumerate(pool):
+            old = b.bind_output(name, buf)
+            ms = launch_ms()
+            probes += 1
+            b.bind_output(name, old)
+            if ms < best_ms:
+                best_ms, best_k = ms, k
+        if best_k is not None:
+            pool[best_k] = b.bind_output(name, pool[best_k])
+    kept_ms = launch_ms() if probes else first_ms
+    if kept_ms >= first_ms:          # the search bought nothing (noise): stay with what came first
+        for name in names:
+            b.bind_output(name, original[name])
+        kept_ms = first_ms
+    bound = {id(buf) for buf in b.out_bufs.values()}
+    for buf in everything:
+        if id(buf) not in bound:
             buf.free()
-    return b, {'trials': len(seen), 'probe_launch_ms': seen, 'kept_ms': seen[keep]}
+    return b, {'trials': sets + 1, 'probes': probes, 'first_come_launch_ms': round(first_ms, 4),
+               'kept_launch_ms': round(kept_ms, 4)}
 
 
 def free_port():
@@ -474,10 +502,11 @@ def main():
                        'planes_in': 10 if args.masks else 7, 'planes_out': 7,
                        'sharding': f'tiles by rank x{world}, no collective',
                        'control_plane': cp.backend,
-                       'arena_placement': dict(placement, note='output planes in the fastest of `trials` candidate '
-                                               'allocations, chosen before warm-up (the rate is a property of the physical '
-                                               'range the writes land in; roofline.realloc_spread shows what arbitrary '
-                                               'single-arena placements give)'),
+                       'arena_placement': dict(placement, note='every output plane in the fastest of `trials` candidate '
+                                               'allocations (one pass of coordinate descent with the kernel itself as the '
+                                               'probe, before warm-up): the rate is a property of the physical ranges the '
+                                               'seven write streams land in; roofline.realloc_spread shows what arbitrary '
+                                               'single-arena placements give'),
                        'kernel': kernel_info},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),

@@ -662,7 +662,8 @@ class Context:
 class DeviceBatch:
     """Band-planar batch resident in HBM: every plane is [n_tiles][tile_stride].
 
-    Owns one arena (two with separate_outputs); plane offsets are 256-byte aligned and, by default, the tile stride is
+    Owns one arena (with separate_outputs: one for the inputs and one allocation per output plane); plane offsets are
+    256-byte aligned and, by default, the tile stride is
     H*W rounded up to a multiple of 256 pixels, so every tile starts on a 256-byte boundary
     in every plane (contiguous tiles of 3660 x 3660 do not: 13,395,600 = 144 mod 256, which
     costs ~20 % of the HBM rate).  `tile_align=1` gives contiguous tiles.
@@ -671,9 +672,9 @@ class DeviceBatch:
 
     def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=(), tile_align=256, plane_skew=0,
                  separate_outputs=False):
-        """separate_outputs: the output planes get an allocation of their own (`out_arena`), so that it can
-        be chosen among several candidates (`new_output_arena` / `use_output_arena`): on MI355X the kernel's
-        rate depends on which physical range its WRITE streams land in."""
+        """separate_outputs: every output plane gets an allocation of its own, so that each can be chosen among
+        several candidates (`new_plane_buffer` / `bind_output`): on MI355X the kernel's rate depends on which
+        physical ranges its WRITE streams land in."""
         self.ctx, self.n_tiles, self.height, self.width = ctx, n_tiles, height, width
         self.n_pixels = height * width
         self.tile_stride = -(-self.n_pixels // tile_align) * tile_align
@@ -685,16 +686,21 @@ class DeviceBatch:
         cursor = {'in': 0, 'out': 0}
         skew = int(plane_skew)
 
+        self.plane_nbytes = {}
+
         def take(name, nbytes, side):
             # optional skew: plane k starts k*skew bytes later than plain packing,
             # so equal pixel indices of different planes differ in their low
             # address bits (DRAM channel / bank selection)
-            side = side if separate_outputs else 'in'
-            off = cursor[side] + skew * len(self.offsets)
+            self._in_out[name] = side
+            self.plane_nbytes[name] = (nbytes + 255) & ~255
+            if separate_outputs and side == 'out':
+                self.offsets[name] = 0
+                return
+            off = cursor['in'] + skew * len(self.offsets)
             off = (off + 255) & ~255
             self.offsets[name] = off
-            self._in_out[name] = side
-            cursor[side] = off + ((nbytes + 255) & ~255)
+            cursor['in'] = off + ((nbytes + 255) & ~255)
 
         for b in BAND_NAMES:
             take(b, total * 2, 'in')
@@ -710,9 +716,10 @@ class DeviceBatch:
             take(name, total, 'out')
         take('counters', n_tiles * 24, 'in')
         self.arena = ctx.malloc(cursor['in'])
-        self.out_bytes = cursor['out']
-        self.out_arena = ctx.malloc(self.out_bytes) if separate_outputs else self.arena
-        self.nbytes = cursor['in'] + cursor['out']
+        out_names = ['diag'] + self.out_layers
+        self.out_bufs = {n: ctx.malloc(self.plane_nbytes[n]) for n in out_names} if separate_outputs else {}
+        self.out_bytes = sum(self.plane_nbytes[n] for n in out_names)
+        self.nbytes = cursor['in'] + (self.out_bytes if separate_outputs else 0)
         base = self.arena.ptr
         self.pin = PlanesIn()
         for i, b in enumerate(BAND_NAMES):
@@ -727,24 +734,23 @@ class DeviceBatch:
         self.counters_ptr = base + self.offsets['counters']
 
     def _bind_outputs(self):
-        base = self.out_arena.ptr
-        self.pout.diag = base + self.offsets['diag']
-        for name in self.out_layers:
-            setattr(self.pout, name, base + self.offsets[name])
+        for name in ['diag'] + self.out_layers:
+            setattr(self.pout, name, self._arena_of(name).ptr + self.offsets[name])
 
-    def new_output_arena(self):
-        """Another allocation that could hold the output planes (separate_outputs only)."""
-        assert self.out_arena is not self.arena, 'DeviceBatch was built with one arena'
-        return self.ctx.malloc(self.out_bytes)
+    def new_plane_buffer(self, name):
+        """Another allocation that could hold output plane `name` (separate_outputs only)."""
+        assert self.out_bufs, 'DeviceBatch was built with one arena'
+        return self.ctx.malloc(self.plane_nbytes[name])
 
-    def use_output_arena(self, buf):
-        """Point the output planes at `buf` (from new_output_arena); returns the arena used before."""
-        old, self.out_arena = self.out_arena, buf
-        self._bind_outputs()
+    def bind_output(self, name, buf):
+        """Point output plane `name` at `buf` (from new_plane_buffer); returns the buffer used before."""
+        assert buf.nbytes >= self.plane_nbytes[name]
+        old, self.out_bufs[name] = self.out_bufs[name], buf
+        setattr(self.pout, name, buf.ptr)
         return old
 
     def _arena_of(self, name):
-        return self.out_arena if self._in_out[name] == 'out' else self.arena
+        return self.out_bufs.get(name, self.arena)
 
     def synth(self, seed, tile0=0, stream=None):
         self.ctx.synth_batch(seed, tile0, self.geom, self.pin, stream)
@@ -775,6 +781,7 @@ class DeviceBatch:
                                    self.offsets['counters']).reshape(self.n_tiles, 3)
 
     def free(self):
-        if self.out_arena is not self.arena:
-            self.out_arena.free()
+        for buf in self.out_bufs.values():
+            buf.free()
+        self.out_bufs = {}
         self.arena.free()
