@@ -48,7 +48,7 @@ def parse_args():
                          'spread of the kernel rate (it depends on where the arena lands, DESIGN.md section 5)')
     ap.add_argument('--placement-trials', type=int, default=6,
                     help='candidate allocations per output plane; each plane keeps the one under which the kernel runs '
-                         'fastest (1 = first come)')
+                         'fastest (1 = first come, 0 = one arena for all planes)')
     ap.add_argument('--plan-only', action='store_true',
                     help='no GPU work: bring the ranks up (gloo), print the sharding plan of this command line as '
                          'JSON and exit (tests/test_shard_gloo.py drives the launcher path with it)')
@@ -266,10 +266,14 @@ def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
     them `trials - 1` spare allocations per output plane are made (side by side: a freed range would simply be
     handed out again), and one pass of coordinate descent binds each plane in turn (DIAG first) to the candidate
     under which `launches` launches of the real kernel run fastest.  The spares are freed afterwards.  Outside the
-    timed region; `--placement-trials 1` takes what comes first."""
+    timed region; `--placement-trials 1` takes what comes first, 0 puts all planes in ONE allocation."""
     from proteus_amd import _capi
     from proteus_amd.synth import SEED
     import torch
+    if trials <= 0:                 # one arena for everything, as a plain caller would allocate it
+        b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks)
+        b.synth(SEED, tile0=tile0)
+        return b, {'trials': 0, 'probes': 0}
     b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=True)
     b.synth(SEED, tile0=tile0)
     names = ['diag'] + list(b.out_layers)
@@ -502,7 +506,8 @@ def main():
                        'planes_in': 10 if args.masks else 7, 'planes_out': 7,
                        'sharding': f'tiles by rank x{world}, no collective',
                        'control_plane': cp.backend,
-                       'arena_placement': dict(placement, note='every output plane in the fastest of `trials` candidate '
+                       'arena_placement': dict(placement, note='one arena for all planes') if not placement['trials'] else
+                       dict(placement, note='every output plane in the fastest of `trials` candidate '
                                                'allocations (one pass of coordinate descent with the kernel itself as the '
                                                'probe, before warm-up): the rate is a property of the physical ranges the '
                                                'seven write streams land in; roofline.realloc_spread shows what arbitrary '

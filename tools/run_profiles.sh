@@ -12,7 +12,7 @@ if [[ "$WHAT" == *hot* ]]; then
 for m in "" "--masks"; do
   d=gpurun_out/prof$( [ -n "$m" ] && echo _masks )
   rm -rf "$d"; mkdir -p "$d"
-  B="python3 bench.py --tiles $TILES $m --no-cpu-baseline --no-single-tile --realloc-repeats 0 --placement-trials 1"
+  B="python3 bench.py --tiles $TILES $m --no-cpu-baseline --no-single-tile --realloc-repeats 0 --placement-trials 0"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -- $B --steps 20 --warmup 3 > "$d/bench_trace.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/pmc_fetch" -- $B --steps 3 --warmup 1 --no-parity > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/pmc_write" -- $B --steps 3 --warmup 1 --no-parity > /dev/null 2>&1

@@ -131,6 +131,21 @@ def main():
             row.append(rate())
         out.setdefault('cloud_sweep', []).append(row)
     out['cloud_sweep_slabs'] = free_small
+    # and the READ side: band 0 copied into every DIAG-sized slab in turn (DIAG stays where the sets above put it)
+    bind(big[base_d], [small[i] for i in base_u])
+    band0 = b.pin.band[0]
+    for rnd in range(2):
+        row = []
+        for d in range(len(big)):
+            if d == base_d:
+                row.append(None)
+                continue
+            hip.check(hip.lib.hipMemcpy(ctypes.c_void_p(big[d].ptr), ctypes.c_void_p(band0), ctypes.c_size_t(2 * S), 3))
+            b.pin.band[0] = big[d].ptr
+            row.append(rate())
+        b.pin.band[0] = band0
+        row.append(rate())             # last entry: band 0 where the arena has it
+        out.setdefault('band0_sweep', []).append(row)
     print(json.dumps(out, indent=1))
 
 
