@@ -257,16 +257,13 @@ def realloc_spread(ctx, params, n_tiles, masks, repeats, launches=5):
             'frac_max': round(rates[-1] / HBM_PEAK_GBS, 4)}
 
 
-def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
+def place_batch(ctx, params, n_tiles, tile0, masks, trials):
     """Allocate the resident batch.  The kernel's rate depends on WHERE in HBM its output planes land -- a stable
     property of the physical ranges (tools/placement_probe.py, tools/slab_probe.py, profiles/r02_placement_probe.json,
-    profiles/r02_slab_probe.json: reads stream at ~7.1 TB/s everywhere; with the seven write streams in different
-    ranges the same launch takes 11.3 - 12.0 ms, and moving ONE u8 plane changes it by up to 1.5 %, repeatably) --
-    so a long-lived batch is worth placing.  The inputs get one allocation and every output plane its own; beside
-    them `trials - 1` spare allocations per output plane are made (side by side: a freed range would simply be
-    handed out again), and one pass of coordinate descent binds each plane in turn (DIAG first) to the candidate
-    under which `launches` launches of the real kernel run fastest.  The spares are freed afterwards.  Outside the
-    timed region; `--placement-trials 1` takes what comes first, 0 puts all planes in ONE allocation."""
+    profiles/r02_slab_probe.json) -- so a long-lived batch is worth placing: the inputs get one allocation, every
+    output plane its own, and DeviceBatch.place_outputs chooses each plane among `trials` candidate allocations with
+    the kernel itself as the probe.  Outside the timed region; `--placement-trials 1` takes what comes first, 0 puts
+    all planes in ONE allocation."""
     from proteus_amd import _capi
     from proteus_amd.synth import SEED
     import torch
@@ -276,61 +273,8 @@ def place_batch(ctx, params, n_tiles, tile0, masks, trials, launches=3):
         return b, {'trials': 0, 'probes': 0}
     b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=True)
     b.synth(SEED, tile0=tile0)
-    names = ['diag'] + list(b.out_layers)
-
-    def launch_ms():
-        b.classify(params)
-        ctx.synchronize()
-        e0, e1 = ctx.event(), ctx.event()
-        ctx.record(e0)
-        for _ in range(launches):
-            b.classify(params)
-        ctx.record(e1)
-        ctx.synchronize()
-        ms = ctx.elapsed_ms(e0, e1) / launches
-        ctx.destroy_event(e0)
-        ctx.destroy_event(e1)
-        return ms
-
-    # spare candidates: whole sets of output planes, as many as fit beside the batch (8 GB kept back)
     free_bytes, _ = torch.cuda.mem_get_info()
-    sets = max(0, min(trials - 1, int(max(0, free_bytes - 8e9) // b.out_bytes)))
-    pools = {}          # plane size -> spare buffers
-    try:
-        for _ in range(sets):
-            for name in names:
-                pools.setdefault(b.plane_nbytes[name], []).append(b.new_plane_buffer(name))
-    except RuntimeError:            # hipMalloc refused: search among what there is
-        pass
-    original = {name: b.out_bufs[name] for name in names}
-    everything = list(original.values()) + [buf for pool in pools.values() for buf in pool]
-    first_ms = launch_ms()
-    probes = 0
-    for name in names:
-        pool = pools.get(b.plane_nbytes[name], [])
-        if not pool:
-            continue
-        best_ms, best_k = launch_ms(), None
-        for k, buf in enumerate(pool):
-            old = b.bind_output(name, buf)
-            ms = launch_ms()
-            probes += 1
-            b.bind_output(name, old)
-            if ms < best_ms:
-                best_ms, best_k = ms, k
-        if best_k is not None:
-            pool[best_k] = b.bind_output(name, pool[best_k])
-    kept_ms = launch_ms() if probes else first_ms
-    if kept_ms >= first_ms:          # the search bought nothing (noise): stay with what came first
-        for name in names:
-            b.bind_output(name, original[name])
-        kept_ms = first_ms
-    bound = {id(buf) for buf in b.out_bufs.values()}
-    for buf in everything:
-        if id(buf) not in bound:
-            buf.free()
-    return b, {'trials': sets + 1, 'probes': probes, 'first_come_launch_ms': round(first_ms, 4),
-               'kept_launch_ms': round(kept_ms, 4)}
+    return b, b.place_outputs(params, candidates=trials, free_bytes=free_bytes)
 
 
 def free_port():

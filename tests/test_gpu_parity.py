@@ -567,6 +567,45 @@ def test_cover_mode_device_batch(ctx):
     batch.free()
 
 
+def test_output_planes_in_separate_allocations(ctx):
+    """DeviceBatch(separate_outputs=True): one allocation per output plane, re-bound among candidates by
+    place_outputs (what bench.py does to the headline batch).  Wherever the planes end up, the layers and
+    counters are those of the one-arena batch and of the oracle."""
+    n_tiles, h, w = 3, 200, 264
+    one = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, extra_layers=('wtr1_aerosol',))
+    sep = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, extra_layers=('wtr1_aerosol',), separate_outputs=True)
+    p = _capi.default_params()
+    for b in (one, sep):
+        b.synth(SEED, tile0=9)
+    before = {name: sep.out_bufs[name].ptr for name in sep.out_bufs}
+    rec = sep.place_outputs(p, candidates=3, launches=1)
+    n_u8 = len(before) - 1          # every u8 plane tries every spare of its size: 2 sets x n_u8 spares
+    assert rec['trials'] == 3 and rec['probes'] == 2 + n_u8 * 2 * n_u8
+    assert rec['kept_launch_ms'] <= rec['first_come_launch_ms']
+    assert len({buf.ptr for buf in sep.out_bufs.values()}) == len(before)          # still one buffer per plane
+    # re-bind one plane by hand as well
+    spare = sep.new_plane_buffer('conf')
+    old = sep.bind_output('conf', spare)
+    assert old.ptr != spare.ptr and sep.pout.conf == spare.ptr
+    old.free()
+    for b in (one, sep):
+        b.classify(p)
+    ctx.synchronize()
+    assert np.array_equal(one.read_counters(), sep.read_counters())
+    for t in range(n_tiles):
+        s_ = synth_tile(9 + t, h, w, with_masks=True)
+        exp = c_oracle.classify(p, s_['bands'], s_['fmask'], land=s_['land'], shad=s_['shad'], ocean=s_['ocean'])
+        for key in ('diag', 'wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+            got = sep.read_tile(key, t)
+            assert np.array_equal(got, one.read_tile(key, t)), (key, t)
+            assert np.array_equal(got, exp[key]), (key, t)
+        assert sep.read_counters()[t].tolist() == exp['counters'].tolist()
+    one.free()
+    sep.free()
+    with pytest.raises(AssertionError):
+        one.place_outputs(p)
+
+
 # ---- terrain shadow layer (SURVEY.md row f1) --------------------------------------------
 SHADOW_GOLDENS = ['s_default', 's_low_sun', 's_noon_north', 's_other_thresholds', 's_thin',
                   's_terraced_flat_tie', 's_terraced_low_sun', 's_terraced_high_sun']
