@@ -36,6 +36,7 @@ struct dswx_ctx {
     int cover_kernel = 8;                  // 'cover' stage 2: words per window row (8 = 256-column windows, 4 = 128)
     int host_pipeline = 1;                 // 0 forces the synchronous host path
     int host_chunks = 8;                   // pieces per tile of the pipelined host path
+    int shadow_grid_pad = 1;               // dswx_shadow_v3: grid.x rounded up to a multiple of this (lab A/B, see the launch)
     std::string last_kernel;
     int tune_lut_wps = 0;    // table-driven kernel: launch bound (4, 5, 6; 0 = automatic)
     int tune_wps = 6;        // launch bound of the direct kernel without masks (4, 6, 8)

@@ -22,7 +22,7 @@ int dswx_lab_attach(dswx_ctx_t* ctx);
 
 /* A/B switches (what round 1 read from DSWX_* environment variables): "fused_variant" (-1 automatic,
  * 0 direct kernel, 3 table-driven kernel, 1/2/4/5 lab structures), "tune_wps", "tune_lut_wps",
- * "tune_ablate", "tune_pipe_blocks", "cover_kernel", "host_pipeline", "host_chunks". */
+ * "tune_ablate", "tune_pipe_blocks", "cover_kernel", "host_pipeline", "host_chunks", "shadow_grid_pad". */
 int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value);
 
 /* Roofline probe: streams exactly the bytes dswx_classify_device streams for the same arguments

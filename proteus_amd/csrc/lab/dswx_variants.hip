@@ -683,6 +683,10 @@ int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value) {
     else if (k == "tune_pipe_blocks") ctx->lab.tune_pipe_blocks = value;
     else if (k == "cover_kernel") ctx->cover_kernel = value;
     else if (k == "host_pipeline") ctx->host_pipeline = value;
+    else if (k == "shadow_grid_pad") {
+        if (value < 1 || value > 64) return dswx_fail(DSWX_ERR_ARG, "shadow_grid_pad out of range");
+        ctx->shadow_grid_pad = value;
+    }
     else if (k == "host_chunks") {
         if (value < 1 || value > 256) return dswx_fail(DSWX_ERR_ARG, "host_chunks out of range");
         ctx->host_chunks = value;

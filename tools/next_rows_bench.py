@@ -73,6 +73,15 @@ def main():
             out['f1_shadow'][f'{tag}_{mode}'] = {
                 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n, 'algorithmic_bytes_per_tile': nbytes // n,
                 'GBps': nbytes / avg / 1e6, 'frac_of_8TBps': nbytes / avg / 1e6 / 8000, 'Mpix_s': n * T * T / avg / 1e3}
+        if a.lab and tag == 'quads_filter_v3':
+            # launch-geometry A/B through the lab switch: grid.x as it comes (15 for 3660 columns) vs padded to 8 | grid.x
+            for pad in (1, 8, 16):
+                c2 = _capi.Context(0)
+                c2.lab_configure(shadow_grid_pad=pad)
+                avg, mn = timed(c2, lambda: c2.shadow_layer_device(d_dem.ptr, n, H, W, margin, sun, np.sin(az), np.cos(az),
+                                                                   -5.0, 40.0, d_sh.ptr, float32=True), a.reps)
+                out['f1_shadow'][f'ab_grid_pad_{pad}_legacy_f32'] = {'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n}
+                c2.close()
         d_dem.free()
         d_sh.free()
     dem = synth_dem(3, T + 2 * MARGIN, T + 2 * MARGIN)
