@@ -277,9 +277,10 @@ int dswx_synth_batch(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0,
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_device_free(dswx_ctx_t* ctx, void* ptr);
 /* Page-locked host memory.  dswx_classify_host() recognises buffers allocated here (or
- * registered with hipHostRegister) and, when EVERY plane pointer is page-locked and the mode
- * is not 'cover', runs upload / classify / download as a three-stream pipeline over pieces
- * of each tile instead of the synchronous copy-compute-copy sequence.  There is no
+ * registered with hipHostRegister) and, when EVERY plane pointer is page-locked, works on
+ * them in place: the host planes are mapped into the device's address space and the kernels
+ * read the inputs and write the layers across PCIe themselves (zero copy, both directions at
+ * once, every mode) instead of the synchronous copy-compute-copy sequence.  There is no
  * reference counterpart (numpy arrays are pageable); results are identical. */
 int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_host_free(dswx_ctx_t* ctx, void* ptr);

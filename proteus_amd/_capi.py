@@ -411,8 +411,8 @@ class Context:
 
     def pinned_empty(self, shape, dtype):
         """numpy array over page-locked memory (dswx_host_alloc).  When every plane handed to
-        classify_host() is such an array the library pipelines upload / classify / download
-        over three streams; outputs are then allocated page-locked as well.  Page-locking is
+        classify_host() is such an array the library works on them in place (zero copy: the kernels
+        read and write the host planes across PCIe); outputs are then allocated page-locked as well.  Page-locking is
         slow (~0.1 ms per MB), so released spans go to a per-context pool and are reused."""
         dtype = np.dtype(dtype)
         nbytes = max(int(np.prod(shape, dtype=np.int64)) * dtype.itemsize, 1)

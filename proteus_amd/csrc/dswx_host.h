@@ -34,7 +34,8 @@ struct dswx_ctx {
     // Fixed in production; libdswx_lab.so (experiments, A/B tools, variant tests) changes them through
     // dswx_lab_configure -- the product library reads no environment variable.
     int cover_kernel = 8;                  // 'cover' stage 2: words per window row (8 = 256-column windows, 4 = 128)
-    int host_pipeline = 1;                 // 0 forces the synchronous host path
+    int host_pipeline = 2;                 // page-locked host planes: 2 zero copy, 1 staged three-stream pipeline (lab A/B),
+                                           // 0 forces the synchronous path
     int host_chunks = 8;                   // pieces per tile of the pipelined host path
     int shadow_grid_pad = 1;               // dswx_shadow_v3: grid.x rounded up to a multiple of this (lab A/B, see the launch)
     std::string last_kernel;

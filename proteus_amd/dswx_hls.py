@@ -1149,7 +1149,7 @@ def generate_dswx_layers(input_list,
     # HLS v1 (a single HDF4 file, :4972-4980) needs GDAL's HDF4 driver; every input goes
     # through the v2 per-band GeoTIFF loader, which reports what is missing
     # band planes are decoded straight into page-locked memory so that the library can
-    # pipeline upload / classify / download (dswx_host_alloc, include/dswx_hip.h)
+    # work on them in place across PCIe (zero copy; dswx_host_alloc, include/dswx_hip.h)
     ok = _load_hls_product_v2(list(input_list), image, md, flag_debug=flag_debug,
                               alloc=lambda shape, dt: get_context(device).pinned_empty(shape, dt))
     if not ok:

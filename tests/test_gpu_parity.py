@@ -135,16 +135,19 @@ def _pinned_copy(ctx, a):
     return q
 
 
-@pytest.mark.parametrize('chunks', [1, 3, 8])
+@pytest.mark.parametrize('chunks', ['zero_copy', 1, 3, 8])
 @pytest.mark.parametrize('geom', [(1, 333, 517, False), (3, 300, 301, True), (2, 1, 7, True), (1, 1100, 900, True)])
 def test_pinned_pipelined_host_path(chunks, geom):
-    """dswx_classify_host from page-locked buffers (dswx_host_alloc): the three-stream pipeline over
-    flat pieces of each tile gives the same planes and the same per-tile counters as the C oracle,
-    for ragged piece sizes, several tiles, optional planes and the float64 debug indices."""
+    """dswx_classify_host from page-locked buffers (dswx_host_alloc).  Product: ZERO COPY -- the kernels work on
+    the host planes across PCIe.  Lab A/B (host_pipeline=1): the three-stream pipeline over flat pieces of each
+    tile.  Both give the same planes and the same per-tile counters as the C oracle, for ragged piece sizes,
+    several tiles, optional planes and the float64 debug indices."""
     c = _capi.Context(0)
     try:
-        if chunks != 8:                        # 8 is the product's fixed value; others through the lab switch
-            c.lab_configure(host_chunks=chunks)
+        zero_copy = chunks == 'zero_copy'
+        tag = 'zero copy across PCIe' if zero_copy else 'pipelined over 3 streams'
+        if not zero_copy:                      # the staged pipeline and its piece count through the lab switches
+            c.lab_configure(host_pipeline=1, host_chunks=chunks)
         n_tiles, h, w, masks = geom
         tiles = [synth_tile(70 + t, h, w, with_masks=True) for t in range(n_tiles)]
         stack = lambda f: np.stack([f(t) for t in tiles]) if n_tiles > 1 else f(tiles[0])
@@ -155,11 +158,11 @@ def test_pinned_pipelined_host_path(chunks, geom):
         p = _capi.make_params(collapse_wtr_classes=True)
         layers = ALL_LAYERS + ('browse', 'mndwi')
         got = c.classify_host(bands, fmask, p, layers=layers, **kw)
-        assert 'pipelined over 3 streams' in c.last_kernel_info() and c.is_pinned(got['wtr'])
+        assert tag in c.last_kernel_info() and c.is_pinned(got['wtr'])
         # the synchronous path on pageable copies of the same inputs is the comparator ...
         ref = c.classify_host([np.array(b) for b in bands], np.array(fmask), p, layers=layers,
                               **{k: np.array(v) for k, v in kw.items()})
-        assert 'pipelined' not in c.last_kernel_info()
+        assert 'pipelined' not in c.last_kernel_info() and 'zero copy' not in c.last_kernel_info()
         for k in layers:
             assert np.array_equal(got[k], ref[k], equal_nan=True), k
         assert np.array_equal(got['counters'], ref['counters'])
@@ -171,14 +174,20 @@ def test_pinned_pipelined_host_path(chunks, geom):
             for k in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
                 assert np.array_equal(got[k][t] if n_tiles > 1 else got[k], exp[k]), (t, k)
             assert got['counters'][t].tolist() == exp['counters'].tolist()
-        # a subset of the layers and no counters through the same pipeline
+        # a subset of the layers and no counters through the same path
         sub = c.classify_host(bands, fmask, p, layers=('conf', 'wtr'), counters=False, **kw)
-        assert 'pipelined' in c.last_kernel_info() and set(sub) == {'conf', 'wtr'}
+        assert tag in c.last_kernel_info() and set(sub) == {'conf', 'wtr'}
         assert np.array_equal(sub['conf'], ref['conf']) and np.array_equal(sub['wtr'], ref['wtr'])
-        # 'cover' mode is a neighbourhood operation: it must take the whole-tile path
+        # 'cover' mode is a neighbourhood operation: the piece pipeline cannot take it (whole-tile path), the
+        # zero-copy path can -- same layers as from pageable copies
         pc = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
-        c.classify_host(bands, fmask, pc, **kw)
-        assert 'pipelined' not in c.last_kernel_info()
+        gotc = c.classify_host(bands, fmask, pc, **kw)
+        assert 'pipelined' not in c.last_kernel_info() and ('zero copy' in c.last_kernel_info()) == zero_copy
+        refc = c.classify_host([np.array(b) for b in bands], np.array(fmask), pc,
+                               **{k: np.array(v) for k, v in kw.items()})
+        assert 'zero copy' not in c.last_kernel_info()
+        for k in refc:
+            assert np.array_equal(gotc[k], refc[k]), k
     finally:
         c.close()
 
