@@ -3,7 +3,7 @@
 hugging the thresholds) through dswx_classify_host, every layer and the counters compared with
 the scalar C oracle.  Exit code 1 and a JSON description of the first mismatch on failure.
 
-    python tests/fuzz_parity.py [--iters 300] [--seed 1] [--variant N] [--device-batch]
+    python tests/fuzz_parity.py [--iters 300] [--seed 1] [--variant N] [--device-batch] [--pinned]
 
 (Lives under tests/ because it uses the oracle, which only tests/, smoke() and bench.py's CPU baseline may do;
 its name keeps pytest from collecting it.)
@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--variant', default=None, help='fused-kernel structure for this run (libdswx_lab.so switch: 0..5)')
     ap.add_argument('--device-batch', action='store_true', help='soak the device-resident batch entry instead')
+    ap.add_argument('--pinned', action='store_true', help='inputs in page-locked arrays: the zero-copy host path')
     a = ap.parse_args()
     ctx = _capi.Context(0)
     if a.variant is not None:
@@ -125,7 +126,16 @@ def main():
             apply_aerosol_class_remapping=cs['aerosol'], aerosol_fmask_values=cs['lists'],
             collapse_wtr_classes=cs['collapse'], aerosol_max_nir=cs['aer_nir'])
         kw = {k: s[k] for k in ('land', 'shad', 'ocean') if cs[k]}
+        if a.pinned:
+            def pin(x):
+                q = ctx.pinned_empty(x.shape, x.dtype)
+                q[...] = x
+                return q
+            bands, fmask, kw = [pin(b) for b in bands], pin(fmask), {k: pin(v) for k, v in kw.items()}
         got = ctx.classify_host(bands, fmask, p, **kw)
+        if a.pinned and 'zero copy' not in ctx.last_kernel_info():
+            print(json.dumps({'ok': False, 'iteration': it, 'why': 'not the zero-copy path', 'kernel': ctx.last_kernel_info()}))
+            return 1
         kernels[ctx.last_kernel_info().split(' ')[0]] = kernels.get(ctx.last_kernel_info().split(' ')[0], 0) + 1
         exp = c_oracle.classify(p, bands, fmask, **kw)
         bad = [k for k in ALL_LAYERS if not np.array_equal(got[k], exp[k])]
