@@ -204,6 +204,12 @@ __device__ __forceinline__ uint32_t shadow_quad(const ShadowArgs& a, const Shado
 // 0.0141 -> 0.0157 ms per tile (0.0149 with the remap per tile instead of per launch) -- slower, as for the
 // fused kernel in round 1; the plain order stays.  Waves per block (stacked in y; ms per tile, legacy promotion):
 // 1: 0.0177, 2: 0.0133, 4: 0.0126, 8: 0.0133, 16: 0.0147 -- taller blocks save halo re-reads but run slower.
+// Halving the L1 traffic does not help either: a variant in which every lane loads only its own 16 bytes of a row
+// and takes the two halo values of the centre row from its neighbours through DPP wave shifts (one 16-byte + one
+// 4-byte load per row instead of four 8-byte ones) measured 0.0140-0.0143 against 0.0131-0.0135 in the same process.
+// What the kernel runs into is issue: ~196 VALU (two v_rsq_f32 per pixel pair at quarter rate among them) and
+// ~130 SALU instructions per wave of 512 pixels keep the SIMDs' VALU 63 % busy (profiles/r02_next_rows_pmc.json:
+// SQ_ACTIVE_INST_VALU x 4 / SIMD cycles) while the waves are short -- memory and arithmetic no longer overlap fully.
 // (The waves of a block MUST be stacked in y: they share their halo rows through the CU's L1.  Numbering the
 // work items along the rows instead -- no idle lanes at the row ends -- measured 0.0173.)
 constexpr int SHADOW_ROWS = 2, SHADOW_WAVES = 4;     // waves (stacked in y) per block

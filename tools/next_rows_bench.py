@@ -75,7 +75,7 @@ def main():
                 'GBps': nbytes / avg / 1e6, 'frac_of_8TBps': nbytes / avg / 1e6 / 8000, 'Mpix_s': n * T * T / avg / 1e3}
         if a.lab and tag == 'quads_filter_v3':
             # launch-geometry A/B through the lab switch: grid.x as it comes (15 for 3660 columns) vs padded to 8 | grid.x
-            for pad in (1, 8, 16):
+            for pad in (1, 8):
                 c2 = _capi.Context(0)
                 c2.lab_configure(shadow_grid_pad=pad)
                 avg, mn = timed(c2, lambda: c2.shadow_layer_device(d_dem.ptr, n, H, W, margin, sun, np.sin(az), np.cos(az),
