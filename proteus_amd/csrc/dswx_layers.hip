@@ -210,6 +210,9 @@ __device__ __forceinline__ uint32_t shadow_quad(const ShadowArgs& a, const Shado
 // What the kernel runs into is issue: ~196 VALU (two v_rsq_f32 per pixel pair at quarter rate among them) and
 // ~130 SALU instructions per wave of 512 pixels keep the SIMDs' VALU 63 % busy (profiles/r02_next_rows_pmc.json:
 // SQ_ACTIVE_INST_VALU x 4 / SIMD cycles) while the waves are short -- memory and arithmetic no longer overlap fully.
+// Nor does trading SALU for VALU: the filter's decisions in sign-bit form (three packed differences per pixel pair,
+// v_bitop3 / v_perm per pixel instead of v_cmp -> SGPR pair -> s_and / s_or -> v_cndmask chains: same VALU count,
+// 25 SALU fewer per row) measured 0.0138-0.0143 against 0.0130-0.0133 for this compare form in one process.
 // (The waves of a block MUST be stacked in y: they share their halo rows through the CU's L1.  Numbering the
 // work items along the rows instead -- no idle lanes at the row ends -- measured 0.0173.)
 constexpr int SHADOW_ROWS = 2, SHADOW_WAVES = 4;     // waves (stacked in y) per block
