@@ -752,7 +752,7 @@ class DeviceBatch:
     def _arena_of(self, name):
         return self.out_bufs.get(name, self.arena)
 
-    def place_outputs(self, params, candidates=6, launches=3, keep_free_bytes=8 << 30, free_bytes=None):
+    def place_outputs(self, params, candidates=6, launches=3, keep_free_bytes=8 << 30, free_bytes=None, passes=1):
         """Choose WHERE in HBM every output plane lives (separate_outputs only; the batch must hold its inputs).
 
         On MI355X the fused kernel's rate depends on the physical ranges its seven write streams land in -- a
@@ -760,7 +760,7 @@ class DeviceBatch:
         placements, and moving ONE u8 plane changes it by up to 1.5 %, repeatably) -- so a long-lived batch is
         worth placing.  Beside the planes, `candidates - 1` spare allocations per output plane are made (side by
         side: a freed range would simply be handed out again; bounded by `free_bytes`, the free device memory
-        as the caller knows it, minus `keep_free_bytes`), and one pass of coordinate descent binds each plane in
+        as the caller knows it, minus `keep_free_bytes`), and `passes` passes of coordinate descent bind each plane in
         turn (DIAG first) to the candidate under which `launches` launches of the real kernel run fastest.  The
         spares are freed; if the search buys nothing the first-come planes stay.  Returns a record of the search."""
         assert self.out_bufs, 'DeviceBatch was built with one arena'
@@ -795,7 +795,7 @@ class DeviceBatch:
         everything = list(original.values()) + [buf for pool in pools.values() for buf in pool]
         first_ms = launch_ms()
         probes = 0
-        for name in names:
+        for name in names * passes:
             pool = pools.get(self.plane_nbytes[name], [])
             if not pool:
                 continue
