@@ -22,7 +22,8 @@ def poll():
         time.sleep(0.3)
 
 
-ctx = _capi.Context(0)
+lib = [x[4:] for x in sys.argv if x.startswith('LIB=')]
+ctx = _capi.Context(0, lib_path=os.path.abspath(lib[0]) if lib else None)      # LIB=path: another build of the product library
 p = _capi.default_params()
 masks = '--masks' in sys.argv
 b = _capi.DeviceBatch(ctx, 256, 3660, 3660, masks=masks)
