@@ -419,6 +419,35 @@ def test_headline_batch_256_tiles_past_2_31(ctx, masks):
         batch.free()
 
 
+def test_batch_512_tiles_past_2_32_pixels(ctx):
+    """BASELINE.json configs[3] per-GPU share at ITS OWN size: 512 resident 3660 x 3660 tiles (144 GB) in one call.
+    The pixel offset of a tile passes 2^32 at tile 321 and the byte offset of an int16 plane 2^33: tiles on both
+    sides of that cliff and the last one against the scalar C oracle, the planes in HBM against the numpy generator."""
+    n_tiles, h, w = 512, 3660, 3660
+    batch = _capi.DeviceBatch(ctx, n_tiles, h, w)
+    try:
+        assert 321 * batch.tile_stride > 2 ** 32 > 320 * batch.tile_stride
+        batch.synth(SEED, tile0=0)
+        p = _capi.default_params()
+        batch.classify(p)
+        ctx.synchronize()
+        assert 'dswx_classify_lut' in ctx.last_kernel_info() and f',{n_tiles})' in ctx.last_kernel_info()
+        cnt = batch.read_counters()
+        for t in (320, 321, 511):
+            s = synth_tile(t, h, w)
+            bands = [batch.read_tile(b, t) for b in _capi.BAND_NAMES]
+            for got_b, exp_b in zip(bands, s['bands']):
+                assert np.array_equal(got_b, exp_b), t
+            fm = batch.read_tile('fmask', t)
+            assert np.array_equal(fm, s['fmask'])
+            exp = c_oracle.classify(p, bands, fm)
+            for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+                assert np.array_equal(batch.read_tile(key, t), exp[key]), (key, t)
+            assert cnt[t].tolist() == exp['counters'].tolist(), t
+    finally:
+        batch.free()
+
+
 def test_gpu_quotient_enumeration(ctx):
     """Every (green, swir1) pair with green in a 1024-value stride set and swir1 over
     all of int16 (clip off => every reachable (n, d), incl. wrap and d == 0): DIAG bits
