@@ -37,8 +37,9 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--tiles', type=int, default=256,
-                    help='resident tiles per GPU (weak scaling: the work of a step; strong: the chunk size)')
+    ap.add_argument('--tiles', type=int, default=0,
+                    help='resident tiles per GPU (weak scaling: the work of a step, default 256 = BASELINE configs[2]; '
+                         'strong: the chunk size, default 512 = the per-GPU share of configs[3] at 8 GPUs)')
     ap.add_argument('--total-tiles', type=int, default=0,
                     help='strong scaling: tiles of the whole job, split over the ranks (BASELINE configs[3]: 4096)')
     ap.add_argument('--allow-gloo', action='store_true',
@@ -59,7 +60,10 @@ def parse_args():
     ap.add_argument('--no-single-tile', action='store_true',
                     help='skip the configs[1] leg (profiling runs: keeps the kernel statistics to the batch launches)')
     ap.add_argument('--cpu-parallel-worker', type=int, default=0, help=argparse.SUPPRESS)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.tiles <= 0:
+        args.tiles = 512 if args.total_tiles > 0 else 256
+    return args
 
 
 def cpu_baseline_sample(n_tiles=4):

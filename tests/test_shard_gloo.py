@@ -127,7 +127,7 @@ def test_bench_self_launch_weak_scaling_and_single_rank_plan():
     assert out['scaling'] == 'weak' and out['tiles_per_step_all_ranks'] == 6
     assert [r['first_tile'] for r in out['ranks']] == [0, 3]
     # N = 1 walks configs[3] alone, in resident chunks
-    res = _bench('--total-tiles', '4096', '--tiles', '512', '--plan-only')
+    res = _bench('--total-tiles', '4096', '--plan-only')         # default chunk in strong mode: 512 resident tiles
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
     assert out['ranks'][0]['launches'] == [512] * 8 and out['tiles_per_step_all_ranks'] == 4096
 
