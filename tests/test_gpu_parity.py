@@ -162,7 +162,7 @@ def test_pinned_pipelined_host_path(chunks, geom):
         # the synchronous path on pageable copies of the same inputs is the comparator ...
         ref = c.classify_host([np.array(b) for b in bands], np.array(fmask), p, layers=layers,
                               **{k: np.array(v) for k, v in kw.items()})
-        assert 'pipelined' not in c.last_kernel_info() and 'zero copy' not in c.last_kernel_info()
+        assert 'pipelined' not in c.last_kernel_info() and 'zero copy' not in c.last_kernel_info()    # below 1 Mpx: staged copies
         for k in layers:
             assert np.array_equal(got[k], ref[k], equal_nan=True), k
         assert np.array_equal(got['counters'], ref['counters'])
@@ -322,12 +322,49 @@ def test_full_size_tile_vs_numpy_oracle(ctx):
     s = synth_tile(0, h, w)
     p = _capi.default_params()
     got = ctx.classify_host(s['bands'], s['fmask'], p)
-    assert 'dswx_classify_lut' in ctx.last_kernel_info()      # aligned single tile -> table-driven
+    # plain numpy planes of this size are page-locked in place for the call and read / written across PCIe
+    assert 'page-locked in place' in ctx.last_kernel_info() and 'zero copy' in ctx.last_kernel_info()
     exp = o.classify_tile(s['bands'], s['fmask'])
     for layer, key in NAME.items():
         assert np.array_equal(got[key], exp[layer]), layer
     c = exp['counters']
     assert got['counters'][0].tolist() == [c['n_valid'], c['n_cloud_and_valid'], c['n_not_ocean']]
+
+
+def test_pageable_planes_locked_in_place(ctx):
+    """dswx_classify_host on plain (pageable) numpy planes of >= 1 Mpixel: page-locked in place for the call, zero copy.
+    Views into one stacked array share pages at their seams (merged before registering); a second call on the same
+    arrays must work (everything is unregistered afterwards); the synchronous path (lab switch) is the comparator."""
+    h, w = 1200, 1000
+    s = synth_tile(41, h, w, with_masks=True)
+    stack = np.stack(s['bands'])                       # six views into ONE array: plane seams inside shared pages
+    bands = [stack[k] for k in range(6)]
+    p = _capi.default_params()
+    kw = dict(land=s['land'], shad=s['shad'], ocean=s['ocean'])
+    c0 = _capi.Context(0)
+    try:
+        c0.lab_configure(host_pipeline=0)
+        ref = c0.classify_host(bands, s['fmask'], p, layers=ALL_LAYERS, **kw)
+        assert 'zero copy' not in c0.last_kernel_info()
+    finally:
+        c0.close()
+    for rep in range(2):
+        got = ctx.classify_host(bands, s['fmask'], p, layers=ALL_LAYERS, **kw)
+        assert 'page-locked in place' in ctx.last_kernel_info()
+        for k in ALL_LAYERS:
+            assert np.array_equal(got[k], ref[k]), k
+        assert np.array_equal(got['counters'], ref['counters'])
+    exp = c_oracle.classify(p, bands, s['fmask'], **kw)
+    for k in ALL_LAYERS:
+        assert np.array_equal(got[k], exp[k]), k
+    # 'cover' mode takes the same path
+    pc = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
+    gotc = ctx.classify_host(bands, s['fmask'], pc, **kw)
+    assert 'page-locked in place' in ctx.last_kernel_info()
+    e = o.classify_tile(bands, s['fmask'], landcover=s['land'], shadow=s['shad'], ocean_mask=s['ocean'],
+                        mask_adjacent_to_cloud_mode='cover')
+    for layer, key in NAME.items():
+        assert np.array_equal(gotc[key], e[layer]), layer
 
 
 def test_full_size_batch_properties(ctx):
