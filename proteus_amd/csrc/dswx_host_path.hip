@@ -221,12 +221,18 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
     if (n_tiles == 0 || P == 0) return DSWX_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->host_pipeline == 2 || (ctx->host_pipeline && params->mask_adjacent_to_cloud_mode != DSWX_ADJ_COVER)) {
+        // a plane counts as page-locked when its first AND last byte are
+        const size_t npx = (size_t)n_tiles * (size_t)P;
+        auto locked_span = [](const void* p, size_t bytes) {
+            return !p || (is_pinned_host(p) && is_pinned_host(static_cast<const char*>(p) + bytes - 1));
+        };
         bool pinned = true;
-        for (int k = 0; k < 6 && pinned; ++k) pinned = is_pinned_host(in->band[k]);
-        const void* const rest[] = {in->fmask, in->land, in->shad, in->ocean, out->diag, out->wtr1, out->wtr1_aerosol,
-                                    out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud, out->browse, out->mndwi,
-                                    out->ndvi, out->awesh};
-        for (const void* p : rest) pinned = pinned && (!p || is_pinned_host(p));
+        for (int k = 0; k < 6 && pinned; ++k) pinned = locked_span(in->band[k], npx * 2);
+        const void* const rest[] = {in->fmask, in->land, in->shad, in->ocean, out->wtr1, out->wtr1_aerosol,
+                                    out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud, out->browse};
+        for (const void* p : rest) pinned = pinned && locked_span(p, npx);
+        pinned = pinned && locked_span(out->diag, npx * 2) && locked_span(out->mndwi, npx * 8) &&
+                 locked_span(out->ndvi, npx * 8) && locked_span(out->awesh, npx * 8);
         if (pinned && ctx->host_pipeline == 2) return classify_host_zero_copy(ctx, params, n_tiles, height, width, in, out, counters);
         if (pinned) return classify_host_pipelined(ctx, params, n_tiles, P, in, out, counters);
     }
@@ -239,7 +245,8 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
         struct Span { uintptr_t lo, hi; };
         std::vector<Span> want, locked;
         auto add = [&](const void* p, size_t bytes) {
-            if (p && !is_pinned_host(p)) want.push_back({reinterpret_cast<uintptr_t>(p), reinterpret_cast<uintptr_t>(p) + bytes});
+            if (p && !(is_pinned_host(p) && is_pinned_host(static_cast<const char*>(p) + bytes - 1)))
+                want.push_back({reinterpret_cast<uintptr_t>(p), reinterpret_cast<uintptr_t>(p) + bytes});
         };
         const size_t px = (size_t)n_tiles * (size_t)P;
         for (int k = 0; k < 6; ++k) add(in->band[k], px * 2);
