@@ -476,6 +476,9 @@ def main():
                          'kernel_source_hash': _build.hot_kernel_hash()},
             'parity_check': parity,
         }
+        if placement.get('first_come_launch_ms'):      # what the same planes gave where they first came to lie (3-launch probe)
+            out['roofline']['frac_first_come_placement'] = round(
+                px_per_launch * bytes_per_px / (placement['first_come_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if world == 1 and args.realloc_repeats > 0:
             try:
                 batch.free()
