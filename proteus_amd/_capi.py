@@ -809,11 +809,21 @@ class DeviceBatch:
                     best_ms, best_k = ms, k
             if best_k is not None:
                 pool[best_k] = self.bind_output(name, pool[best_k])
-        kept_ms = launch_ms() if probes else first_ms
-        if kept_ms >= first_ms:          # the search bought nothing (noise): stay with what came first
+        kept_ms = first_ms
+        if probes:
+            # judge the outcome under equal conditions (the part is warmer now than at `first_ms`): the chosen
+            # planes and the first-come planes back to back, and keep the better set
+            chosen = dict(self.out_bufs)
+            chosen_ms = launch_ms()
             for name in names:
                 self.bind_output(name, original[name])
-            kept_ms = first_ms
+            again_ms = launch_ms()
+            if chosen_ms < again_ms:
+                for name in names:
+                    self.bind_output(name, chosen[name])
+                kept_ms = chosen_ms
+            else:                        # the search bought nothing: stay with what came first
+                kept_ms = again_ms
         bound = {id(buf) for buf in self.out_bufs.values()}
         for buf in everything:
             if id(buf) not in bound:
