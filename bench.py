@@ -9,7 +9,10 @@ in HBM before the timed region.
   default (weak scaling)        every GPU owns T = 256 resident tiles: BASELINE configs[2] at N = 1
   --total-tiles M (strong)      BASELINE configs[3]: M (e.g. 4096) tiles split contiguously over the
                                 N ranks (proteus_amd.shard.tile_range); a rank walks its share in
-                                resident chunks of <= T tiles, so N = 1 works too
+                                resident chunks of <= T tiles (default 512), so N = 1 works too
+The resident batch is PLACED before warm-up (--placement-trials): every output plane in the
+fastest of a few candidate allocations, the kernel itself as the probe; `roofline.frac_first_come_placement`
+and `roofline.realloc_spread` keep what unplaced allocations give in the same line.
 Tiles are independent: there is no data-path collective.  RCCL (torch.distributed 'nccl') carries
 only the barrier around the timed region and the MAX over ranks of the elapsed time.
 

@@ -683,7 +683,7 @@ class DeviceBatch:
         self.total = total
         self.offsets = {}          # name -> byte offset inside its arena
         self._in_out = {}          # name -> 'in' | 'out'
-        cursor = {'in': 0, 'out': 0}
+        cursor = {'in': 0}          # bytes taken in the arena
         skew = int(plane_skew)
 
         self.plane_nbytes = {}
