@@ -57,7 +57,11 @@ __global__ __launch_bounds__(256) void dswx_cover_dilate(const KArgs a) {
     constexpr int CP_W = 32 * NW, CP_OUT_W = CP_W - 2 * CP_HALO, NQ = NW + 1;     // NQ: 16-byte loads per row
     // one LDS area, two lives: staging of the bitmap rows -> row exchange of the dilations
     constexpr int ROW_DW = 4 * NQ;
-    constexpr int STAGE_DW = STAGED ? CP_H * ROW_DW : 0, XCH_DW = 2 * (CP_H + 2) * NW;     // (CP_H (NW + 1) <= XCH_DW)
+    // the bitmap rows are staged in STAGE_PASSES passes of CP_H / STAGE_PASSES rows, so that the staging area is no
+    // larger than the row exchange that re-uses it: 16.5 KB per block instead of 36.9 KB (8 words per row), i.e. six
+    // resident blocks per CU (the VGPR limit) instead of four
+    constexpr int STAGE_PASSES = NW == 8 ? 2 : 1, STAGE_ROWS = CP_H / STAGE_PASSES;
+    constexpr int STAGE_DW = STAGED ? STAGE_ROWS * ROW_DW : 0, XCH_DW = 2 * (CP_H + 2) * NW;     // (CP_H (NW + 1) <= XCH_DW)
     constexpr int RAW_DW = STAGE_DW > XCH_DW ? STAGE_DW : XCH_DW;
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[RAW_DW];
     __shared__ uint32_t s_vote[2][4];
@@ -83,16 +87,22 @@ __global__ __launch_bounds__(256) void dswx_cover_dilate(const KArgs a) {
     };
     uint32_t d[4 * NQ];
     if (STAGED) {
-        for (int id = t; id < CP_H * NQ; id += 256) {
-            const int r = id / NQ, q = id - r * NQ;
-            const u32x4_a4 v = load_quad(y0 + r, q);
-            *reinterpret_cast<uint4*>(&s_raw[r * ROW_DW + 4 * q]) = make_uint4(v.x, v.y, v.z, v.w);
-        }
-        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const uint4 v = *reinterpret_cast<const uint4*>(&s_raw[t * ROW_DW + 4 * q]);
-            d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+        for (int pass = 0; pass < STAGE_PASSES; ++pass) {
+            if (pass) __syncthreads();              // the rows of the previous pass have been taken
+            for (int id = t; id < STAGE_ROWS * NQ; id += 256) {
+                const int r = id / NQ, q = id - r * NQ;
+                const u32x4_a4 v = load_quad(y0 + pass * STAGE_ROWS + r, q);
+                *reinterpret_cast<uint4*>(&s_raw[r * ROW_DW + 4 * q]) = make_uint4(v.x, v.y, v.z, v.w);
+            }
+            __syncthreads();
+            if (t / STAGE_ROWS == pass) {           // wave-uniform: STAGE_ROWS is a multiple of 64
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(&s_raw[(t - pass * STAGE_ROWS) * ROW_DW + 4 * q]);
+                    d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+                }
+            }
         }
     } else {
 #pragma unroll
