@@ -480,3 +480,83 @@ def test_compare_products(tmp_path, capsys):
     assert '(x: 4, y: 3)' in capsys.readouterr().out
     assert D.compare_dswx_hls_products(f1, f4) is False
     assert D.compare_dswx_hls_products(f1, str(tmp_path / 'missing.tif')) is False
+
+
+def test_output_plane_placement_bookkeeping():
+    """DeviceBatch.place_outputs against a stand-in context whose 'launch time' is a known function of the buffers
+    the output planes are bound to (no GPU): the coordinate descent must end on the cheapest buffer for every plane,
+    free every buffer that is not bound at the end exactly once, keep the bound ones alive -- and stay with the
+    first-come planes when nothing is cheaper."""
+    from proteus_amd import _capi
+
+    class Buf:
+        def __init__(self, ctx, nbytes):
+            self.ctx, self.nbytes, self.freed = ctx, nbytes, 0
+            ctx.n += 1
+            self.ptr = ctx.n << 20
+            ctx.bufs[self.ptr] = self
+
+        def free(self):
+            self.freed += 1
+
+    class Ctx:
+        """launch time = 10 ms + cost of every buffer an output plane points at; `cost` maps the order of allocation"""
+        def __init__(self, cost):
+            self.n, self.bufs, self.cost, self.now, self.launches = 0, {}, cost, 0.0, 0
+
+        def malloc(self, nbytes):
+            return Buf(self, nbytes)
+
+        def classify_batch(self, params, geom, pin, pout, counters, stream=None):
+            names = ['diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud']
+            self.now += 10.0 + sum(self.cost(self.bufs[getattr(pout, n)]) for n in names)
+            self.launches += 1
+
+        def synchronize(self, stream=None):
+            pass
+
+        def event(self):
+            return [0.0]
+
+        def record(self, e, stream=None):
+            e[0] = self.now
+
+        def elapsed_ms(self, a, b):
+            return b[0] - a[0]
+
+        def destroy_event(self, e):
+            pass
+
+    # allocation order: 1 = input arena, 2..8 = the seven first-come planes, then two spare sets (9..15, 16..22)
+    cost = lambda buf: {3: 5.0, 9: -1.0, 12: -2.0, 18: -3.0, 20: 4.0}.get(buf.ptr >> 20, 0.0)
+    ctx = Ctx(cost)
+    b = _capi.DeviceBatch(ctx, 2, 8, 16, separate_outputs=True)
+    first = dict(b.out_bufs)
+    rec = b.place_outputs(None, candidates=3, launches=2)
+    assert rec['trials'] == 3 and rec['probes'] == 2 + 6 * 12        # DIAG: 2 spares; six u8 planes x 12 spares
+    bound = {n: buf.ptr >> 20 for n, buf in b.out_bufs.items()}
+    assert bound['diag'] == 9                                        # the cheaper of the two DIAG-sized spares (9: -1, 16: 0)
+    # the u8 planes end on the cheap spares 12 and 18 (and leave the expensive first-come 3); nobody sits on 20
+    assert {12, 18} <= set(bound.values()) and 3 not in bound.values() and 20 not in bound.values()
+    assert rec['kept_launch_ms'] < rec['first_come_launch_ms']
+    alive = {id(x) for x in b.out_bufs.values()}
+    for buf in ctx.bufs.values():
+        if buf is b.arena:
+            assert buf.freed == 0
+        else:
+            assert buf.freed == (0 if id(buf) in alive else 1), buf.ptr >> 20
+    assert len(alive) == 7
+    # nothing cheaper anywhere: the first-come planes stay, every spare is freed
+    ctx2 = Ctx(lambda buf: 0.0 if buf.ptr >> 20 <= 8 else 1.0)
+    b2 = _capi.DeviceBatch(ctx2, 2, 8, 16, separate_outputs=True)
+    first2 = {n: buf.ptr for n, buf in b2.out_bufs.items()}
+    rec2 = b2.place_outputs(None, candidates=2)
+    assert {n: buf.ptr for n, buf in b2.out_bufs.items()} == first2
+    assert all(buf.freed == (1 if buf.ptr >> 20 > 8 else 0) for buf in ctx2.bufs.values())
+    assert rec2['kept_launch_ms'] == rec2['first_come_launch_ms']
+    # memory bound: with room for one spare set only, one set is tried
+    ctx3 = Ctx(lambda buf: 0.0)
+    b3 = _capi.DeviceBatch(ctx3, 2, 8, 16, separate_outputs=True)
+    rec3 = b3.place_outputs(None, candidates=6, keep_free_bytes=0, free_bytes=int(b3.out_bytes * 1.5))
+    assert rec3['trials'] == 2
+    assert first  # (kept alive until here)
