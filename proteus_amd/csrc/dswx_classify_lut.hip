@@ -15,10 +15,18 @@
 
 // WPS: launch bound.  EXTRAS: also the browse plane and the stage-1 scratch of 'cover' mode (the cover
 // state byte, looked up in Tables::extra, and the bitmaps of the four dilation predicates).
+// The EXTRAS instantiations carry 4.5 KiB of tables per block and, as a straight-line body, 125 VGPRs: as a loop over
+// several 8-pixel groups per thread a block reloads a quarter of the tables per pixel and the body fits 90 VGPRs.
+// 'cover' mode, 32 tiles, one process, three contexts per build (GB/s of 24 B/px): 1 group 4598 / 4615 / 4610, 2 groups
+// 4844 / 4830 / 4825, 4 groups 4898 / 4893 (and 4459 in the context whose scratch planes landed badly: the stage-1
+// scratch is placement-sensitive like every other plane).  The plain and masks instantiations
+// lose 3 - 8 % with more than one group per thread (5964 -> 5640 -> 5466 GB/s), as in round 1.
+constexpr int LUT_EXTRAS_CHUNKS = 4;
+
 template <bool MASKS, bool EXTRAS, int WPS>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
                                                              const Tables* __restrict__ tabs) {
-    constexpr int LUT_CHUNKS = 1;
+    constexpr int LUT_CHUNKS = EXTRAS ? LUT_EXTRAS_CHUNKS : 1;     // 8-pixel groups per thread
     __shared__ uint32_t s_lut1[128];
     __shared__ uint16_t s_fm16[256];
     __shared__ uint8_t s_land8[MASKS ? 256 : 4];
@@ -105,10 +113,11 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
     }
 }
 
-void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, int* threads, long long* gx) {
+void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int* threads, long long* gx) {
     (void)ctx;
+    const long long per_block = 256LL * (extras ? LUT_EXTRAS_CHUNKS : 1);
     *threads = 256;
-    *gx = (groups + 255) / 256;
+    *gx = (groups + per_block - 1) / per_block;
 }
 
 int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 block, hipStream_t s, char* info,

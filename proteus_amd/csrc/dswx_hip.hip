@@ -595,7 +595,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             const bool variant = vsel != 0 && (plain_outputs || vsel == 3) && dma16_ok;
             int threads = 256;
             long long gx_ll = (groups + 255) / 256;
-            if (variant && vsel == 3) dswx_lut_geometry(ctx, groups, &threads, &gx_ll);
+            if (variant && vsel == 3) dswx_lut_geometry(ctx, groups, !plain_outputs, &threads, &gx_ll);
             else if (variant) ctx->lab.geometry(ctx, vsel, groups, nt, &threads, &gx_ll);
             const int64_t gx = gx_ll;
             const int waves = threads / 64;

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--masks', action='store_true')
     ap.add_argument('--tile-align', type=int, default=256)
+    ap.add_argument('--mode', default='mask', choices=['mask', 'ignore', 'cover'], help="mask_adjacent_to_cloud_mode ('cover': the three-kernel path)")
     a = ap.parse_args()
     ctxs = []
     for v in a.variants:
@@ -45,7 +46,7 @@ def main():
     batch = _capi.DeviceBatch(base, a.tiles, 3660, 3660, masks=a.masks, tile_align=a.tile_align)
     batch.synth(SEED)
     base.synchronize()
-    p = _capi.default_params()
+    p = _capi.make_params(mask_adjacent_to_cloud_mode=a.mode)
     px = a.tiles * 3660 * 3660
     bpp = 24 if a.masks else 21
     res = {v: [] for v in a.variants}
