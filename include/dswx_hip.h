@@ -280,10 +280,10 @@ int dswx_device_free(dswx_ctx_t* ctx, void* ptr);
  * registered with hipHostRegister) and, when EVERY plane pointer is page-locked, works on
  * them in place: the host planes are mapped into the device's address space and the kernels
  * read the inputs and write the layers across PCIe themselves (zero copy, both directions at
- * once, every mode) instead of the synchronous copy-compute-copy sequence.  Pageable planes of
- * one Mpixel or more are page-locked in place for the duration of the call (hipHostRegister /
- * hipHostUnregister) and take the same path; smaller ones, and memory that cannot be registered,
- * are copied.  There is no reference counterpart (numpy arrays are pageable); results are identical. */
+ * once, every mode) instead of the synchronous copy-compute-copy sequence that pageable planes
+ * get.  Prefer buffers from dswx_host_alloc to registering arbitrary memory: pages that are
+ * registered but not resident (never touched) are not a safe target for kernel writes.  There is
+ * no reference counterpart (numpy arrays are pageable); results are identical. */
 int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_host_free(dswx_ctx_t* ctx, void* ptr);
 int dswx_memcpy_h2d(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);

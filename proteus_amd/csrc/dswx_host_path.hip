@@ -1,15 +1,11 @@
 // dswx_host_path.hip -- dswx_classify_host: the host-pointer entry of the classifier.
-// Small pageable buffers: one tile at a time, copy -> classify -> copy on one stream; larger ones are page-locked in
-// place for the call and take the zero-copy path.  Page-locked
+// Pageable buffers: one tile at a time, copy -> classify -> copy on one stream.  Page-locked
 // buffers (dswx_host_alloc / hipHostRegister): ZERO COPY -- the kernels read the input planes and write the
 // layers across PCIe themselves, both directions at once (3.9 Gpixel/s for 13 B in + 8 B out per pixel,
 // measured on four 3660^2 tiles; the staged three-stream pipeline below it reaches 3.05 and stays as a lab A/B).
 #include <hip/hip_runtime.h>
 #include <cstring>
-#include <algorithm>
-#include <cstdint>
 #include <string>
-#include <vector>
 
 #include "dswx_host.h"
 
@@ -236,50 +232,12 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
         if (pinned && ctx->host_pipeline == 2) return classify_host_zero_copy(ctx, params, n_tiles, height, width, in, out, counters);
         if (pinned) return classify_host_pipelined(ctx, params, n_tiles, P, in, out, counters);
     }
-    // Pageable planes of a worthwhile size (what a caller holding plain numpy arrays passes): page-lock them IN PLACE
-    // for the duration of the call and take the zero-copy path -- registering 281 MB of touched memory costs 0.6 ms
-    // on the MI355X host, never-touched output pages ~5 ms per 100 MB (their first-touch faults, which the copy
-    // path pays as well), against 16 ms for the staged copies of the synchronous path below.  Anything that cannot
-    // be registered (read-only mappings, ranges another registration overlaps) falls through to that path.
-    if (ctx->host_pipeline == 2 && (size_t)n_tiles * (size_t)P >= ((size_t)1 << 20)) {
-        struct Span { uintptr_t lo, hi; };
-        std::vector<Span> want, locked;
-        auto add = [&](const void* p, size_t bytes) {
-            if (p && !(is_pinned_host(p) && is_pinned_host(static_cast<const char*>(p) + bytes - 1)))
-                want.push_back({reinterpret_cast<uintptr_t>(p), reinterpret_cast<uintptr_t>(p) + bytes});
-        };
-        const size_t px = (size_t)n_tiles * (size_t)P;
-        for (int k = 0; k < 6; ++k) add(in->band[k], px * 2);
-        const void* const u8s[] = {in->fmask, in->land, in->shad, in->ocean, out->wtr1, out->wtr1_aerosol, out->wtr2,
-                                   out->wtr, out->bwtr, out->conf, out->cloud, out->browse};
-        for (const void* p : u8s) add(p, px);
-        add(out->diag, px * 2);
-        add(out->mndwi, px * 8); add(out->ndvi, px * 8); add(out->awesh, px * 8);
-        // planes that are views into one array share pages at their seams: register page-merged ranges
-        std::sort(want.begin(), want.end(), [](const Span& a, const Span& b) { return a.lo < b.lo; });
-        std::vector<Span> merged;
-        for (const Span& w : want) {
-            const uintptr_t lo = w.lo & ~uintptr_t(4095), hi = (w.hi + 4095) & ~uintptr_t(4095);
-            if (!merged.empty() && lo <= merged.back().hi) { if (hi > merged.back().hi) merged.back().hi = hi; }
-            else merged.push_back({lo, hi});
-        }
-        bool ok = true;
-        for (const Span& m : merged) {
-            if (hipHostRegister(reinterpret_cast<void*>(m.lo), m.hi - m.lo, hipHostRegisterDefault) != hipSuccess) {
-                (void)hipGetLastError();
-                ok = false;
-                break;
-            }
-            locked.push_back(m);
-        }
-        int rc = DSWX_OK;
-        if (ok) rc = classify_host_zero_copy(ctx, params, n_tiles, height, width, in, out, counters);
-        for (const Span& sp : locked) (void)hipHostUnregister(reinterpret_cast<void*>(sp.lo));
-        if (ok) {
-            if (rc == DSWX_OK && !locked.empty()) ctx->last_kernel += ", pageable planes page-locked in place for the call";
-            return rc;
-        }
-    }
+    // (Page-locking pageable planes IN PLACE for the duration of the call -- hipHostRegister on page-merged ranges, then
+    // the zero-copy path -- was built and measured in round 2: 4.5 - 5.2 ms instead of 10.7 ms per 3660^2 tile from plain
+    // numpy arrays.  It is NOT used: about one run in twenty of the parity suite came back with a few wrong pixels in a
+    // freshly allocated, never-touched output array.  Transiently registered user memory is not pinned the way
+    // hipHostMalloc memory is (the driver follows the CPU page tables through MMU notifiers), and kernel WRITES into
+    // pages that are being faulted in, migrated or collapsed underneath were not reliable.  Pageable planes are copied.)
     // pageable host buffers (or 'cover' mode): one tile at a time through a grow-only device
     // arena: planes at 256-byte aligned offsets so the vector kernel is always eligible
     auto rnd = [](size_t x) { return (x + 255) & ~size_t(255); };

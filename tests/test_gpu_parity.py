@@ -322,8 +322,7 @@ def test_full_size_tile_vs_numpy_oracle(ctx):
     s = synth_tile(0, h, w)
     p = _capi.default_params()
     got = ctx.classify_host(s['bands'], s['fmask'], p)
-    # plain numpy planes of this size are page-locked in place for the call and read / written across PCIe
-    assert 'page-locked in place' in ctx.last_kernel_info() and 'zero copy' in ctx.last_kernel_info()
+    assert 'dswx_classify_lut' in ctx.last_kernel_info()      # aligned single tile -> table-driven
     exp = o.classify_tile(s['bands'], s['fmask'])
     for layer, key in NAME.items():
         assert np.array_equal(got[key], exp[layer]), layer
@@ -331,40 +330,80 @@ def test_full_size_tile_vs_numpy_oracle(ctx):
     assert got['counters'][0].tolist() == [c['n_valid'], c['n_cloud_and_valid'], c['n_not_ocean']]
 
 
-def test_pageable_planes_locked_in_place(ctx):
-    """dswx_classify_host on plain (pageable) numpy planes of >= 1 Mpixel: page-locked in place for the call, zero copy.
-    Views into one stacked array share pages at their seams (merged before registering); a second call on the same
-    arrays must work (everything is unregistered afterwards); the synchronous path (lab switch) is the comparator."""
-    h, w = 1200, 1000
-    s = synth_tile(41, h, w, with_masks=True)
-    stack = np.stack(s['bands'])                       # six views into ONE array: plane seams inside shared pages
-    bands = [stack[k] for k in range(6)]
-    p = _capi.default_params()
-    kw = dict(land=s['land'], shad=s['shad'], ocean=s['ocean'])
-    c0 = _capi.Context(0)
-    try:
-        c0.lab_configure(host_pipeline=0)
-        ref = c0.classify_host(bands, s['fmask'], p, layers=ALL_LAYERS, **kw)
-        assert 'zero copy' not in c0.last_kernel_info()
-    finally:
-        c0.close()
-    for rep in range(2):
-        got = ctx.classify_host(bands, s['fmask'], p, layers=ALL_LAYERS, **kw)
-        assert 'page-locked in place' in ctx.last_kernel_info()
-        for k in ALL_LAYERS:
-            assert np.array_equal(got[k], ref[k]), k
-        assert np.array_equal(got['counters'], ref['counters'])
-    exp = c_oracle.classify(p, bands, s['fmask'], **kw)
-    for k in ALL_LAYERS:
-        assert np.array_equal(got[k], exp[k]), k
-    # 'cover' mode takes the same path
-    pc = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
-    gotc = ctx.classify_host(bands, s['fmask'], pc, **kw)
-    assert 'page-locked in place' in ctx.last_kernel_info()
-    e = o.classify_tile(bands, s['fmask'], landcover=s['land'], shadow=s['shad'], ocean_mask=s['ocean'],
-                        mask_adjacent_to_cloud_mode='cover')
-    for layer, key in NAME.items():
-        assert np.array_equal(gotc[key], e[layer]), layer
+@pytest.mark.parametrize('align', [256, 16, 1])
+def test_zero_copy_writes_stay_inside_the_planes(ctx, align):
+    """The zero-copy host path lets the kernels write into the CALLER's memory, where an overrun that a device arena
+    would hide corrupts the heap.  Every plane is carved out of one page-locked buffer filled with a canary, at offsets
+    of the given alignment (256 -> table-driven kernels, 16 -> direct kernels, 1 -> generic kernel) and odd spacing;
+    after the call every byte outside the output planes must be untouched -- all nine kernel flavours, both modes."""
+    import ctypes
+    gap = 256
+    kinds = set()
+    for (n, h, w) in [(1, 333, 517), (2, 257, 301), (3, 64, 9), (1, 1, 7), (1, 1000, 1003)]:
+        for mode in ('mask', 'cover'):
+            for masks in (False, True):
+                P = h * w
+                names_u8 = ['wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'] + (['browse'] if align == 16 else [])
+                sizes = {'diag': 2 * n * P, **{k: n * P for k in names_u8}}
+                insz = {**{f'band{k}': 2 * n * P for k in range(6)}, 'fmask': n * P}
+                if masks:
+                    insz.update(land=n * P, shad=n * P, ocean=n * P)
+                total = sum(sizes.values()) + sum(insz.values()) + (gap + 520) * (len(sizes) + len(insz) + 2) + 4096
+                buf = ctx.pinned_empty((total,), np.uint8)
+                buf[:] = 0xA5
+                ptr, off = {}, gap
+
+                def take(name, nbytes, min_align):
+                    nonlocal off
+                    a_ = max(min_align, align)
+                    off = (off + a_ - 1) // a_ * a_
+                    ptr[name] = off
+                    off += nbytes + gap + 1
+                tiles = [synth_tile(11 + t, h, w, with_masks=True) for t in range(n)]
+                for k in range(6):
+                    take(f'band{k}', 2 * n * P, 2)
+                    buf[ptr[f'band{k}']:ptr[f'band{k}'] + 2 * n * P] = np.stack([t['bands'][k] for t in tiles]).view(np.uint8).ravel()
+                for m in ['fmask'] + (['land', 'shad', 'ocean'] if masks else []):
+                    take(m, n * P, 1)
+                    buf[ptr[m]:ptr[m] + n * P] = np.stack([t[m] for t in tiles]).ravel()
+                take('diag', 2 * n * P, 2)
+                for k in names_u8:
+                    take(k, n * P, 1)
+                assert off <= total
+                snapshot = buf.copy()
+                base = buf.ctypes.data
+                pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
+                for k in range(6):
+                    pin.band[k] = base + ptr[f'band{k}']
+                pin.fmask = base + ptr['fmask']
+                if masks:
+                    pin.land, pin.shad, pin.ocean = base + ptr['land'], base + ptr['shad'], base + ptr['ocean']
+                pout.diag = base + ptr['diag']
+                for k in names_u8:
+                    setattr(pout, k, base + ptr[k])
+                cnt = np.zeros((n, 3), np.int64)
+                p = _capi.make_params(mask_adjacent_to_cloud_mode=mode)
+                _capi._check(ctx.lib.dswx_classify_host(ctx.handle, ctypes.byref(p), n, h, w, ctypes.byref(pin),
+                                                        ctypes.byref(pout), _capi._host_ptr(cnt)))
+                info = ctx.last_kernel_info()
+                assert 'zero copy' in info, info
+                kinds.add(info.split(' grid')[0])
+                outside = np.ones(total, bool)
+                for k, sz in sizes.items():
+                    outside[ptr[k]:ptr[k] + sz] = False
+                stray = np.nonzero((buf != snapshot) & outside)[0]
+                assert len(stray) == 0, (align, (n, h, w), mode, masks, len(stray), int(stray[0]), info)
+                # and the planes themselves are right
+                if mode == 'mask':
+                    t0 = tiles[0]
+                    kw = dict(land=t0['land'], shad=t0['shad'], ocean=t0['ocean']) if masks else {}
+                    exp = c_oracle.classify(p, t0['bands'], t0['fmask'], **kw)
+                    assert np.array_equal(buf[ptr['wtr']:ptr['wtr'] + P].reshape(h, w), exp['wtr'])
+                    assert np.array_equal(buf[ptr['diag']:ptr['diag'] + 2 * P].view(np.uint16).reshape(h, w), exp['diag'])
+                del buf
+    # 256 -> table-driven (+ generic for the ragged tails), 16 -> direct, 1 -> generic only
+    want = {256: 'dswx_classify_lut', 16: 'dswx_classify_v8', 1: 'dswx_classify_v1'}[align]
+    assert any(want in k for k in kinds), kinds
 
 
 def test_full_size_batch_properties(ctx):

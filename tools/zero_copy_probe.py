@@ -57,30 +57,22 @@ def main():
         results[mode]['counters'] = cnt.copy()
         del bands, fm, outs
         ctx.close()
-    # pageable planes (plain numpy arrays, as a caller of the reference's seam holds them): page-locked in place for the
-    # call (product) vs the synchronous staged copies (lab switch host_pipeline=0); fresh np.empty outputs every call
-    for mode, switch in (('pageable_locked_in_place', None), ('pageable_synchronous_copies', {'host_pipeline': 0})):
-        ctx = _capi.Context(0)
-        if switch:
-            ctx.lab_configure(**switch)
-        p = _capi.default_params()
-        bands = [np.ascontiguousarray(np.broadcast_to(s['bands'][i], (n, T, T))) for i in range(6)]
-        fm = np.ascontiguousarray(np.broadcast_to(s['fmask'], (n, T, T)))
-        times = []
-        for rep in range(4):
-            t0 = time.perf_counter()
-            res = ctx.classify_host(bands, fm, p, layers=LAYERS)
-            times.append(time.perf_counter() - t0)
-        best = min(times[1:])
-        out[mode] = {'ms': round(best * 1e3, 2), 'Gpx_s': round(n * T * T / best / 1e9, 3), 'kernel': ctx.last_kernel_info(),
-                     'note': 'through the Python wrapper: includes allocating the numpy outputs'}
-        results[mode] = {k: np.array(res[k]) for k in LAYERS}
-        results[mode]['counters'] = res['counters'].copy()
-        ctx.close()
+    # pageable planes (plain numpy arrays, as a caller of the reference's seam holds them): synchronous staged copies
+    ctx = _capi.Context(0)
+    p = _capi.default_params()
+    bands = [np.ascontiguousarray(np.broadcast_to(s['bands'][i], (n, T, T))) for i in range(6)]
+    fm = np.ascontiguousarray(np.broadcast_to(s['fmask'], (n, T, T)))
+    times = []
+    for rep in range(4):
+        t0 = time.perf_counter()
+        res = ctx.classify_host(bands, fm, p, layers=LAYERS)
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    out['pageable_synchronous_copies'] = {'ms': round(best * 1e3, 2), 'Gpx_s': round(n * T * T / best / 1e9, 3), 'kernel': ctx.last_kernel_info(),
+                                          'note': 'through the Python wrapper: includes allocating the numpy outputs'}
+    out['pageable_identical'] = all(np.array_equal(res[k], results['zero_copy'][k]) for k in LAYERS)
+    ctx.close()
     a, b = list(results.values())[:2]
-    out['pageable_identical'] = all(np.array_equal(results['pageable_locked_in_place'][k], results['zero_copy'][k]) and
-                                    np.array_equal(results['pageable_synchronous_copies'][k], results['zero_copy'][k])
-                                    for k in results['zero_copy'])
     out['identical'] = all(np.array_equal(a[k], b[k]) for k in a)
     print(json.dumps(out, indent=1))
 
