@@ -276,14 +276,13 @@ int dswx_synth_batch(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0,
 /* ---- device plumbing for hosts without another HIP binding ------------------- */
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_device_free(dswx_ctx_t* ctx, void* ptr);
-/* Page-locked host memory.  dswx_classify_host() recognises buffers allocated here (or
- * registered with hipHostRegister) and, when EVERY plane pointer is page-locked, works on
- * them in place: the host planes are mapped into the device's address space and the kernels
- * read the inputs and write the layers across PCIe themselves (zero copy, both directions at
- * once, every mode) instead of the synchronous copy-compute-copy sequence that pageable planes
- * get.  Prefer buffers from dswx_host_alloc to registering arbitrary memory: pages that are
- * registered but not resident (never touched) are not a safe target for kernel writes.  There is
- * no reference counterpart (numpy arrays are pageable); results are identical. */
+/* Page-locked host memory.  dswx_classify_host() recognises buffers allocated HERE and, when
+ * EVERY plane lies inside such a buffer, works on them in place: the host planes are mapped into
+ * the device's address space and the kernels read the inputs and write the layers across PCIe
+ * themselves (zero copy, both directions at once, every mode) instead of the synchronous
+ * copy-compute-copy sequence.  Any other memory -- pageable, or page-locked by the caller with
+ * hipHostRegister, whose pages need not be resident -- is copied.  There is no reference
+ * counterpart (numpy arrays are pageable); results are identical. */
 int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_host_free(dswx_ctx_t* ctx, void* ptr);
 int dswx_memcpy_h2d(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);

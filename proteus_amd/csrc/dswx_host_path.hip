@@ -1,13 +1,32 @@
 // dswx_host_path.hip -- dswx_classify_host: the host-pointer entry of the classifier.
-// Pageable buffers: one tile at a time, copy -> classify -> copy on one stream.  Page-locked
-// buffers (dswx_host_alloc / hipHostRegister): ZERO COPY -- the kernels read the input planes and write the
+// Pageable buffers (and memory a caller page-locked itself): one tile at a time, copy -> classify -> copy on one
+// stream.  Buffers from dswx_host_alloc: ZERO COPY -- the kernels read the input planes and write the
 // layers across PCIe themselves, both directions at once (3.9 Gpixel/s for 13 B in + 8 B out per pixel,
 // measured on four 3660^2 tiles; the staged three-stream pipeline below it reaches 3.05 and stays as a lab A/B).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string>
 
+#include <map>
+#include <mutex>
+
 #include "dswx_host.h"
+
+// The page-locked spans this library handed out (dswx_host_alloc): allocated AND resident, the only host memory
+// the kernels are let loose on directly (zero copy).  Memory a caller registered itself (hipHostRegister) is
+// page-locked in HIP's eyes too, but its pages need not be resident -- see the note in dswx_classify_host.
+static std::mutex g_spans_mutex;
+static std::map<uintptr_t, size_t> g_spans;        // base -> bytes
+
+static bool in_own_span(const void* p, size_t bytes) {
+    if (!p) return true;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    std::lock_guard<std::mutex> lock(g_spans_mutex);
+    auto it = g_spans.upper_bound(a);
+    if (it == g_spans.begin()) return false;
+    --it;
+    return a >= it->first && a + bytes <= it->first + it->second;
+}
 
 extern "C" {
 
@@ -15,13 +34,20 @@ int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out) {
     if (!ctx || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    const size_t n = bytes ? bytes : 1;
+    HIP_TRY(hipHostMalloc(out, n, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lock(g_spans_mutex);
+    g_spans[reinterpret_cast<uintptr_t>(*out)] = n;
     return DSWX_OK;
 }
 
 int dswx_host_free(dswx_ctx_t* ctx, void* ptr) {
     if (!ctx) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     if (!ptr) return DSWX_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_spans_mutex);
+        g_spans.erase(reinterpret_cast<uintptr_t>(ptr));
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipHostFree(ptr));
     return DSWX_OK;
@@ -217,18 +243,22 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
     if (n_tiles == 0 || P == 0) return DSWX_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->host_pipeline == 2 || (ctx->host_pipeline && params->mask_adjacent_to_cloud_mode != DSWX_ADJ_COVER)) {
-        // a plane counts as page-locked when its first AND last byte are
+        // zero copy (product): every plane inside a span of dswx_host_alloc; staged pipeline (lab): any page-locked
+        // memory, first AND last byte of every plane
         const size_t npx = (size_t)n_tiles * (size_t)P;
-        auto locked_span = [](const void* p, size_t bytes) {
-            return !p || (is_pinned_host(p) && is_pinned_host(static_cast<const char*>(p) + bytes - 1));
+        const bool own = ctx->host_pipeline == 2;
+        auto ok_span = [&](const void* p, size_t bytes) {
+            if (!p) return true;
+            if (own) return in_own_span(p, bytes);
+            return is_pinned_host(p) && is_pinned_host(static_cast<const char*>(p) + bytes - 1);
         };
         bool pinned = true;
-        for (int k = 0; k < 6 && pinned; ++k) pinned = locked_span(in->band[k], npx * 2);
+        for (int k = 0; k < 6 && pinned; ++k) pinned = ok_span(in->band[k], npx * 2);
         const void* const rest[] = {in->fmask, in->land, in->shad, in->ocean, out->wtr1, out->wtr1_aerosol,
                                     out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud, out->browse};
-        for (const void* p : rest) pinned = pinned && locked_span(p, npx);
-        pinned = pinned && locked_span(out->diag, npx * 2) && locked_span(out->mndwi, npx * 8) &&
-                 locked_span(out->ndvi, npx * 8) && locked_span(out->awesh, npx * 8);
+        for (const void* p : rest) pinned = pinned && ok_span(p, npx);
+        pinned = pinned && ok_span(out->diag, npx * 2) && ok_span(out->mndwi, npx * 8) &&
+                 ok_span(out->ndvi, npx * 8) && ok_span(out->awesh, npx * 8);
         if (pinned && ctx->host_pipeline == 2) return classify_host_zero_copy(ctx, params, n_tiles, height, width, in, out, counters);
         if (pinned) return classify_host_pipelined(ctx, params, n_tiles, P, in, out, counters);
     }
