@@ -15,8 +15,9 @@
 // The page-locked spans this library handed out (dswx_host_alloc): allocated AND resident, the only host memory
 // the kernels are let loose on directly (zero copy).  Memory a caller registered itself (hipHostRegister) is
 // page-locked in HIP's eyes too, but its pages need not be resident -- see the note in dswx_classify_host.
-static std::mutex g_spans_mutex;
-static std::map<uintptr_t, size_t> g_spans;        // base -> bytes
+// (heap objects that are never destroyed: frees that arrive while the process exits must still find them)
+static std::mutex& g_spans_mutex = *new std::mutex;
+static std::map<uintptr_t, size_t>& g_spans = *new std::map<uintptr_t, size_t>;        // base -> bytes
 
 static bool in_own_span(const void* p, size_t bytes) {
     if (!p) return true;
