@@ -281,7 +281,10 @@ def place_batch(ctx, params, n_tiles, tile0, masks, trials):
     b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=True)
     b.synth(SEED, tile0=tile0)
     free_bytes, _ = torch.cuda.mem_get_info()
-    return b, b.place_outputs(params, candidates=trials, free_bytes=free_bytes)
+    try:
+        return b, b.place_outputs(params, candidates=trials, free_bytes=free_bytes)
+    except Exception as e:          # the search is an optimisation: the planes bound now are valid whatever happened
+        return b, {'trials': 1, 'probes': 0, 'error': f'{type(e).__name__}: {e}'[:300]}
 
 
 def free_port():

@@ -793,41 +793,45 @@ class DeviceBatch:
             pass
         original = {name: self.out_bufs[name] for name in names}
         everything = list(original.values()) + [buf for pool in pools.values() for buf in pool]
-        first_ms = launch_ms()
+        first_ms = kept_ms = 0.0
         probes = 0
-        for name in names * passes:
-            pool = pools.get(self.plane_nbytes[name], [])
-            if not pool:
-                continue
-            best_ms, best_k = launch_ms(), None
-            for k, buf in enumerate(pool):
-                old = self.bind_output(name, buf)
-                ms = launch_ms()
-                probes += 1
-                self.bind_output(name, old)
-                if ms < best_ms:
-                    best_ms, best_k = ms, k
-            if best_k is not None:
-                pool[best_k] = self.bind_output(name, pool[best_k])
-        kept_ms = first_ms
-        if probes:
-            # judge the outcome under equal conditions (the part is warmer now than at `first_ms`): the chosen
-            # planes and the first-come planes back to back, and keep the better set
-            chosen = dict(self.out_bufs)
-            chosen_ms = launch_ms()
-            for name in names:
-                self.bind_output(name, original[name])
-            again_ms = launch_ms()
-            if chosen_ms < again_ms:
+        try:
+            first_ms = launch_ms()
+            for name in names * passes:
+                pool = pools.get(self.plane_nbytes[name], [])
+                if not pool:
+                    continue
+                best_ms, best_k = launch_ms(), None
+                for k, buf in enumerate(pool):
+                    old = self.bind_output(name, buf)
+                    ms = launch_ms()
+                    probes += 1
+                    self.bind_output(name, old)
+                    if ms < best_ms:
+                        best_ms, best_k = ms, k
+                if best_k is not None:
+                    pool[best_k] = self.bind_output(name, pool[best_k])
+            kept_ms = first_ms
+            if probes:
+                # judge the outcome under equal conditions (the part is warmer now than at `first_ms`): the chosen
+                # planes and the first-come planes back to back, and keep the better set
+                chosen = dict(self.out_bufs)
+                chosen_ms = launch_ms()
                 for name in names:
-                    self.bind_output(name, chosen[name])
-                kept_ms = chosen_ms
-            else:                        # the search bought nothing: stay with what came first
-                kept_ms = again_ms
-        bound = {id(buf) for buf in self.out_bufs.values()}
-        for buf in everything:
-            if id(buf) not in bound:
-                buf.free()
+                    self.bind_output(name, original[name])
+                again_ms = launch_ms()
+                if chosen_ms < again_ms:
+                    for name in names:
+                        self.bind_output(name, chosen[name])
+                    kept_ms = chosen_ms
+                else:                        # the search bought nothing: stay with what came first
+                    kept_ms = again_ms
+        finally:
+            # whatever happened, exactly the buffers the planes point at stay alive
+            bound = {id(buf) for buf in self.out_bufs.values()}
+            for buf in everything:
+                if id(buf) not in bound:
+                    buf.free()
         return {'trials': sets + 1, 'probes': probes, 'first_come_launch_ms': round(first_ms, 4),
                 'kept_launch_ms': round(kept_ms, 4)}
 
