@@ -8,11 +8,11 @@ from proteus_amd.synth import SEED
 ctx = _capi.Context(0)
 p = _capi.default_params()
 out = []
-for cand, passes in ((6, 1), (6, 2), (8, 1), (8, 2)):
+for cand, passes, launches in ((6, 1, 3), (6, 2, 5), (6, 1, 5), (6, 2, 3), (6, 1, 3), (6, 2, 5)):
     b = _capi.DeviceBatch(ctx, 256, 3660, 3660, separate_outputs=True)
     b.synth(SEED)
     free_bytes, _ = torch.cuda.mem_get_info()
-    rec = b.place_outputs(p, candidates=cand, free_bytes=free_bytes, passes=passes)
+    rec = b.place_outputs(p, candidates=cand, free_bytes=free_bytes, passes=passes, launches=launches)
     # settle: 20 launches
     for _ in range(3):
         b.classify(p)
@@ -24,7 +24,7 @@ for cand, passes in ((6, 1), (6, 2), (8, 1), (8, 2)):
     ctx.record(e1)
     ctx.synchronize()
     ms = ctx.elapsed_ms(e0, e1) / 20
-    rec.update(candidates=cand, passes=passes, launch_ms_20=round(ms, 4), frac=round(256 * 3660 * 3660 * 21 / ms / 1e6 / 8000, 4))
+    rec.update(candidates=cand, passes=passes, launches=launches, launch_ms_20=round(ms, 4), frac=round(256 * 3660 * 3660 * 21 / ms / 1e6 / 8000, 4))
     out.append(rec)
     b.free()
 print(json.dumps(out, indent=1))
