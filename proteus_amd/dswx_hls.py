@@ -861,31 +861,35 @@ def _gdal_byte(band_array):
 
 def save_dswx_product(layers, output_file, dswx_metadata_dict, geo_tags,
                       output_files_list=None):
-    """Multi-band product (:2601-2707): ALWAYS the ten Byte bands of band_description_dict, in its order
-    (WTR, BWTR, CONF, DIAG, WTR-1, WTR-2, LAND, SHAD, CLOUD, DEM), nodata 255 -- band k of this file is
-    band k of a reference-made product.  As there:
+    """Multi-band product (:2601-2707).  The file is created with the ten Byte bands of band_description_dict
+    (:2663-2666), but the writing loop (:2673-2686) walks that dict and SKIPS, without advancing its band
+    index, every name that was not passed to the call.  generate_dswx_layers passes wtr, bwtr, diag, wtr_1,
+    wtr_2, land, shad, cloud, dem and never conf (:5383-5397), so a reference-made product is
+        1 WTR, 2 BWTR, 3 DIAG, 4 WTR-1, 5 WTR-2, 6 LAND, 7 SHAD, 8 CLOUD, 9 DEM, 10 never written (zeros)
+    and that is what `layers` (dict: name -> array or None; a name that is ABSENT is skipped the same way)
+    produces here.  As there:
       * DIAG (UInt16 decimal digits) and DEM (Float32) go through GDAL's Byte conversion (`_gdal_byte`),
         i.e. they saturate at 255 (:2666 creates every band as GDT_Byte);
-      * every band carries the description of the FIRST band: `description` is assigned once from
-        band_description_dict inside the loop and never reset (:2686-2687);
+      * every written band carries the description of the FIRST band: `description` is assigned once from
+        band_description_dict inside the loop and never reset (:2686-2687); unwritten bands have none;
       * WTR, WTR-1, WTR-2 arrive collapsed (the kernel applied _collapse_wtr_classes, :2688-2689).
-    A layer that was not produced (LAND / SHAD / DEM without their ancillary inputs; the reference
+    A layer that was passed as None (LAND / SHAD / DEM without their ancillary inputs; the reference
     would raise on WriteArray(None)) is a plane of nodata."""
-    names = list(band_description_dict)
-    first = next((np.asarray(v) for v in layers.values() if v is not None), None)
+    names = [n for n in band_description_dict if n in layers]
+    first = next((np.asarray(layers[n]) for n in names if layers[n] is not None), None)
     if first is None:
         raise ValueError('save_dswx_product: no layer to save')
     shape = first.shape
-    stack = np.full((len(names),) + shape, UINT8_FILL_VALUE, dtype=np.uint8)
+    nbands = len(band_description_dict)
+    stack = np.zeros((nbands,) + shape, dtype=np.uint8)             # an unwritten GTiff band reads as zeros
     for i, n in enumerate(names):
-        if layers.get(n) is not None:
-            stack[i] = _gdal_byte(layers[n])
-    description = band_description_dict[names[0]]
+        stack[i] = UINT8_FILL_VALUE if layers[n] is None else _gdal_byte(layers[n])
+    descriptions = [band_description_dict[names[0]]] * len(names) + [''] * (nbands - len(names))
     _makedirs(output_file)
 
     def job():
         geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict,
-                              nodata=UINT8_FILL_VALUE, descriptions=[description] * len(names),
+                              nodata=UINT8_FILL_VALUE, descriptions=descriptions,
                               overviews=geotiff.COG_OVERVIEW_FACTORS)
         logger.info(f'file saved: {output_file}')
     if output_files_list is not None:
@@ -1338,7 +1342,8 @@ def generate_dswx_layers(input_list,
         output_files_list.append(output_browse_image)
     if output_file and not output_file.endswith('.vrt'):
         # the multi-band file carries the post-aerosol WTR-1 (in-place remap, :5260 -> :5389)
-        save_dswx_product({'WTR': res['wtr'], 'BWTR': res['bwtr'], 'CONF': res['conf'], 'DIAG': res['diag'],
+        # CONF is NOT passed (:5383-5397): the loop skips it and the bands after BWTR move up one (see there)
+        save_dswx_product({'WTR': res['wtr'], 'BWTR': res['bwtr'], 'DIAG': res['diag'],
                            'WTR-1': res['wtr1_aerosol'], 'WTR-2': res['wtr2'],
                            'LAND': landcover_mask, 'SHAD': shadow_layer, 'CLOUD': res['cloud'], 'DEM': dem},
                           output_file, md, geo_tags, output_files_list=output_files_list)

@@ -184,17 +184,19 @@ def test_api_with_masks_and_multiband(tmp_path):
     conf, _ = geotiff.read_geotiff(str(tmp_path / 'conf.tif'))
     assert np.array_equal(conf, exp['CONF'])
     stack, info = geotiff.read_geotiff(out)
-    # the reference's fixed ten-band Byte layout (:2658-2667), band_description_dict order; WTR-1 is the
-    # post-aerosol one; DIAG saturates like GDT_Byte; no DEM here -> nodata plane; every band carries the
-    # first band's description (the reference never resets `description`, :2686-2687)
-    names = list(D.band_description_dict)
-    assert info.bands == 10 and info.descriptions == [D.band_description_dict['WTR']] * 10
-    want = {'WTR': exp['WTR'], 'BWTR': exp['BWTR'], 'CONF': exp['CONF'],
+    # the reference's multi-band file: ten Byte bands created (:2663-2666), nine written -- the call never passes
+    # conf and the loop skips it without advancing the band index (:5383-5397, :2673-2686); WTR-1 is the
+    # post-aerosol one; DIAG saturates like GDT_Byte; no DEM here -> nodata plane; band 10 stays unwritten;
+    # every written band carries the first band's description (never reset, :2686-2687)
+    written = ['WTR', 'BWTR', 'DIAG', 'WTR-1', 'WTR-2', 'LAND', 'SHAD', 'CLOUD', 'DEM']
+    assert info.bands == 10 and info.descriptions == [D.band_description_dict['WTR']] * 9 + ['']
+    want = {'WTR': exp['WTR'], 'BWTR': exp['BWTR'],
             'DIAG': np.minimum(exp['DIAG'], 255).astype(np.uint8),
             'WTR-1': exp['WTR-1-AEROSOL'], 'WTR-2': exp['WTR-2'], 'LAND': s['land'],
             'SHAD': s['shad'], 'CLOUD': exp['CLOUD'], 'DEM': np.full(exp['WTR'].shape, 255, np.uint8)}
-    for i, n in enumerate(names):
+    for i, n in enumerate(written):
         assert np.array_equal(stack[i], want[n]), n
+    assert not stack[9].any()
     assert info.metadata['OCEAN_MASKING_ENABLED'] == 'TRUE'
     # 'cover' mode goes through the split (dilation) path
     ok = D.generate_dswx_layers(files, mask_adjacent_to_cloud_mode='cover',

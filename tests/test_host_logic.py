@@ -202,32 +202,41 @@ def test_writes_are_atomic(tmp_path, monkeypatch):
 
 
 def test_multiband_product_has_the_reference_band_layout(tmp_path):
-    """save_dswx_product always writes the ten Byte bands of band_description_dict in its order
-    (reference :2658-2667), so band k here is band k of a reference-made product: WTR-1 is band 5, CLOUD
-    band 9; DIAG / DEM go through GDAL's Byte conversion; missing layers are nodata planes."""
+    """ADVICE r01 + r02: the reference creates ten Byte bands (:2663-2666) but its writing loop skips, WITHOUT
+    advancing the band index, every name of band_description_dict that was not passed (:2673-2686), and the
+    multi-band call never passes conf (:5383-5397).  Band k here is band k of a reference-made product:
+    WTR, BWTR, DIAG, WTR-1, WTR-2, LAND, SHAD, CLOUD, DEM, and a tenth band that is never written.
+    DIAG / DEM go through GDAL's Byte conversion; layers passed as None are nodata planes."""
     rng = np.random.default_rng(5)
     shape = (40, 50)
     u8 = lambda: rng.integers(0, 5, size=shape).astype(np.uint8)   # noqa: E731
     diag = rng.choice(np.array([0, 1, 11, 111, 10101, 11111, 65535], np.uint16), size=shape)
     dem = rng.normal(120.0, 200.0, size=shape).astype(np.float32)
     dem[0, 0] = np.nan
-    layers = {'WTR': u8(), 'BWTR': u8(), 'CONF': u8(), 'DIAG': diag, 'WTR-1': u8(), 'WTR-2': u8(),
+    layers = {'WTR': u8(), 'BWTR': u8(), 'DIAG': diag, 'WTR-1': u8(), 'WTR-2': u8(),
               'LAND': None, 'SHAD': rng.integers(0, 2, size=shape).astype(bool), 'CLOUD': u8(), 'DEM': dem}
     out = str(tmp_path / 'product.tif')
     D.save_dswx_product(layers, out, {'A': 'b'}, None)
     stack, info = geotiff.read_geotiff(out)
-    names = list(D.band_description_dict)
-    assert names == ['WTR', 'BWTR', 'CONF', 'DIAG', 'WTR-1', 'WTR-2', 'LAND', 'SHAD', 'CLOUD', 'DEM']
+    assert list(D.band_description_dict) == ['WTR', 'BWTR', 'CONF', 'DIAG', 'WTR-1', 'WTR-2', 'LAND', 'SHAD',
+                                             'CLOUD', 'DEM']
+    written = ['WTR', 'BWTR', 'DIAG', 'WTR-1', 'WTR-2', 'LAND', 'SHAD', 'CLOUD', 'DEM']
     assert info.bands == 10 and stack.dtype == np.uint8 and info.nodata == 255.0
-    for n in ('WTR', 'BWTR', 'CONF', 'WTR-1', 'WTR-2', 'CLOUD'):
-        assert np.array_equal(stack[names.index(n)], layers[n]), n
-    assert np.array_equal(stack[3], np.minimum(diag, 255).astype(np.uint8))            # saturated like GDT_Byte
-    assert np.array_equal(stack[6], np.full(shape, 255, np.uint8))                     # LAND not produced
-    assert np.array_equal(stack[7], layers['SHAD'].astype(np.uint8))
+    for n in ('WTR', 'BWTR', 'WTR-1', 'WTR-2', 'CLOUD'):
+        assert np.array_equal(stack[written.index(n)], layers[n]), n
+    assert np.array_equal(stack[2], np.minimum(diag, 255).astype(np.uint8))            # saturated like GDT_Byte
+    assert np.array_equal(stack[5], np.full(shape, 255, np.uint8))                     # LAND not produced
+    assert np.array_equal(stack[6], layers['SHAD'].astype(np.uint8))
     want_dem = np.floor(np.clip(np.nan_to_num(dem.astype(np.float64), nan=0.0), 0, 255) + 0.5).astype(np.uint8)
-    assert np.array_equal(stack[9], want_dem) and stack[9][0, 0] == 0
-    # the reference assigns `description` once and never resets it (:2686-2687): every band carries WTR's
-    assert info.descriptions == [D.band_description_dict['WTR']] * 10
+    assert np.array_equal(stack[8], want_dem) and stack[8][0, 0] == 0
+    assert not stack[9].any()                                                          # band 10: never written
+    # the reference assigns `description` once and never resets it (:2686-2687): every written band carries WTR's
+    assert info.descriptions == [D.band_description_dict['WTR']] * 9 + ['']
+    # a CONF plane passed explicitly takes band 3, as the reference's loop would place it
+    D.save_dswx_product(dict(layers, CONF=u8()), out, {'A': 'b'}, None)
+    stack2, info2 = geotiff.read_geotiff(out)
+    assert np.array_equal(stack2[3], stack[2]) and np.array_equal(stack2[9], stack[8])
+    assert info2.descriptions == [D.band_description_dict['WTR']] * 10
 
 
 def test_cog_validator_rejects_bad_layouts(tmp_path):

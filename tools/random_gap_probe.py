@@ -30,6 +30,11 @@ def main():
     ap.add_argument('--quantum', type=int, default=2 << 20)
     ap.add_argument('--sweep', default='distance')
     ap.add_argument('--total-gb', type=float, default=0.0, help='arena size (default: batch + slack)')
+    ap.add_argument('--in-base-gib', type=float, default=0.0, help='outpos sweep: where the packed input planes start')
+    ap.add_argument('--out-from-gib', type=float, default=-1.0, help='outpos sweep: first start of the packed output planes (default: end of inputs)')
+    ap.add_argument('--out-to-gib', type=float, default=-1.0)
+    ap.add_argument('--out-step-gib', type=float, default=1.5)
+    ap.add_argument('--points-gib', default='', help='outpos sweep: explicit output starts, comma separated (after the range)')
     a = ap.parse_args()
     ctx = _capi.Context(0)
     params = _capi.default_params()
@@ -70,7 +75,46 @@ def main():
         return round(px * 21 / ms / 1e6, 1)
 
     counters_buf = ctx.malloc(a.tiles * 24)
-    out = {'tiles': a.tiles, 'quantum': a.quantum, 'layouts': []}
+    out = {'tiles': a.tiles, 'quantum': a.quantum, 'arena_bytes': arena.nbytes, 'arena_ptr': hex(arena.ptr), 'layouts': []}
+    if a.sweep == 'outpos':
+        # round 3: WHERE in the (first, large) allocation of a fresh process do the seven write streams run fast?
+        # Inputs packed at --in-base-gib and generated once; the packed output region is moved through the arena.
+        GiB = 1 << 30
+        in_sz, out_sz = sum(sizes[:7]), sum(sizes[7:])
+        in_base = int(a.in_base_gib * GiB)
+        offs_in = [in_base + sum(sizes[:k]) for k in range(7)]
+        pin0, _ = bind(offs_in + [0] * 7)
+        ctx.synth_batch(SEED, 0, geom, pin0)
+        starts = []
+        lo = a.out_from_gib if a.out_from_gib >= 0 else (in_base + in_sz) / GiB
+        hi = a.out_to_gib if a.out_to_gib >= 0 else (arena.nbytes - out_sz) / GiB
+        x = lo
+        while x <= hi + 1e-9:
+            starts.append(x)
+            x += a.out_step_gib
+        starts += [float(v) for v in a.points_gib.split(',') if v]
+        out.update({'inputs_at_GiB': [round(in_base / GiB, 2), round((in_base + in_sz) / GiB, 2)], 'outputs_GiB': round(out_sz / GiB, 2)})
+        for st in starts:
+            o0 = (int(st * GiB) + 255) & ~255
+            if o0 + out_sz > arena.nbytes or (o0 < in_base + in_sz and o0 + out_sz > in_base):
+                continue
+            offs = offs_in + [o0 + sum(sizes[7:7 + j]) for j in range(7)]
+            pin, pout = bind(offs)
+            for _ in range(2):
+                ctx.classify_batch(params, geom, pin, pout, counters_buf.ptr)
+            ctx.synchronize()
+            e0, e1 = ctx.event(), ctx.event()
+            ctx.record(e0)
+            for _ in range(a.reps):
+                ctx.classify_batch(params, geom, pin, pout, counters_buf.ptr)
+            ctx.record(e1)
+            ctx.synchronize()
+            ms = ctx.elapsed_ms(e0, e1) / a.reps
+            ctx.destroy_event(e0)
+            ctx.destroy_event(e1)
+            out['layouts'].append({'out_start_GiB': round(st, 2), 'GBps': round(px * 21 / ms / 1e6, 1)})
+        print(json.dumps(out))
+        return
 
     def packed(order):
         off, offsets = 0, [0] * 14
