@@ -60,6 +60,10 @@ def parse_args():
                     help='also stream LAND/SHAD/OCEAN planes (BASELINE config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--distinct-chunks', action='store_true',
+                    help='strong scaling: after the timed region, generate every later chunk of the rank\'s share with '
+                         'its own tile indices, classify it and check its first and last tile (the timed walk re-streams '
+                         'the resident planes)')
     ap.add_argument('--no-single-tile', action='store_true',
                     help='skip the configs[1] leg (profiling runs: keeps the kernel statistics to the batch launches)')
     ap.add_argument('--cpu-parallel-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -193,25 +197,62 @@ def single_tile_leg(ctx, params, masks, reps=50):
                     'working set 281 MB (Infinity-Cache assisted), launch-latency bound'}
 
 
-def parity_spot_check(ctx, batch, params, tiles):
-    """Not timed: tiles of the timed batch against the scalar C oracle -- the first, the middle and the
-    LAST one (at 256 tiles the last sits past 2^31 pixels / 2^32 bytes into every plane)."""
+def parity_spot_check(ctx, batch, params, tiles, tile0=0):
+    """Not timed: tiles of the resident batch against the scalar C oracle, and their INPUT planes against the
+    numpy generator for the tile index the plan gives them (`tile0` + position: a rank whose share starts at
+    tile `lo` must hold tiles lo, lo+1, ... -- a wrong offset is a parity failure, not a detail)."""
     import numpy as np
     from oracle import c_oracle
     from proteus_amd import _capi
+    from proteus_amd.synth import synth_tile
     cnt = batch.read_counters()
+    checked = [tile0 + t for t in tiles]
     for tile in tiles:
         bands = [batch.read_tile(b, tile) for b in _capi.BAND_NAMES]
+        fmask = batch.read_tile('fmask', tile)
         kw = {}
         if batch.masks:
             kw = {m: batch.read_tile(m, tile) for m in ('land', 'shad', 'ocean')}
-        exp = c_oracle.classify(params, bands, batch.read_tile('fmask', tile), **kw)
+        want = synth_tile(tile0 + tile, TILE, TILE, with_masks=batch.masks)
+        same = all(np.array_equal(a, b) for a, b in zip(bands, want['bands'])) and np.array_equal(fmask, want['fmask']) \
+            and all(np.array_equal(kw[m], want[m]) for m in kw)
+        if not same:
+            return {'tiles': checked, 'result': f'resident tile {tile} is not synthetic tile {tile0 + tile}'}
+        exp = c_oracle.classify(params, bands, fmask, **kw)
         for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
             if not np.array_equal(batch.read_tile(key, tile), exp[key]):
-                return {'tiles': list(tiles), 'result': f'MISMATCH in {key} of tile {tile}'}
+                return {'tiles': checked, 'result': f'MISMATCH in {key} of tile {tile0 + tile}'}
         if cnt[tile].tolist() != exp['counters'].tolist():
-            return {'tiles': list(tiles), 'result': f'MISMATCH in counters of tile {tile}'}
-    return {'tiles': list(tiles), 'result': 'bit-exact'}
+            return {'tiles': checked, 'result': f'MISMATCH in counters of tile {tile0 + tile}'}
+    return {'tiles': checked, 'result': 'bit-exact'}
+
+
+def rank_parity(ctx, batch, params, rank, tile0, n_tiles, chunks, distinct):
+    """This rank's parity record (every rank runs it; the records are gathered into the line): first, middle and
+    LAST tile of the resident batch (at 256 tiles the last sits past 2^31 pixels / 2^32 bytes into every plane);
+    with --distinct-chunks every later chunk of a strong-scaling walk is generated with ITS tile indices, classified
+    and checked on its first and last tile, so every chunk of the rank's share is classified once under a check."""
+    from proteus_amd.synth import SEED
+    if len(chunks) > 1:                 # leave the full resident batch classified
+        batch.classify(params)
+        ctx.synchronize()
+    rec = parity_spot_check(ctx, batch, params, sorted({0, n_tiles // 2, n_tiles - 1}), tile0)
+    rec = dict(rank=rank, first_tile=tile0, **rec)
+    if distinct and len(chunks) > 1 and rec['result'] == 'bit-exact':
+        start = tile0
+        for j, c in enumerate(chunks):
+            if j:
+                batch.synth(SEED, tile0=start)
+                batch.classify(params, n_tiles=c)
+                ctx.synchronize()
+                more = parity_spot_check(ctx, batch, params, sorted({0, c - 1}), start)
+                rec['tiles'] += more['tiles']
+                if more['result'] != 'bit-exact':
+                    rec['result'] = more['result']
+                    break
+            start += c
+        rec['distinct_chunks'] = len(chunks)
+    return rec
 
 
 def pmc_traffic(masks, n_tiles):
@@ -265,24 +306,20 @@ def realloc_spread(ctx, params, n_tiles, masks, repeats, launches=5):
 
 
 def place_batch(ctx, params, n_tiles, tile0, masks, trials):
-    """Allocate the resident batch.  The kernel's rate depends on WHERE in HBM its output planes land -- a stable
-    property of the physical ranges (tools/placement_probe.py, tools/slab_probe.py, profiles/r02_placement_probe.json,
-    profiles/r02_slab_probe.json) -- so a long-lived batch is worth placing: the inputs get one allocation, every
-    output plane its own, and DeviceBatch.place_outputs chooses each plane among `trials` candidate allocations with
-    the kernel itself as the probe.  Outside the timed region; `--placement-trials 1` takes what comes first, 0 puts
-    all planes in ONE allocation."""
+    """Allocate the resident batch through the library (dswx_batch_create).  The kernel's rate depends on WHERE in HBM
+    its output planes land -- a stable property of the allocation that no layout rule predicts from one process to the
+    next (profiles/r03_placement_rule_trials.json) -- so a long-lived batch is worth placing:
+    the inputs get one allocation, every output plane its own, and dswx_batch_place_search (C-ABI; one pass of
+    coordinate descent over `trials` candidate allocations per plane, the kernel itself as the probe) binds each.
+    Outside the timed region; `--placement-trials 1` takes what comes first, 0 puts all planes in ONE allocation."""
     from proteus_amd import _capi
     from proteus_amd.synth import SEED
-    import torch
-    if trials <= 0:                 # one arena for everything, as a plain caller would allocate it
-        b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks)
-        b.synth(SEED, tile0=tile0)
-        return b, {'trials': 0, 'probes': 0}
-    b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=True)
+    b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=trials > 0)
     b.synth(SEED, tile0=tile0)
-    free_bytes, _ = torch.cuda.mem_get_info()
+    if trials <= 1:                 # 0: one arena for everything, as a plain caller would allocate it; 1: first come
+        return b, {'trials': max(trials, 0), 'probes': 0}
     try:
-        return b, b.place_outputs(params, candidates=trials, free_bytes=free_bytes)
+        return b, b.place_search(params, candidates=trials)
     except Exception as e:          # the search is an optimisation: the planes bound now are valid whatever happened
         return b, {'trials': 1, 'probes': 0, 'error': f'{type(e).__name__}: {e}'[:300]}
 
@@ -383,12 +420,10 @@ def main():
     batch, placement = place_batch(ctx, params, n_tiles, tile0, args.masks,
                                    1 if share_device else args.placement_trials)
     barrier = cp.barrier
-    # a partial last chunk classifies the first `c` tiles of the resident batch
-    geoms = {c: _capi.BatchGeom(c, TILE, TILE, batch.tile_stride) for c in set(chunks)}
 
     def one_step():
-        for c in chunks:
-            ctx.classify_batch(params, geoms[c], batch.pin, batch.pout, batch.counters_ptr)
+        for c in chunks:            # dswx_batch_classify: a partial last chunk = the first `c` resident tiles
+            batch.classify(params, n_tiles=c)
 
     for _ in range(args.warmup):
         one_step()
@@ -417,14 +452,14 @@ def main():
     total_px_per_step = cp.sum_over_ranks(my_tiles) * TILE * TILE
 
     parity = None
-    if rank == 0 and not args.no_parity:
+    if not args.no_parity:              # EVERY rank checks its own tiles; the records are gathered into the line
         try:
-            if len(chunks) > 1:                 # leave the full resident batch classified
-                batch.classify(params)
-                ctx.synchronize()
-            parity = parity_spot_check(ctx, batch, params, sorted({0, n_tiles // 2, n_tiles - 1}))
+            mine = rank_parity(ctx, batch, params, rank, tile0, n_tiles, chunks, args.distinct_chunks)
         except Exception as e:          # the checker failing is reported, not fatal to the measurement
-            parity = {'result': f'not checked ({type(e).__name__}: {e})'[:300]}
+            mine = {'rank': rank, 'first_tile': tile0, 'result': f'not checked ({type(e).__name__}: {e})'[:300]}
+        records = cp.gather_objects(mine)
+        bad = [r['result'] for r in records if r['result'] != 'bit-exact']
+        parity = {'result': bad[0] if bad else 'bit-exact', 'ranks': records}
 
     if rank == 0:
         bytes_per_px = 24 if args.masks else 21      # 13+8 (16+8 with masks)
@@ -461,11 +496,13 @@ def main():
                        'sharding': f'tiles by rank x{world}, no collective',
                        'control_plane': cp.backend,
                        'arena_placement': dict(placement, note='one arena for all planes') if not placement['trials'] else
-                       dict(placement, note='every output plane in the fastest of `trials` candidate '
-                                               'allocations (one pass of coordinate descent with the kernel itself as the '
-                                               'probe, before warm-up): the rate is a property of the physical ranges the '
-                                               'seven write streams land in; roofline.realloc_spread shows what arbitrary '
-                                               'single-arena placements give'),
+                       dict(placement, note='dswx_batch_place_search (C-ABI): every output plane in the fastest of '
+                                               '`trials` candidate allocations (one pass of coordinate descent with the '
+                                               'kernel itself as the probe, before warm-up): the rate is a property of '
+                                               'the ranges the seven write streams land in; first_come_launch_ms = the '
+                                               'first-come planes timed back to back with the kept ones at the end of the '
+                                               'search; roofline.realloc_spread shows what unplaced single-arena '
+                                               'allocations give'),
                        'kernel': kernel_info},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
@@ -482,7 +519,7 @@ def main():
                          'kernel_source_hash': _build.hot_kernel_hash()},
             'parity_check': parity,
         }
-        if placement.get('first_come_launch_ms'):      # what the same planes gave where they first came to lie (3-launch probe)
+        if placement.get('first_come_launch_ms'):      # the first-come planes, timed back to back with the kept set (3-launch probes)
             out['roofline']['frac_first_come_placement'] = round(
                 px_per_launch * bytes_per_px / (placement['first_come_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if world == 1 and args.realloc_repeats > 0:

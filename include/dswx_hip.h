@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DSWX_ABI_VERSION 3
+#define DSWX_ABI_VERSION 4
 
 enum {
     DSWX_OK = 0,
@@ -273,6 +273,89 @@ int dswx_synth_fill(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0, int64_t n_til
 int dswx_synth_batch(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0,
                      const dswx_batch_geom_t* geom, const dswx_planes_in_t* in, void* stream);
 
+/* ---- resident batches: allocation and placement of the planes (ABI v4) ---------
+ * The seam at dswx_hls.py:5225-5286 works on arrays the caller already holds; a service that keeps a
+ * batch of tiles resident in HBM (bench.py, proteus_amd/batch.py) needs them allocated -- and on MI355X
+ * WHERE the seven output planes lie decides between 0.71 and 0.80 of the HBM peak for the same launch
+ * (the rate follows the position of the write streams in the address space, with
+ * a 32-GiB structure; round 3 looked for a layout RULE and found none that holds from one process to
+ * the next -- profiles/r03_placement_rule_trials.json).  dswx_batch_create allocates the planes of a
+ * batch (one hipMalloc, packed); dswx_batch_place_search is the opt-in measured placement that bench.py
+ * uses, so the placed rate is available to every caller of this ABI, not to a Python helper only. */
+typedef struct dswx_batch dswx_batch_t;
+
+/* plane indices of dswx_batch_layout_t */
+enum {
+    DSWX_PLANE_BAND0 = 0,      /* blue, green, red, nir, swir1, swir2 = 0..5 (int16) */
+    DSWX_PLANE_FMASK = 6,
+    DSWX_PLANE_LAND = 7, DSWX_PLANE_SHAD = 8, DSWX_PLANE_OCEAN = 9,          /* DSWX_BATCH_MASKS */
+    DSWX_PLANE_DIAG = 10,      /* uint16 */
+    DSWX_PLANE_WTR1 = 11, DSWX_PLANE_WTR1_AEROSOL = 12, DSWX_PLANE_WTR2 = 13, DSWX_PLANE_WTR = 14,
+    DSWX_PLANE_BWTR = 15, DSWX_PLANE_CONF = 16, DSWX_PLANE_CLOUD = 17, DSWX_PLANE_BROWSE = 18,
+    DSWX_PLANE_COUNTERS = 19,  /* int64 [n_tiles][3] */
+    DSWX_BATCH_MAX_PLANES = 20
+};
+
+/* flags of dswx_batch_create / dswx_batch_layout */
+enum {
+    DSWX_BATCH_MASKS = 1 << 0,            /* LAND, SHAD, OCEAN input planes (BASELINE config 5) */
+    DSWX_BATCH_WTR1_AEROSOL = 1 << 1,     /* optional output planes */
+    DSWX_BATCH_BROWSE = 1 << 2,
+    /* layout: default = ONE allocation, inputs then outputs back to back (what a plain caller does) */
+    DSWX_BATCH_SEPARATE_OUTPUTS = 1 << 10 /* one allocation for the inputs, one per output plane: what
+                                             dswx_batch_place_search needs */
+};
+
+typedef struct dswx_batch_layout {
+    int64_t tile_stride;                              /* pixels, as resolved (see dswx_batch_create) */
+    uint64_t arena_bytes;                             /* the single allocation (SEPARATE_OUTPUTS: the inputs') */
+    uint64_t plane_bytes[DSWX_BATCH_MAX_PLANES];      /* 0 = plane absent */
+    uint64_t plane_offset[DSWX_BATCH_MAX_PLANES];     /* inside the arena (SEPARATE_OUTPUTS: 0 for outputs) */
+    uint64_t write_span_bytes;                        /* first byte of the first to last byte of the last
+                                                         output plane (0 with SEPARATE_OUTPUTS) */
+} dswx_batch_layout_t;
+
+typedef struct dswx_batch_info {
+    dswx_batch_geom_t geom;           /* tile_stride resolved */
+    uint32_t flags;
+    int32_t n_allocations;
+    uint64_t bytes_allocated;         /* HBM the batch holds */
+    /* record of the last dswx_batch_place_search (zeros if none ran) */
+    int32_t search_candidates;
+    int32_t search_probes;            /* probe measurements taken (each `launches` launches) */
+    float first_come_launch_ms;       /* the planes as first allocated ... */
+    float kept_launch_ms;             /* ... and as kept, timed back to back at the end of the search */
+} dswx_batch_info_t;
+
+/* The layout rule alone (pure function, no device needed): where dswx_batch_create would put every
+ * plane.  geom->tile_stride 0 = height*width rounded up to a multiple of 256 pixels (every tile of
+ * every plane then starts on a 256-byte boundary: the fast kernel, see the top of this file); any
+ * other value is taken as given (>= height*width).  Plane offsets are 256-byte aligned. */
+int dswx_batch_layout(const dswx_batch_geom_t* geom, uint32_t flags, dswx_batch_layout_t* out);
+
+int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t flags,
+                      dswx_batch_t** out);
+int dswx_batch_destroy(dswx_batch_t* batch);
+/* Device pointers of the planes (absent planes NULL), the resolved geometry and the counters array
+ * ([n_tiles][3] int64); any output argument may be NULL.  Hand them to dswx_classify_batch /
+ * dswx_synth_batch, or use the two conveniences below. */
+int dswx_batch_planes(const dswx_batch_t* batch, dswx_batch_geom_t* geom, dswx_planes_in_t* in,
+                      dswx_planes_out_t* out, int64_t** counters);
+int dswx_batch_info(const dswx_batch_t* batch, dswx_batch_info_t* info);
+/* dswx_classify_batch over the first `n_tiles` resident tiles (0 = all), counters included. */
+int dswx_batch_classify(dswx_batch_t* batch, const dswx_params_t* params, int64_t n_tiles,
+                        void* stream);
+/* dswx_synth_batch into the resident input planes: tiles tile0 .. tile0 + n_tiles - 1. */
+int dswx_batch_synth(dswx_batch_t* batch, uint64_t seed, int64_t tile0, void* stream);
+/* Opt-in, measured placement (DSWX_BATCH_SEPARATE_OUTPUTS batches whose inputs are resident): beside
+ * every output plane `candidates - 1` spare allocations are made (as many sets as fit while
+ * `keep_free_bytes` of device memory stay free), and one pass of coordinate descent binds each plane in
+ * turn (DIAG first) to the candidate under which `launches` launches of the real kernel run fastest;
+ * the chosen and the first-come planes are then timed back to back and the better set is kept.  The
+ * spares are freed.  Output pointers change: call dswx_batch_planes again.  Synchronous. */
+int dswx_batch_place_search(dswx_batch_t* batch, const dswx_params_t* params, int32_t candidates,
+                            int32_t launches, uint64_t keep_free_bytes);
+
 /* ---- device plumbing for hosts without another HIP binding ------------------- */
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_device_free(dswx_ctx_t* ctx, void* ptr);
@@ -284,6 +367,7 @@ int dswx_device_free(dswx_ctx_t* ctx, void* ptr);
  * hipHostRegister, whose pages need not be resident -- is copied.  There is no reference
  * counterpart (numpy arrays are pageable); results are identical. */
 int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out);
+/* ctx may be NULL here (a span may outlive the context it was allocated through). */
 int dswx_host_free(dswx_ctx_t* ctx, void* ptr);
 int dswx_memcpy_h2d(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);
 int dswx_memcpy_d2h(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);

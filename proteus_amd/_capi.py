@@ -12,7 +12,7 @@ import numpy as np
 
 from . import build as _build
 
-DSWX_ABI_VERSION = 3
+DSWX_ABI_VERSION = 4
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALIGN = 0, -1, -2, -3, -4, -5
 ADJ_MODES = {'mask': 0, 'ignore': 1, 'cover': 2}
 BAND_NAMES = ('blue', 'green', 'red', 'nir', 'swir1', 'swir2')
@@ -29,7 +29,9 @@ EXPORTED_SYMBOLS = (
     'dswx_synth_fill', 'dswx_device_malloc',
     'dswx_device_free', 'dswx_host_alloc', 'dswx_host_free', 'dswx_memcpy_h2d', 'dswx_memcpy_d2h', 'dswx_memset_d',
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
-    'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info')
+    'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info',
+    'dswx_batch_layout', 'dswx_batch_create', 'dswx_batch_destroy', 'dswx_batch_planes', 'dswx_batch_info',
+    'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search')
 
 
 class DswxError(RuntimeError):
@@ -71,6 +73,27 @@ class PlanesOut(ctypes.Structure):
     _fields_ = ([('diag', ctypes.c_void_p)] +
                 [(n, ctypes.c_void_p) for n in U8_LAYERS] +
                 [(n, ctypes.c_void_p) for n in F64_LAYERS])
+
+
+# resident batches (include/dswx_hip.h, ABI v4)
+BATCH_MASKS, BATCH_WTR1_AEROSOL, BATCH_BROWSE, BATCH_SEPARATE_OUTPUTS = 1, 2, 4, 1 << 10
+BATCH_MAX_PLANES = 20
+PLANE_INDEX = dict(blue=0, green=1, red=2, nir=3, swir1=4, swir2=5, fmask=6, land=7, shad=8, ocean=9, diag=10,
+                   wtr1=11, wtr1_aerosol=12, wtr2=13, wtr=14, bwtr=15, conf=16, cloud=17, browse=18, counters=19)
+
+
+class BatchLayout(ctypes.Structure):
+    _fields_ = [('tile_stride', ctypes.c_int64), ('arena_bytes', ctypes.c_uint64),
+                ('plane_bytes', ctypes.c_uint64 * BATCH_MAX_PLANES),
+                ('plane_offset', ctypes.c_uint64 * BATCH_MAX_PLANES),
+                ('write_span_bytes', ctypes.c_uint64)]
+
+
+class BatchInfo(ctypes.Structure):
+    _fields_ = [('geom', BatchGeom), ('flags', ctypes.c_uint32), ('n_allocations', ctypes.c_int32),
+                ('bytes_allocated', ctypes.c_uint64), ('search_candidates', ctypes.c_int32),
+                ('search_probes', ctypes.c_int32), ('first_come_launch_ms', ctypes.c_float),
+                ('kept_launch_ms', ctypes.c_float)]
 
 
 _lib = None
@@ -168,6 +191,17 @@ def load_library(path=None):
         'dswx_event_elapsed_ms': (ctypes.c_int, [vp, vp, vp,
                                                  ctypes.POINTER(ctypes.c_float)]),
         'dswx_last_kernel_info': (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_size_t]),
+        'dswx_batch_layout': (ctypes.c_int, [ctypes.POINTER(BatchGeom), ctypes.c_uint32,
+                                             ctypes.POINTER(BatchLayout)]),
+        'dswx_batch_create': (ctypes.c_int, [vp, ctypes.POINTER(BatchGeom), ctypes.c_uint32, pp]),
+        'dswx_batch_destroy': (ctypes.c_int, [vp]),
+        'dswx_batch_planes': (ctypes.c_int, [vp, ctypes.POINTER(BatchGeom), ctypes.POINTER(PlanesIn),
+                                             ctypes.POINTER(PlanesOut), pp]),
+        'dswx_batch_info': (ctypes.c_int, [vp, ctypes.POINTER(BatchInfo)]),
+        'dswx_batch_classify': (ctypes.c_int, [vp, ctypes.POINTER(Params), i64, vp]),
+        'dswx_batch_synth': (ctypes.c_int, [vp, ctypes.c_uint64, i64, vp]),
+        'dswx_batch_place_search': (ctypes.c_int, [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
+                                                   ctypes.c_uint64]),
     }
     for name, (res, args) in sig.items():
         if alt and not hasattr(lib, name):
@@ -393,12 +427,22 @@ class Context:
         self._pinned = {}          # page-locked host spans: address -> bytes
         self._pinned_pool = {}     # released spans by size
         self._pinned_pool_bytes = 0
-        self._pinned_lock = threading.Lock()   # reader threads allocate, finalizers release on any thread
+        self._pinned_lock = threading.RLock()  # reader threads allocate; finalizers release on ANY thread, also (cyclic GC) on
+                                               # one that is inside the lock already: re-entrant
 
     def close(self):
         if self.handle:
-            self.lib.dswx_ctx_destroy(self.handle)
-            self.handle = None
+            with self._pinned_lock:
+                # the pool's spans belong to no array any more: hand them back before the context goes.  Spans of
+                # arrays that are still alive are freed by their finalizers (dswx_host_free takes a NULL context).
+                for nbytes, spans in self._pinned_pool.items():
+                    for addr in spans:
+                        self._pinned.pop(addr, None)
+                        self.lib.dswx_host_free(self.handle, ctypes.c_void_p(addr))
+                self._pinned_pool = {}
+                self._pinned_pool_bytes = 0
+                handle, self.handle = self.handle, None
+            self.lib.dswx_ctx_destroy(handle)
 
     def __del__(self):
         try:
@@ -432,19 +476,19 @@ class Context:
         arr = np.frombuffer(raw, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape) \
             if int(np.prod(shape, dtype=np.int64)) else np.empty(shape, dtype)
 
-        def release(ctx_ref=weakref.ref(self), addr=addr, nbytes=nbytes):
+        def release(ctx_ref=weakref.ref(self), lib=self.lib, addr=addr, nbytes=nbytes):
             ctx = ctx_ref()
-            if ctx is None or not ctx.handle:
+            if ctx is None:
+                lib.dswx_host_free(None, ctypes.c_void_p(addr))      # the context is gone: the span still is ours to free
                 return
             with ctx._pinned_lock:
-                keep = ctx._pinned_pool_bytes + nbytes <= ctx.PINNED_POOL_CAP
+                keep = bool(ctx.handle) and ctx._pinned_pool_bytes + nbytes <= ctx.PINNED_POOL_CAP
                 if keep:
                     ctx._pinned_pool.setdefault(nbytes, []).append(addr)
                     ctx._pinned_pool_bytes += nbytes
                 else:
                     ctx._pinned.pop(addr, None)
-            if not keep:
-                ctx.lib.dswx_host_free(ctx.handle, ctypes.c_void_p(addr))
+                    lib.dswx_host_free(ctx.handle, ctypes.c_void_p(addr))
         weakref.finalize(raw, release)
         return arr
 
@@ -659,212 +703,142 @@ class Context:
         return buf.value.decode()
 
 
-class DeviceBatch:
-    """Band-planar batch resident in HBM: every plane is [n_tiles][tile_stride].
+def batch_layout(n_tiles, height, width, masks=False, extra_layers=(), tile_stride=0, separate_outputs=False):
+    """dswx_batch_layout: where dswx_batch_create puts every plane (pure function, no device).  Returns
+    {'tile_stride', 'arena_bytes', 'write_span_bytes', 'planes': {name: (offset, nbytes)}}."""
+    flags = _batch_flags(masks, extra_layers, separate_outputs)
+    lay = BatchLayout()
+    geom = BatchGeom(n_tiles, height, width, tile_stride)
+    _check(load_library().dswx_batch_layout(ctypes.byref(geom), flags, ctypes.byref(lay)))
+    planes = {name: (int(lay.plane_offset[k]), int(lay.plane_bytes[k])) for name, k in PLANE_INDEX.items()
+              if lay.plane_bytes[k]}
+    return {'tile_stride': int(lay.tile_stride), 'arena_bytes': int(lay.arena_bytes),
+            'write_span_bytes': int(lay.write_span_bytes), 'planes': planes}
 
-    Owns one arena (with separate_outputs: one for the inputs and one allocation per output plane); plane offsets are
-    256-byte aligned and, by default, the tile stride is
-    H*W rounded up to a multiple of 256 pixels, so every tile starts on a 256-byte boundary
-    in every plane (contiguous tiles of 3660 x 3660 do not: 13,395,600 = 144 mod 256, which
-    costs ~20 % of the HBM rate).  `tile_align=1` gives contiguous tiles.
+
+def _batch_flags(masks, extra_layers, separate_outputs):
+    unknown = [x for x in extra_layers if x not in ('wtr1_aerosol', 'browse')]
+    if unknown:
+        raise ValueError(f'a resident batch has no plane {unknown[0]!r}')
+    return ((BATCH_MASKS if masks else 0) | (BATCH_WTR1_AEROSOL if 'wtr1_aerosol' in extra_layers else 0)
+            | (BATCH_BROWSE if 'browse' in extra_layers else 0) | (BATCH_SEPARATE_OUTPUTS if separate_outputs else 0))
+
+
+class DeviceBatch:
+    """Band-planar batch resident in HBM (dswx_batch_t of include/dswx_hip.h): every plane is [n_tiles][tile_stride].
+
+    The LIBRARY allocates and lays out the planes (dswx_batch_create: one allocation, 256-byte aligned plane
+    offsets; with separate_outputs one for the inputs and one per output plane, which is what `place_search`
+    needs).  By default the tile stride is H*W rounded up to a multiple of 256 pixels, so every tile starts on a
+    256-byte boundary in every plane (contiguous tiles of 3660 x 3660 do not: 13,395,600 = 144 mod 256, which
+    costs ~20 % of the HBM rate); `tile_align=1` gives contiguous tiles.
     Used by bench.py, the multi-GPU driver and the device-path parity tests.
     """
 
-    def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=(), tile_align=256, plane_skew=0,
+    def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=(), tile_align=256,
                  separate_outputs=False):
-        """separate_outputs: every output plane gets an allocation of its own, so that each can be chosen among
-        several candidates (`new_plane_buffer` / `bind_output`): on MI355X the kernel's rate depends on which
-        physical ranges its WRITE streams land in."""
         self.ctx, self.n_tiles, self.height, self.width = ctx, n_tiles, height, width
         self.n_pixels = height * width
-        self.tile_stride = -(-self.n_pixels // tile_align) * tile_align
-        self.geom = BatchGeom(n_tiles, height, width, self.tile_stride)
-        total = n_tiles * self.tile_stride
-        self.total = total
-        self.offsets = {}          # name -> byte offset inside its arena
-        self._in_out = {}          # name -> 'in' | 'out'
-        cursor = {'in': 0}          # bytes taken in the arena
-        skew = int(plane_skew)
-
-        self.plane_nbytes = {}
-
-        def take(name, nbytes, side):
-            # optional skew: plane k starts k*skew bytes later than plain packing,
-            # so equal pixel indices of different planes differ in their low
-            # address bits (DRAM channel / bank selection)
-            self._in_out[name] = side
-            self.plane_nbytes[name] = (nbytes + 255) & ~255
-            if separate_outputs and side == 'out':
-                self.offsets[name] = 0
-                return
-            off = cursor['in'] + skew * len(self.offsets)
-            off = (off + 255) & ~255
-            self.offsets[name] = off
-            cursor['in'] = off + ((nbytes + 255) & ~255)
-
-        for b in BAND_NAMES:
-            take(b, total * 2, 'in')
-        take('fmask', total, 'in')
         self.masks = masks
-        if masks:
-            for m in ('land', 'shad', 'ocean'):
-                take(m, total, 'in')
-        take('diag', total * 2, 'out')
-        self.out_layers = ['wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'] + \
-            [x for x in extra_layers if x in U8_LAYERS]
-        for name in self.out_layers:
-            take(name, total, 'out')
-        take('counters', n_tiles * 24, 'in')
-        self.arena = ctx.malloc(cursor['in'])
-        out_names = ['diag'] + self.out_layers
-        self.out_bufs = {n: ctx.malloc(self.plane_nbytes[n]) for n in out_names} if separate_outputs else {}
-        self.out_bytes = sum(self.plane_nbytes[n] for n in out_names)
-        self.nbytes = cursor['in'] + (self.out_bytes if separate_outputs else 0)
-        base = self.arena.ptr
-        self.pin = PlanesIn()
-        for i, b in enumerate(BAND_NAMES):
-            self.pin.band[i] = base + self.offsets[b]
-        self.pin.fmask = base + self.offsets['fmask']
-        if masks:
-            self.pin.land = base + self.offsets['land']
-            self.pin.shad = base + self.offsets['shad']
-            self.pin.ocean = base + self.offsets['ocean']
-        self.pout = PlanesOut()
-        self._bind_outputs()
-        self.counters_ptr = base + self.offsets['counters']
+        stride = -(-self.n_pixels // tile_align) * tile_align
+        flags = _batch_flags(masks, extra_layers, separate_outputs)
+        h = ctypes.c_void_p()
+        geom = BatchGeom(n_tiles, height, width, stride)
+        if stride == 0:                 # an empty tile: let the library resolve the stride (0 stays 0)
+            geom.tile_stride = 0
+        _check(ctx.lib.dswx_batch_create(ctx.handle, ctypes.byref(geom), flags, ctypes.byref(h)))
+        self.handle = h
+        self.out_layers = ['wtr1'] + (['wtr1_aerosol'] if 'wtr1_aerosol' in extra_layers else []) + \
+            ['wtr2', 'wtr', 'bwtr', 'conf', 'cloud'] + (['browse'] if 'browse' in extra_layers else [])
+        self._rebind()
 
-    def _bind_outputs(self):
-        for name in ['diag'] + self.out_layers:
-            setattr(self.pout, name, self._arena_of(name).ptr + self.offsets[name])
+    def _rebind(self):
+        """Fetch the plane pointers (they change when place_search re-binds output planes)."""
+        self.geom, self.pin, self.pout = BatchGeom(), PlanesIn(), PlanesOut()
+        cnt = ctypes.c_void_p()
+        _check(self.ctx.lib.dswx_batch_planes(self.handle, ctypes.byref(self.geom), ctypes.byref(self.pin),
+                                              ctypes.byref(self.pout), ctypes.byref(cnt)))
+        self.tile_stride = int(self.geom.tile_stride)
+        self.counters_ptr = cnt.value
+        info = self.info()
+        self.nbytes = info['bytes_allocated']
 
-    def new_plane_buffer(self, name):
-        """Another allocation that could hold output plane `name` (separate_outputs only)."""
-        assert self.out_bufs, 'DeviceBatch was built with one arena'
-        return self.ctx.malloc(self.plane_nbytes[name])
+    def info(self):
+        bi = BatchInfo()
+        _check(self.ctx.lib.dswx_batch_info(self.handle, ctypes.byref(bi)))
+        return {'bytes_allocated': int(bi.bytes_allocated), 'n_allocations': int(bi.n_allocations),
+                'flags': int(bi.flags), 'search_candidates': int(bi.search_candidates),
+                'search_probes': int(bi.search_probes),
+                'first_come_launch_ms': float(bi.first_come_launch_ms), 'kept_launch_ms': float(bi.kept_launch_ms)}
 
-    def bind_output(self, name, buf):
-        """Point output plane `name` at `buf` (from new_plane_buffer); returns the buffer used before."""
-        assert buf.nbytes >= self.plane_nbytes[name]
-        old, self.out_bufs[name] = self.out_bufs[name], buf
-        setattr(self.pout, name, buf.ptr)
-        return old
-
-    def _arena_of(self, name):
-        return self.out_bufs.get(name, self.arena)
-
-    def place_outputs(self, params, candidates=6, launches=3, keep_free_bytes=8 << 30, free_bytes=None, passes=1):
-        """Choose WHERE in HBM every output plane lives (separate_outputs only; the batch must hold its inputs).
-
-        On MI355X the fused kernel's rate depends on the physical ranges its seven write streams land in -- a
-        stable property of the allocation (the same launch takes 11.3 - 12.0 ms over
-        placements, and moving ONE u8 plane changes it by up to 1.5 %, repeatably) -- so a long-lived batch is
-        worth placing.  Beside the planes, `candidates - 1` spare allocations per output plane are made (side by
-        side: a freed range would simply be handed out again; bounded by `free_bytes`, the free device memory
-        as the caller knows it, minus `keep_free_bytes`), and `passes` passes of coordinate descent bind each plane in
-        turn (DIAG first) to the candidate under which `launches` launches of the real kernel run fastest.  The
-        spares are freed; if the search buys nothing the first-come planes stay.  Returns a record of the search."""
-        assert self.out_bufs, 'DeviceBatch was built with one arena'
-        names = ['diag'] + list(self.out_layers)
-        ctx = self.ctx
-
-        def launch_ms():
-            self.classify(params)
-            ctx.synchronize()
-            e0, e1 = ctx.event(), ctx.event()
-            ctx.record(e0)
-            for _ in range(launches):
-                self.classify(params)
-            ctx.record(e1)
-            ctx.synchronize()
-            ms = ctx.elapsed_ms(e0, e1) / launches
-            ctx.destroy_event(e0)
-            ctx.destroy_event(e1)
-            return ms
-
-        sets = max(0, candidates - 1)
-        if free_bytes is not None:
-            sets = min(sets, int(max(0, free_bytes - keep_free_bytes) // self.out_bytes))
-        pools = {}          # plane size -> spare buffers
-        try:
-            for _ in range(sets):
-                for name in names:
-                    pools.setdefault(self.plane_nbytes[name], []).append(self.new_plane_buffer(name))
-        except RuntimeError:            # hipMalloc refused: search among what there is
-            pass
-        original = {name: self.out_bufs[name] for name in names}
-        everything = list(original.values()) + [buf for pool in pools.values() for buf in pool]
-        first_ms = kept_ms = 0.0
-        probes = 0
-        try:
-            first_ms = launch_ms()
-            for name in names * passes:
-                pool = pools.get(self.plane_nbytes[name], [])
-                if not pool:
-                    continue
-                best_ms, best_k = launch_ms(), None
-                for k, buf in enumerate(pool):
-                    old = self.bind_output(name, buf)
-                    ms = launch_ms()
-                    probes += 1
-                    self.bind_output(name, old)
-                    if ms < best_ms:
-                        best_ms, best_k = ms, k
-                if best_k is not None:
-                    pool[best_k] = self.bind_output(name, pool[best_k])
-            kept_ms = first_ms
-            if probes:
-                # judge the outcome under equal conditions (the part is warmer now than at `first_ms`): the chosen
-                # planes and the first-come planes back to back, and keep the better set
-                chosen = dict(self.out_bufs)
-                chosen_ms = launch_ms()
-                for name in names:
-                    self.bind_output(name, original[name])
-                again_ms = launch_ms()
-                if chosen_ms < again_ms:
-                    for name in names:
-                        self.bind_output(name, chosen[name])
-                    kept_ms = chosen_ms
-                else:                        # the search bought nothing: stay with what came first
-                    kept_ms = again_ms
-        finally:
-            # whatever happened, exactly the buffers the planes point at stay alive
-            bound = {id(buf) for buf in self.out_bufs.values()}
-            for buf in everything:
-                if id(buf) not in bound:
-                    buf.free()
-        return {'trials': sets + 1, 'probes': probes, 'first_come_launch_ms': round(first_ms, 4),
-                'kept_launch_ms': round(kept_ms, 4)}
+    def place_search(self, params, candidates=6, launches=3, keep_free_bytes=8 << 30):
+        """dswx_batch_place_search: measured placement of the output planes (separate_outputs batches whose inputs
+        are resident).  On MI355X the fused kernel's rate depends on the ranges its seven write streams land in --
+        a stable property of the allocation -- so a long-lived batch is worth placing.
+        Returns the record of the search."""
+        _check(self.ctx.lib.dswx_batch_place_search(self.handle, ctypes.byref(params), int(candidates),
+                                                    int(launches), int(keep_free_bytes)))
+        self._rebind()
+        i = self.info()
+        return {'trials': i['search_candidates'], 'probes': i['search_probes'],
+                'first_come_launch_ms': round(i['first_come_launch_ms'], 4),
+                'kept_launch_ms': round(i['kept_launch_ms'], 4)}
 
     def synth(self, seed, tile0=0, stream=None):
-        self.ctx.synth_batch(seed, tile0, self.geom, self.pin, stream)
+        _check(self.ctx.lib.dswx_batch_synth(self.handle, int(seed), int(tile0),
+                                             ctypes.c_void_p(stream) if stream else None))
 
-    def classify(self, params, stream=None, counters=True):
-        self.ctx.classify_batch(params, self.geom, self.pin, self.pout,
-                                self.counters_ptr if counters else None, stream)
+    def classify(self, params, stream=None, counters=True, n_tiles=0):
+        """The first `n_tiles` resident tiles (0 = all).  counters=False goes through dswx_classify_batch with a
+        NULL counters pointer (dswx_batch_classify always counts)."""
+        if counters:
+            _check(self.ctx.lib.dswx_batch_classify(self.handle, ctypes.byref(params), int(n_tiles),
+                                                    ctypes.c_void_p(stream) if stream else None))
+        else:
+            geom = BatchGeom(n_tiles or self.n_tiles, self.height, self.width, self.tile_stride)
+            self.ctx.classify_batch(params, geom, self.pin, self.pout, None, stream)
+
+    def _plane(self, name):
+        if name in BAND_NAMES:
+            return self.pin.band[BAND_NAMES.index(name)], np.int16
+        if name in ('fmask', 'land', 'shad', 'ocean'):
+            return getattr(self.pin, name), np.uint8
+        return getattr(self.pout, name), (np.uint16 if name == 'diag' else np.uint8)
 
     def read_tile(self, name, tile):
         """Download one plane of one tile as [H,W]."""
-        if name in BAND_NAMES:
-            dt, sz = np.int16, 2
-        elif name == 'diag':
-            dt, sz = np.uint16, 2
-        else:
-            dt, sz = np.uint8, 1
-        off = self.offsets[name] + tile * self.tile_stride * sz
-        return self._arena_of(name).download(dt, self.n_pixels, off).reshape(self.height, self.width)
+        ptr, dt = self._plane(name)
+        out = np.empty(self.n_pixels, dtype=dt)
+        if out.nbytes:
+            _check(self.ctx.lib.dswx_memcpy_d2h(
+                self.ctx.handle, _host_ptr(out),
+                ctypes.c_void_p(ptr + tile * self.tile_stride * out.itemsize), out.nbytes))
+        return out.reshape(self.height, self.width)
 
     def write_tile(self, name, tile, arr):
-        sz = 2 if name in BAND_NAMES else 1
-        dt = np.int16 if name in BAND_NAMES else np.uint8
-        self._arena_of(name).upload(np.ascontiguousarray(arr, dtype=dt).ravel(),
-                                    self.offsets[name] + tile * self.tile_stride * sz)
+        ptr, dt = self._plane(name)
+        arr = np.ascontiguousarray(arr, dtype=dt).ravel()
+        assert arr.size == self.n_pixels
+        if arr.nbytes:
+            _check(self.ctx.lib.dswx_memcpy_h2d(
+                self.ctx.handle, ctypes.c_void_p(ptr + tile * self.tile_stride * arr.itemsize), _host_ptr(arr),
+                arr.nbytes))
 
     def read_counters(self):
-        return self.arena.download(np.int64, self.n_tiles * 3,
-                                   self.offsets['counters']).reshape(self.n_tiles, 3)
+        out = np.empty((self.n_tiles, 3), dtype=np.int64)
+        if out.nbytes:
+            _check(self.ctx.lib.dswx_memcpy_d2h(self.ctx.handle, _host_ptr(out),
+                                                ctypes.c_void_p(self.counters_ptr), out.nbytes))
+        return out
 
     def free(self):
-        for buf in self.out_bufs.values():
-            buf.free()
-        self.out_bufs = {}
-        self.arena.free()
+        if self.handle:
+            self.ctx.lib.dswx_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            if self.ctx.handle:
+                self.free()
+        except Exception:
+            pass

@@ -9,6 +9,8 @@ gpurun snapshot.  `python -m proteus_amd.build` or __graft_entry__.build() call 
 (tests, bench.py, smoke) calls build(): it is a no-op when the libraries are newer than their sources,
 so an edited kernel can never be measured or tested through a stale binary.
 """
+import contextlib
+import fcntl
 import hashlib
 import os
 import shutil
@@ -20,7 +22,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LAB = os.path.join(CSRC, 'lab')
 SOURCES = [os.path.join(CSRC, n) for n in ('dswx_hip.hip', 'dswx_classify_lut.hip', 'dswx_cover.hip',
-                                           'dswx_layers.hip', 'dswx_host_path.hip')]
+                                           'dswx_layers.hip', 'dswx_host_path.hip', 'dswx_batch.hip')]
 HEADERS = [os.path.join(CSRC, n) for n in ('dswx_device.h', 'dswx_host.h', 'dswx_tables.h')]
 LAB_SOURCES = [os.path.join(LAB, n) for n in ('dswx_variants.hip', 'dswx_probes.hip')]
 LAB_HEADERS = [os.path.join(LAB, 'dswx_lab.h')]
@@ -75,20 +77,41 @@ def _run(cmd, verbose):
         raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
 
 
-def build(force=False, verbose=False):
-    """Compile the product library if missing or older than its sources; return its path.
-    Without hipcc an existing library is used as it is (the GPU box always has hipcc)."""
-    if not force and not is_stale():
-        return LIB_PATH
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time across processes (ranks, xdist workers, batch workers all call build()): the
+    others wait here and then find the library fresh."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def _need_hipcc(lib):
     hipcc = find_hipcc()
     if hipcc is None:
-        if os.path.exists(LIB_PATH):
+        # never a stale binary: a library older than its sources is not what the sources say
+        raise RuntimeError(f'hipcc not found and {os.path.relpath(lib, ROOT)} is '
+                           + ('older than its sources' if os.path.exists(lib) else 'missing')
+                           + ' (need ROCm for the gfx950 build)')
+    return hipcc
+
+
+def build(force=False, verbose=False):
+    """Compile the product library if missing or older than its sources; return its path.
+    Stale or missing without hipcc raises: no entry point ever runs an old binary."""
+    if not force and not is_stale():
+        return LIB_PATH
+    with _build_lock():
+        if not force and not is_stale():            # another process built it while this one waited
             return LIB_PATH
-        raise RuntimeError('hipcc not found (need ROCm for the gfx950 build)')
-    os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = f'{LIB_PATH}.{os.getpid()}.tmp'
-    _run([hipcc] + HIPCC_FLAGS + ['-I', INCLUDE, '-I', CSRC] + SOURCES + ['-o', tmp], verbose)
-    os.replace(tmp, LIB_PATH)
+        hipcc = _need_hipcc(LIB_PATH)
+        tmp = f'{LIB_PATH}.{os.getpid()}.tmp'
+        _run([hipcc] + HIPCC_FLAGS + ['-I', INCLUDE, '-I', CSRC] + SOURCES + ['-o', tmp], verbose)
+        os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
@@ -97,15 +120,14 @@ def build_lab(force=False, verbose=False):
     build(force=False, verbose=verbose)
     if not force and not lab_is_stale():
         return LAB_PATH
-    hipcc = find_hipcc()
-    if hipcc is None:
-        if os.path.exists(LAB_PATH):
+    with _build_lock():
+        if not force and not lab_is_stale():
             return LAB_PATH
-        raise RuntimeError('hipcc not found (need ROCm for the gfx950 build)')
-    tmp = f'{LAB_PATH}.{os.getpid()}.tmp'
-    _run([hipcc] + HIPCC_FLAGS + ['-I', INCLUDE, '-I', CSRC, '-I', LAB] + LAB_SOURCES +
-         ['-L', LIB_DIR, '-ldswx_hip', '-Wl,-rpath,$ORIGIN', '-o', tmp], verbose)
-    os.replace(tmp, LAB_PATH)
+        hipcc = _need_hipcc(LAB_PATH)
+        tmp = f'{LAB_PATH}.{os.getpid()}.tmp'
+        _run([hipcc] + HIPCC_FLAGS + ['-I', INCLUDE, '-I', CSRC, '-I', LAB] + LAB_SOURCES +
+             ['-L', LIB_DIR, '-ldswx_hip', '-Wl,-rpath,$ORIGIN', '-o', tmp], verbose)
+        os.replace(tmp, LAB_PATH)
     return LAB_PATH
 
 

@@ -1,0 +1,369 @@
+// dswx_batch.hip -- resident batches: the planes of a batch allocated by the library (dswx_batch_create) and
+// the opt-in measured placement of the output planes (dswx_batch_place_search).  include/dswx_hip.h
+// "resident batches" documents the C-ABI; DESIGN.md section 5 has the measurements.
+//
+// Why placement at all.  On MI355X the rate of the fused kernel follows where its seven WRITE streams lie in
+// the address space (reads stream at 7 TB/s anywhere; moving the INPUT planes by 170 GiB changes nothing).
+// Moving the packed output region of a 256-tile batch (25.5 GiB) through one large allocation, the same launch
+// runs at 0.70 - 0.74 of the HBM peak in some ranges and at 0.79 - 0.80 in others, with a structure of about
+// 32 GiB (profiles/r03_write_stream_map.json: reproducible between fresh processes of one box for arenas
+// >= 150 GB, similar but not equal between boxes).  Round 3 tried to turn that into a layout RULE (a fixed gap,
+// a fixed offset, alternating output and input planes, separate allocations in either order) and none holds
+// from one fresh process to the next for an allocation of the batch's own size: the same rule gives 0.70 - 0.80
+// (profiles/r03_placement_rule_trials.json).  So the placement stays a measurement -- but one the library
+// makes, behind the C-ABI.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "dswx_host.h"
+
+namespace {
+
+constexpr uint64_t kAlign = 256;
+inline uint64_t up256(uint64_t v) { return (v + (kAlign - 1)) & ~(kAlign - 1); }
+
+struct PlaneSet {
+    std::vector<int> in, out;    // plane indices present, in ABI order
+};
+
+PlaneSet planes_of(uint32_t flags) {
+    PlaneSet s;
+    for (int k = 0; k < 6; ++k) s.in.push_back(DSWX_PLANE_BAND0 + k);
+    s.in.push_back(DSWX_PLANE_FMASK);
+    if (flags & DSWX_BATCH_MASKS) {
+        s.in.push_back(DSWX_PLANE_LAND);
+        s.in.push_back(DSWX_PLANE_SHAD);
+        s.in.push_back(DSWX_PLANE_OCEAN);
+    }
+    s.out.push_back(DSWX_PLANE_DIAG);
+    s.out.push_back(DSWX_PLANE_WTR1);
+    if (flags & DSWX_BATCH_WTR1_AEROSOL) s.out.push_back(DSWX_PLANE_WTR1_AEROSOL);
+    s.out.push_back(DSWX_PLANE_WTR2);
+    s.out.push_back(DSWX_PLANE_WTR);
+    s.out.push_back(DSWX_PLANE_BWTR);
+    s.out.push_back(DSWX_PLANE_CONF);
+    s.out.push_back(DSWX_PLANE_CLOUD);
+    if (flags & DSWX_BATCH_BROWSE) s.out.push_back(DSWX_PLANE_BROWSE);
+    return s;
+}
+
+inline int elem_bytes(int plane) {
+    return (plane <= DSWX_PLANE_BAND0 + 5 || plane == DSWX_PLANE_DIAG) ? 2 : 1;
+}
+
+int layout_mode(uint32_t flags, uint32_t* mode) {
+    *mode = flags & DSWX_BATCH_SEPARATE_OUTPUTS;
+    return DSWX_OK;
+}
+
+}  // namespace
+
+struct dswx_batch {
+    dswx_ctx* ctx = nullptr;
+    dswx_batch_geom_t geom = {};
+    uint32_t flags = 0;
+    dswx_batch_layout_t lay = {};
+    void* arena = nullptr;
+    void* own[DSWX_BATCH_MAX_PLANES] = {};     // SEPARATE_OUTPUTS: the allocation an output plane lives in
+    void* ptr[DSWX_BATCH_MAX_PLANES] = {};     // device address of every plane
+    int search_candidates = 0, search_probes = 0;
+    float first_ms = 0.f, kept_ms = 0.f;
+};
+
+static void bind_structs(const dswx_batch* b, dswx_planes_in_t* in, dswx_planes_out_t* out) {
+    if (in) {
+        memset(in, 0, sizeof *in);
+        for (int k = 0; k < 6; ++k) in->band[k] = (const int16_t*)b->ptr[DSWX_PLANE_BAND0 + k];
+        in->fmask = (const uint8_t*)b->ptr[DSWX_PLANE_FMASK];
+        in->land = (const uint8_t*)b->ptr[DSWX_PLANE_LAND];
+        in->shad = (const uint8_t*)b->ptr[DSWX_PLANE_SHAD];
+        in->ocean = (const uint8_t*)b->ptr[DSWX_PLANE_OCEAN];
+    }
+    if (out) {
+        memset(out, 0, sizeof *out);
+        out->diag = (uint16_t*)b->ptr[DSWX_PLANE_DIAG];
+        out->wtr1 = (uint8_t*)b->ptr[DSWX_PLANE_WTR1];
+        out->wtr1_aerosol = (uint8_t*)b->ptr[DSWX_PLANE_WTR1_AEROSOL];
+        out->wtr2 = (uint8_t*)b->ptr[DSWX_PLANE_WTR2];
+        out->wtr = (uint8_t*)b->ptr[DSWX_PLANE_WTR];
+        out->bwtr = (uint8_t*)b->ptr[DSWX_PLANE_BWTR];
+        out->conf = (uint8_t*)b->ptr[DSWX_PLANE_CONF];
+        out->cloud = (uint8_t*)b->ptr[DSWX_PLANE_CLOUD];
+        out->browse = (uint8_t*)b->ptr[DSWX_PLANE_BROWSE];
+    }
+}
+
+extern "C" {
+
+int dswx_batch_layout(const dswx_batch_geom_t* geom, uint32_t flags, dswx_batch_layout_t* out) {
+    if (!geom || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (geom->n_tiles < 0 || geom->height < 0 || geom->width < 0 || geom->tile_stride < 0)
+        return dswx_fail(DSWX_ERR_ARG, "negative size");
+    uint32_t mode;
+    if (int rc = layout_mode(flags, &mode)) return rc;
+    if (flags & ~(uint32_t)(DSWX_BATCH_MASKS | DSWX_BATCH_WTR1_AEROSOL | DSWX_BATCH_BROWSE | DSWX_BATCH_SEPARATE_OUTPUTS))
+        return dswx_fail(DSWX_ERR_ARG, "unknown batch flag in 0x%x", flags);
+    memset(out, 0, sizeof *out);
+    const int64_t P = geom->height * geom->width;
+    int64_t stride = geom->tile_stride ? geom->tile_stride : (P + 255) / 256 * 256;
+    if (stride < P) return dswx_fail(DSWX_ERR_ARG, "tile_stride smaller than the tile");
+    out->tile_stride = stride;
+    const uint64_t px = (uint64_t)geom->n_tiles * (uint64_t)stride;
+    const PlaneSet ps = planes_of(flags);
+    for (int k : ps.in) out->plane_bytes[k] = up256(px * elem_bytes(k));
+    for (int k : ps.out) out->plane_bytes[k] = up256(px * elem_bytes(k));
+    out->plane_bytes[DSWX_PLANE_COUNTERS] = up256((uint64_t)geom->n_tiles * DSWX_N_COUNTERS * sizeof(int64_t));
+
+    uint64_t cur = 0;
+    auto take = [&](int k) {
+        out->plane_offset[k] = cur;
+        cur += out->plane_bytes[k] ? out->plane_bytes[k] : kAlign;      // an empty batch still has distinct addresses
+    };
+    for (int k : ps.in) take(k);
+    if (mode != DSWX_BATCH_SEPARATE_OUTPUTS)
+        for (int k : ps.out) take(k);
+    take(DSWX_PLANE_COUNTERS);
+    out->arena_bytes = cur;
+    if (mode != DSWX_BATCH_SEPARATE_OUTPUTS) {
+        uint64_t lo = ~0ull, hi = 0;
+        for (int k : ps.out) {
+            lo = out->plane_offset[k] < lo ? out->plane_offset[k] : lo;
+            const uint64_t end = out->plane_offset[k] + out->plane_bytes[k];
+            hi = end > hi ? end : hi;
+        }
+        out->write_span_bytes = hi - lo;
+    }
+    return DSWX_OK;
+}
+
+int dswx_batch_destroy(dswx_batch_t* b) {
+    if (!b) return DSWX_OK;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    for (void* p : b->own)
+        if (p) (void)hipFree(p);
+    if (b->arena) (void)hipFree(b->arena);
+    delete b;
+    return DSWX_OK;
+}
+
+int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t flags, dswx_batch_t** out) {
+    if (!ctx || !geom || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    dswx_batch_layout_t lay;
+    if (int rc = dswx_batch_layout(geom, flags, &lay)) return rc;
+    uint32_t mode;
+    if (int rc = layout_mode(flags, &mode)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    dswx_batch* b = new dswx_batch();
+    b->ctx = ctx;
+    b->geom = *geom;
+    b->geom.tile_stride = lay.tile_stride;
+    b->flags = flags;
+    b->lay = lay;
+    hipError_t e = hipMalloc(&b->arena, lay.arena_bytes);
+    const PlaneSet ps = planes_of(flags);
+    if (e == hipSuccess && mode == DSWX_BATCH_SEPARATE_OUTPUTS)
+        for (int k : ps.out) {
+            e = hipMalloc(&b->own[k], lay.plane_bytes[k] ? lay.plane_bytes[k] : kAlign);
+            if (e != hipSuccess) break;
+        }
+    if (e != hipSuccess) {
+        dswx_batch_destroy(b);
+        return dswx_fail(DSWX_ERR_HIP, "dswx_batch_create: hipMalloc failed: %s (arena of %llu bytes)",
+                         hipGetErrorString(e), (unsigned long long)lay.arena_bytes);
+    }
+    for (int k : ps.in) b->ptr[k] = (char*)b->arena + lay.plane_offset[k];
+    for (int k : ps.out) b->ptr[k] = b->own[k] ? b->own[k] : (char*)b->arena + lay.plane_offset[k];
+    b->ptr[DSWX_PLANE_COUNTERS] = (char*)b->arena + lay.plane_offset[DSWX_PLANE_COUNTERS];
+    *out = b;
+    return DSWX_OK;
+}
+
+int dswx_batch_planes(const dswx_batch_t* b, dswx_batch_geom_t* geom, dswx_planes_in_t* in, dswx_planes_out_t* out,
+                      int64_t** counters) {
+    if (!b) return dswx_fail(DSWX_ERR_ARG, "batch is NULL");
+    if (geom) *geom = b->geom;
+    bind_structs(b, in, out);
+    if (counters) *counters = (int64_t*)b->ptr[DSWX_PLANE_COUNTERS];
+    return DSWX_OK;
+}
+
+int dswx_batch_info(const dswx_batch_t* b, dswx_batch_info_t* info) {
+    if (!b || !info) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    memset(info, 0, sizeof *info);
+    info->geom = b->geom;
+    info->flags = b->flags;
+    info->n_allocations = 1;
+    info->bytes_allocated = b->lay.arena_bytes;
+    for (int k = 0; k < DSWX_BATCH_MAX_PLANES; ++k)
+        if (b->own[k]) {
+            ++info->n_allocations;
+            info->bytes_allocated += b->lay.plane_bytes[k] ? b->lay.plane_bytes[k] : kAlign;
+        }
+    info->search_candidates = b->search_candidates;
+    info->search_probes = b->search_probes;
+    info->first_come_launch_ms = b->first_ms;
+    info->kept_launch_ms = b->kept_ms;
+    return DSWX_OK;
+}
+
+int dswx_batch_classify(dswx_batch_t* b, const dswx_params_t* params, int64_t n_tiles, void* stream) {
+    if (!b) return dswx_fail(DSWX_ERR_ARG, "batch is NULL");
+    if (n_tiles < 0 || n_tiles > b->geom.n_tiles)
+        return dswx_fail(DSWX_ERR_ARG, "n_tiles %lld outside the batch (%lld resident)", (long long)n_tiles,
+                         (long long)b->geom.n_tiles);
+    dswx_batch_geom_t g = b->geom;
+    if (n_tiles) g.n_tiles = n_tiles;
+    dswx_planes_in_t in;
+    dswx_planes_out_t out;
+    bind_structs(b, &in, &out);
+    return dswx_classify_batch(b->ctx, params, &g, &in, &out, (int64_t*)b->ptr[DSWX_PLANE_COUNTERS], stream);
+}
+
+int dswx_batch_synth(dswx_batch_t* b, uint64_t seed, int64_t tile0, void* stream) {
+    if (!b) return dswx_fail(DSWX_ERR_ARG, "batch is NULL");
+    dswx_planes_in_t in;
+    bind_structs(b, &in, nullptr);
+    return dswx_synth_batch(b->ctx, seed, tile0, &b->geom, &in, stream);
+}
+
+// `launches` launches of the real kernel over the whole batch, after one untimed launch; ms per launch
+static int probe_ms(dswx_batch* b, const dswx_params_t* params, int launches, hipEvent_t e0, hipEvent_t e1, float* ms) {
+    hipStream_t s = b->ctx->stream;
+    if (int rc = dswx_batch_classify(b, params, 0, nullptr)) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < launches; ++i)
+        if (int rc = dswx_batch_classify(b, params, 0, nullptr)) return rc;
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+    *ms /= (float)launches;
+    return DSWX_OK;
+}
+
+int dswx_batch_place_search(dswx_batch_t* b, const dswx_params_t* params, int32_t candidates, int32_t launches,
+                            uint64_t keep_free_bytes) {
+    if (!b || !params) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (!(b->flags & DSWX_BATCH_SEPARATE_OUTPUTS))
+        return dswx_fail(DSWX_ERR_ARG, "dswx_batch_place_search needs a DSWX_BATCH_SEPARATE_OUTPUTS batch");
+    if (candidates < 1 || launches < 1) return dswx_fail(DSWX_ERR_ARG, "candidates and launches must be positive");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    const PlaneSet ps = planes_of(b->flags);
+    uint64_t out_bytes = 0;
+    for (int k : ps.out) out_bytes += b->lay.plane_bytes[k] ? b->lay.plane_bytes[k] : kAlign;
+
+    // spare sets, side by side (a freed range would simply be handed out again), bounded by free memory
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    int sets = candidates - 1;
+    const uint64_t room = free_b > keep_free_bytes ? free_b - keep_free_bytes : 0;
+    if ((uint64_t)sets * out_bytes > room) sets = (int)(room / (out_bytes ? out_bytes : 1));
+    std::vector<std::vector<void*>> spare(DSWX_BATCH_MAX_PLANES);      // per plane: candidates of ITS size
+    bool full = true;
+    for (int sidx = 0; sidx < sets && full; ++sidx)
+        for (int k : ps.out) {
+            void* p = nullptr;
+            if (hipMalloc(&p, b->lay.plane_bytes[k] ? b->lay.plane_bytes[k] : kAlign) != hipSuccess) {
+                (void)hipGetLastError();        // refused: search among what there is
+                full = false;
+                break;
+            }
+            spare[k].push_back(p);
+        }
+    // planes of equal size share a pool: a candidate one plane did not take is a candidate for the next
+    auto pool_of = [&](int k) -> std::vector<void*>& {
+        for (int j : ps.out)
+            if (b->lay.plane_bytes[j] == b->lay.plane_bytes[k]) return spare[j];
+        return spare[k];
+    };
+    for (int k : ps.out) {
+        std::vector<void*>& pool = pool_of(k);
+        if (&pool != &spare[k]) {
+            pool.insert(pool.end(), spare[k].begin(), spare[k].end());
+            spare[k].clear();
+        }
+    }
+    void* original[DSWX_BATCH_MAX_PLANES];
+    memcpy(original, b->own, sizeof original);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = DSWX_OK;
+    int probes = 0;
+    float first_ms = 0.f, kept_ms = 0.f;
+    auto bind = [&](int k, void* p) { b->own[k] = p; b->ptr[k] = p; };
+    do {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            rc = dswx_fail(DSWX_ERR_HIP, "hipEventCreate failed");
+            break;
+        }
+        if ((rc = probe_ms(b, params, launches, e0, e1, &first_ms))) break;
+        kept_ms = first_ms;
+        for (int k : ps.out) {
+            std::vector<void*>& pool = pool_of(k);
+            if (pool.empty()) continue;
+            float best_ms;
+            if ((rc = probe_ms(b, params, launches, e0, e1, &best_ms))) break;
+            int best = -1;
+            void* mine = b->own[k];
+            for (size_t c = 0; c < pool.size(); ++c) {
+                bind(k, pool[c]);
+                float ms;
+                rc = probe_ms(b, params, launches, e0, e1, &ms);
+                bind(k, mine);
+                if (rc) break;
+                ++probes;
+                if (ms < best_ms) { best_ms = ms; best = (int)c; }
+            }
+            if (rc) break;
+            if (best >= 0) {
+                bind(k, pool[best]);
+                pool[best] = mine;
+            }
+        }
+        if (rc || !probes) break;
+        // judge the outcome under equal conditions (the part is warmer now than at first_ms): the chosen planes
+        // and the first-come planes back to back; keep the better set
+        void* chosen[DSWX_BATCH_MAX_PLANES];
+        memcpy(chosen, b->own, sizeof chosen);
+        float chosen_ms, again_ms;
+        if ((rc = probe_ms(b, params, launches, e0, e1, &chosen_ms))) break;
+        for (int k : ps.out) bind(k, original[k]);
+        if ((rc = probe_ms(b, params, launches, e0, e1, &again_ms))) break;
+        first_ms = again_ms;
+        if (chosen_ms < again_ms) {
+            for (int k : ps.out) bind(k, chosen[k]);
+            kept_ms = chosen_ms;
+        } else {
+            kept_ms = again_ms;
+        }
+    } while (false);
+    if (rc)          // whatever happened, the planes a caller may already hold stay valid
+        for (int k : ps.out) bind(k, original[k]);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    // exactly the allocations the planes point at stay alive
+    (void)hipStreamSynchronize(b->ctx->stream);
+    std::vector<void*> all;
+    for (int k : ps.out) {
+        all.push_back(original[k]);
+        all.insert(all.end(), spare[k].begin(), spare[k].end());
+    }
+    std::sort(all.begin(), all.end());       // a first-come plane that lost its place sits in a pool as well
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    for (void* p : all) {
+        bool bound = false;
+        for (int k : ps.out) bound = bound || b->own[k] == p;
+        if (!bound) (void)hipFree(p);
+    }
+    if (rc) return rc;
+    b->search_candidates = sets + 1;
+    b->search_probes = probes;
+    b->first_ms = first_ms;
+    b->kept_ms = kept_ms;
+    return DSWX_OK;
+}
+
+}  // extern "C"

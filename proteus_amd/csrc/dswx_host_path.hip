@@ -43,13 +43,14 @@ int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out) {
 }
 
 int dswx_host_free(dswx_ctx_t* ctx, void* ptr) {
-    if (!ctx) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    // ctx may be NULL: a span can outlive the context it was allocated through (a host array still alive when its
+    // context is destroyed); page-locked host memory is not tied to the current device
     if (!ptr) return DSWX_OK;
     {
         std::lock_guard<std::mutex> lock(g_spans_mutex);
         g_spans.erase(reinterpret_cast<uintptr_t>(ptr));
     }
-    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx) HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipHostFree(ptr));
     return DSWX_OK;
 }

@@ -25,7 +25,7 @@ from tests.test_gpu_parity import _random_case, ALL_LAYERS   # noqa: E402
 
 def device_batch_soak(ctx, rng, a, kernels):
     """Device-resident batches with random geometry: tile count, ragged tile sizes, tile-stride
-    alignment (1 / 8 / 16 / 64 / 256 px), plane skews (pointer alignment), optional planes and layers,
+    alignment (1 / 8 / 16 / 64 / 256 px), one allocation or one per output plane, optional planes and layers,
     counters on / off, 'mask' / 'ignore' / 'cover'; every tile against the oracle."""
     from oracle import dswx_oracle as o
     from tests.test_c_oracle import NAME
@@ -35,10 +35,10 @@ def device_batch_soak(ctx, rng, a, kernels):
         h, w = int(rng.integers(1, 120)), int(rng.integers(1, 150))
         align = int(rng.choice([1, 8, 16, 64, 256]))
         masks = bool(rng.integers(2))
-        skew = int(rng.choice([0, 0, 16, 48, 272]))
+        separate = bool(rng.integers(4) == 0)
         extra = tuple(x for x in ('wtr1_aerosol', 'browse') if rng.integers(2))
         batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=masks, extra_layers=extra, tile_align=align,
-                                  plane_skew=skew)
+                                  separate_outputs=separate)
         batch.synth(777 + it, tile0=it)
         mode = str(rng.choice(['mask', 'ignore', 'cover']))
         p = _capi.make_params(

@@ -682,26 +682,28 @@ def test_cover_mode_device_batch(ctx):
 
 
 def test_output_planes_in_separate_allocations(ctx):
-    """DeviceBatch(separate_outputs=True): one allocation per output plane, re-bound among candidates by
-    place_outputs (what bench.py does to the headline batch).  Wherever the planes end up, the layers and
-    counters are those of the one-arena batch and of the oracle."""
+    """DeviceBatch(separate_outputs=True) = dswx_batch_create(DSWX_BATCH_SEPARATE_OUTPUTS): one allocation per output
+    plane, re-bound among candidates by dswx_batch_place_search (what bench.py does to the headline batch, now
+    inside the library).  Wherever the planes end up, the layers and counters are those of the one-arena batch and
+    of the oracle."""
     n_tiles, h, w = 3, 200, 264
     one = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, extra_layers=('wtr1_aerosol',))
     sep = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, extra_layers=('wtr1_aerosol',), separate_outputs=True)
+    assert one.info()['n_allocations'] == 1 and sep.info()['n_allocations'] == 1 + 8
+    assert sep.info()['bytes_allocated'] == one.info()['bytes_allocated']
     p = _capi.default_params()
     for b in (one, sep):
         b.synth(SEED, tile0=9)
-    before = {name: sep.out_bufs[name].ptr for name in sep.out_bufs}
-    rec = sep.place_outputs(p, candidates=3, launches=1)
+    names = ['diag'] + sep.out_layers
+    before = {name: getattr(sep.pout, name) for name in names}
+    rec = sep.place_search(p, candidates=3, launches=1)
     n_u8 = len(before) - 1          # every u8 plane tries every spare of its size: 2 sets x n_u8 spares
     assert rec['trials'] == 3 and rec['probes'] == 2 + n_u8 * 2 * n_u8
     assert rec['kept_launch_ms'] > 0 and rec['first_come_launch_ms'] > 0
-    assert len({buf.ptr for buf in sep.out_bufs.values()}) == len(before)          # still one buffer per plane
-    # re-bind one plane by hand as well
-    spare = sep.new_plane_buffer('conf')
-    old = sep.bind_output('conf', spare)
-    assert old.ptr != spare.ptr and sep.pout.conf == spare.ptr
-    old.free()
+    assert rec['kept_launch_ms'] <= rec['first_come_launch_ms']                     # the better set was kept
+    after = {name: getattr(sep.pout, name) for name in names}
+    assert len(set(after.values())) == len(before) and None not in after.values()  # still one buffer per plane
+    assert sep.info()['n_allocations'] == 1 + 8                                     # the spares are gone
     for b in (one, sep):
         b.classify(p)
     ctx.synchronize()
@@ -714,10 +716,17 @@ def test_output_planes_in_separate_allocations(ctx):
             assert np.array_equal(got, one.read_tile(key, t)), (key, t)
             assert np.array_equal(got, exp[key]), (key, t)
         assert sep.read_counters()[t].tolist() == exp['counters'].tolist()
+    # a partial walk: the first two resident tiles only (bench.py's last chunk of a strong-scaling share)
+    sep.write_tile('wtr', 2, np.full((h, w), 77, np.uint8))
+    sep.classify(p, n_tiles=2)
+    ctx.synchronize()
+    assert (sep.read_tile('wtr', 2) == 77).all() and np.array_equal(sep.read_tile('wtr', 1), one.read_tile('wtr', 1))
+    with pytest.raises(_capi.DswxError):
+        sep.classify(p, n_tiles=4)                     # more than resident
+    with pytest.raises(_capi.DswxError):
+        one.place_search(p)                            # one arena: nothing to re-bind
     one.free()
     sep.free()
-    with pytest.raises(AssertionError):
-        one.place_outputs(p)
 
 
 # ---- terrain shadow layer --------------------------------------------

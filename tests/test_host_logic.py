@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: GeoTIFF I/O, runconfig handling, CLI, metadata,
 product comparison and the error conventions of the reference interface."""
+import ctypes
 import os
 import struct
 import sys
@@ -491,81 +492,44 @@ def test_compare_products(tmp_path, capsys):
     assert D.compare_dswx_hls_products(f1, str(tmp_path / 'missing.tif')) is False
 
 
-def test_output_plane_placement_bookkeeping():
-    """DeviceBatch.place_outputs against a stand-in context whose 'launch time' is a known function of the buffers
-    the output planes are bound to (no GPU): the coordinate descent must end on the cheapest buffer for every plane,
-    free every buffer that is not bound at the end exactly once, keep the bound ones alive -- and stay with the
-    first-come planes when nothing is cheaper."""
+def test_resident_batch_layout_rule():
+    """dswx_batch_layout (pure function of the C-ABI, no device): where dswx_batch_create puts every plane.
+    256-byte aligned offsets, no overlap, tile stride padded to 256 px by default, inputs then outputs, counters last;
+    with SEPARATE_OUTPUTS the arena holds the inputs only."""
     from proteus_amd import _capi
-
-    class Buf:
-        def __init__(self, ctx, nbytes):
-            self.ctx, self.nbytes, self.freed = ctx, nbytes, 0
-            ctx.n += 1
-            self.ptr = ctx.n << 20
-            ctx.bufs[self.ptr] = self
-
-        def free(self):
-            self.freed += 1
-
-    class Ctx:
-        """launch time = 10 ms + cost of every buffer an output plane points at; `cost` maps the order of allocation"""
-        def __init__(self, cost):
-            self.n, self.bufs, self.cost, self.now, self.launches = 0, {}, cost, 0.0, 0
-
-        def malloc(self, nbytes):
-            return Buf(self, nbytes)
-
-        def classify_batch(self, params, geom, pin, pout, counters, stream=None):
-            names = ['diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud']
-            self.now += 10.0 + sum(self.cost(self.bufs[getattr(pout, n)]) for n in names)
-            self.launches += 1
-
-        def synchronize(self, stream=None):
-            pass
-
-        def event(self):
-            return [0.0]
-
-        def record(self, e, stream=None):
-            e[0] = self.now
-
-        def elapsed_ms(self, a, b):
-            return b[0] - a[0]
-
-        def destroy_event(self, e):
-            pass
-
-    # allocation order: 1 = input arena, 2..8 = the seven first-come planes, then two spare sets (9..15, 16..22)
-    cost = lambda buf: {3: 5.0, 9: -1.0, 12: -2.0, 18: -3.0, 20: 4.0}.get(buf.ptr >> 20, 0.0)
-    ctx = Ctx(cost)
-    b = _capi.DeviceBatch(ctx, 2, 8, 16, separate_outputs=True)
-    first = dict(b.out_bufs)
-    rec = b.place_outputs(None, candidates=3, launches=2)
-    assert rec['trials'] == 3 and rec['probes'] == 2 + 6 * 12        # DIAG: 2 spares; six u8 planes x 12 spares
-    bound = {n: buf.ptr >> 20 for n, buf in b.out_bufs.items()}
-    assert bound['diag'] == 9                                        # the cheaper of the two DIAG-sized spares (9: -1, 16: 0)
-    # the u8 planes end on the cheap spares 12 and 18 (and leave the expensive first-come 3); nobody sits on 20
-    assert {12, 18} <= set(bound.values()) and 3 not in bound.values() and 20 not in bound.values()
-    assert rec['kept_launch_ms'] < rec['first_come_launch_ms']
-    alive = {id(x) for x in b.out_bufs.values()}
-    for buf in ctx.bufs.values():
-        if buf is b.arena:
-            assert buf.freed == 0
-        else:
-            assert buf.freed == (0 if id(buf) in alive else 1), buf.ptr >> 20
-    assert len(alive) == 7
-    # nothing cheaper anywhere: the first-come planes stay, every spare is freed
-    ctx2 = Ctx(lambda buf: 0.0 if buf.ptr >> 20 <= 8 else 1.0)
-    b2 = _capi.DeviceBatch(ctx2, 2, 8, 16, separate_outputs=True)
-    first2 = {n: buf.ptr for n, buf in b2.out_bufs.items()}
-    rec2 = b2.place_outputs(None, candidates=2)
-    assert {n: buf.ptr for n, buf in b2.out_bufs.items()} == first2
-    assert all(buf.freed == (1 if buf.ptr >> 20 > 8 else 0) for buf in ctx2.bufs.values())
-    assert rec2['kept_launch_ms'] == rec2['first_come_launch_ms']
-    # memory bound: with room for one spare set only, one set is tried
-    ctx3 = Ctx(lambda buf: 0.0)
-    b3 = _capi.DeviceBatch(ctx3, 2, 8, 16, separate_outputs=True)
-    rec3 = b3.place_outputs(None, candidates=6, keep_free_bytes=0, free_bytes=int(b3.out_bytes * 1.5))
-    assert rec3['trials'] == 2
-    assert first  # (kept alive until here)
+    T = 3660
+    lay = _capi.batch_layout(256, T, T)
+    assert lay['tile_stride'] == 13395712 and lay['tile_stride'] % 256 == 0 and lay['tile_stride'] >= T * T
+    px = 256 * lay['tile_stride']
+    order = sorted(lay['planes'], key=lambda n: lay['planes'][n][0])
+    assert order == list(_capi.BAND_NAMES) + ['fmask', 'diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud', 'counters']
+    cur = 0
+    for name in order:
+        off, nbytes = lay['planes'][name]
+        assert off == cur and off % 256 == 0, name
+        want = 256 * 24 if name == 'counters' else px * (2 if name in _capi.BAND_NAMES + ('diag',) else 1)
+        assert nbytes == (want + 255) // 256 * 256, name
+        cur = off + nbytes
+    assert lay['arena_bytes'] == cur == 21 * px + 256 * 24               # SURVEY 8(d): 13 + 8 bytes per pixel
+    assert lay['write_span_bytes'] == 8 * px
+    # the optional planes, an explicit (contiguous) stride, a ragged size
+    lay = _capi.batch_layout(3, 7, 9, masks=True, extra_layers=('wtr1_aerosol', 'browse'), tile_stride=63)
+    assert lay['tile_stride'] == 63 and set(lay['planes']) == set(_capi.PLANE_INDEX)
+    spans = sorted(lay['planes'].values())
+    assert all(a[0] + a[1] <= b[0] for a, b in zip(spans, spans[1:]))   # no overlap
+    assert all(off % 256 == 0 for off, _ in spans)
+    # one allocation per output plane: the arena is the inputs' (+ counters)
+    sep = _capi.batch_layout(256, T, T, separate_outputs=True)
+    assert sep['arena_bytes'] == 13 * px + 256 * 24 and sep['write_span_bytes'] == 0
+    assert all(sep['planes'][n][0] == 0 for n in ('diag', 'wtr1', 'cloud'))
+    # errors
+    with pytest.raises(_capi.DswxError):
+        _capi.batch_layout(2, 8, 8, tile_stride=63)                        # smaller than the tile
+    with pytest.raises(_capi.DswxError):
+        _capi.batch_layout(-1, 8, 8)
+    with pytest.raises(ValueError):
+        _capi.batch_layout(1, 8, 8, extra_layers=('mndwi',))
+    lib = _capi.load_library()
+    lay_c, geom = _capi.BatchLayout(), _capi.BatchGeom(1, 8, 8, 0)
+    assert lib.dswx_batch_layout(ctypes.byref(geom), 1 << 20, ctypes.byref(lay_c)) == _capi.ERR_ARG   # unknown flag
+    assert b'unknown batch flag' in lib.dswx_last_error()

@@ -19,6 +19,13 @@ def stub_source():
     return m.group(1).replace("ctypes.CDLL('libdswx_hip.so')", f"ctypes.CDLL({_capi.library_path()!r})")
 
 
+def batch_stub_source():
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r"```python\n(# src/proteus/_dswx_hip_batch\.py\n.*?)```", text, re.S)
+    assert m, 'batch stub block not found in INTEGRATION.md'
+    return m.group(1)
+
+
 def test_stub_structures_match_the_header():
     """Only the declarations (no context is created on a CPU-only box)."""
     src = stub_source()
@@ -30,6 +37,16 @@ def test_stub_structures_match_the_header():
         assert ctypes.sizeof(mine) == ctypes.sizeof(ref), name
         assert [(f[0], getattr(mine, f[0]).offset) for f in mine._fields_] == \
             [(f[0], getattr(ref, f[0]).offset) for f in ref._fields_], name
+    # the resident-batch stub's declarations (everything before its first function)
+    bsrc = batch_stub_source()
+    ns['ctypes'] = ctypes
+    exec(compile(bsrc[:bsrc.index('def _ok(rc):')], 'INTEGRATION.md (batch)', 'exec'), ns)
+    for name, ref in (('BatchGeom', _capi.BatchGeom), ('BatchInfo', _capi.BatchInfo)):
+        mine = ns[name]
+        assert ctypes.sizeof(mine) == ctypes.sizeof(ref), name
+        assert [(f[0], getattr(mine, f[0]).offset) for f in mine._fields_] == \
+            [(f[0], getattr(ref, f[0]).offset) for f in ref._fields_], name
+    assert (ns['DSWX_BATCH_MASKS'], ns['DSWX_BATCH_SEPARATE_OUTPUTS']) == (_capi.BATCH_MASKS, _capi.BATCH_SEPARATE_OUTPUTS)
 
 
 @pytest.mark.gpu
@@ -48,3 +65,46 @@ def test_stub_runs_and_matches_the_oracle():
     c = exp['counters']
     assert counters.tolist() == [c['n_valid'], c['n_cloud_and_valid'], c['n_not_ocean']]
     ns['_lib'].dswx_ctx_destroy(ns['_ctx'])
+
+
+@pytest.mark.gpu
+def test_batch_stub_runs_and_matches_the_oracle():
+    """the placed, resident batch through the C-ABI alone -- dswx_batch_create,
+    dswx_batch_planes, dswx_batch_place_search, dswx_batch_classify, dswx_batch_info, dswx_batch_destroy as the
+    INTEGRATION.md stub binds them (no proteus_amd._capi in the call path)."""
+    from oracle import c_oracle
+    from proteus_amd.synth import SEED, synth_tile
+    ns = {}
+    exec(compile(stub_source(), 'INTEGRATION.md', 'exec'), ns)
+    exec(compile(batch_stub_source(), 'INTEGRATION.md (batch)', 'exec'), ns)
+    lib, ctx = ns['_lib'], ns['_ctx']
+    n_tiles, h, w = 5, 120, 200
+    params = ns['default_params']()
+
+    def upload(geom, pin):
+        assert geom.tile_stride == 24064 and geom.tile_stride % 256 == 0          # 24,000 px padded to 256
+        assert lib.dswx_synth_batch(ctx, ctypes.c_uint64(SEED), ctypes.c_int64(40), ctypes.byref(geom),
+                                    ctypes.byref(pin), None) == 0
+
+    for place in (True, False):
+        handle, geom, pin, pout, counters, info = ns['resident_batch'](n_tiles, h, w, params, upload, place=place)
+        assert info.n_allocations == (8 if place else 1) and info.geom.tile_stride == geom.tile_stride
+        if place:
+            assert info.search_candidates == 3 and info.search_probes == 2 + 6 * 12
+            assert 0 < info.kept_launch_ms <= info.first_come_launch_ms
+        else:
+            assert info.search_probes == 0
+        cnt = np.empty((n_tiles, 3), np.int64)
+        assert lib.dswx_memcpy_d2h(ctx, ctypes.c_void_p(cnt.ctypes.data), counters, ctypes.c_size_t(cnt.nbytes)) == 0
+        for t in range(n_tiles):
+            s = synth_tile(40 + t, h, w)
+            exp = c_oracle.classify(params, s['bands'], s['fmask'])
+            for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+                got = np.empty((h, w), np.uint16 if key == 'diag' else np.uint8)
+                src = getattr(pout, key) + t * geom.tile_stride * got.itemsize
+                assert lib.dswx_memcpy_d2h(ctx, ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(src),
+                                           ctypes.c_size_t(got.nbytes)) == 0
+                assert np.array_equal(got, exp[key]), (key, t, place)
+            assert cnt[t].tolist() == exp['counters'].tolist()
+        assert lib.dswx_batch_destroy(handle) == 0
+    lib.dswx_ctx_destroy(ctx)

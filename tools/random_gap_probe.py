@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--out-from-gib', type=float, default=-1.0, help='outpos sweep: first start of the packed output planes (default: end of inputs)')
     ap.add_argument('--out-to-gib', type=float, default=-1.0)
     ap.add_argument('--out-step-gib', type=float, default=1.5)
+    ap.add_argument('--span-gib', type=float, default=0.0, help='interleave sweep: minimum span of the write streams')
     ap.add_argument('--points-gib', default='', help='outpos sweep: explicit output starts, comma separated (after the range)')
     a = ap.parse_args()
     ctx = _capi.Context(0)
@@ -44,6 +45,39 @@ def main():
     px = a.tiles * T * T
     sizes = [2 * S] * 6 + [S] + [2 * S] + [S] * 6            # 6 bands, fmask | diag, 6 u8 layers
     slack = int(a.slack_gb * 1e9)
+    if a.sweep.startswith('separate'):
+        # round 3: what a fresh process gets with TWO allocations (inputs, outputs) made in a given order
+        order = a.sweep.split(':')[1] if ':' in a.sweep else 'in,out'
+        bufs = {}
+        for which in order.split(','):
+            bufs[which] = ctx.malloc((sum(sizes[:7]) if which == 'in' else sum(sizes[7:])) + (1 << 20))
+        pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
+        off = 0
+        for i in range(6):
+            pin.band[i] = bufs['in'].ptr + off
+            off += sizes[i]
+        pin.fmask = bufs['in'].ptr + off
+        pout.diag = bufs['out'].ptr
+        off = sizes[7]
+        for name in ('wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+            setattr(pout, name, bufs['out'].ptr + off)
+            off += S
+        cb = ctx.malloc(a.tiles * 24)
+        ctx.synth_batch(SEED, 0, geom, pin)
+        for _ in range(2):
+            ctx.classify_batch(params, geom, pin, pout, cb.ptr)
+        ctx.synchronize()
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0)
+        for _ in range(a.reps):
+            ctx.classify_batch(params, geom, pin, pout, cb.ptr)
+        ctx.record(e1)
+        ctx.synchronize()
+        ms = ctx.elapsed_ms(e0, e1) / a.reps
+        print(json.dumps({'tiles': a.tiles, 'kind': 'separate allocations', 'order': order,
+                          'in_ptr': hex(bufs['in'].ptr), 'out_ptr': hex(bufs['out'].ptr),
+                          'GBps': round(px * 21 / ms / 1e6, 1)}))
+        return
     arena = ctx.malloc(int(a.total_gb * 1e9) if a.total_gb else sum(sizes) + slack + (1 << 20))
     slack = arena.nbytes - sum(sizes) - (1 << 20)
     rng = random.Random(11)
@@ -162,6 +196,38 @@ def main():
         return offsets
 
     GB = 1 << 30
+    if a.sweep == 'interleave':
+        # round 3: the write streams spread over the arena by ALTERNATING output and input planes (no memory
+        # wasted) vs packed inputs-then-outputs, both moved through the arena; --span-gib stretches the
+        # interleaved layout with equal gaps in front of the output planes until the write streams span that much
+        il = [7, 0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13, 6]
+
+        def interleaved(span_gib):
+            natural = sum(sizes[k] for k in il[:-2])            # start of the first to start of the last output plane
+            extra = max(0, int(span_gib * GB) - natural) // 6 & ~255
+            off, offsets = 0, [0] * 14
+            for n, k in enumerate(il):
+                if k >= 7 and n:
+                    off += extra
+                offsets[k] = off
+                off += sizes[k]
+            return offsets, off
+        bases = [float(v) for v in a.points_gib.split(',') if v] or [0.0]
+        for b_gib in bases:
+            row = {'base_GiB': b_gib}
+            for name, (offs, end) in (('packed', (packed(range(14)), sum(sizes))),
+                                      ('interleaved', interleaved(0)),
+                                      ('interleaved_span', interleaved(a.span_gib))):
+                if name == 'interleaved_span' and not a.span_gib:
+                    continue
+                b = int(b_gib * GB)
+                if b + end > arena.nbytes:
+                    continue
+                row[name] = rate(*bind([o + b for o in offs]), counters_buf.ptr)
+                row[name + '_bytes'] = end
+            out['layouts'].append(row)
+        print(json.dumps(out))
+        return
     if a.sweep == 'period':
         # the output region moved away from the input region in 3 GB steps: is the rate periodic in the distance?
         for g_gb in range(0, 130, 3):
