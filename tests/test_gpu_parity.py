@@ -575,9 +575,9 @@ def test_kernel_variants_parity(variant, tag):
         # a device-resident multi-tile batch, masks partly present
         batch = _capi.DeviceBatch(c2, 3, 128, 144, masks=True, extra_layers=('wtr1_aerosol',))
         batch.synth(SEED, tile0=11)
-        batch.pin.shad = None
+        batch.pin.shad = None            # the caller's own plane set over the batch's planes: dswx_classify_batch
         p = _capi.default_params()
-        batch.classify(p)
+        c2.classify_batch(p, batch.geom, batch.pin, batch.pout, batch.counters_ptr)
         c2.synchronize()
         cnt = batch.read_counters()
         for t in range(3):

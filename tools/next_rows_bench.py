@@ -40,6 +40,32 @@ def timed(ctx, fn, reps, inner=10):
     return sum(ms) / len(ms), min(ms)
 
 
+def coherent_fmask(fmask, seed, clear_noise=True):
+    """tests/test_gpu_parity.py::blobby_fmask at full tile size: the same patches (adjacent-to-cloud diamonds, snow
+    discs), stamped into local windows instead of evaluated over the whole raster per patch.  clear_noise: the
+    white-noise snow bits of the synthetic Fmask are dropped as well, so that snow exists in the discs only
+    (False = exactly the test generator)."""
+    h, w = fmask.shape
+    rng = np.random.default_rng(seed)
+    adj = np.zeros((h, w), bool)
+    snow = np.zeros((h, w), bool)
+
+    def stamp(dst, cy, cx, ry, rx, inside):
+        y0, y1, x0, x1 = max(cy - ry, 0), min(cy + ry + 1, h), max(cx - rx, 0), min(cx + rx + 1, w)
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        dst[y0:y1, x0:x1] |= inside(yy - cy, xx - cx)
+    for _ in range(max(3, h * w // 1500)):
+        cy, cx, r = int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(2, 14))
+        stamp(adj, cy, cx, r, 2 * r + 1, lambda dy, dx: (np.abs(dy) + np.abs(dx) // 2) < r)
+        cy, cx, r = int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(1, 5))
+        stamp(snow, cy, cx, r, r, lambda dy, dx: dy * dy + dx * dx < r * r)
+    valid = fmask != 255
+    out = np.where(valid & adj, (fmask | 4) & ~np.uint8(2 | 8), fmask & ~np.uint8(4)).astype(np.uint8)
+    if clear_noise:
+        out = np.where(valid, out & ~np.uint8(16), out).astype(np.uint8)
+    return np.where(valid & snow, out | 16, out).astype(np.uint8)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--tiles', type=int, default=32,
@@ -116,6 +142,19 @@ def main():
                             'algorithmic_bytes_per_tile': T * T * 24, 'GBps_of_24B_per_px': n * T * T * 24 / avg / 1e6,
                             'frac_of_8TBps': n * T * T * 24 / avg / 1e6 / 8000,
                             'Mpix_s': n * T * T / avg / 1e3}
+    # the same on spatially COHERENT Fmask: the synthetic Fmask is white noise, the worst case
+    # for the dilations' early exit (every window holds snow and adjacent pixels); real Fmask has patches
+    fm = coherent_fmask(batch.read_tile('fmask', 0), 1234)
+    for t in range(n):
+        batch.write_tile('fmask', t, fm)
+    avg_c, mn_c = timed(ctx, lambda: batch.classify(pc), a.reps)
+    avg_cm, _ = timed(ctx, lambda: batch.classify(pm), a.reps)
+    out['f2_cover_mode']['coherent_fmask'] = {
+        'ms_per_tile': avg_c / n, 'ms_min_per_tile': mn_c / n, 'fused_mask_mode_ms_per_tile': avg_cm / n,
+        'frac_of_8TBps': n * T * T * 24 / avg_c / 1e6 / 8000,
+        'fmask': 'adjacent-to-cloud diamonds (radius 2-13) and snow discs (radius 1-4), one per 1500 pixels, stamped '
+                 'on tile 0\'s synthetic Fmask with its white-noise snow and adjacent bits cleared; the same plane in every tile',
+        'pixels_adjacent': float((fm[fm != 255] & 4 != 0).mean()), 'pixels_snow': float((fm[fm != 255] & 16 != 0).mean())}
     if a.lab:
         # window width A/B of the stage-2 kernel through the lab switch (libdswx_lab.so)
         for name, switch in (('window_4_words', {'cover_kernel': 4}), ('window_8_words_direct', {'cover_kernel': 24}),

@@ -6,7 +6,7 @@
 # (never env / bash -c / a launcher: the profiler initialises the GPU before the program starts).
 export TMPDIR=/tmp
 TILES=${TILES:-256}
-WHAT="${*:-hot next}"
+WHAT="${*:-hot placed next}"
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAVES"
 if [[ "$WHAT" == *hot* ]]; then
 for m in "" "--masks"; do
@@ -18,6 +18,14 @@ for m in "" "--masks"; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/pmc_write" -- $B --steps 3 --warmup 1 --no-parity > /dev/null 2>&1
   rocprofv3 --pmc $SQ --output-format csv -d "$d/pmc_sq" -- $B --steps 3 --warmup 1 --no-parity > /dev/null 2>&1
 done
+fi
+if [[ "$WHAT" == *placed* ]]; then
+# the DEFAULT bench configuration (every output plane placed by dswx_batch_place_search, --placement-trials 6) under the
+# kernel trace: the trace then holds the search's probe launches too; tools/summarize_profiles.py --placed keeps the last
+# `steps` full-batch dispatches = the timed region
+d=gpurun_out/prof_placed
+rm -rf "$d"; mkdir -p "$d"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -- python3 bench.py --tiles $TILES --no-cpu-baseline --no-single-tile --realloc-repeats 0 --steps 20 --warmup 3 > "$d/bench_trace.log" 2>&1
 fi
 if [[ "$WHAT" == *next* ]]; then
 # the rows next to the hot path (shadow, cover, land-cover): kernel trace + the same three counter passes

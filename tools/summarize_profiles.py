@@ -90,21 +90,82 @@ def summarize_next_rows(a, out):
     print(json.dumps(summary, indent=1))
 
 
+def summarize_placed(a, out):
+    """The kernel trace of `bench.py` in its DEFAULT configuration (output planes placed by dswx_batch_place_search).
+    The trace also holds the search's probe launches (other plane bindings, slower by design) and the warm-up; the
+    timed region = the LAST `steps` full-batch dispatches of the fused kernel.  Writes
+      profiles/rNN_kernel_stats_placed.csv              rocprofv3-style stats rows over the timed-region dispatches
+      profiles/rNN_kernel_stats_placed_all_launches.csv the rocprofv3 --stats summary as it came (probes included)
+      profiles/rNN_placed_summary.json                  per-dispatch durations, the bench line of the same run"""
+    src = a.src if a.src else os.path.join(ROOT, 'gpurun_out', 'prof_placed')
+    tag = f'r{int(a.round):02d}'
+    stats = one(os.path.join(src, 'trace', '**', '*kernel_stats.csv'))
+    shutil.copy(stats, os.path.join(out, f'{tag}_kernel_stats_placed_all_launches.csv'))
+    line = None
+    blog = os.path.join(src, 'bench_trace.log')
+    for l in open(blog):
+        if l.startswith('{"metric"'):
+            line = json.loads(l)
+    shutil.copy(blog, os.path.join(out, f'{tag}_placed_bench_under_rocprof.log'))
+    steps = line['steps'] * line['config']['launches_per_step']
+    trace = list(csv.DictReader(open(one(os.path.join(src, 'trace', '**', '*kernel_trace.csv')))))
+    trace.sort(key=lambda r: int(r['Start_Timestamp']))
+    disp = [r for r in trace if a.kernel in r['Kernel_Name']]
+    gmax = max(int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) for r in disp)
+    full = [r for r in disp if int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) == gmax]
+    timed = full[-steps:]
+    t0, t1 = int(timed[0]['Start_Timestamp']), int(timed[-1]['End_Timestamp'])
+    rows = {}
+    for r in trace:                 # every kernel that ran inside the timed region (the counters kernel too)
+        if t0 <= int(r['Start_Timestamp']) and int(r['End_Timestamp']) <= t1:
+            rows.setdefault(r['Kernel_Name'], []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    total = sum(sum(v) for v in rows.values())
+    with open(os.path.join(out, f'{tag}_kernel_stats_placed.csv'), 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+        for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([name, len(v), sum(v), f'{sum(v) / len(v):.1f}', f'{100.0 * sum(v) / total:.4f}', min(v), max(v)])
+    durs = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in timed]
+    bpp = line['roofline']['algorithmic_bytes_per_pixel']
+    px = line['roofline']['pixels_per_launch']
+    avg = sum(durs) / len(durs)
+    summary = {
+        'what': 'rocprofv3 --kernel-trace of `python3 bench.py --tiles 256 --steps 20 --warmup 3` in its default '
+                'configuration (--placement-trials 6: dswx_batch_place_search); the timed region = the last '
+                f'{steps} full-batch dispatches of the fused kernel, the earlier ones are the search probes and the warm-up',
+        'kernel': timed[0]['Kernel_Name'], 'full_batch_dispatches_in_trace': len(full), 'timed_region_dispatches': len(durs),
+        'trace_avg_ms': avg / 1e6, 'trace_min_ms': min(durs) / 1e6, 'trace_max_ms': max(durs) / 1e6,
+        'trace_GBps': px * bpp / avg, 'trace_frac_of_8TBps': px * bpp / avg / 8000.0,
+        'bench_line_launch_ms_avg': line['roofline']['launch_ms_avg'], 'bench_line_frac': line['roofline']['frac'],
+        'bench_line_ms_per_step': line['ms_per_step'],
+        'bench_line_frac_first_come_placement': line['roofline'].get('frac_first_come_placement'),
+        'trace_vs_bench_launch_avg': avg / 1e6 / line['roofline']['launch_ms_avg'],
+        'placement': line['config']['arena_placement'],
+        'timed_dispatch_ns': durs,
+    }
+    json.dump(summary, open(os.path.join(out, f'{tag}_placed_summary.json'), 'w'), indent=1)
+    print(json.dumps({k: v for k, v in summary.items() if k != 'timed_dispatch_ns'}, indent=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('round')
     ap.add_argument('tiles', type=int)
     ap.add_argument('--masks', action='store_true')
     ap.add_argument('--next-rows', action='store_true', help='digest gpurun_out/prof_next instead of the hot kernel')
+    ap.add_argument('--placed', action='store_true',
+                    help='digest gpurun_out/prof_placed: the kernel trace of the default (placed) bench configuration')
     ap.add_argument('--src', default=None)
     ap.add_argument('--kernel', default='dswx_classify')
     a = ap.parse_args()
     out = os.path.join(ROOT, 'profiles')
     os.makedirs(out, exist_ok=True)
     if a.src is None:
-        a.src = os.path.join(ROOT, 'gpurun_out', 'prof_next' if a.next_rows else ('prof_masks' if a.masks else 'prof'))
+        a.src = os.path.join(ROOT, 'gpurun_out', 'prof_placed' if a.placed else 'prof_next' if a.next_rows else ('prof_masks' if a.masks else 'prof'))
     if a.next_rows:
         return summarize_next_rows(a, out)
+    if a.placed:
+        return summarize_placed(a, out)
     tag = f'r{int(a.round):02d}' + ('_masks' if a.masks else '')
     stats = one(os.path.join(a.src, 'trace', '**', '*kernel_stats.csv'))
     shutil.copy(stats, os.path.join(out, f'{tag}_kernel_stats.csv'))
