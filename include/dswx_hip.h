@@ -335,6 +335,8 @@ int dswx_batch_layout(const dswx_batch_geom_t* geom, uint32_t flags, dswx_batch_
 
 int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t flags,
                       dswx_batch_t** out);
+/* Frees every allocation of the batch.  A batch must not be USED after its context is destroyed; destroying it
+ * afterwards is allowed. */
 int dswx_batch_destroy(dswx_batch_t* batch);
 /* Device pointers of the planes (absent planes NULL), the resolved geometry and the counters array
  * ([n_tiles][3] int64); any output argument may be NULL.  Hand them to dswx_classify_batch /

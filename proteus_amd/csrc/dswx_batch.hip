@@ -62,6 +62,7 @@ int layout_mode(uint32_t flags, uint32_t* mode) {
 
 struct dswx_batch {
     dswx_ctx* ctx = nullptr;
+    int device = -1;                           // of ctx; kept here so that destroy works after the context is gone
     dswx_batch_geom_t geom = {};
     uint32_t flags = 0;
     dswx_batch_layout_t lay = {};
@@ -105,11 +106,16 @@ int dswx_batch_layout(const dswx_batch_geom_t* geom, uint32_t flags, dswx_batch_
     if (int rc = layout_mode(flags, &mode)) return rc;
     if (flags & ~(uint32_t)(DSWX_BATCH_MASKS | DSWX_BATCH_WTR1_AEROSOL | DSWX_BATCH_BROWSE | DSWX_BATCH_SEPARATE_OUTPUTS))
         return dswx_fail(DSWX_ERR_ARG, "unknown batch flag in 0x%x", flags);
+    if (geom->height > (1LL << 30) || geom->width > (1LL << 30) || geom->n_tiles > (1LL << 32) ||
+        geom->tile_stride > (1LL << 46))
+        return dswx_fail(DSWX_ERR_ARG, "batch geometry out of range");
     memset(out, 0, sizeof *out);
     const int64_t P = geom->height * geom->width;
     int64_t stride = geom->tile_stride ? geom->tile_stride : (P + 255) / 256 * 256;
     if (stride < P) return dswx_fail(DSWX_ERR_ARG, "tile_stride smaller than the tile");
     out->tile_stride = stride;
+    if (geom->n_tiles && (uint64_t)stride > (1ull << 46) / (uint64_t)geom->n_tiles)          // 64 TiB of pixels: no overflow below
+        return dswx_fail(DSWX_ERR_ARG, "batch too large");
     const uint64_t px = (uint64_t)geom->n_tiles * (uint64_t)stride;
     const PlaneSet ps = planes_of(flags);
     for (int k : ps.in) out->plane_bytes[k] = up256(px * elem_bytes(k));
@@ -140,7 +146,7 @@ int dswx_batch_layout(const dswx_batch_geom_t* geom, uint32_t flags, dswx_batch_
 
 int dswx_batch_destroy(dswx_batch_t* b) {
     if (!b) return DSWX_OK;
-    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    if (b->device >= 0) (void)hipSetDevice(b->device);
     for (void* p : b->own)
         if (p) (void)hipFree(p);
     if (b->arena) (void)hipFree(b->arena);
@@ -158,6 +164,7 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
     HIP_TRY(hipSetDevice(ctx->device));
     dswx_batch* b = new dswx_batch();
     b->ctx = ctx;
+    b->device = ctx->device;
     b->geom = *geom;
     b->geom.tile_stride = lay.tile_stride;
     b->flags = flags;

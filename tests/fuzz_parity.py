@@ -76,7 +76,7 @@ def device_batch_soak(ctx, rng, a, kernels):
             if bad:
                 print(json.dumps({'ok': False, 'iteration': it, 'tile': t, 'geom': [n_tiles, h, w, align],
                                   'masks': masks, 'mode': mode, 'extra': extra, 'layers': bad,
-                                  'skew': skew, 'kernel': ctx.last_kernel_info()},
+                                  'separate': separate, 'kernel': ctx.last_kernel_info()},
                                  default=str))
                 return 1
         batch.free()
