@@ -291,7 +291,66 @@ TILE_CASES = [
     dict(name='t250x230_cover_land_custom', tile=19, H=250, W=230, land=1, mode='cover', blobs='discs',
          lists='custom'),
     dict(name='t96x120_cover_no_aerosol', tile=20, H=96, W=120, shad=1, ocean=1, mode='cover', aerosol=False),
+    # round 3: the ITERATION COUNTS of the two masked dilations (:2060 iterations=10, :2075 iterations=7) pinned on the
+    # reference's own output: one-pixel-wide corridors of adjacent-to-cloud pixels of length 1 ... 25 with a snow seed
+    # at one end / in the middle / outside, over land and over water (where the second dilation grows back), cloud
+    # pixels blocking the way, corridors that run into the raster edge or across the 222-pixel window seams of the
+    # dilation kernel in x and in y, two-pixel-wide and L-shaped ones
+    dict(name='t260x300_cover_corridors', tile=21, H=260, W=300, mode='cover', blobs='corridors'),
 ]
+
+
+def _corridor_tile(H, W):
+    """Bands and Fmask of the 'corridors' case: every pixel valid; land = the survey's known answer
+    (500,600,700,3000,2500,1500) -> WTR-1 0, water = (300,400,300,200,100,50) -> DIAG 11111 / WTR-1 1."""
+    land_px, water_px = (500, 600, 700, 3000, 2500, 1500), (300, 400, 300, 200, 100, 50)
+    water = np.zeros((H, W), bool)
+    fm = np.zeros((H, W), np.uint8)
+    ADJ, SNOW, CLOUDBIT = 4, 16, 2
+
+    def stroke(cells, kind, L):
+        # cells: the corridor's pixels in order; kind selects seed / surface / obstacle
+        cells = [(y, x) for y, x in cells if 0 <= y < H and 0 <= x < W]
+        for y, x in cells:
+            fm[y, x] |= ADJ
+            if kind in (1, 2, 5):
+                water[y, x] = True
+        if not cells:
+            return
+        if kind in (0, 1, 3, 4):                      # snow seed ON the first corridor pixel
+            fm[cells[0]] |= SNOW
+        if kind in (2, 5):                            # seed in the middle
+            fm[cells[len(cells) // 2]] |= SNOW
+        if kind == 3 and len(cells) > 6:              # a cloud pixel in the way (CLOUD != 0: not in the area)
+            fm[cells[6]] |= CLOUDBIT
+        if kind == 4 and len(cells) > 3:              # water only on the far half: the second dilation's mask
+            for y, x in cells[len(cells) // 2:]:
+                water[y, x] = True
+        if kind == 5:                                 # and a second seed at the far end
+            fm[cells[-1]] |= SNOW
+    lengths = [1, 2, 5, 7, 8, 9, 10, 11, 12, 15, 17, 18, 25]
+    n = 0
+    # horizontal corridors in the upper half, three rows apart (4-neighbourhood: they do not touch)
+    for y in range(2, 128, 3):
+        x = 3 + (n * 37) % 60
+        while x < W + 10:
+            L, kind = lengths[n % len(lengths)], n % 6
+            stroke([(y, x + i) for i in range(L)], kind, L)
+            x += L + 4 + (n % 3)
+            n += 1
+    # vertical corridors in the lower half, three columns apart; they cross y = 222 and run into the bottom edge
+    for x in range(2, W, 3):
+        y = 132 + (n * 29) % 40
+        while y < H + 10:
+            L, kind = lengths[n % len(lengths)], n % 6
+            stroke([(y + i, x) for i in range(L)], kind, L)
+            y += L + 4 + (n % 3)
+            n += 1
+    # a few two-pixel-wide and L-shaped corridors over the horizontal ones' right margin are not needed: widen some
+    for y in range(2, 128, 12):
+        fm[y + 1, 40:70] |= fm[y, 40:70] & ADJ       # two rows wide where the row above is a corridor
+    bands = [np.where(water, w, l).astype(np.int16) for l, w in zip(land_px, water_px)]
+    return bands, fm
 
 
 def gen_tiles(ref):
@@ -335,6 +394,8 @@ def gen_tiles(ref):
                 fmask = np.where(blob & (fmask != 255), fmask & ~np.uint8(2 | 8), fmask).astype(np.uint8)
                 fmask = np.where(blob & (fmask != 255), fmask | 4, fmask & ~np.uint8(4)).astype(np.uint8)
             fmask = np.where(snowb & (fmask != 255), fmask | 16, fmask).astype(np.uint8)
+            if case.get('blobs') == 'corridors':
+                bands, fmask = _corridor_tile(H, W)
         land = s['land'] if case.get('land') else None
         shad = s['shad'].astype(bool) if case.get('shad') else None
         ocean = s['ocean'] if case.get('ocean') else None
