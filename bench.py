@@ -50,9 +50,13 @@ def parse_args():
     ap.add_argument('--realloc-repeats', type=int, default=5,
                     help='N = 1: after the timed region, re-allocate the batch this many times and report the '
                          'spread of the kernel rate (it depends on where the arena lands, DESIGN.md section 5)')
-    ap.add_argument('--placement-trials', type=int, default=6,
-                    help='candidate allocations per output plane; each plane keeps the one under which the kernel runs '
-                         'fastest (1 = first come, 0 = one arena for all planes)')
+    ap.add_argument('--placement', default='slide', choices=['slide', 'search', 'first', 'arena'],
+                    help='how the resident batch is placed before warm-up (DESIGN.md section 6): slide = '
+                         'dswx_batch_place_slide (the packed output region timed at 25 offsets of a range 48 GiB longer than '
+                         'itself), search = dswx_batch_place_search (--placement-trials candidate allocations per output '
+                         'plane), first = one allocation per output plane as they come, arena = all planes in one hipMalloc')
+    ap.add_argument('--placement-trials', type=int, default=None,
+                    help='implies --placement search (>= 2 candidates per output plane), first (1) or arena (0)')
     ap.add_argument('--plan-only', action='store_true',
                     help='no GPU work: bring the ranks up (gloo), print the sharding plan of this command line as '
                          'JSON and exit (tests/test_shard_gloo.py drives the launcher path with it)')
@@ -70,6 +74,10 @@ def parse_args():
     args = ap.parse_args()
     if args.tiles <= 0:
         args.tiles = 512 if args.total_tiles > 0 else 256
+    if args.placement_trials is not None:
+        args.placement = 'arena' if args.placement_trials <= 0 else 'first' if args.placement_trials == 1 else 'search'
+    elif args.placement == 'search':
+        args.placement_trials = 6
     return args
 
 
@@ -305,23 +313,29 @@ def realloc_spread(ctx, params, n_tiles, masks, repeats, launches=5):
             'frac_max': round(rates[-1] / HBM_PEAK_GBS, 4)}
 
 
-def place_batch(ctx, params, n_tiles, tile0, masks, trials):
-    """Allocate the resident batch through the library (dswx_batch_create).  The kernel's rate depends on WHERE in HBM
-    its output planes land -- a stable property of the allocation that no layout rule predicts from one process to the
-    next (profiles/r03_placement_rule_trials.json) -- so a long-lived batch is worth placing:
-    the inputs get one allocation, every output plane its own, and dswx_batch_place_search (C-ABI; one pass of
-    coordinate descent over `trials` candidate allocations per plane, the kernel itself as the probe) binds each.
-    Outside the timed region; `--placement-trials 1` takes what comes first, 0 puts all planes in ONE allocation."""
+def place_batch(ctx, params, n_tiles, tile0, masks, how, trials):
+    """Allocate the resident batch through the library (dswx_batch_create) and place it.  The kernel's rate depends on
+    WHERE in the address space its output planes lie -- a stable property of the allocation that no layout rule predicts
+    from one process to the next (profiles/r03_placement_rule_trials.json) -- so a long-lived batch
+    is worth placing, outside the timed region:
+      slide   dswx_batch_place_slide: the packed output region timed at offsets 0, 2, ... 48 GiB of a range that much
+              longer than itself (HIP virtual memory management: the unused part goes back to the device)
+      search  dswx_batch_place_search: one allocation per output plane, each bound to the fastest of `trials` candidates
+      first   one allocation per output plane, as they come;   arena   all planes in ONE hipMalloc (a plain caller)"""
     from proteus_amd import _capi
     from proteus_amd.synth import SEED
-    b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=trials > 0)
+    b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=how in ('search', 'first'),
+                          sliding_outputs=how == 'slide')
     b.synth(SEED, tile0=tile0)
-    if trials <= 1:                 # 0: one arena for everything, as a plain caller would allocate it; 1: first come
-        return b, {'trials': max(trials, 0), 'probes': 0}
+    rec = {'how': how, 'probes': 0}
     try:
-        return b, b.place_search(params, candidates=trials)
-    except Exception as e:          # the search is an optimisation: the planes bound now are valid whatever happened
-        return b, {'trials': 1, 'probes': 0, 'error': f'{type(e).__name__}: {e}'[:300]}
+        if how == 'slide':
+            rec.update(b.place_slide(params))
+        elif how == 'search':
+            rec.update(b.place_search(params, candidates=trials))
+    except Exception as e:          # the placement is an optimisation: the planes bound now are valid whatever happened
+        rec['error'] = f'{type(e).__name__}: {e}'[:300]
+    return b, rec
 
 
 def free_port():
@@ -418,7 +432,8 @@ def main():
     strong = args.total_tiles > 0
     my_tiles, tile0, n_tiles, chunks = rank_plan(args, rank, world)
     batch, placement = place_batch(ctx, params, n_tiles, tile0, args.masks,
-                                   1 if share_device else args.placement_trials)
+                                   'first' if share_device and args.placement != 'arena' else args.placement,
+                                   args.placement_trials)
     barrier = cp.barrier
 
     def one_step():
@@ -495,14 +510,17 @@ def main():
                        'planes_in': 10 if args.masks else 7, 'planes_out': 7,
                        'sharding': f'tiles by rank x{world}, no collective',
                        'control_plane': cp.backend,
-                       'arena_placement': dict(placement, note='one arena for all planes') if not placement['trials'] else
-                       dict(placement, note='dswx_batch_place_search (C-ABI): every output plane in the fastest of '
-                                               '`trials` candidate allocations (one pass of coordinate descent with the '
-                                               'kernel itself as the probe, before warm-up): the rate is a property of '
-                                               'the ranges the seven write streams land in; first_come_launch_ms = the '
-                                               'first-come planes timed back to back with the kept ones at the end of the '
-                                               'search; roofline.realloc_spread shows what unplaced single-arena '
-                                               'allocations give'),
+                       'arena_placement': dict(placement, note={
+                           'arena': 'all planes in one hipMalloc (dswx_batch_create without flags)',
+                           'first': 'inputs in one allocation, every output plane in its own, as they come',
+                           'slide': 'dswx_batch_place_slide (C-ABI): the packed output region timed at `positions` offsets of '
+                                    'a range longer than itself, the best kept, the rest of the range returned to the device; '
+                                    'first_come_launch_ms = the first-come range timed back to back with the kept one',
+                           'search': 'dswx_batch_place_search (C-ABI): every output plane in the fastest of `trials` candidate '
+                                     'allocations (one pass of coordinate descent, the kernel itself as the probe); '
+                                     'first_come_launch_ms = the first-come planes timed back to back with the kept ones',
+                       }[placement['how']] + '; before warm-up, outside the timed region; roofline.realloc_spread shows what '
+                                             'unplaced single-arena allocations give'),
                        'kernel': kernel_info},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),

@@ -302,15 +302,19 @@ enum {
     DSWX_BATCH_WTR1_AEROSOL = 1 << 1,     /* optional output planes */
     DSWX_BATCH_BROWSE = 1 << 2,
     /* layout: default = ONE allocation, inputs then outputs back to back (what a plain caller does) */
-    DSWX_BATCH_SEPARATE_OUTPUTS = 1 << 10 /* one allocation for the inputs, one per output plane: what
-                                             dswx_batch_place_search needs */
+    DSWX_BATCH_SEPARATE_OUTPUTS = 1 << 10, /* one allocation for the inputs, one per output plane: what
+                                              dswx_batch_place_search needs */
+    DSWX_BATCH_SLIDING_OUTPUTS = 1 << 11   /* the output planes packed in a range of the virtual address space that
+                                              is backed chunk by chunk (HIP virtual memory management): what
+                                              dswx_batch_place_slide needs */
 };
 
 typedef struct dswx_batch_layout {
     int64_t tile_stride;                              /* pixels, as resolved (see dswx_batch_create) */
     uint64_t arena_bytes;                             /* the single allocation (SEPARATE_OUTPUTS: the inputs') */
     uint64_t plane_bytes[DSWX_BATCH_MAX_PLANES];      /* 0 = plane absent */
-    uint64_t plane_offset[DSWX_BATCH_MAX_PLANES];     /* inside the arena (SEPARATE_OUTPUTS: 0 for outputs) */
+    uint64_t plane_offset[DSWX_BATCH_MAX_PLANES];     /* inside the arena (SEPARATE_OUTPUTS: 0 for outputs;
+                                                         SLIDING_OUTPUTS: inside the output region) */
     uint64_t write_span_bytes;                        /* first byte of the first to last byte of the last
                                                          output plane (0 with SEPARATE_OUTPUTS) */
 } dswx_batch_layout_t;
@@ -357,6 +361,17 @@ int dswx_batch_synth(dswx_batch_t* batch, uint64_t seed, int64_t tile0, void* st
  * spares are freed.  Output pointers change: call dswx_batch_planes again.  Synchronous. */
 int dswx_batch_place_search(dswx_batch_t* batch, const dswx_params_t* params, int32_t candidates,
                             int32_t launches, uint64_t keep_free_bytes);
+/* The cheaper measured placement (DSWX_BATCH_SLIDING_OUTPUTS batches whose inputs are resident).  The rate follows
+ * the POSITION of the packed output region in the address space with a structure of ~32 GiB, so
+ * one dimension is enough: a range `slack_bytes` longer than the output planes is mapped beside the current one
+ * (bounded so that `keep_free_bytes` of device memory stay free), the kernel is timed (`launches` launches) with the
+ * output region at offsets 0, step_bytes, 2 step_bytes, ... of it, the best position and the first-come range are
+ * then timed back to back, and the better one is kept: of the wide range only the chunks under the chosen position
+ * stay mapped, everything else goes back to the device at once.  slack / step + 1 probes (25 at 48 GiB / 2 GiB:
+ * about 1 s for 256 tiles) and slack_bytes of transient memory, against 185 probes and five spare sets of planes
+ * for dswx_batch_place_search.  Output pointers change: call dswx_batch_planes again.  Synchronous. */
+int dswx_batch_place_slide(dswx_batch_t* batch, const dswx_params_t* params, uint64_t slack_bytes,
+                           uint64_t step_bytes, int32_t launches, uint64_t keep_free_bytes);
 
 /* ---- device plumbing for hosts without another HIP binding ------------------- */
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);

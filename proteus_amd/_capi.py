@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info',
     'dswx_batch_layout', 'dswx_batch_create', 'dswx_batch_destroy', 'dswx_batch_planes', 'dswx_batch_info',
-    'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search')
+    'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search', 'dswx_batch_place_slide')
 
 
 class DswxError(RuntimeError):
@@ -76,7 +76,7 @@ class PlanesOut(ctypes.Structure):
 
 
 # resident batches (include/dswx_hip.h, ABI v4)
-BATCH_MASKS, BATCH_WTR1_AEROSOL, BATCH_BROWSE, BATCH_SEPARATE_OUTPUTS = 1, 2, 4, 1 << 10
+BATCH_MASKS, BATCH_WTR1_AEROSOL, BATCH_BROWSE, BATCH_SEPARATE_OUTPUTS, BATCH_SLIDING_OUTPUTS = 1, 2, 4, 1 << 10, 1 << 11
 BATCH_MAX_PLANES = 20
 PLANE_INDEX = dict(blue=0, green=1, red=2, nir=3, swir1=4, swir2=5, fmask=6, land=7, shad=8, ocean=9, diag=10,
                    wtr1=11, wtr1_aerosol=12, wtr2=13, wtr=14, bwtr=15, conf=16, cloud=17, browse=18, counters=19)
@@ -202,6 +202,8 @@ def load_library(path=None):
         'dswx_batch_synth': (ctypes.c_int, [vp, ctypes.c_uint64, i64, vp]),
         'dswx_batch_place_search': (ctypes.c_int, [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
                                                    ctypes.c_uint64]),
+        'dswx_batch_place_slide': (ctypes.c_int, [vp, ctypes.POINTER(Params), ctypes.c_uint64, ctypes.c_uint64,
+                                                  ctypes.c_int32, ctypes.c_uint64]),
     }
     for name, (res, args) in sig.items():
         if alt and not hasattr(lib, name):
@@ -703,10 +705,11 @@ class Context:
         return buf.value.decode()
 
 
-def batch_layout(n_tiles, height, width, masks=False, extra_layers=(), tile_stride=0, separate_outputs=False):
+def batch_layout(n_tiles, height, width, masks=False, extra_layers=(), tile_stride=0, separate_outputs=False,
+                 sliding_outputs=False):
     """dswx_batch_layout: where dswx_batch_create puts every plane (pure function, no device).  Returns
     {'tile_stride', 'arena_bytes', 'write_span_bytes', 'planes': {name: (offset, nbytes)}}."""
-    flags = _batch_flags(masks, extra_layers, separate_outputs)
+    flags = _batch_flags(masks, extra_layers, separate_outputs, sliding_outputs)
     lay = BatchLayout()
     geom = BatchGeom(n_tiles, height, width, tile_stride)
     _check(load_library().dswx_batch_layout(ctypes.byref(geom), flags, ctypes.byref(lay)))
@@ -716,12 +719,13 @@ def batch_layout(n_tiles, height, width, masks=False, extra_layers=(), tile_stri
             'write_span_bytes': int(lay.write_span_bytes), 'planes': planes}
 
 
-def _batch_flags(masks, extra_layers, separate_outputs):
+def _batch_flags(masks, extra_layers, separate_outputs, sliding_outputs=False):
     unknown = [x for x in extra_layers if x not in ('wtr1_aerosol', 'browse')]
     if unknown:
         raise ValueError(f'a resident batch has no plane {unknown[0]!r}')
     return ((BATCH_MASKS if masks else 0) | (BATCH_WTR1_AEROSOL if 'wtr1_aerosol' in extra_layers else 0)
-            | (BATCH_BROWSE if 'browse' in extra_layers else 0) | (BATCH_SEPARATE_OUTPUTS if separate_outputs else 0))
+            | (BATCH_BROWSE if 'browse' in extra_layers else 0) | (BATCH_SEPARATE_OUTPUTS if separate_outputs else 0)
+            | (BATCH_SLIDING_OUTPUTS if sliding_outputs else 0))
 
 
 class DeviceBatch:
@@ -736,12 +740,12 @@ class DeviceBatch:
     """
 
     def __init__(self, ctx, n_tiles, height, width, masks=False, extra_layers=(), tile_align=256,
-                 separate_outputs=False):
+                 separate_outputs=False, sliding_outputs=False):
         self.ctx, self.n_tiles, self.height, self.width = ctx, n_tiles, height, width
         self.n_pixels = height * width
         self.masks = masks
         stride = -(-self.n_pixels // tile_align) * tile_align
-        flags = _batch_flags(masks, extra_layers, separate_outputs)
+        flags = _batch_flags(masks, extra_layers, separate_outputs, sliding_outputs)
         h = ctypes.c_void_p()
         geom = BatchGeom(n_tiles, height, width, stride)
         if stride == 0:                 # an empty tile: let the library resolve the stride (0 stays 0)
@@ -781,6 +785,18 @@ class DeviceBatch:
         self._rebind()
         i = self.info()
         return {'trials': i['search_candidates'], 'probes': i['search_probes'],
+                'first_come_launch_ms': round(i['first_come_launch_ms'], 4),
+                'kept_launch_ms': round(i['kept_launch_ms'], 4)}
+
+    def place_slide(self, params, slack_bytes=48 << 30, step_bytes=2 << 30, launches=3, keep_free_bytes=8 << 30):
+        """dswx_batch_place_slide: the output region (sliding_outputs batches) timed at offsets 0, step, 2 step, ...
+        of a range `slack_bytes` longer than itself; the best position is kept and the rest of the range returned to the
+        device.  Returns the record of the search."""
+        _check(self.ctx.lib.dswx_batch_place_slide(self.handle, ctypes.byref(params), int(slack_bytes), int(step_bytes),
+                                                   int(launches), int(keep_free_bytes)))
+        self._rebind()
+        i = self.info()
+        return {'positions': i['search_candidates'], 'probes': i['search_probes'],
                 'first_come_launch_ms': round(i['first_come_launch_ms'], 4),
                 'kept_launch_ms': round(i['kept_launch_ms'], 4)}
 

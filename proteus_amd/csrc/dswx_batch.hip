@@ -53,8 +53,90 @@ inline int elem_bytes(int plane) {
     return (plane <= DSWX_PLANE_BAND0 + 5 || plane == DSWX_PLANE_DIAG) ? 2 : 1;
 }
 
+// A reserved range of the virtual address space backed chunk by chunk by physical allocations (HIP virtual
+// memory management): unlike a hipMalloc, it can give back the chunks it no longer needs.  The sliding
+// placement maps a range longer than the output planes, times the kernel with the planes at several offsets,
+// and keeps only the chunks under the best one.
+struct VmRange {
+    char* va = nullptr;
+    size_t reserved = 0, chunk = 0;
+    int device = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handle;
+    std::vector<char> mapped;
+
+    size_t mapped_bytes() const {
+        size_t n = 0;
+        for (char m : mapped) n += m ? chunk : 0;
+        return n;
+    }
+    void destroy() {
+        for (size_t i = 0; i < handle.size(); ++i)
+            if (mapped[i]) {
+                (void)hipMemUnmap(va + i * chunk, chunk);
+                (void)hipMemRelease(handle[i]);
+            }
+        handle.clear();
+        mapped.clear();
+        if (va) (void)hipMemAddressFree(va, reserved);
+        va = nullptr;
+        reserved = 0;
+    }
+    // reserve `bytes` (rounded up to whole chunks), back all of it, make it accessible from `dev`
+    hipError_t create(int dev, size_t bytes, size_t chunk_bytes) {
+        device = dev;
+        chunk = chunk_bytes;
+        const size_t n = (bytes + chunk - 1) / chunk;
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        void* base = nullptr;
+        hipError_t e = hipMemAddressReserve(&base, n * chunk, 0, nullptr, 0);
+        if (e != hipSuccess) return e;
+        va = static_cast<char*>(base);
+        reserved = n * chunk;
+        for (size_t i = 0; i < n; ++i) {
+            hipMemGenericAllocationHandle_t h;
+            e = hipMemCreate(&h, chunk, &prop, 0);
+            if (e == hipSuccess) {
+                e = hipMemMap(va + i * chunk, chunk, 0, h, 0);
+                if (e != hipSuccess) (void)hipMemRelease(h);
+            }
+            if (e != hipSuccess) { destroy(); return e; }
+            handle.push_back(h);
+            mapped.push_back(1);
+        }
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, reserved, &acc, 1);
+        if (e != hipSuccess) destroy();
+        return e;
+    }
+    // give back every chunk that lies wholly outside [lo, hi)
+    void trim(size_t lo, size_t hi) {
+        for (size_t i = 0; i < handle.size(); ++i) {
+            const size_t c0 = i * chunk, c1 = c0 + chunk;
+            if (mapped[i] && (c1 <= lo || c0 >= hi)) {
+                (void)hipMemUnmap(va + c0, chunk);
+                (void)hipMemRelease(handle[i]);
+                mapped[i] = 0;
+            }
+        }
+    }
+};
+
+// chunk size of a range that holds `bytes` of planes: 2 MiB ... 1 GiB, about an eighth of the planes
+size_t chunk_for(size_t bytes) {
+    const size_t mib2 = size_t(2) << 20, gib = size_t(1) << 30;
+    size_t c = (bytes / 8 + mib2 - 1) / mib2 * mib2;
+    return c < mib2 ? mib2 : (c > gib ? gib : c);
+}
+
 int layout_mode(uint32_t flags, uint32_t* mode) {
-    *mode = flags & DSWX_BATCH_SEPARATE_OUTPUTS;
+    *mode = flags & (DSWX_BATCH_SEPARATE_OUTPUTS | DSWX_BATCH_SLIDING_OUTPUTS);
+    if (*mode == (DSWX_BATCH_SEPARATE_OUTPUTS | DSWX_BATCH_SLIDING_OUTPUTS))
+        return dswx_fail(DSWX_ERR_ARG, "DSWX_BATCH_SEPARATE_OUTPUTS and DSWX_BATCH_SLIDING_OUTPUTS exclude each other");
     return DSWX_OK;
 }
 
@@ -69,6 +151,8 @@ struct dswx_batch {
     void* arena = nullptr;
     void* own[DSWX_BATCH_MAX_PLANES] = {};     // SEPARATE_OUTPUTS: the allocation an output plane lives in
     void* ptr[DSWX_BATCH_MAX_PLANES] = {};     // device address of every plane
+    VmRange* range = nullptr;                  // SLIDING_OUTPUTS: the range the output region lives in ...
+    size_t region_offset = 0;                  // ... and where in it
     int search_candidates = 0, search_probes = 0;
     float first_ms = 0.f, kept_ms = 0.f;
 };
@@ -104,7 +188,8 @@ int dswx_batch_layout(const dswx_batch_geom_t* geom, uint32_t flags, dswx_batch_
         return dswx_fail(DSWX_ERR_ARG, "negative size");
     uint32_t mode;
     if (int rc = layout_mode(flags, &mode)) return rc;
-    if (flags & ~(uint32_t)(DSWX_BATCH_MASKS | DSWX_BATCH_WTR1_AEROSOL | DSWX_BATCH_BROWSE | DSWX_BATCH_SEPARATE_OUTPUTS))
+    if (flags & ~(uint32_t)(DSWX_BATCH_MASKS | DSWX_BATCH_WTR1_AEROSOL | DSWX_BATCH_BROWSE | DSWX_BATCH_SEPARATE_OUTPUTS |
+                           DSWX_BATCH_SLIDING_OUTPUTS))
         return dswx_fail(DSWX_ERR_ARG, "unknown batch flag in 0x%x", flags);
     if (geom->height > (1LL << 30) || geom->width > (1LL << 30) || geom->n_tiles > (1LL << 32) ||
         geom->tile_stride > (1LL << 46))
@@ -128,11 +213,16 @@ int dswx_batch_layout(const dswx_batch_geom_t* geom, uint32_t flags, dswx_batch_
         cur += out->plane_bytes[k] ? out->plane_bytes[k] : kAlign;      // an empty batch still has distinct addresses
     };
     for (int k : ps.in) take(k);
-    if (mode != DSWX_BATCH_SEPARATE_OUTPUTS)
+    if (mode == 0)
         for (int k : ps.out) take(k);
     take(DSWX_PLANE_COUNTERS);
     out->arena_bytes = cur;
-    if (mode != DSWX_BATCH_SEPARATE_OUTPUTS) {
+    if (mode == DSWX_BATCH_SLIDING_OUTPUTS) {       // offsets inside the output REGION, which lives in a range of its own
+        cur = 0;
+        for (int k : ps.out) take(k);
+        out->write_span_bytes = cur;
+    }
+    if (mode == 0) {
         uint64_t lo = ~0ull, hi = 0;
         for (int k : ps.out) {
             lo = out->plane_offset[k] < lo ? out->plane_offset[k] : lo;
@@ -150,6 +240,7 @@ int dswx_batch_destroy(dswx_batch_t* b) {
     for (void* p : b->own)
         if (p) (void)hipFree(p);
     if (b->arena) (void)hipFree(b->arena);
+    if (b->range) { b->range->destroy(); delete b->range; }
     delete b;
     return DSWX_OK;
 }
@@ -176,13 +267,19 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
             e = hipMalloc(&b->own[k], lay.plane_bytes[k] ? lay.plane_bytes[k] : kAlign);
             if (e != hipSuccess) break;
         }
+    if (e == hipSuccess && mode == DSWX_BATCH_SLIDING_OUTPUTS) {
+        const size_t bytes = lay.write_span_bytes ? lay.write_span_bytes : kAlign;
+        b->range = new VmRange();
+        e = b->range->create(ctx->device, bytes, chunk_for(bytes));
+    }
     if (e != hipSuccess) {
         dswx_batch_destroy(b);
-        return dswx_fail(DSWX_ERR_HIP, "dswx_batch_create: hipMalloc failed: %s (arena of %llu bytes)",
+        return dswx_fail(DSWX_ERR_HIP, "dswx_batch_create: device allocation failed: %s (arena of %llu bytes)",
                          hipGetErrorString(e), (unsigned long long)lay.arena_bytes);
     }
     for (int k : ps.in) b->ptr[k] = (char*)b->arena + lay.plane_offset[k];
-    for (int k : ps.out) b->ptr[k] = b->own[k] ? b->own[k] : (char*)b->arena + lay.plane_offset[k];
+    for (int k : ps.out)
+        b->ptr[k] = b->own[k] ? b->own[k] : (b->range ? b->range->va : (char*)b->arena) + lay.plane_offset[k];
     b->ptr[DSWX_PLANE_COUNTERS] = (char*)b->arena + lay.plane_offset[DSWX_PLANE_COUNTERS];
     *out = b;
     return DSWX_OK;
@@ -209,6 +306,10 @@ int dswx_batch_info(const dswx_batch_t* b, dswx_batch_info_t* info) {
             ++info->n_allocations;
             info->bytes_allocated += b->lay.plane_bytes[k] ? b->lay.plane_bytes[k] : kAlign;
         }
+    if (b->range) {
+        ++info->n_allocations;
+        info->bytes_allocated += b->range->mapped_bytes();
+    }
     info->search_candidates = b->search_candidates;
     info->search_probes = b->search_probes;
     info->first_come_launch_ms = b->first_ms;
@@ -368,6 +469,93 @@ int dswx_batch_place_search(dswx_batch_t* b, const dswx_params_t* params, int32_
     if (rc) return rc;
     b->search_candidates = sets + 1;
     b->search_probes = probes;
+    b->first_ms = first_ms;
+    b->kept_ms = kept_ms;
+    return DSWX_OK;
+}
+
+// Sliding placement: see include/dswx_hip.h.
+int dswx_batch_place_slide(dswx_batch_t* b, const dswx_params_t* params, uint64_t slack_bytes, uint64_t step_bytes,
+                           int32_t launches, uint64_t keep_free_bytes) {
+    if (!b || !params) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (!(b->flags & DSWX_BATCH_SLIDING_OUTPUTS) || !b->range)
+        return dswx_fail(DSWX_ERR_ARG, "dswx_batch_place_slide needs a DSWX_BATCH_SLIDING_OUTPUTS batch");
+    if (launches < 1 || step_bytes == 0) return dswx_fail(DSWX_ERR_ARG, "launches and step_bytes must be positive");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    const PlaneSet ps = planes_of(b->flags);
+    const size_t region = b->lay.write_span_bytes ? b->lay.write_span_bytes : kAlign;
+    const size_t step = (size_t)((step_bytes + 255) & ~(uint64_t)255);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    // the wider range is held BESIDE the current one while the search runs
+    const uint64_t room = free_b > keep_free_bytes + region ? free_b - keep_free_bytes - region : 0;
+    size_t slack = (size_t)(slack_bytes < room ? slack_bytes : room);
+    slack = slack / step * step;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    VmRange* wide = nullptr;
+    void* first_ptr[DSWX_BATCH_MAX_PLANES];
+    memcpy(first_ptr, b->ptr, sizeof first_ptr);
+    auto bind_at = [&](char* base) {
+        for (int k : ps.out) b->ptr[k] = base + b->lay.plane_offset[k];
+    };
+    int rc = DSWX_OK, positions = 0;
+    float first_ms = 0.f, kept_ms = 0.f;
+    do {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            rc = dswx_fail(DSWX_ERR_HIP, "hipEventCreate failed");
+            break;
+        }
+        if ((rc = probe_ms(b, params, launches, e0, e1, &first_ms))) break;
+        kept_ms = first_ms;
+        if (slack == 0) break;                      // no room to slide in: the planes stay where they are
+        wide = new VmRange();
+        const size_t chunk = chunk_for(region);
+        hipError_t e = wide->create(b->ctx->device, region + slack, chunk);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            delete wide;
+            wide = nullptr;
+            break;                                  // refused: nothing to choose from
+        }
+        size_t best_off = 0;
+        float best_ms = 0.f;
+        for (size_t off = 0; off + region <= wide->reserved; off += step) {
+            bind_at(wide->va + off);
+            float ms;
+            if ((rc = probe_ms(b, params, launches, e0, e1, &ms))) break;
+            if (positions == 0 || ms < best_ms) { best_ms = ms; best_off = off; }
+            ++positions;
+        }
+        if (rc) break;
+        // equal conditions (the part is warmer now): the best position and the first-come range back to back
+        float chosen_ms, again_ms;
+        bind_at(wide->va + best_off);
+        if ((rc = probe_ms(b, params, launches, e0, e1, &chosen_ms))) break;
+        memcpy(b->ptr, first_ptr, sizeof first_ptr);
+        if ((rc = probe_ms(b, params, launches, e0, e1, &again_ms))) break;
+        first_ms = again_ms;
+        if (chosen_ms < again_ms) {
+            (void)hipStreamSynchronize(b->ctx->stream);
+            wide->trim(best_off, best_off + region);
+            b->range->destroy();
+            delete b->range;
+            b->range = wide;
+            wide = nullptr;
+            b->region_offset = best_off;
+            bind_at(b->range->va + best_off);
+            kept_ms = chosen_ms;
+        } else {
+            kept_ms = again_ms;
+        }
+    } while (false);
+    if (rc) memcpy(b->ptr, first_ptr, sizeof first_ptr);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    if (wide) { wide->destroy(); delete wide; }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    b->search_candidates = positions;
+    b->search_probes = positions;
     b->first_ms = first_ms;
     b->kept_ms = kept_ms;
     return DSWX_OK;

@@ -729,6 +729,49 @@ def test_output_planes_in_separate_allocations(ctx):
     sep.free()
 
 
+def test_output_region_in_a_sliding_range(ctx):
+    """DeviceBatch(sliding_outputs=True) = dswx_batch_create(DSWX_BATCH_SLIDING_OUTPUTS): the output planes packed in a
+    range of the virtual address space backed chunk by chunk, moved by dswx_batch_place_slide to the offset where the
+    kernel runs fastest (what bench.py does to the headline batch).  Wherever the region ends up, the layers and
+    counters are the oracle's, and the memory of the wide range is returned."""
+    n_tiles, h, w = 3, 200, 264
+    b = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, extra_layers=('browse',), sliding_outputs=True)
+    lay = _capi.batch_layout(n_tiles, h, w, masks=True, extra_layers=('browse',), sliding_outputs=True)
+    region = lay['write_span_bytes']
+    assert region == sum(lay['planes'][n][1] for n in ['diag'] + b.out_layers)
+    assert lay['planes']['diag'][0] == 0 and lay['planes']['wtr1'][0] == lay['planes']['diag'][1]
+    chunk = 2 << 20
+    held = b.info()['bytes_allocated']
+    assert b.info()['n_allocations'] == 2 and held == lay['arena_bytes'] + chunk       # 1.4 MB of planes: one 2 MiB chunk
+    p = _capi.default_params()
+    b.synth(SEED, tile0=21)
+    first = b.pout.diag
+    rec = b.place_slide(p, slack_bytes=16 << 20, step_bytes=2 << 20, launches=1)
+    assert rec['positions'] == 9 and rec['probes'] == 9                                # offsets 0, 2, ... 16 MiB
+    assert 0 < rec['kept_launch_ms'] <= rec['first_come_launch_ms']
+    assert b.info()['bytes_allocated'] in (held, held + chunk)                          # a region may straddle two chunks
+    moved = b.pout.diag != first
+    assert b.pout.diag % 256 == 0 and b.pout.wtr1 - b.pout.diag == lay['planes']['wtr1'][0]
+    b.classify(p)
+    ctx.synchronize()
+    for t in range(n_tiles):
+        s_ = synth_tile(21 + t, h, w, with_masks=True)
+        exp = c_oracle.classify(p, s_['bands'], s_['fmask'], land=s_['land'], shad=s_['shad'], ocean=s_['ocean'])
+        for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+            assert np.array_equal(b.read_tile(key, t), exp[key]), (key, t, moved)
+        assert b.read_counters()[t].tolist() == exp['counters'].tolist()
+    # no room to slide in: the planes stay where they are, the record says so
+    rec = b.place_slide(p, slack_bytes=0)
+    assert rec['positions'] == 0 and rec['kept_launch_ms'] == rec['first_come_launch_ms']
+    one = _capi.DeviceBatch(ctx, 1, 8, 8)
+    with pytest.raises(_capi.DswxError):
+        one.place_slide(p)                              # not a sliding batch
+    with pytest.raises(_capi.DswxError):
+        _capi.DeviceBatch(ctx, 1, 8, 8, separate_outputs=True, sliding_outputs=True)
+    one.free()
+    b.free()
+
+
 # ---- terrain shadow layer (SURVEY.md row f1) --------------------------------------------
 SHADOW_GOLDENS = ['s_default', 's_low_sun', 's_noon_north', 's_other_thresholds', 's_thin',
                   's_terraced_flat_tie', 's_terraced_low_sun', 's_terraced_high_sun']
