@@ -53,8 +53,10 @@ def parse_args():
     ap.add_argument('--placement', default='slide', choices=['slide', 'search', 'first', 'arena'],
                     help='how the resident batch is placed before warm-up (DESIGN.md section 6): slide = '
                          'dswx_batch_place_slide (the packed output region timed at 25 offsets of a range 48 GiB longer than '
-                         'itself), search = dswx_batch_place_search (--placement-trials candidate allocations per output '
+                         'itself, then every plane refined among the free places of that range), search = dswx_batch_place_search (--placement-trials candidate allocations per output '
                          'plane), first = one allocation per output plane as they come, arena = all planes in one hipMalloc')
+    ap.add_argument('--slide-refine', type=int, default=1, help='--placement slide: passes of per-plane refinement (0 = the packed region only)')
+    ap.add_argument('--slide-slack-gib', type=float, default=48.0, help='--placement slide: length of the range beyond the planes')
     ap.add_argument('--placement-trials', type=int, default=None,
                     help='implies --placement search (>= 2 candidates per output plane), first (1) or arena (0)')
     ap.add_argument('--plan-only', action='store_true',
@@ -313,13 +315,14 @@ def realloc_spread(ctx, params, n_tiles, masks, repeats, launches=5):
             'frac_max': round(rates[-1] / HBM_PEAK_GBS, 4)}
 
 
-def place_batch(ctx, params, n_tiles, tile0, masks, how, trials):
+def place_batch(ctx, params, n_tiles, tile0, masks, how, trials, refine=1, slack_gib=48.0):
     """Allocate the resident batch through the library (dswx_batch_create) and place it.  The kernel's rate depends on
     WHERE in the address space its output planes lie -- a stable property of the allocation that no layout rule predicts
     from one process to the next (profiles/r03_placement_rule_trials.json) -- so a long-lived batch
     is worth placing, outside the timed region:
       slide   dswx_batch_place_slide: the packed output region timed at offsets 0, 2, ... 48 GiB of a range that much
-              longer than itself (HIP virtual memory management: the unused part goes back to the device)
+              longer than itself, four spread layouts, then `refine` passes in which every plane tries the free places
+              of the range (HIP virtual memory management: the unused part goes back to the device)
       search  dswx_batch_place_search: one allocation per output plane, each bound to the fastest of `trials` candidates
       first   one allocation per output plane, as they come;   arena   all planes in ONE hipMalloc (a plain caller)"""
     from proteus_amd import _capi
@@ -330,7 +333,7 @@ def place_batch(ctx, params, n_tiles, tile0, masks, how, trials):
     rec = {'how': how, 'probes': 0}
     try:
         if how == 'slide':
-            rec.update(b.place_slide(params))
+            rec.update(b.place_slide(params, slack_bytes=int(slack_gib * (1 << 30)), refine_passes=refine))
         elif how == 'search':
             rec.update(b.place_search(params, candidates=trials))
     except Exception as e:          # the placement is an optimisation: the planes bound now are valid whatever happened
@@ -433,7 +436,7 @@ def main():
     my_tiles, tile0, n_tiles, chunks = rank_plan(args, rank, world)
     batch, placement = place_batch(ctx, params, n_tiles, tile0, args.masks,
                                    'first' if share_device and args.placement != 'arena' else args.placement,
-                                   args.placement_trials)
+                                   args.placement_trials, args.slide_refine, args.slide_slack_gib)
     barrier = cp.barrier
 
     def one_step():
@@ -513,8 +516,9 @@ def main():
                        'arena_placement': dict(placement, note={
                            'arena': 'all planes in one hipMalloc (dswx_batch_create without flags)',
                            'first': 'inputs in one allocation, every output plane in its own, as they come',
-                           'slide': 'dswx_batch_place_slide (C-ABI): the packed output region timed at `positions` offsets of '
-                                    'a range longer than itself, the best kept, the rest of the range returned to the device; '
+                           'slide': 'dswx_batch_place_slide (C-ABI): `positions` candidate placements of the output planes inside '
+                                    'a range 48 GiB longer than they are (packed at every 2 GiB, spread, then per-plane '
+                                    'refinement), the best kept, the rest of the range returned to the device; '
                                     'first_come_launch_ms = the first-come range timed back to back with the kept one',
                            'search': 'dswx_batch_place_search (C-ABI): every output plane in the fastest of `trials` candidate '
                                      'allocations (one pass of coordinate descent, the kernel itself as the probe); '

@@ -367,11 +367,19 @@ int dswx_batch_place_search(dswx_batch_t* batch, const dswx_params_t* params, in
  * (bounded so that `keep_free_bytes` of device memory stay free), the kernel is timed (`launches` launches) with the
  * output region at offsets 0, step_bytes, 2 step_bytes, ... of it, the best position and the first-come range are
  * then timed back to back, and the better one is kept: of the wide range only the chunks under the chosen position
- * stay mapped, everything else goes back to the device at once.  slack / step + 1 probes (25 at 48 GiB / 2 GiB:
+ * stay mapped, everything else goes back to the device at once.  After the packed positions `spread_gaps` more
+ * candidates are tried: the planes spread over the range with equal gaps of 1/spread_gaps ... 1 x the largest gap that
+ * fits (0 = packed positions only).  `refine_passes` passes of refinement follow: from the best candidate, every
+ * plane in turn (DIAG first) tries the other free places of the range on a grid of 2 step_bytes and keeps the best
+ * (the per-plane freedom of dswx_batch_place_search without its spare allocations; ~12 probes per plane and pass).
+ * slack / step + 1 + spread_gaps probes without refinement (25 + 4 at 48 GiB / 2 GiB:
  * about 1 s for 256 tiles) and slack_bytes of transient memory, against 185 probes and five spare sets of planes
- * for dswx_batch_place_search.  Output pointers change: call dswx_batch_planes again.  Synchronous. */
+ * for dswx_batch_place_search.  Output pointers change: call dswx_batch_planes again.  Synchronous.
+ * (Address ranges the library reserved are retired, not freed, when a range is dropped -- only address space, never
+ * memory: re-reserving freed addresses proved unsafe on ROCm 7.2 / gfx950, see VmRange::destroy in dswx_batch.hip.) */
 int dswx_batch_place_slide(dswx_batch_t* batch, const dswx_params_t* params, uint64_t slack_bytes,
-                           uint64_t step_bytes, int32_t launches, uint64_t keep_free_bytes);
+                           uint64_t step_bytes, int32_t spread_gaps, int32_t refine_passes,
+                           int32_t launches, uint64_t keep_free_bytes);
 
 /* ---- device plumbing for hosts without another HIP binding ------------------- */
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);

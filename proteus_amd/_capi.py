@@ -203,7 +203,7 @@ def load_library(path=None):
         'dswx_batch_place_search': (ctypes.c_int, [vp, ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_int32,
                                                    ctypes.c_uint64]),
         'dswx_batch_place_slide': (ctypes.c_int, [vp, ctypes.POINTER(Params), ctypes.c_uint64, ctypes.c_uint64,
-                                                  ctypes.c_int32, ctypes.c_uint64]),
+                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64]),
     }
     for name, (res, args) in sig.items():
         if alt and not hasattr(lib, name):
@@ -788,12 +788,14 @@ class DeviceBatch:
                 'first_come_launch_ms': round(i['first_come_launch_ms'], 4),
                 'kept_launch_ms': round(i['kept_launch_ms'], 4)}
 
-    def place_slide(self, params, slack_bytes=48 << 30, step_bytes=2 << 30, launches=3, keep_free_bytes=8 << 30):
+    def place_slide(self, params, slack_bytes=48 << 30, step_bytes=2 << 30, spread_gaps=4, refine_passes=1,
+                    launches=3, keep_free_bytes=8 << 30):
         """dswx_batch_place_slide: the output region (sliding_outputs batches) timed at offsets 0, step, 2 step, ...
         of a range `slack_bytes` longer than itself; the best position is kept and the rest of the range returned to the
         device.  Returns the record of the search."""
         _check(self.ctx.lib.dswx_batch_place_slide(self.handle, ctypes.byref(params), int(slack_bytes), int(step_bytes),
-                                                   int(launches), int(keep_free_bytes)))
+                                                   int(spread_gaps), int(refine_passes), int(launches),
+                                                   int(keep_free_bytes)))
         self._rebind()
         i = self.info()
         return {'positions': i['search_candidates'], 'probes': i['search_probes'],

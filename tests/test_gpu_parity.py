@@ -746,7 +746,7 @@ def test_output_region_in_a_sliding_range(ctx):
     p = _capi.default_params()
     b.synth(SEED, tile0=21)
     first = b.pout.diag
-    rec = b.place_slide(p, slack_bytes=16 << 20, step_bytes=2 << 20, launches=1)
+    rec = b.place_slide(p, slack_bytes=16 << 20, step_bytes=2 << 20, spread_gaps=0, launches=1)
     assert rec['positions'] == 9 and rec['probes'] == 9                                # offsets 0, 2, ... 16 MiB
     assert 0 < rec['kept_launch_ms'] <= rec['first_come_launch_ms']
     assert b.info()['bytes_allocated'] in (held, held + chunk)                          # a region may straddle two chunks
@@ -760,6 +760,21 @@ def test_output_region_in_a_sliding_range(ctx):
         for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
             assert np.array_equal(b.read_tile(key, t), exp[key]), (key, t, moved)
         assert b.read_counters()[t].tolist() == exp['counters'].tolist()
+    # with the spread candidates (equal gaps between the planes): every plane may end in a chunk of its own
+    # ... and one pass of per-plane refinement (each plane tries the free places of the range on a 4 MiB grid)
+    rec = b.place_slide(p, slack_bytes=32 << 20, step_bytes=2 << 20, spread_gaps=4, refine_passes=1, launches=1)
+    assert rec['positions'] > 17 + 8 and b.info()['bytes_allocated'] <= held + 8 * chunk
+    names = ['diag'] + b.out_layers
+    ptrs = [getattr(b.pout, n) for n in names]
+    assert all(q % 256 == 0 for q in ptrs)
+    spans = sorted((q, q + lay['planes'][n][1]) for q, n in zip(ptrs, names))
+    assert all(a[1] <= c[0] for a, c in zip(spans, spans[1:]))                       # no overlap
+    b.classify(p)
+    ctx.synchronize()
+    s_ = synth_tile(22, h, w, with_masks=True)
+    exp = c_oracle.classify(p, s_['bands'], s_['fmask'], land=s_['land'], shad=s_['shad'], ocean=s_['ocean'])
+    for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+        assert np.array_equal(b.read_tile(key, 1), exp[key]), key
     # no room to slide in: the planes stay where they are, the record says so
     rec = b.place_slide(p, slack_bytes=0)
     assert rec['positions'] == 0 and rec['kept_launch_ms'] == rec['first_come_launch_ms']
@@ -770,6 +785,39 @@ def test_output_region_in_a_sliding_range(ctx):
         _capi.DeviceBatch(ctx, 1, 8, 8, separate_outputs=True, sliding_outputs=True)
     one.free()
     b.free()
+
+
+def test_sliding_range_survives_repeated_placement(ctx):
+    """Regression for a hazard of HIP virtual memory management on this stack: a range placed twice used to free the
+    address range of the first placement, a later reservation got the same addresses back, and kernels wrote through
+    stale translations (layers read back zeroed in roughly one case in five).  The library now retires address ranges
+    instead of freeing them.  Random geometry, allocation churn in between, two placements per batch, every tile of
+    every layer against the C oracle."""
+    rng = np.random.default_rng(2026)
+    p = _capi.default_params()
+    for it in range(24):
+        n_tiles, h, w = int(rng.integers(1, 5)), int(rng.integers(50, 700)), int(rng.integers(50, 700))
+        masks = bool(rng.integers(2))
+        for junk in [ctx.malloc(int(rng.integers(1, 64)) << 20) for _ in range(int(rng.integers(0, 4)))]:
+            junk.free()
+        b = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=masks, sliding_outputs=True)
+        b.synth(SEED, tile0=100 + it)
+        region = _capi.batch_layout(n_tiles, h, w, masks=masks, sliding_outputs=True)['write_span_bytes']
+        for rep in range(2):
+            b.place_slide(p, slack_bytes=int(region * rng.uniform(0.5, 3.0)),
+                          step_bytes=int(rng.choice([1 << 20, 2 << 20, 5 << 19, 3 << 20])),
+                          spread_gaps=int(rng.integers(0, 5)), refine_passes=int(rng.integers(0, 2)), launches=1)
+            b.classify(p)
+            ctx.synchronize()
+            cnt = b.read_counters()
+            for t in range(n_tiles):
+                s_ = synth_tile(100 + it + t, h, w, with_masks=masks)
+                kw = dict(land=s_['land'], shad=s_['shad'], ocean=s_['ocean']) if masks else {}
+                exp = c_oracle.classify(p, s_['bands'], s_['fmask'], **kw)
+                for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+                    assert np.array_equal(b.read_tile(key, t), exp[key]), (it, rep, t, key)
+                assert cnt[t].tolist() == exp['counters'].tolist()
+        b.free()
 
 
 # ---- terrain shadow layer (SURVEY.md row f1) --------------------------------------------

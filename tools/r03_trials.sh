@@ -10,7 +10,7 @@ if [[ "${1:-rules}" == rules ]]; then
   for i in 1 2 3; do $B --placement-trials 6 >> $o 2>>gpurun_out/trials.err; done
 else
   o=gpurun_out/slide_trials.jsonl; : > $o
-  for i in 1 2 3 4 5 6 7 8 9 10; do $B --placement slide >> $o 2>>gpurun_out/slide_trials.err; done
+  for i in 1 2 3 4 5 6 7 8 9 10; do $B --placement slide ${SLIDE_FLAGS:-} >> $o 2>>gpurun_out/slide_trials.err; done
   for i in 1 2 3; do $B --placement search >> $o 2>>gpurun_out/slide_trials.err; done
   for i in 1 2 3; do $B --placement arena >> $o 2>>gpurun_out/slide_trials.err; done
 fi
