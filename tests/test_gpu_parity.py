@@ -746,7 +746,7 @@ def test_output_region_in_a_sliding_range(ctx):
     p = _capi.default_params()
     b.synth(SEED, tile0=21)
     first = b.pout.diag
-    rec = b.place_slide(p, slack_bytes=16 << 20, step_bytes=2 << 20, spread_gaps=0, launches=1)
+    rec = b.place_slide(p, slack_bytes=16 << 20, step_bytes=2 << 20, spread_gaps=0, refine_passes=0, launches=1)
     assert rec['positions'] == 9 and rec['probes'] == 9                                # offsets 0, 2, ... 16 MiB
     assert 0 < rec['kept_launch_ms'] <= rec['first_come_launch_ms']
     assert b.info()['bytes_allocated'] in (held, held + chunk)                          # a region may straddle two chunks

@@ -46,7 +46,8 @@ def test_stub_structures_match_the_header():
         assert ctypes.sizeof(mine) == ctypes.sizeof(ref), name
         assert [(f[0], getattr(mine, f[0]).offset) for f in mine._fields_] == \
             [(f[0], getattr(ref, f[0]).offset) for f in ref._fields_], name
-    assert (ns['DSWX_BATCH_MASKS'], ns['DSWX_BATCH_SEPARATE_OUTPUTS']) == (_capi.BATCH_MASKS, _capi.BATCH_SEPARATE_OUTPUTS)
+    assert (ns['DSWX_BATCH_MASKS'], ns['DSWX_BATCH_SEPARATE_OUTPUTS'], ns['DSWX_BATCH_SLIDING_OUTPUTS']) == \
+        (_capi.BATCH_MASKS, _capi.BATCH_SEPARATE_OUTPUTS, _capi.BATCH_SLIDING_OUTPUTS)
 
 
 @pytest.mark.gpu
@@ -86,11 +87,15 @@ def test_batch_stub_runs_and_matches_the_oracle():
         assert lib.dswx_synth_batch(ctx, ctypes.c_uint64(SEED), ctypes.c_int64(40), ctypes.byref(geom),
                                     ctypes.byref(pin), None) == 0
 
-    for place in (True, False):
-        handle, geom, pin, pout, counters, info = ns['resident_batch'](n_tiles, h, w, params, upload, place=place)
-        assert info.n_allocations == (8 if place else 1) and info.geom.tile_stride == geom.tile_stride
-        if place:
+    for place in ('slide', 'search', None):
+        handle, geom, pin, pout, counters, info = ns['resident_batch'](n_tiles, h, w, params, upload, place=place,
+                                                                       slack=24 << 20, step=2 << 20)
+        assert info.n_allocations == {'slide': 2, 'search': 8, None: 1}[place] and info.geom.tile_stride == geom.tile_stride
+        if place == 'search':
             assert info.search_candidates == 3 and info.search_probes == 2 + 6 * 12
+        if place == 'slide':
+            assert info.search_probes > 13 + 7                 # 13 packed offsets, the spread layouts, one refinement pass
+        if place:
             assert 0 < info.kept_launch_ms <= info.first_come_launch_ms
         else:
             assert info.search_probes == 0
