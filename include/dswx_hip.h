@@ -280,8 +280,9 @@ int dswx_synth_batch(dswx_ctx_t* ctx, uint64_t seed, int64_t tile0,
  * (the rate follows the position of the write streams in the address space, with
  * a 32-GiB structure; round 3 looked for a layout RULE and found none that holds from one process to
  * the next -- profiles/r03_placement_rule_trials.json).  dswx_batch_create allocates the planes of a
- * batch (one hipMalloc, packed); dswx_batch_place_search is the opt-in measured placement that bench.py
- * uses, so the placed rate is available to every caller of this ABI, not to a Python helper only. */
+ * batch (one hipMalloc, packed, unless a flag says otherwise); dswx_batch_place_slide (what bench.py uses)
+ * and dswx_batch_place_search are the opt-in measured placements, so the placed rate is available to
+ * every caller of this ABI, not to a Python helper only. */
 typedef struct dswx_batch dswx_batch_t;
 
 /* plane indices of dswx_batch_layout_t */

@@ -11,7 +11,10 @@
 // a fixed offset, alternating output and input planes, separate allocations in either order) and none holds
 // from one fresh process to the next for an allocation of the batch's own size: the same rule gives 0.70 - 0.80
 // (profiles/r03_placement_rule_trials.json).  So the placement stays a measurement -- but one the library
-// makes, behind the C-ABI.
+// makes, behind the C-ABI, in two forms: dswx_batch_place_slide (the output planes in a range of the virtual
+// address space that is longer than they are and backed chunk by chunk: ~100 candidate placements inside it,
+// the chunks under the best one kept, the rest returned) and dswx_batch_place_search (one hipMalloc per output
+// plane, each bound to the fastest of a few spare allocations).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
