@@ -327,10 +327,18 @@ def place_batch(ctx, params, n_tiles, tile0, masks, how, trials, refine=1, slack
       first   one allocation per output plane, as they come;   arena   all planes in ONE hipMalloc (a plain caller)"""
     from proteus_amd import _capi
     from proteus_amd.synth import SEED
-    b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=how in ('search', 'first'),
-                          sliding_outputs=how == 'slide')
-    b.synth(SEED, tile0=tile0)
     rec = {'how': how, 'probes': 0}
+    try:
+        b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=how in ('search', 'first'),
+                              sliding_outputs=how == 'slide')
+    except _capi.DswxError as e:
+        if how != 'slide' or e.code != _capi.ERR_UNSUPPORTED:
+            raise
+        # no virtual memory management on this device: the other measured placement
+        how, trials = 'search', trials or 6
+        rec = {'how': how, 'probes': 0, 'fallback': str(e)[:200]}
+        b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=True)
+    b.synth(SEED, tile0=tile0)
     try:
         if how == 'slide':
             rec.update(b.place_slide(params, slack_bytes=int(slack_gib * (1 << 30)), refine_passes=refine))

@@ -263,6 +263,12 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
     uint32_t mode;
     if (int rc = layout_mode(flags, &mode)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (mode == DSWX_BATCH_SLIDING_OUTPUTS) {
+        int vmm = 0;
+        if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device) != hipSuccess || !vmm)
+            return dswx_fail(DSWX_ERR_UNSUPPORTED, "DSWX_BATCH_SLIDING_OUTPUTS needs HIP virtual memory management, which device "
+                             "%d does not report; use DSWX_BATCH_SEPARATE_OUTPUTS + dswx_batch_place_search", ctx->device);
+    }
     dswx_batch* b = new dswx_batch();
     b->ctx = ctx;
     b->device = ctx->device;
