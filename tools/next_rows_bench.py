@@ -71,6 +71,7 @@ def main():
     ap.add_argument('--tiles', type=int, default=32,
                     help='tiles per launch (8 tiles = 0.1 ms launches whose ramp / tail cost ~10 %%)')
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--unplaced', action='store_true', help="'cover' batch in one plain allocation (no placement)")
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--lab', action='store_true', help='also time lab A/B switches (libdswx_lab.so)')
     a = ap.parse_args()
@@ -129,15 +130,18 @@ def main():
         b.free()
 
     # ---- f2 'cover' mode: the split path on a device batch with masks
-    batch = _capi.DeviceBatch(ctx, n, T, T, masks=True)
-    batch.synth(SEED)
-    ctx.synchronize()
     pc = _capi.make_params(mask_adjacent_to_cloud_mode='cover')
     pm = _capi.make_params(mask_adjacent_to_cloud_mode='mask')
+    # the output planes placed like the headline batch's (dswx_batch_place_slide, the 'cover' launch itself as the
+    # probe): unplaced, the same code measured 0.0666 and 0.0732 ms per tile in two rounds -- allocation luck
+    batch = _capi.DeviceBatch(ctx, n, T, T, masks=True, sliding_outputs=not a.unplaced)
+    batch.synth(SEED)
+    ctx.synchronize()
+    placement = None if a.unplaced else batch.place_slide(pc, slack_bytes=24 << 30, step_bytes=1 << 30)
     avg, mn = timed(ctx, lambda: batch.classify(pc), a.reps)
     info = ctx.last_kernel_info()
     avg_m, _ = timed(ctx, lambda: batch.classify(pm), a.reps)
-    out['f2_cover_mode'] = {'kernel': info, 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n,
+    out['f2_cover_mode'] = {'kernel': info, 'output_plane_placement': placement, 'ms_per_tile': avg / n, 'ms_min_per_tile': mn / n,
                             'fused_mask_mode_ms_per_tile': avg_m / n,
                             'algorithmic_bytes_per_tile': T * T * 24, 'GBps_of_24B_per_px': n * T * T * 24 / avg / 1e6,
                             'frac_of_8TBps': n * T * T * 24 / avg / 1e6 / 8000,
