@@ -549,9 +549,13 @@ def main():
                          'kernel_source_hash': _build.hot_kernel_hash()},
             'parity_check': parity,
         }
-        if placement.get('first_come_launch_ms'):      # the first-come planes, timed back to back with the kept set (3-launch probes)
-            out['roofline']['frac_first_come_placement'] = round(
-                px_per_launch * bytes_per_px / (placement['first_come_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if placement.get('first_come_launch_ms'):
+            # the first-come planes and the kept ones, timed back to back at the end of the placement (3-launch probes:
+            # compare THESE two with each other; sustained rates over the timed steps run 1.5 - 2 % below such probes)
+            def probe_frac(ms):
+                return round(px_per_launch * bytes_per_px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            out['roofline']['frac_first_come_placement'] = probe_frac(placement['first_come_launch_ms'])
+            out['roofline']['frac_kept_placement_probe'] = probe_frac(placement['kept_launch_ms'])
         if world == 1 and args.realloc_repeats > 0:
             try:
                 batch.free()
