@@ -213,6 +213,12 @@ __device__ __forceinline__ uint32_t shadow_quad(const ShadowArgs& a, const Shado
 // Nor does trading SALU for VALU: the filter's decisions in sign-bit form (three packed differences per pixel pair,
 // v_bitop3 / v_perm per pixel instead of v_cmp -> SGPR pair -> s_and / s_or -> v_cndmask chains: same VALU count,
 // 25 SALU fewer per row) measured 0.0138-0.0143 against 0.0130-0.0133 for this compare form in one process.
+// Round 3, the last structure not yet tried -- long waves WITH deep prefetch (a wave marches down 16 ... 128 output rows
+// of its 256-pixel column strip with 3 ... 5 DEM rows in flight ahead of the row it computes, the row window rotating by
+// register renaming; halo re-reads fall to 2 rows per strip segment): bit-identical, and 0.0145 (16 rows, 3 ahead) /
+// 0.0153 (32, 3) / 0.0156 - 0.0170 (32, 5) / 0.0166 - 0.0176 (64, 5) / 0.0172 - 0.0184 (128, 5) against 0.0130 - 0.0131 for
+// this kernel in the same process.  Longer is slower and deeper is slower: the registers of the rows in flight cost
+// resident waves, and the halo traffic they save was never what the kernel waited for.
 // (The waves of a block MUST be stacked in y: they share their halo rows through the CU's L1.  Numbering the
 // work items along the rows instead -- no idle lanes at the row ends -- measured 0.0173.)
 constexpr int SHADOW_ROWS = 2, SHADOW_WAVES = 4;     // waves (stacked in y) per block
