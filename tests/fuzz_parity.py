@@ -25,7 +25,8 @@ from tests.test_gpu_parity import _random_case, ALL_LAYERS   # noqa: E402
 
 def device_batch_soak(ctx, rng, a, kernels):
     """Device-resident batches with random geometry: tile count, ragged tile sizes, tile-stride
-    alignment (1 / 8 / 16 / 64 / 256 px), one allocation or one per output plane, optional planes and layers,
+    alignment (1 / 8 / 16 / 64 / 256 px), one allocation / one per output plane / a VMM-backed sliding range (sometimes
+    placed first), optional planes and layers,
     counters on / off, 'mask' / 'ignore' / 'cover'; every tile against the oracle."""
     from oracle import dswx_oracle as o
     from tests.test_c_oracle import NAME
@@ -35,10 +36,10 @@ def device_batch_soak(ctx, rng, a, kernels):
         h, w = int(rng.integers(1, 120)), int(rng.integers(1, 150))
         align = int(rng.choice([1, 8, 16, 64, 256]))
         masks = bool(rng.integers(2))
-        separate = bool(rng.integers(4) == 0)
+        form = str(rng.choice(['arena', 'arena', 'separate', 'sliding']))
         extra = tuple(x for x in ('wtr1_aerosol', 'browse') if rng.integers(2))
         batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=masks, extra_layers=extra, tile_align=align,
-                                  separate_outputs=separate)
+                                  separate_outputs=form == 'separate', sliding_outputs=form == 'sliding')
         batch.synth(777 + it, tile0=it)
         mode = str(rng.choice(['mask', 'ignore', 'cover']))
         p = _capi.make_params(
@@ -47,6 +48,11 @@ def device_batch_soak(ctx, rng, a, kernels):
             collapse_wtr_classes=cs['collapse'],
             aerosol_max_nir=None if mode == 'cover' else cs['aer_nir'])   # the numpy oracle fixes it at 1000
         use_counters = bool(rng.integers(4))
+        if form == 'sliding' and rng.integers(2):       # place it first: the planes move inside a wider range
+            batch.place_slide(p, slack_bytes=int(rng.integers(1, 9)) << 20, step_bytes=1 << 20,
+                              spread_gaps=int(rng.integers(0, 3)), refine_passes=int(rng.integers(0, 2)), launches=1)
+        elif form == 'separate' and rng.integers(2):
+            batch.place_search(p, candidates=2, launches=1)
         batch.classify(p, counters=use_counters)
         ctx.synchronize()
         key = ctx.last_kernel_info().split(' grid')[0]
@@ -76,7 +82,7 @@ def device_batch_soak(ctx, rng, a, kernels):
             if bad:
                 print(json.dumps({'ok': False, 'iteration': it, 'tile': t, 'geom': [n_tiles, h, w, align],
                                   'masks': masks, 'mode': mode, 'extra': extra, 'layers': bad,
-                                  'separate': separate, 'kernel': ctx.last_kernel_info()},
+                                  'form': form, 'kernel': ctx.last_kernel_info()},
                                  default=str))
                 return 1
         batch.free()
