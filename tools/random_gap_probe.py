@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Can the gain of scattered output planes (tools/slab_probe.py) be had inside ONE allocation?
+"""Can the gain of scattered output planes (round 2's slab probe, profiles/r02_slab_probe.json) be had inside ONE allocation?
 
 One big allocation; the 14 planes of a T-tile batch are laid out with per-plane RANDOM gaps (multiples of `--quantum`)
 instead of the uniform gaps tools/placement_probe.py tried.  If random in-arena layouts reach what separately
