@@ -63,6 +63,12 @@ enum { DSWX_N_VALID = 0, DSWX_N_CLOUD_AND_VALID = 1, DSWX_N_NOT_OCEAN = 2,
  *  - collapse_wtr_classes: FLAG_COLLAPSE_WTR_CLASSES (:26); when set, WTR, WTR-1,
  *    WTR-1-AEROSOL and WTR-2 leave in the collapsed form the reference SAVES
  *    (_collapse_wtr_classes :2578-2598, applied at :2688-2689).
+ *  - offset_and_scale_inputs: flag_offset_and_scale_inputs (CLI --offset-and-scale-inputs, :2300-2302).  When set,
+ *    every clipped reflectance becomes band_scale[k] * (float32(value) - band_offset[k]) -- the `scale_factor` and
+ *    `add_offset` of the band's metadata (:2295-2298) -- and the whole chain (indices, five tests, `nir <=
+ *    aerosol_max_nir`, `nir > lcmask_nir`) is evaluated in float32 as numpy does on float32 arrays (thresholds rounded
+ *    to float32 first: a Python float is a weak scalar against a float32 array).  The fill test stays on the raw
+ *    integers.  A generic one-pixel-per-thread kernel: the production configuration leaves this off.
  *  - browse_*: the keyword arguments of _compute_browse_array (:3057-3064); the browse
  *    layer is derived from the UNCOLLAPSED WTR (PSW-aggressive is dropped before the
  *    collapse, :3112-3119), which only exists inside the kernel.
@@ -84,8 +90,10 @@ typedef struct dswx_params {
     int32_t browse_cloud_to_nodata;
     int32_t browse_snow_to_nodata;
     int32_t browse_ocean_masked_to_nodata;
-    int32_t reserved_;
+    int32_t offset_and_scale_inputs;       /* ABI <= 3: reserved, zero */
     uint8_t aerosol_fmask_lut[4][256];
+    double band_scale[6];                  /* only read when offset_and_scale_inputs != 0 */
+    double band_offset[6];
 } dswx_params_t;
 
 /* Inputs.  band[] order: blue, green, red, nir, swir1, swir2 (raw int16 as read

@@ -81,6 +81,41 @@ int oracle_classify(const dswx_params_t* p, int64_t n, const dswx_planes_in_t* i
         if (mndwi > p->pswt_2_mndwi && (double)blue < p->pswt_2_blue && (double)swir1 < p->pswt_2_swir1 &&
             (double)swir2 < p->pswt_2_swir2 && (double)nir < p->pswt_2_nir)
             dd += 16;
+        /* flag_offset_and_scale_inputs (:2300-2302): the same tests on float32 reflectances, every operation a float32
+         * operation as numpy performs it on float32 arrays (volatile stores keep each intermediate a rounded float;
+         * Python-float thresholds are weak scalars: rounded to float32 first) */
+        float nir_f = 0.0f;
+        if (p->offset_and_scale_inputs) {
+            volatile float f[6], t;
+            for (int k = 0; k < 6; ++k) {
+                t = (float)v[k] - (float)p->band_offset[k];
+                f[k] = (float)p->band_scale[k] * t;
+            }
+            const float fb = f[0], fg = f[1], fr = f[2], fn = f[3], fs1 = f[4], fs2 = f[5];
+            volatile float num = fg - fs1, den = fg + fs1;
+            volatile float mndwi_f = num / den;
+            volatile float mbsrv_f = fg + fr, mbsrn_f = fn + fs1;
+            volatile float a1 = 2.5f * fg, a2 = 1.5f * mbsrn_f, a3 = 0.25f * fs2;
+            volatile float aw = fb + a1;
+            aw = aw - a2;
+            aw = aw - a3;
+            volatile float num2 = fn - fr, den2 = fn + fr;
+            volatile float ndvi_f = num2 / den2;
+            dd = 0;
+            if (mndwi_f > (float)p->wigt) dd += 1;
+            if (mbsrv_f > mbsrn_f) dd += 2;
+            if (aw > (float)p->awgt) dd += 4;
+            if (mndwi_f > (float)p->pswt_1_mndwi && fs1 < (float)p->pswt_1_swir1 && fn < (float)p->pswt_1_nir &&
+                ndvi_f < (float)p->pswt_1_ndvi)
+                dd += 8;
+            if (mndwi_f > (float)p->pswt_2_mndwi && fb < (float)p->pswt_2_blue && fs1 < (float)p->pswt_2_swir1 &&
+                fs2 < (float)p->pswt_2_swir2 && fn < (float)p->pswt_2_nir)
+                dd += 16;
+            nir_f = fn;
+        }
+        const int nir_le_aerosol_max = p->offset_and_scale_inputs ? nir_f <= (float)p->aerosol_max_nir
+                                                                  : (double)nir <= p->aerosol_max_nir;
+        const int nir_bright = p->offset_and_scale_inputs ? nir_f > (float)p->lcmask_nir : (double)nir > p->lcmask_nir;
         if (invalid) dd = 32; /* :5227 */
         /* generate_interpreted_layer :1687-1707, _get_binary_representation :4286-4317 */
         uint8_t w1 = dd < 32 ? k_interp[dd] : 255;
@@ -107,8 +142,7 @@ int oracle_classify(const dswx_params_t* p, int64_t n, const dswx_planes_in_t* i
         if (p->apply_aerosol_class_remapping) {
             static const int cls_of_row[4] = {0, 2, 3, 4};
             for (int k = 0; k < 4; ++k) {
-                if (p->aerosol_fmask_lut[k][fm] && w1a == cls_of_row[k] &&
-                    (double)nir <= p->aerosol_max_nir) {
+                if (p->aerosol_fmask_lut[k][fm] && w1a == cls_of_row[k] && nir_le_aerosol_max) {
                     w1a = 1;
                     if (cl != 255) cl |= 8;
                 }
@@ -123,7 +157,7 @@ int oracle_classify(const dswx_params_t* p, int64_t n, const dswx_planes_in_t* i
         }
         if (in->land != NULL) {
             const uint8_t ld = in->land[i];
-            const int bright = (double)nir > p->lcmask_nir;
+            const int bright = nir_bright;
             if (ld == 201 && bright && psw) w2 = 0;
             if (ld < 100 && bright && psw) w2 = 0;
             if (ld >= 100 && ld < 200 && water) w2 = 0;

@@ -80,12 +80,15 @@ class Thresholds:
 # A0  input conditioning  (_load_hls_band_from_file :2195-2209, :2224-2226, :2298-2299)
 # ---------------------------------------------------------------------------
 def condition_inputs(bands, fmask, band_fills=(-9999.,) * 6, fmask_fill=255.,
-                     clip_negative_reflectance=True):
+                     clip_negative_reflectance=True, offset_and_scale=None):
     """bands: six int16 arrays (blue, green, red, nir, swir1, swir2).
 
     Returns (clipped_bands, invalid) with `invalid` the cumulative
     `image == fill_value` over the six bands and Fmask; reflectances (not
-    Fmask) are then clipped to >= 1.
+    Fmask) are then clipped to >= 1.  offset_and_scale: six (scale_factor,
+    add_offset) pairs = flag_offset_and_scale_inputs (:2300-2302): each clipped
+    band becomes `scale_factor * (float32(image) - offset)` and the whole chain
+    then runs on float32 arrays.
     """
     invalid = None
     for img, fill in list(zip(bands, band_fills)) + [(fmask, fmask_fill)]:
@@ -97,6 +100,9 @@ def condition_inputs(bands, fmask, band_fills=(-9999.,) * 6, fmask_fill=255.,
         invalid = np.zeros(fmask.shape, dtype=bool)
     if clip_negative_reflectance:
         bands = [np.clip(img, 1, None) for img in bands]
+    if offset_and_scale is not None:
+        bands = [float(sf) * (np.asarray(img, dtype=np.float32) - float(off))       # :2300-2302, Python-float scalars
+                 for img, (sf, off) in zip(bands, offset_and_scale)]
     return list(bands), invalid
 
 
@@ -315,7 +321,7 @@ def classify_tile(bands, fmask, thr=None, *, landcover=None, shadow=None,
                   clip_negative_reflectance=True,
                   mask_adjacent_to_cloud_mode='mask',
                   apply_aerosol=True, aerosol_fmask_values=None,
-                  collapse=True, with_indices=False):
+                  collapse=True, with_indices=False, offset_and_scale=None):
     """Run the whole per-pixel chain on one tile, in the reference's order.
 
     `bands` are the RAW int16 planes as read from file (fill values still in
@@ -328,7 +334,7 @@ def classify_tile(bands, fmask, thr=None, *, landcover=None, shadow=None,
     if thr is None:
         thr = Thresholds()
     (blue, green, red, nir, swir1, swir2), invalid = condition_inputs(
-        bands, fmask, band_fills, fmask_fill, clip_negative_reflectance)
+        bands, fmask, band_fills, fmask_fill, clip_negative_reflectance, offset_and_scale)
     invalid_ind = np.where(invalid)
 
     cloud = compute_preliminary_cloud_layer(fmask, mask_adjacent_to_cloud_mode)

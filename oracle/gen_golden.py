@@ -35,6 +35,10 @@ ALT_THRESHOLDS = {
                   pswt_2_mndwi=-1.0),
     'thirds': dict(wigt=1.0 / 3.0, pswt_1_mndwi=-1.0 / 3.0, pswt_1_ndvi=2.0 / 3.0,
                    pswt_2_mndwi=-0.2),
+    # the band thresholds of the defaults in reflectance units (x 1e-4): what a caller of
+    # flag_offset_and_scale_inputs has to supply for the tests to mean anything
+    'reflectance': dict(pswt_1_nir=0.15, pswt_1_swir1=0.09, pswt_2_blue=0.1, pswt_2_nir=0.25,
+                        pswt_2_swir1=0.3, pswt_2_swir2=0.1, lcmask_nir=0.12),
 }
 
 
@@ -209,7 +213,7 @@ THR_KEYS = ('wigt', 'awgt', 'pswt_1_mndwi', 'pswt_1_nir', 'pswt_1_swir1',
 
 # ---------------------------------------------------------------------------
 def run_reference_chain(ref, bands_raw, fmask, thr, land, shad, ocean, mode,
-                        apply_aerosol, aerosol_lists, band_fills, fmask_fill):
+                        apply_aerosol, aerosol_lists, band_fills, fmask_fill, offset_and_scale=None):
     """The reference's own functions in the orchestrator's order."""
     # A0 -- _load_hls_band_from_file :2195-2209, :2298-2299 (GDAL part skipped)
     invalid = None
@@ -217,7 +221,12 @@ def run_reference_chain(ref, bands_raw, fmask, thr, land, shad, ocean, mode,
         eq = img == fill
         invalid = eq if invalid is None else np.logical_or(invalid, eq)
     assert ref.FLAG_CLIP_NEGATIVE_REFLECTANCE
-    blue, green, red, nir, swir1, swir2 = [np.clip(b, 1, None) for b in bands_raw]
+    clipped = [np.clip(b, 1, None) for b in bands_raw]
+    if offset_and_scale is not None:
+        # flag_offset_and_scale_inputs, the reference's own statement (:2300-2302) with its float() metadata values (:2295-2298)
+        clipped = [float(scale_factor) * (np.asarray(image, dtype=np.float32) - float(offset))
+                   for image, (scale_factor, offset) in zip(clipped, offset_and_scale)]
+    blue, green, red, nir, swir1, swir2 = clipped
     invalid_ind = np.where(invalid)
     valid_array = ~invalid
     # :5088-5136
@@ -297,6 +306,13 @@ TILE_CASES = [
     # pixels blocking the way, corridors that run into the raster edge or across the 222-pixel window seams of the
     # dilation kernel in x and in y, two-pixel-wide and L-shaped ones
     dict(name='t260x300_cover_corridors', tile=21, H=260, W=300, mode='cover', blobs='corridors'),
+    # round 3: flag_offset_and_scale_inputs -- the chain on float32 reflectances (:2300-2302), with thresholds in
+    # reflectance units, with the default (digital-number) thresholds, and with a different scale / offset per band
+    dict(name='t96_scaled_reflectance_thr', tile=22, H=96, W=96, land=1, shad=1, ocean=1, thr='reflectance',
+         scale=[(0.0001, 0.0)] * 6),
+    dict(name='t64_scaled_default_thr', tile=23, H=64, W=64, scale=[(0.0001, 0.0)] * 6),
+    dict(name='t80x72_scaled_mixed', tile=24, H=80, W=72, land=1, thr='reflectance', mode='ignore',
+         scale=[(0.0001, 0.0), (0.0001, 10.0), (0.0002, -50.0), (0.0001, 3.5), (0.00005, 0.0), (0.0001, -0.25)]),
 ]
 
 
@@ -405,12 +421,14 @@ def gen_tiles(ref):
         lists = CUSTOM_AEROSOL if case.get('lists') == 'custom' else DEFAULT_AEROSOL
         res = run_reference_chain(ref, bands, fmask, thr, land, shad, ocean, mode,
                                   case.get('aerosol', True), lists,
-                                  band_fills, fmask_fill)
+                                  band_fills, fmask_fill, offset_and_scale=case.get('scale'))
         store = {'in_bands': np.stack(bands), 'in_fmask': fmask,
                  'thr': np.array([getattr(thr, k) for k in THR_KEYS], dtype=np.float64),
                  'band_fills': np.array(band_fills), 'fmask_fill': np.array(fmask_fill),
                  'mode': np.array(mode), 'apply_aerosol': np.array(case.get('aerosol', True)),
                  'aerosol_lists': np.array([','.join(map(str, l)) for l in lists])}
+        if case.get('scale'):
+            store['offset_and_scale'] = np.array(case['scale'], dtype=np.float64)      # [6][2]: scale_factor, add_offset
         if land is not None:
             store['in_land'] = land
         if shad is not None:

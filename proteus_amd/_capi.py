@@ -54,8 +54,10 @@ class Params(ctypes.Structure):
                  ('browse_cloud_to_nodata', ctypes.c_int32),
                  ('browse_snow_to_nodata', ctypes.c_int32),
                  ('browse_ocean_masked_to_nodata', ctypes.c_int32),
-                 ('reserved_', ctypes.c_int32),
-                 ('aerosol_fmask_lut', (ctypes.c_uint8 * 256) * 4)])
+                 ('offset_and_scale_inputs', ctypes.c_int32),
+                 ('aerosol_fmask_lut', (ctypes.c_uint8 * 256) * 4),
+                 ('band_scale', ctypes.c_double * 6),
+                 ('band_offset', ctypes.c_double * 6)])
 
 
 class BatchGeom(ctypes.Structure):
@@ -267,12 +269,13 @@ def make_params(thresholds=None, *, band_fills=None, fmask_fill=255.0,
                 collapse_wtr_classes=True, aerosol_max_nir=None,
                 exclude_psw_aggressive_in_browse=True, not_water_in_browse='white',
                 cloud_in_browse='gray', snow_in_browse='cyan',
-                set_ocean_masked_to_nodata=True):
+                set_ocean_masked_to_nodata=True, offset_and_scale=None):
     """Build a dswx_params_t.
 
     thresholds: object with the HlsThresholds attributes, or dict, or None
     (defaults).  aerosol_fmask_values: {class: [fmask values]} for the WTR-1
-    classes 0, 2, 3, 4, or None (defaults).  Unknown modes raise the same
+    classes 0, 2, 3, 4, or None (defaults).  offset_and_scale: six (scale_factor, add_offset) pairs =
+    flag_offset_and_scale_inputs (dswx_hls.py:2300-2302): the chain on float32 reflectances.  Unknown modes raise the same
     Exception text as the reference (dswx_hls.py:1977-1981).
     """
     p = default_params()
@@ -302,6 +305,12 @@ def make_params(thresholds=None, *, band_fills=None, fmask_fill=255.0,
     p.browse_cloud_to_nodata = int(cloud_in_browse == 'nodata')
     p.browse_snow_to_nodata = int(snow_in_browse == 'nodata')
     p.browse_ocean_masked_to_nodata = int(bool(set_ocean_masked_to_nodata))
+    if offset_and_scale is not None:
+        if len(offset_and_scale) != 6:
+            raise ValueError('offset_and_scale needs six (scale_factor, add_offset) pairs')
+        p.offset_and_scale_inputs = 1
+        for i, (sf, off) in enumerate(offset_and_scale):
+            p.band_scale[i], p.band_offset[i] = float(sf), float(off)
     if aerosol_fmask_values is not None:
         for row, cls in enumerate((0, 2, 3, 4)):
             for v in range(256):

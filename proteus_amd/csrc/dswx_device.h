@@ -32,6 +32,11 @@ struct DevParams {
                             // (0,1,2,3,4,252,253,254,255), _compute_browse_array :3057-3129
     uint32_t aer_lut[64];   // byte v: bit c set <=> Fmask v remaps WTR-1 class c
                             // (all zero when aerosol remapping is disabled)
+    // flag_offset_and_scale_inputs (:2300-2302): the chain on float32 reflectances (generic kernel only)
+    int32_t f32_mode;
+    float f_scale[6], f_offset[6];
+    float f_thr[12];        // the twelve thresholds in dswx_params_t order, rounded to float32
+    float f_aer_nir;        // AEROSOL_REMAPPING_MAX_NIR rounded to float32
 };
 
 struct KArgs {
@@ -241,6 +246,49 @@ __device__ __forceinline__ void classify_px(const DevParams& P, uint32_t aer_bit
     // A9 / A10 predicates that depend on the pixel's own inputs
     const bool remap = (((aer_bits >> (w1 & 7u)) & 1u) != 0u) & (n <= P.aer_nir_max);
     const bool bright = n >= P.lc_nir_min;
+    const bool shadrule = (shad == 0) & (land != 200);
+    const bool lcpsw = ((land == 201) | ((uint32_t)land < 100u)) & bright;
+    const bool lchigh = (uint32_t)(land - 100) < 100u;
+    px_chain(P, w1, remap, pc, (fm & 16) != 0, shadrule, lcpsw, lchigh, o);
+}
+
+// flag_offset_and_scale_inputs: the same pixel with the reflectances scaled to float32 after fill test and clip
+// (:2300-2302: scale_factor * (float32(image) - offset)) and every index, test and nir comparison in float32, operation
+// by operation as numpy evaluates :1872-1913, :1238-1240, :1150-1207 on float32 arrays (no contraction: the library is
+// built with -ffp-contract=off; hipcc's float32 division is correctly rounded).
+__device__ __forceinline__ void classify_px_f32(const DevParams& P, uint32_t aer_bits,
+                                                int b, int g, int r, int n, int s1, int s2, int fm,
+                                                int land, int shad, int ocean, PxOut& o,
+                                                bool& is_valid, bool& is_cloud_and_valid) {
+    const bool invalid = (b == P.band_fill[0]) | (g == P.band_fill[1]) | (r == P.band_fill[2]) |
+                         (n == P.band_fill[3]) | (s1 == P.band_fill[4]) | (s2 == P.band_fill[5]) |
+                         (fm == P.fmask_fill);
+    b = max(b, P.clip_min); g = max(g, P.clip_min); r = max(r, P.clip_min);
+    n = max(n, P.clip_min); s1 = max(s1, P.clip_min); s2 = max(s2, P.clip_min);
+    const float fb = P.f_scale[0] * ((float)b - P.f_offset[0]), fg = P.f_scale[1] * ((float)g - P.f_offset[1]);
+    const float fr = P.f_scale[2] * ((float)r - P.f_offset[2]), fn = P.f_scale[3] * ((float)n - P.f_offset[3]);
+    const float fs1 = P.f_scale[4] * ((float)s1 - P.f_offset[4]), fs2 = P.f_scale[5] * ((float)s2 - P.f_offset[5]);
+    const float mndwi = (fg - fs1) / (fg + fs1);
+    const float mbsrv = fg + fr, mbsrn = fn + fs1;
+    const float awesh = ((fb + 2.5f * fg) - 1.5f * mbsrn) - 0.25f * fs2;
+    const float ndvi = (fn - fr) / (fn + fr);
+    const float* T = P.f_thr;       // wigt awgt p1_mndwi p1_nir p1_swir1 p1_ndvi p2_mndwi p2_blue p2_nir p2_swir1 p2_swir2 lcmask_nir
+    const bool t1 = mndwi > T[0];
+    const bool t2 = mbsrv > mbsrn;
+    const bool t3 = awesh > T[1];
+    const bool t4 = (mndwi > T[2]) & (fs1 < T[4]) & (fn < T[3]) & (ndvi < T[5]);
+    const bool t5 = (mndwi > T[6]) & (fb < T[7]) & (fs1 < T[9]) & (fs2 < T[10]) & (fn < T[8]);
+    const uint32_t dd = (uint32_t)t1 | ((uint32_t)t2 << 1) | ((uint32_t)t3 << 2) |
+                        ((uint32_t)t4 << 3) | ((uint32_t)t5 << 4);
+    uint32_t w1;
+    px_w1(dd, invalid, ocean == 0, o.diag, w1);
+    uint32_t pc = (fm & P.shadow_bits) ? 1u : 0u;
+    pc += (fm & 2) ? 4u : 0u;
+    const bool valid = (!invalid) & (ocean != 0);
+    is_valid = valid;
+    is_cloud_and_valid = valid & (pc != 0u);
+    const bool remap = (((aer_bits >> (w1 & 7u)) & 1u) != 0u) & (fn <= P.f_aer_nir);
+    const bool bright = fn > T[11];
     const bool shadrule = (shad == 0) & (land != 200);
     const bool lcpsw = ((land == 201) | ((uint32_t)land < 100u)) & bright;
     const bool lchigh = (uint32_t)(land - 100) < 100u;

@@ -223,8 +223,12 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
         PxOut o;
         bool ok, cv;
         const int fm = a.in.fmask[off];
-        classify_px(a.P, lut[fm], a.in.band[0][off], a.in.band[1][off], a.in.band[2][off], a.in.band[3][off],
-                    a.in.band[4][off], a.in.band[5][off], fm, land, shad, ocean, o, ok, cv);
+        if (a.P.f32_mode)       // flag_offset_and_scale_inputs: the chain on float32 reflectances (block-uniform)
+            classify_px_f32(a.P, lut[fm], a.in.band[0][off], a.in.band[1][off], a.in.band[2][off], a.in.band[3][off],
+                            a.in.band[4][off], a.in.band[5][off], fm, land, shad, ocean, o, ok, cv);
+        else
+            classify_px(a.P, lut[fm], a.in.band[0][off], a.in.band[1][off], a.in.band[2][off], a.in.band[3][off],
+                        a.in.band[4][off], a.in.band[5][off], fm, land, shad, ocean, o, ok, cv);
         c0 = ok ? 1u : 0u; c1 = cv ? 1u : 0u; c2 = (uint32_t)ocean;
         if (a.out.diag) a.out.diag[off] = (uint16_t)o.diag;
         if (a.out.wtr1) a.out.wtr1[off] = (uint8_t)o.wtr1;
@@ -380,6 +384,17 @@ int dswx_make_dev_params(const dswx_params_t* p, DevParams* d) {
             d->browse_lut[k >> 2] |= (uint32_t)v << (8 * (k & 3));
         }
     }
+    d->f32_mode = p->offset_and_scale_inputs ? 1 : 0;
+    if (d->f32_mode) {
+        for (int i = 0; i < 6; ++i) {
+            if (!std::isfinite(p->band_scale[i]) || !std::isfinite(p->band_offset[i]))
+                return dswx_fail(DSWX_ERR_ARG, "band_scale / band_offset must be finite when offset_and_scale_inputs is set");
+            d->f_scale[i] = (float)p->band_scale[i];
+            d->f_offset[i] = (float)p->band_offset[i];
+        }
+        for (int i = 0; i < 12; ++i) d->f_thr[i] = (float)thr[i];
+        d->f_aer_nir = (float)p->aerosol_max_nir;
+    }
     const int cls_of_row[4] = {0, 2, 3, 4};
     for (int v = 0; v < 256 && p->apply_aerosol_class_remapping; ++v) {
         uint32_t bits = 0;
@@ -410,7 +425,7 @@ int dswx_params_default(dswx_params_t* p) {
     p->pswt_1_mndwi = -0.44; p->pswt_1_nir = 1500; p->pswt_1_swir1 = 900; p->pswt_1_ndvi = 0.7;
     p->pswt_2_mndwi = -0.5; p->pswt_2_blue = 1000; p->pswt_2_nir = 2500; p->pswt_2_swir1 = 3000;
     p->pswt_2_swir2 = 1000; p->lcmask_nir = 1200;
-    for (int i = 0; i < 6; ++i) p->band_fill[i] = -9999.0;
+    for (int i = 0; i < 6; ++i) { p->band_fill[i] = -9999.0; p->band_scale[i] = 1.0; }      // scale 1, offset 0: only read when offset_and_scale_inputs is set
     p->fmask_fill = 255.0;
     p->aerosol_max_nir = 0.1 / 0.0001;
     p->clip_negative_reflectance = 1;
@@ -532,6 +547,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     }
 
     const bool any_index = out->mndwi || out->ndvi || out->awesh;
+    if (any_index && a.P.f32_mode)
+        return dswx_fail(DSWX_ERR_UNSUPPORTED, "the float64 index planes describe the integer chain; not available with offset_and_scale_inputs");
     const bool masks = in->land || in->shad || in->ocean;
     // the fused kernel needs every plane 16-byte aligned at every tile start
     bool vec_ok = (tile_stride % 16 == 0) || n_tiles == 1;
@@ -577,7 +594,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         if (b.cover_state) { b.cover_state += shift; b.cover_bits += t0 * b.cover_bits_stride; b.cover_snow += t0 * b.cover_snow_stride; }
         b.px_begin = 0;
         b.partials = nullptr;
-        const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
+        // the float32 chain (flag_offset_and_scale_inputs) exists in the generic kernel only
+        const int64_t groups = (vec_ok && !a.P.f32_mode) ? (n_pixels >> 3) : 0;
         // the finishing kernel of the vector path WRITES the counters; only the generic kernel
         // alone (atomic adds) needs them zeroed first
         if (groups == 0 && b.counters)

@@ -726,10 +726,9 @@ def _save_output_rgb_file(red, green, blue, output_file, offset_dict, scale_dict
     keys = ('swir1', 'nir', 'red') if flag_infrared else ('red', 'green', 'blue')
     planes = []
     for arr, key in zip((red, green, blue), keys):
-        if not flag_offset_and_scale_inputs:
-            arr = scale_dict[key] * (np.asarray(arr, dtype=np.float32) - offset_dict[key])
-        else:
-            arr = np.array(arr, dtype=np.float32)
+        # the reference scales here unless the loader already did (flag_offset_and_scale_inputs, :3013): the same
+        # statement on the same clipped planes either way; this host keeps the integer planes and scales here in both cases
+        arr = scale_dict[key] * (np.asarray(arr, dtype=np.float32) - offset_dict[key])
         if invalid_mask is not None:
             arr[invalid_mask] = np.nan
         planes.append(np.asarray(arr, dtype=np.float32))
@@ -1125,11 +1124,6 @@ def generate_dswx_layers(input_list,
         msg = f'ERROR mask adjacent to cloud/cloud-shadow mode: {mask_adjacent_to_cloud_mode}'
         logger.info(msg)
         raise Exception(msg)
-    if flag_offset_and_scale_inputs:
-        raise NotImplementedError(
-            'flag_offset_and_scale_inputs: the reference then converts every band to float32 '
-            'reflectance (:2300-2302) and runs the whole chain on those floats; this library '
-            'implements the int16 path the production configuration uses (the flag defaults to False)')
     if shoreline_shapefile is not None:
         if str(shoreline_shapefile).lower().endswith(('.tif', '.tiff')):
             # the same rule as for the DEM and the land-cover maps: an ancillary input that is ALREADY a raster
@@ -1238,6 +1232,10 @@ def generate_dswx_layers(input_list,
         aerosol_fmask_values=dict(zip((0, 2, 3, 4), aerosol_lists)),
         collapse_wtr_classes=FLAG_COLLAPSE_WTR_CLASSES,
         aerosol_max_nir=AEROSOL_REMAPPING_MAX_NIR,
+        # flag_offset_and_scale_inputs (:2300-2302): the kernel scales the clipped reflectances to float32 with every
+        # band's own scale_factor / add_offset metadata and runs the chain on those (generic kernel)
+        offset_and_scale=[(image['scale'][k], image['offset'][k]) for k in _capi.BAND_NAMES]
+        if flag_offset_and_scale_inputs else None,
         exclude_psw_aggressive_in_browse=pick(exclude_psw_aggressive_in_browse,
                                               'exclude_psw_aggressive_in_browse'),
         not_water_in_browse=pick(not_water_in_browse, 'not_water_in_browse'),

@@ -35,6 +35,7 @@ def tile_case(name):
         'land': z['in_land'] if 'in_land' in z else None,
         'shad': z['in_shad'] if 'in_shad' in z else None,
         'ocean': z['in_ocean'] if 'in_ocean' in z else None,
+        'offset_and_scale': [tuple(r) for r in z['offset_and_scale'].tolist()] if 'offset_and_scale' in z else None,
         'expected': {k[4:]: z[k] for k in z.files if k.startswith('out_')},
     }
     return case

@@ -19,7 +19,8 @@ def params_of_case(c, collapse):
         c['thr'], band_fills=c['band_fills'], fmask_fill=c['fmask_fill'],
         mask_adjacent_to_cloud_mode=c['mode'],
         apply_aerosol_class_remapping=c['apply_aerosol'],
-        aerosol_fmask_values=c['aerosol_lists'], collapse_wtr_classes=collapse)
+        aerosol_fmask_values=c['aerosol_lists'], collapse_wtr_classes=collapse,
+        offset_and_scale=c.get('offset_and_scale'))
 
 
 def check_case(res, c, collapse, name):

@@ -71,8 +71,8 @@ def test_abi_version_and_defaults():
 
 
 def test_struct_layout_matches_header():
-    # sizeof(dswx_params_t): 12+6+1+1 doubles, 10 int32, 4*256 bytes
-    assert ctypes.sizeof(_capi.Params) == 20 * 8 + 10 * 4 + 1024
+    # sizeof(dswx_params_t): 12+6+1+1 doubles, 10 int32, 4*256 bytes, 6+6 doubles (band_scale, band_offset)
+    assert ctypes.sizeof(_capi.Params) == 20 * 8 + 10 * 4 + 1024 + 12 * 8
     assert ctypes.sizeof(_capi.PlanesIn) == 10 * 8
     assert ctypes.sizeof(_capi.PlanesOut) == 12 * 8
     assert ctypes.sizeof(_capi.BatchGeom) == 4 * 8
@@ -97,6 +97,12 @@ def test_make_params_field_by_field_against_the_reference_defaults():
             p.browse_snow_to_nodata, p.browse_ocean_masked_to_nodata) == (1, 0, 0, 0, 1)
     lut = np.array([list(r) for r in p.aerosol_fmask_lut])
     assert lut.sum() == 3 + 3 + 5 + 5
+    assert p.offset_and_scale_inputs == 0 and list(p.band_scale) == [1.0] * 6 and list(p.band_offset) == [0.0] * 6
+    r = _capi.make_params(offset_and_scale=[(0.0001, 0.0), (0.0002, 1.0), (1.0, -2.5), (0.5, 0.0), (3.0, 4.0), (1e-4, 7.0)])
+    assert r.offset_and_scale_inputs == 1 and list(r.band_scale) == [0.0001, 0.0002, 1.0, 0.5, 3.0, 1e-4]
+    assert list(r.band_offset) == [0.0, 1.0, -2.5, 0.0, 4.0, 7.0]
+    with pytest.raises(ValueError):
+        _capi.make_params(offset_and_scale=[(1.0, 0.0)] * 5)
     # every knob moved
     thr = {k: float(i) + 0.5 for i, k in enumerate(_capi.THRESHOLD_NAMES)}
     q = _capi.make_params(thr, band_fills=[1.0, None, -3.0, 4.5, 0.0, 32767.0], fmask_fill=None,

@@ -210,6 +210,38 @@ def test_api_with_masks_and_multiband(tmp_path):
         assert info.metadata['MASK_ADJACENT_TO_CLOUD_MODE'] == 'cover'
 
 
+def test_offset_and_scale_inputs_flag(tmp_path):
+    """flag_offset_and_scale_inputs (CLI --offset-and-scale-inputs, reference :2300-2302): the chain on float32
+    reflectances scaled with the bands' own scale_factor / add_offset metadata (0.0001 / 0 in the synthetic files).
+    With the default (digital-number) thresholds and with thresholds in reflectance units; the RGB composite is the
+    same file either way (:3013)."""
+    _, files, _, s = synth_hls.make(str(tmp_path), size=200, tile=6)
+    scale = [(0.0001, 0.0)] * 6
+    refl = dict(pswt_1_nir=0.15, pswt_1_swir1=0.09, pswt_2_blue=0.1, pswt_2_nir=0.25, pswt_2_swir1=0.3,
+                pswt_2_swir2=0.1, lcmask_nir=0.12)
+    for tag, thr_kw in (('dn', {}), ('refl', refl)):
+        thr = D.HlsThresholds()
+        base = o.Thresholds(**thr_kw)
+        for k in _capi.THRESHOLD_NAMES:
+            setattr(thr, k, getattr(base, k))
+        outs = {n: str(tmp_path / f'{tag}_{n}.tif') for n in ('wtr', 'diag', 'conf', 'rgb')}
+        ok = D.generate_dswx_layers(files, hls_thresholds=thr, flag_offset_and_scale_inputs=True,
+                                    output_interpreted_band=outs['wtr'], output_diagnostic_layer=outs['diag'],
+                                    output_confidence_layer=outs['conf'], output_rgb_file=outs['rgb'])
+        assert ok is True
+        exp = o.classify_tile(s['bands'], s['fmask'], base, offset_and_scale=scale)
+        for n, layer in (('wtr', 'WTR'), ('diag', 'DIAG'), ('conf', 'CONF')):
+            arr, _ = geotiff.read_geotiff(outs[n])
+            assert np.array_equal(arr, exp[layer]), (tag, layer)
+        rgb, _ = geotiff.read_geotiff(outs['rgb'])
+        want = np.float32(0.0001) * (np.clip(s['bands'][2], 1, None).astype(np.float32) - np.float32(0.0))
+        valid = exp['DIAG'] != 65535
+        assert rgb.dtype == np.float32 and np.array_equal(rgb[0][valid], want[valid]) and np.isnan(rgb[0][~valid]).all()
+    # the flag changes the result with the default thresholds (every `band < threshold` test turns true)
+    plain = o.classify_tile(s['bands'], s['fmask'])
+    assert not np.array_equal(plain['DIAG'], o.classify_tile(s['bands'], s['fmask'], offset_and_scale=scale)['DIAG'])
+
+
 def test_browse_png_and_rgb_outputs(tmp_path):
     import struct
     import zlib

@@ -729,6 +729,66 @@ def test_output_planes_in_separate_allocations(ctx):
     sep.free()
 
 
+@pytest.mark.parametrize('mode', ['mask', 'ignore', 'cover'])
+def test_offset_and_scale_inputs_vs_both_oracles(ctx, mode):
+    """flag_offset_and_scale_inputs (:2300-2302): the float32 chain of the generic kernel against the numpy oracle and
+    the scalar C oracle (both pinned to the reference-made `*_scaled_*` goldens), over random scales / offsets /
+    thresholds near the data, host entry and device batch, with and without masks."""
+    rng = np.random.default_rng({'mask': 1, 'ignore': 2, 'cover': 3}[mode])
+    for it in range(6):
+        h, w = int(rng.integers(20, 300)), int(rng.integers(20, 300))
+        s = synth_tile(300 + it, h, w, with_masks=True)
+        scale = [(float(rng.choice([1e-4, 2e-4, 5e-5, 1.0])), float(rng.choice([0.0, 0.0, 7.0, -30.5]))) for _ in range(6)]
+        k = scale[3][0]                                   # thresholds in the units the scaled NIR band has
+        thr = dict(wigt=float(rng.uniform(-0.2, 0.3)), awgt=float(rng.uniform(-0.05, 0.05)),
+                   pswt_1_mndwi=-0.44, pswt_1_nir=1500 * k, pswt_1_swir1=900 * scale[4][0], pswt_1_ndvi=0.7,
+                   pswt_2_mndwi=-0.5, pswt_2_blue=1000 * scale[0][0], pswt_2_nir=2500 * k, pswt_2_swir1=3000 * scale[4][0],
+                   pswt_2_swir2=1000 * scale[5][0], lcmask_nir=1200 * k)
+        masks = bool(it % 2)
+        kw = dict(land=s['land'], shad=s['shad'], ocean=s['ocean']) if masks else {}
+        p = _capi.make_params(thr, mask_adjacent_to_cloud_mode=mode, offset_and_scale=scale,
+                              aerosol_max_nir=None if mode == 'cover' else 1000 * k)
+        got = ctx.classify_host(s['bands'], s['fmask'], p, **kw)
+        assert 'dswx_classify_v1' in ctx.last_kernel_info()
+        with np.errstate(all='ignore'):
+            exp = o.classify_tile(s['bands'], s['fmask'], o.Thresholds(**thr), landcover=kw.get('land'),
+                                  shadow=kw.get('shad'), ocean_mask=kw.get('ocean'), mask_adjacent_to_cloud_mode=mode,
+                                  offset_and_scale=scale) if mode == 'cover' else None
+        if mode == 'cover':
+            for layer, key in NAME.items():
+                assert np.array_equal(got[key], exp[layer]), (layer, it)
+        else:
+            expc = c_oracle.classify(p, s['bands'], s['fmask'], **kw)
+            for key in ALL_LAYERS:
+                assert np.array_equal(got[key], expc[key]), (key, it)
+            assert got['counters'][0].tolist() == expc['counters'].tolist()
+            p1000 = _capi.make_params(thr, mask_adjacent_to_cloud_mode=mode, offset_and_scale=scale)
+            with np.errstate(all='ignore'):
+                expn = o.classify_tile(s['bands'], s['fmask'], o.Thresholds(**thr), landcover=kw.get('land'),
+                                       shadow=kw.get('shad'), ocean_mask=kw.get('ocean'),
+                                       mask_adjacent_to_cloud_mode=mode, offset_and_scale=scale)
+            got2 = ctx.classify_host(s['bands'], s['fmask'], p1000, **kw)
+            for layer, key in NAME.items():
+                assert np.array_equal(got2[key], expn[layer]), (layer, it)
+    # a device batch too (aligned tiles would take the table-driven kernel: the float chain must not)
+    b = _capi.DeviceBatch(ctx, 2, 64, 128)
+    b.synth(SEED, tile0=5)
+    scale = [(0.0001, 0.0)] * 6
+    p = _capi.make_params(mask_adjacent_to_cloud_mode=mode, offset_and_scale=scale)
+    b.classify(p)
+    ctx.synchronize()
+    assert 'dswx_classify_v1' in ctx.last_kernel_info()
+    s1 = synth_tile(6, 64, 128)
+    with np.errstate(all='ignore'):
+        e1 = o.classify_tile(s1['bands'], s1['fmask'], mask_adjacent_to_cloud_mode=mode, offset_and_scale=scale)
+    for layer, key in NAME.items():
+        if key != 'wtr1_aerosol':
+            assert np.array_equal(b.read_tile(key, 1), e1[layer]), layer
+    b.free()
+    with pytest.raises(_capi.DswxError):                  # the float64 index planes describe the integer chain
+        ctx.classify_host(s1['bands'], s1['fmask'], p, layers=('diag', 'mndwi'))
+
+
 def test_output_region_in_a_sliding_range(ctx):
     """DeviceBatch(sliding_outputs=True) = dswx_batch_create(DSWX_BATCH_SLIDING_OUTPUTS): the output planes packed in a
     range of the virtual address space backed chunk by chunk, moved by dswx_batch_place_slide to the offset where the

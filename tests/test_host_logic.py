@@ -443,8 +443,6 @@ def test_generate_rejects_bad_parameters(tmp_path):
         D.generate_dswx_layers(files, shoreline_shapefile='coast.shp', apply_ocean_masking=True)
     with pytest.raises(NotImplementedError, match='otsu'):
         D.generate_dswx_layers(files, dem_file='dem.tif', shadow_masking_algorithm='otsu')
-    with pytest.raises(NotImplementedError, match='float32 reflectance'):
-        D.generate_dswx_layers(files, flag_offset_and_scale_inputs=True)
 
 
 def test_grid_margin_detection():

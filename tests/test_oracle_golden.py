@@ -126,7 +126,7 @@ def test_tile_chain(name):
             landcover=c['land'], shadow=c['shad'], ocean_mask=c['ocean'],
             band_fills=c['band_fills'], fmask_fill=c['fmask_fill'],
             mask_adjacent_to_cloud_mode=c['mode'], apply_aerosol=c['apply_aerosol'],
-            aerosol_fmask_values=c['aerosol_lists'], collapse=collapse)
+            aerosol_fmask_values=c['aerosol_lists'], collapse=collapse, offset_and_scale=c['offset_and_scale'])
         for layer in G.LAYERS:
             key = layer + '.collapsed' if (collapse and layer in G.COLLAPSABLE) else layer
             exp = c['expected'][key]
