@@ -126,11 +126,17 @@ def main():
             bands[1][...] = g
             bands[4][...] = np.clip((g * (1 - t['wigt']) / (1 + t['wigt'] + 1e-9)).astype(np.int64)
                                     + rng.integers(-1, 2, size=(h, w)), -32768, 32767)
+        # one case in six: flag_offset_and_scale_inputs, the float32 chain (scales of 1 keep the random thresholds in play;
+        # the uniform-noise and threshold-hugging rasters then probe float32 rounding at the thresholds)
+        scaled = None
+        if rng.integers(6) == 0:
+            scaled = [(float(rng.choice([1.0, 1.0, 0.5, 1e-4, 3.0])), float(rng.choice([0.0, 0.0, 0.5, -100.0, 7.25])))
+                      for _ in range(6)]
         p = _capi.make_params(
             cs['thr'], band_fills=cs['fills'], fmask_fill=cs['fmask_fill'],
             clip_negative_reflectance=cs['clip'], mask_adjacent_to_cloud_mode=cs['mode'],
             apply_aerosol_class_remapping=cs['aerosol'], aerosol_fmask_values=cs['lists'],
-            collapse_wtr_classes=cs['collapse'], aerosol_max_nir=cs['aer_nir'])
+            collapse_wtr_classes=cs['collapse'], aerosol_max_nir=cs['aer_nir'], offset_and_scale=scaled)
         kw = {k: s[k] for k in ('land', 'shad', 'ocean') if cs[k]}
         if a.pinned:
             def pin(x):
@@ -148,7 +154,7 @@ def main():
         if got['counters'][0].tolist() != exp['counters'].tolist():
             bad.append('counters')
         if bad:
-            print(json.dumps({'ok': False, 'iteration': it, 'kind': kind, 'shape': [h, w], 'layers': bad,
+            print(json.dumps({'ok': False, 'iteration': it, 'kind': kind, 'shape': [h, w], 'layers': bad, 'scaled': scaled,
                               'case': {k: (v if not isinstance(v, dict) else v) for k, v in cs.items()}},
                              default=str))
             return 1

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import dswx_oracle as o
 from proteus_amd import dswx_hls as D
-from proteus_amd import geotiff
+from proteus_amd import _capi, geotiff
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
