@@ -64,6 +64,11 @@ def parse_args():
                          'JSON and exit (tests/test_shard_gloo.py drives the launcher path with it)')
     ap.add_argument('--masks', action='store_true',
                     help='also stream LAND/SHAD/OCEAN planes (BASELINE config 5)')
+    ap.add_argument('--chain', action='store_true',
+                    help="BASELINE configs[4]'s per-pixel chain, device-resident: every step computes the terrain shadow "
+                         'layer from DEMs and the LAND layer from WorldCover + CGLS maps straight into the SHAD / LAND planes of '
+                         'the batch (dswx_shadow_layer_batch, dswx_landcover_mask_batch) and classifies with SHAD + LAND + '
+                         'OCEAN on; weak scaling only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--distinct-chunks', action='store_true',
@@ -74,6 +79,10 @@ def parse_args():
                     help='skip the configs[1] leg (profiling runs: keeps the kernel statistics to the batch launches)')
     ap.add_argument('--cpu-parallel-worker', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.chain:
+        if args.total_tiles > 0:
+            ap.error('--chain is a weak-scaling mode (one resident batch per GPU)')
+        args.masks = True
     if args.tiles <= 0:
         args.tiles = 512 if args.total_tiles > 0 else 256
     if args.placement_trials is not None:
@@ -265,6 +274,87 @@ def rank_parity(ctx, batch, params, rank, tile0, n_tiles, chunks, distinct):
     return rec
 
 
+CHAIN_SUN = dict(azimuth=141.0, elevation=35.0, min_slope_angle=-5.0, max_sun_local_inc_angle=40.0)
+CHAIN_FOREST = [111, 113, 115, 116, 121, 123, 125, 126]
+CHAIN_MARGIN = 50                  # DEM_MARGIN_IN_PIXELS (:58)
+CHAIN_DISTINCT = 4                 # distinct synthetic DEMs / land-cover map pairs, cycled over the tiles
+
+
+class ChainInputs:
+    """Device-resident ancillary rasters of --chain: [n][3760][3760] float32 DEMs, [n][10980][10980] WorldCover and
+    [n][3660][3660] CGLS maps (synthetic: proteus_amd.synth), uploaded once before the timed region."""
+
+    def __init__(self, ctx, n_tiles, tile0):
+        import numpy as np
+        from proteus_amd.synth import synth_dem, synth_landcover_inputs
+        self.ctx, self.n, self.tile0 = ctx, n_tiles, tile0
+        self.H = self.W = TILE + 2 * CHAIN_MARGIN
+        self.host = {}
+        for k in range(min(CHAIN_DISTINCT, n_tiles)):
+            wc, cg = synth_landcover_inputs(k, TILE, TILE)
+            self.host[k] = (synth_dem(k, self.H, self.W), wc, cg)
+        dem0, wc0, cg0 = self.host[0]
+        self.d_dem, self.d_wc, self.d_cg = (ctx.malloc(n_tiles * a.nbytes) for a in (dem0, wc0, cg0))
+        for t in range(n_tiles):
+            dem, wc, cg = self.host[self.kind(t)]
+            self.d_dem.upload(dem, t * dem.nbytes)
+            self.d_wc.upload(wc, t * wc.nbytes)
+            self.d_cg.upload(cg, t * cg.nbytes)
+        az, zen = np.radians(CHAIN_SUN['azimuth']), np.radians(90.0 - CHAIN_SUN['elevation'])
+        self.sun = [np.sin(az) * np.sin(zen), np.cos(az) * np.sin(zen), np.cos(zen)]
+        self.sin_az, self.cos_az = np.sin(az), np.cos(az)
+
+    def kind(self, tile):
+        return (self.tile0 + tile) % min(CHAIN_DISTINCT, self.n)
+
+    def layers(self, batch):
+        """The two layer kernels into the SHAD / LAND planes of `batch` (asynchronous, the context's stream)."""
+        self.ctx.shadow_layer_device(self.d_dem.ptr, self.n, self.H, self.W, CHAIN_MARGIN, self.sun, self.sin_az, self.cos_az,
+                                     CHAIN_SUN['min_slope_angle'], CHAIN_SUN['max_sun_local_inc_angle'], batch.pin.shad,
+                                     float32=True, out_tile_stride=batch.tile_stride)
+        self.ctx.landcover_mask_device(self.d_wc.ptr, self.d_cg.ptr, self.n, TILE, TILE, CHAIN_FOREST, batch.pin.land,
+                                       out_tile_stride=batch.tile_stride)
+
+    def free(self):
+        for b in (self.d_dem, self.d_wc, self.d_cg):
+            b.free()
+
+
+def chain_parity(ctx, batch, params, chain, rank, tile0, tiles):
+    """--chain: SHAD against the numpy oracle's terrain shadow layer of the tile's DEM (numpy < 2 promotion, the library's
+    default), LAND against the oracle's aggregation of the tile's maps, the seven layers and the counters against the C
+    oracle fed with THOSE planes; the reflectance bands, Fmask and the ocean plane against the generator."""
+    import numpy as np
+    from oracle import c_oracle
+    from oracle import dswx_oracle as o
+    from proteus_amd import _capi
+    from proteus_amd.synth import synth_tile
+    cnt = batch.read_counters()
+    rec = {'rank': rank, 'first_tile': tile0, 'tiles': [tile0 + t for t in tiles], 'result': 'bit-exact'}
+    for tile in tiles:
+        dem, wc, cg = chain.host[chain.kind(tile)]
+        shad = o.crop_2d_array_all_sides(o.compute_opera_shadow_layer(
+            dem, CHAIN_SUN['azimuth'], CHAIN_SUN['elevation'], CHAIN_SUN['min_slope_angle'],
+            CHAIN_SUN['max_sun_local_inc_angle'], legacy_promotion=True), CHAIN_MARGIN).astype(np.uint8)
+        land = o.landcover_mask_from_warped(wc, cg, CHAIN_FOREST)
+        want = synth_tile(tile0 + tile, TILE, TILE, with_masks=True)
+        bands = [batch.read_tile(b, tile) for b in _capi.BAND_NAMES]
+        fmask, ocean = batch.read_tile('fmask', tile), batch.read_tile('ocean', tile)
+        checks = [('SHAD vs the oracle shadow layer', np.array_equal(batch.read_tile('shad', tile), shad)),
+                  ('LAND vs the oracle aggregation', np.array_equal(batch.read_tile('land', tile), land)),
+                  ('inputs vs the generator', all(np.array_equal(a, b) for a, b in zip(bands, want['bands']))
+                   and np.array_equal(fmask, want['fmask']) and np.array_equal(ocean, want['ocean']))]
+        exp = c_oracle.classify(params, bands, fmask, land=land, shad=shad, ocean=ocean)
+        checks += [(key, np.array_equal(batch.read_tile(key, tile), exp[key]))
+                   for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud')]
+        checks.append(('counters', cnt[tile].tolist() == exp['counters'].tolist()))
+        bad = [name for name, ok in checks if not ok]
+        if bad:
+            rec['result'] = f'MISMATCH in tile {tile0 + tile}: {bad}'
+            break
+    return rec
+
+
 def pmc_traffic(masks, n_tiles):
     """HBM bytes per launch from the committed rocprofv3 PMC passes -- only if they were taken on THIS
     kernel (source hash of dswx_classify_lut.hip + dswx_tables.h + dswx_device.h) and tile count."""
@@ -447,7 +537,11 @@ def main():
                                    args.placement_trials, args.slide_refine, args.slide_slack_gib)
     barrier = cp.barrier
 
+    chain = ChainInputs(ctx, n_tiles, tile0) if args.chain else None
+
     def one_step():
+        if chain:                   # terrain shadow + LAND aggregation into the batch's planes, then the classifier
+            chain.layers(batch)
         for c in chunks:            # dswx_batch_classify: a partial last chunk = the first `c` resident tiles
             batch.classify(params, n_tiles=c)
 
@@ -474,13 +568,34 @@ def main():
     step_ms = [ctx.elapsed_ms(a, b) for a, b in zip(starts, stops)]
     for e in starts + stops:
         ctx.destroy_event(e)
+    chain_split = None
+    if chain and rank == 0:             # after the timed region: the three kernels of a step timed one by one
+        def ms_of(fn, reps=10):
+            fn()
+            ctx.synchronize()
+            e0, e1 = ctx.event(), ctx.event()
+            ctx.record(e0)
+            for _ in range(reps):
+                fn()
+            ctx.record(e1)
+            ctx.synchronize()
+            ms = ctx.elapsed_ms(e0, e1) / reps
+            ctx.destroy_event(e0)
+            ctx.destroy_event(e1)
+            return ms
+        both = ms_of(lambda: chain.layers(batch))
+        land_only = ms_of(lambda: ctx.landcover_mask_device(chain.d_wc.ptr, chain.d_cg.ptr, n_tiles, TILE, TILE, CHAIN_FOREST,
+                                                            batch.pin.land, out_tile_stride=batch.tile_stride))
+        chain_split = {'terrain_shadow_ms': round(both - land_only, 4), 'land_aggregation_ms': round(land_only, 4),
+                       'classify_ms': round(ms_of(lambda: batch.classify(params)), 4)}
     elapsed = cp.max_over_ranks(elapsed)
     total_px_per_step = cp.sum_over_ranks(my_tiles) * TILE * TILE
 
     parity = None
     if not args.no_parity:              # EVERY rank checks its own tiles; the records are gathered into the line
         try:
-            mine = rank_parity(ctx, batch, params, rank, tile0, n_tiles, chunks, args.distinct_chunks)
+            mine = chain_parity(ctx, batch, params, chain, rank, tile0, sorted({0, n_tiles - 1})) if chain else \
+                rank_parity(ctx, batch, params, rank, tile0, n_tiles, chunks, args.distinct_chunks)
         except Exception as e:          # the checker failing is reported, not fatal to the measurement
             mine = {'rank': rank, 'first_tile': tile0, 'result': f'not checked ({type(e).__name__}: {e})'[:300]}
         records = cp.gather_objects(mine)
@@ -489,6 +604,8 @@ def main():
 
     if rank == 0:
         bytes_per_px = 24 if args.masks else 21      # 13+8 (16+8 with masks)
+        if chain:       # + terrain shadow (4 B of DEM incl. its margin + 1 written) + LAND aggregation (9 + 1 + 1 written)
+            bytes_per_px = 24 + (4.0 * chain.H * chain.W / (TILE * TILE) + 1.0) + 11.0
         # dominant kernel: one launch = one resident chunk; a step is len(chunks) launches
         px_per_launch = n_tiles * TILE * TILE
         my_px_per_step = my_tiles * TILE * TILE
@@ -496,6 +613,8 @@ def main():
         achieved = my_px_per_step * bytes_per_px / (avg_step_ms * 1e-3) / 1e9
         avg_launch_ms = avg_step_ms * px_per_launch / my_px_per_step
         traffic, pmc_note = pmc_traffic(args.masks, n_tiles)
+        if chain:
+            traffic, pmc_note = None, 'no PMC pass for the three-kernel chain'
         if strong:
             workload = (f'BASELINE configs[3]: {args.total_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles in all, split '
                         f'contiguously over {world} rank(s); a rank walks its share ({my_tiles} tiles on rank 0) in '
@@ -504,6 +623,11 @@ def main():
         else:
             workload = (f'BASELINE configs[2]: {n_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles per GPU per step, '
                         f'device-resident band-planar batch')
+        if chain:
+            workload = (f"BASELINE configs[4], one GPU's share, device-resident: {n_tiles} synthetic {TILE}x{TILE} tiles per step through "
+                        f'terrain shadow layer (DEM {chain.H}x{chain.W}, margin {CHAIN_MARGIN}) -> LAND aggregation (WorldCover '
+                        f'{3 * TILE}x{3 * TILE} + CGLS) -> fused classifier with SHAD + LAND + OCEAN, the two layers written straight into '
+                        f'the planes of the batch (a step = three kernels; L30 / S30 differ in host-side band mapping only)')
         workload += (f' (tile stride {batch.tile_stride} px = 256-byte aligned tile starts)'
                      + (', LAND+SHAD+OCEAN planes' if args.masks else ''))
         out = {
@@ -537,7 +661,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': traffic,
-                         'algorithmic_bytes_per_pixel': bytes_per_px,
+                         'algorithmic_bytes_per_pixel': round(bytes_per_px, 3),
                          'pixels_per_launch': px_per_launch,
                          'launch_ms_avg': round(avg_launch_ms, 4),
                          'launch_ms_min': round(min(step_ms) * px_per_launch / my_px_per_step, 4),
@@ -549,6 +673,10 @@ def main():
                          'kernel_source_hash': _build.hot_kernel_hash()},
             'parity_check': parity,
         }
+        if chain:
+            out['roofline'].update(chain=chain_split, read_frac_of_peak=None,
+                                   note='achieved / frac = the algorithmic bytes of the three kernels of a step (24 + 5.22 + 11 '
+                                        'per pixel) over the step time')
         if placement.get('first_come_launch_ms'):
             # the first-come planes and the kept ones, timed back to back at the end of the placement (3-launch probes:
             # compare THESE two with each other; sustained rates over the timed steps run 1.5 - 2 % below such probes)
@@ -556,7 +684,7 @@ def main():
                 return round(px_per_launch * bytes_per_px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             out['roofline']['frac_first_come_placement'] = probe_frac(placement['first_come_launch_ms'])
             out['roofline']['frac_kept_placement_probe'] = probe_frac(placement['kept_launch_ms'])
-        if world == 1 and args.realloc_repeats > 0:
+        if world == 1 and args.realloc_repeats > 0 and not chain:
             try:
                 batch.free()
                 batch = None
@@ -564,7 +692,7 @@ def main():
                                                                    args.realloc_repeats)
             except Exception as e:
                 out['roofline']['realloc_spread'] = {'error': f'{type(e).__name__}: {e}'[:300]}
-        if world == 1 and not args.no_single_tile:
+        if world == 1 and not args.no_single_tile and not chain:
             try:
                 out['single_tile'] = single_tile_leg(ctx, params, args.masks)
             except Exception as e:
@@ -578,6 +706,8 @@ def main():
             except Exception as e:      # a reported baseline must never cost the bench line
                 out['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         print(json.dumps(out), flush=True)
+    if chain:
+        chain.free()
     if batch is not None:
         batch.free()
     ctx.close()

@@ -270,6 +270,22 @@ int dswx_landcover_mask_device(dswx_ctx_t* ctx, const uint8_t* worldcover_up3,
                                int32_t n_forest_classes, const int32_t thresholds[4],
                                int32_t year_offset, uint8_t* land, void* stream);
 
+/* The two layer kernels writing straight into the SHAD / LAND planes of a resident batch: as the _device forms, with the
+ * distance between the output rasters of consecutive tiles given explicitly (bytes = pixels; 0 = packed rasters;
+ * dswx_batch_geom_t.tile_stride of the batch whose plane `shadow` / `land` is).  dswx_shadow_layer_batch takes the
+ * pulled-back thresholds like the _q / _q32 forms (float32_arithmetic != 0: slope_arg_max and inc_q_min hold float32
+ * values, numpy < 2 promotion). */
+int dswx_shadow_layer_batch(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height,
+                            int64_t width, int64_t margin, const double sun_vector[3], double sin_azimuth,
+                            double cos_azimuth, double slope_arg_max, double inc_q_min,
+                            int32_t float32_arithmetic, double pixel_spacing_x, double pixel_spacing_y,
+                            uint8_t* shadow, int64_t shadow_tile_stride, void* stream);
+int dswx_landcover_mask_batch(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
+                              int64_t n_tiles, int64_t height, int64_t width,
+                              const int32_t* forest_classes, int32_t n_forest_classes,
+                              const int32_t thresholds[4], int32_t year_offset, uint8_t* land,
+                              int64_t land_tile_stride, void* stream);
+
 /* Deterministic synthetic HLS tiles written straight into HBM (SURVEY.md §8d;
  * same integer recipe as proteus_amd/synth.py).  Fills in->band[0..5], in->fmask
  * and whichever of land/shad/ocean is non-NULL for tiles tile0..tile0+n_tiles-1. */

@@ -31,7 +31,8 @@ EXPORTED_SYMBOLS = (
     'dswx_stream_synchronize', 'dswx_event_create', 'dswx_event_destroy',
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info',
     'dswx_batch_layout', 'dswx_batch_create', 'dswx_batch_destroy', 'dswx_batch_planes', 'dswx_batch_info',
-    'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search', 'dswx_batch_place_slide')
+    'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search', 'dswx_batch_place_slide',
+    'dswx_shadow_layer_batch', 'dswx_landcover_mask_batch')
 
 
 class DswxError(RuntimeError):
@@ -177,6 +178,10 @@ def load_library(path=None):
                                                     ctypes.c_int32, vp]),
         'dswx_landcover_mask_device': (ctypes.c_int, [vp, vp, vp, i64, i64, i64, vp, ctypes.c_int32,
                                                       vp, ctypes.c_int32, vp, vp]),
+        'dswx_shadow_layer_batch': (ctypes.c_int, [vp, vp, i64, i64, i64, i64, ctypes.POINTER(ctypes.c_double * 3)] +
+                                    [ctypes.c_double] * 4 + [ctypes.c_int32, ctypes.c_double, ctypes.c_double, vp, i64, vp]),
+        'dswx_landcover_mask_batch': (ctypes.c_int, [vp, vp, vp, i64, i64, i64, vp, ctypes.c_int32, vp,
+                                                     ctypes.c_int32, vp, i64, vp]),
         'dswx_synth_fill': (ctypes.c_int, [vp, ctypes.c_uint64, i64, i64, i64, i64,
                                            ctypes.POINTER(PlanesIn), vp]),
         'dswx_device_malloc': (ctypes.c_int, [vp, ctypes.c_size_t, pp]),
@@ -621,22 +626,32 @@ class Context:
         return out
 
     def landcover_mask_device(self, wc_ptr, cg_ptr, n_tiles, height, width, forest_classes, out_ptr,
-                              thresholds=(6, 3, 7, 3), year_offset=0, stream=None):
-        """Device-pointer form: [n_tiles][3H][3W] + [n_tiles][H][W] -> [n_tiles][H][W], asynchronous."""
+                              thresholds=(6, 3, 7, 3), year_offset=0, stream=None, out_tile_stride=0):
+        """Device-pointer form: [n_tiles][3H][3W] + [n_tiles][H][W] -> [n_tiles][H][W], asynchronous.
+        out_tile_stride: pixels between the LAND rasters of consecutive tiles (dswx_landcover_mask_batch: the LAND plane
+        of a resident batch); 0 = packed."""
         fc = np.ascontiguousarray(list(forest_classes or []), dtype=np.int32)
         thr = np.ascontiguousarray(thresholds, dtype=np.int32)
-        _check(self.lib.dswx_landcover_mask_device(
+        _check(self.lib.dswx_landcover_mask_batch(
             self.handle, ctypes.c_void_p(wc_ptr), ctypes.c_void_p(cg_ptr), int(n_tiles), int(height),
             int(width), _host_ptr(fc) if fc.size else None, int(fc.size), _host_ptr(thr),
-            int(year_offset), ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream) if stream else None))
+            int(year_offset), ctypes.c_void_p(out_ptr), int(out_tile_stride), ctypes.c_void_p(stream) if stream else None))
 
     def shadow_layer_device(self, dem_ptr, n_tiles, height, width, margin, sun_vector, sin_azimuth,
                             cos_azimuth, min_slope_angle, max_sun_local_inc_angle, out_ptr,
-                            pixel_spacing_x=30, pixel_spacing_y=30, stream=None, float32=False):
+                            pixel_spacing_x=30, pixel_spacing_y=30, stream=None, float32=False, out_tile_stride=0):
         """Device-pointer form: [n_tiles][H][W] float32 DEMs -> [n_tiles][H-2m][W-2m] u8, asynchronous.
-        float32=True: numpy < 2 value-based casting (the _q32 entry point)."""
+        float32=True: numpy < 2 value-based casting (the _q32 entry point).  out_tile_stride != 0: the shadow rasters
+        go that many pixels apart (dswx_shadow_layer_batch: the SHAD plane of a resident batch)."""
         vec = (ctypes.c_double * 3)(*[float(v) for v in sun_vector])
         slope_arg_max, inc_q_min = shadow_thresholds(min_slope_angle, max_sun_local_inc_angle, float32)
+        if out_tile_stride:
+            _check(self.lib.dswx_shadow_layer_batch(
+                self.handle, ctypes.c_void_p(dem_ptr), int(n_tiles), int(height), int(width), int(margin), ctypes.byref(vec),
+                float(sin_azimuth), float(cos_azimuth), float(slope_arg_max), float(inc_q_min), int(bool(float32)),
+                float(pixel_spacing_x), float(pixel_spacing_y), ctypes.c_void_p(out_ptr), int(out_tile_stride),
+                ctypes.c_void_p(stream) if stream else None))
+            return
         fn = self.lib.dswx_shadow_layer_device_q32 if float32 else self.lib.dswx_shadow_layer_device_q
         _check(fn(
             self.handle, ctypes.c_void_p(dem_ptr), int(n_tiles), int(height), int(width), int(margin),

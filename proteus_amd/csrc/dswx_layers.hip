@@ -49,6 +49,7 @@ struct ShadowArgs {
     const float* dem;        // [H][W], with margin
     uint8_t* shadow;         // [H - 2*margin][W - 2*margin]; 1 = not shadow, 0 = shadow
     long long height, width, margin;
+    long long out_stride;    // bytes between the shadow rasters of consecutive tiles ((H - 2 margin) (W - 2 margin) unless a batch says otherwise)
     float spacing_x, neg_abs_spacing_y;
     double sun[3];           // target-to-sun unit vector (x, y, z)
     double sin_az, cos_az;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
     const float dx = d[x < W - 1 ? c + 1 : c] - d[x > 0 ? c - 1 : c];
     const float dy = d[y < H - 1 ? c + W : c] - d[y > 0 ? c - W : c];
     const bool v = shadow_px_exact<F32>(a, dx, x_in ? 0.5f : 1.0f, dy, y_in ? 0.5f : 1.0f);
-    a.shadow[(size_t)blockIdx.z * (size_t)oh * (size_t)ow + (size_t)(oy * ow + ox)] = v ? 1 : 0;
+    a.shadow[(size_t)blockIdx.z * (size_t)a.out_stride + (size_t)(oy * ow + ox)] = v ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64 * SHADOW_WAVES) void dswx_shadow_v3(const Shadow
     const int oy0 = (blockIdx.y * SHADOW_WAVES + (threadIdx.x >> 6)) * SHADOW_ROWS;
     if (4 * oq >= ow || oy0 >= oh) return;
     const float* __restrict__ col = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W + (size_t)(4 * oq + margin);
-    uint8_t* __restrict__ dst = a.shadow + (size_t)blockIdx.z * (size_t)oh * (size_t)ow + (size_t)(4 * oq);
+    uint8_t* __restrict__ dst = a.shadow + (size_t)blockIdx.z * (size_t)a.out_stride + (size_t)(4 * oq);
     struct Row { f32x2 v[4]; };         // d[x-2 .. x+5]; x is even, rows are 8-byte aligned
     auto load_row = [&](int y) {
         const float* r = col + (size_t)(y < H ? y : H - 1) * (size_t)W;        // rows past the last output row: clamped, unused
@@ -269,6 +270,7 @@ struct LandArgs {
     const uint8_t* cgls;     // [H][W]
     uint8_t* land;           // [H][W]
     long long height, width;
+    long long out_stride;    // bytes between the LAND rasters of consecutive tiles (H W unless a batch says otherwise)
     uint32_t forest_bits[8]; // 256-bit set of CGLS forest classes
     int thr_tree, thr_low, thr_high, thr_water;
     int low_class, high_class;   // year_offset, 100 + year_offset (as uint8)
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
         for (int k = 0; k < 4; ++k)
             out |= (uint32_t)land_class(a, cnt[k] & 15u, (cnt[k] >> 4) & 15u, cnt[k] >> 8,
                                         s_forest[(cg[r] >> (8 * k)) & 0xffu] != 0) << (8 * k);
-        __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(a.land + tile * a.height * a.width + (y0 + r) * a.width + 4 * xq));
+        __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(a.land + tile * a.out_stride + (y0 + r) * a.width + 4 * xq));
     }
 }
 
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void dswx_landcover_v1(const LandArgs a) {
     }
     const long long o = tile * a.height * a.width + y * a.width + x;
     const int c = a.cgls[o];
-    a.land[o] = (uint8_t)land_class(a, water, urban, tree, ((a.forest_bits[c >> 5] >> (c & 31)) & 1u) != 0);
+    a.land[tile * a.out_stride + y * a.width + x] = (uint8_t)land_class(a, water, urban, tree, ((a.forest_bits[c >> 5] >> (c & 31)) & 1u) != 0);
 }
 
 // ------------------------------------------------------------------------------
@@ -589,7 +591,7 @@ static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles
                               int64_t margin, const double sun_vector[3], double sin_azimuth,
                               double cos_azimuth, double slope_arg_max, double inc_q_min,
                               double pixel_spacing_x, double pixel_spacing_y, uint8_t* shadow, void* stream,
-                              bool f32) {
+                              bool f32, int64_t shadow_tile_stride = 0) {
     if (!ctx || !dem || !shadow) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     if (n_tiles < 0 || n_tiles > 65535) return dswx_fail(DSWX_ERR_ARG, "n_tiles out of range");
     ShadowArgs a;
@@ -601,10 +603,13 @@ static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const long long ow = width - 2 * margin, oh = height - 2 * margin;
+    if (shadow_tile_stride != 0 && shadow_tile_stride < oh * ow)
+        return dswx_fail(DSWX_ERR_ARG, "shadow_tile_stride smaller than the shadow raster");
+    a.out_stride = shadow_tile_stride ? shadow_tile_stride : oh * ow;
     if ((oh + 3) / 4 > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
     // four pixels per thread behind the filter where the geometry allows 8-byte loads and dword stores
     const bool quads = margin >= 2 && margin % 2 == 0 && width % 2 == 0 && ow % 4 == 0 && aligned_to(dem, 8) &&
-                       aligned_to(shadow, 4);
+                       aligned_to(shadow, 4) && a.out_stride % 4 == 0;
     if (quads) {
         ShadowFilter f;
         shadow_filter(a, f32, &f);
@@ -735,11 +740,43 @@ static int land_args(LandArgs* a, int64_t height, int64_t width, const int32_t* 
     return DSWX_OK;
 }
 
+static int landcover_device_impl(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
+                                 int64_t n_tiles, int64_t height, int64_t width, const int32_t* forest_classes,
+                                 int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset,
+                                 uint8_t* land, int64_t land_tile_stride, void* stream);
+
 int dswx_landcover_mask_device(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
                                int64_t n_tiles, int64_t height, int64_t width, const int32_t* forest_classes,
                                int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset,
                                uint8_t* land, void* stream) {
+    return landcover_device_impl(ctx, worldcover_up3, copernicus, n_tiles, height, width, forest_classes, n_forest_classes,
+                                 thresholds, year_offset, land, 0, stream);
+}
+
+int dswx_landcover_mask_batch(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
+                              int64_t n_tiles, int64_t height, int64_t width, const int32_t* forest_classes,
+                              int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset,
+                              uint8_t* land, int64_t land_tile_stride, void* stream) {
+    return landcover_device_impl(ctx, worldcover_up3, copernicus, n_tiles, height, width, forest_classes, n_forest_classes,
+                                 thresholds, year_offset, land, land_tile_stride, stream);
+}
+
+int dswx_shadow_layer_batch(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles, int64_t height, int64_t width,
+                            int64_t margin, const double sun_vector[3], double sin_azimuth, double cos_azimuth,
+                            double slope_arg_max, double inc_q_min, int32_t float32_arithmetic, double pixel_spacing_x,
+                            double pixel_spacing_y, uint8_t* shadow, int64_t shadow_tile_stride, void* stream) {
+    return shadow_device_impl(ctx, dem, n_tiles, height, width, margin, sun_vector, sin_azimuth, cos_azimuth, slope_arg_max,
+                              inc_q_min, pixel_spacing_x, pixel_spacing_y, shadow, stream, float32_arithmetic != 0,
+                              shadow_tile_stride);
+}
+
+static int landcover_device_impl(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, const uint8_t* copernicus,
+                                 int64_t n_tiles, int64_t height, int64_t width, const int32_t* forest_classes,
+                                 int32_t n_forest_classes, const int32_t thresholds[4], int32_t year_offset,
+                                 uint8_t* land, int64_t land_tile_stride, void* stream) {
     if (!ctx || !worldcover_up3 || !copernicus || !land) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (land_tile_stride != 0 && land_tile_stride < height * width)
+        return dswx_fail(DSWX_ERR_ARG, "land_tile_stride smaller than the raster");
     if (n_tiles < 0 || n_tiles > 65535) return dswx_fail(DSWX_ERR_ARG, "n_tiles out of range");
     LandArgs a;
     int rc = land_args(&a, height, width, forest_classes, n_forest_classes, thresholds, year_offset);
@@ -748,8 +785,10 @@ int dswx_landcover_mask_device(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, c
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     a.wc3 = worldcover_up3; a.cgls = copernicus; a.land = land;
+    a.out_stride = land_tile_stride ? land_tile_stride : height * width;
     // four pixels per thread with dword loads when rows keep 4-byte alignment
-    const bool quad = width % 4 == 0 && aligned_to(worldcover_up3, 4) && aligned_to(copernicus, 4) && aligned_to(land, 4);
+    const bool quad = width % 4 == 0 && aligned_to(worldcover_up3, 4) && aligned_to(copernicus, 4) && aligned_to(land, 4) &&
+                      a.out_stride % 4 == 0;
     if (quad) {
         static_assert(LAND_ROWS == 1, "the flat quad numbering assumes one row per thread");
         const long long quads = (width / 4) * height;

@@ -43,6 +43,20 @@ def test_two_ranks_strong_scaling_every_rank_checks_every_chunk():
     assert out['value'] > 0 and out['roofline']['pixels_per_launch'] == 4 * 3660 * 3660
 
 
+def test_chain_mode_shadow_and_land_layers_into_the_batch():
+    """`bench.py --chain` (BASELINE configs[4]'s per-pixel chain, one GPU's share): terrain shadow layer and LAND
+    aggregation written straight into the SHAD / LAND planes of the resident batch (dswx_shadow_layer_batch,
+    dswx_landcover_mask_batch with the batch's tile stride), then the classifier with SHAD + LAND + OCEAN.  The line's
+    parity record compares SHAD and LAND with the numpy oracle's layers and everything downstream with the C oracle."""
+    out = _bench('--chain', '--tiles', '3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline')
+    assert out['n_gpus'] == 1 and 'configs[4]' in out['config']['workload'] and out['config']['planes_in'] == 10
+    assert out['parity_check']['result'] == 'bit-exact', out['parity_check']
+    assert out['parity_check']['ranks'][0]['tiles'] == [0, 2]
+    r = out['roofline']
+    assert abs(r['algorithmic_bytes_per_pixel'] - (24 + 11 + 4 * 3760 ** 2 / 3660 ** 2 + 1)) < 1e-3
+    assert all(r['chain'][k] > 0 for k in ('terrain_shadow_ms', 'land_aggregation_ms', 'classify_ms'))
+
+
 def test_two_ranks_weak_scaling_rank_offsets():
     out = _bench('--gpus', '2', '--tiles', '3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--masks')
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['tiles_per_step_all_ranks'] == 6
