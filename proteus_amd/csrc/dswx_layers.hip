@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void dswx_landcover_v3(const LandArgs a) {
                                           // argument's bit set is a global load in the middle of the pixel loop)
     {
         const int v = threadIdx.x;
-        s_code[v] = (uint16_t)(((v == 80) | (v == 90) | (v == 95) ? 1 : 0) | (v == 50 ? 16 : 0) | (v == 10 ? 256 : 0));
+        s_code[v] = (uint16_t)((((v == 80) | (v == 90) | (v == 95)) ? 1 : 0) | (v == 50 ? 16 : 0) | (v == 10 ? 256 : 0));
         s_forest[v] = (uint8_t)((a.forest_bits[v >> 5] >> (v & 31)) & 1u);
     }
     __syncthreads();
