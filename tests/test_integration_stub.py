@@ -113,3 +113,59 @@ def test_batch_stub_runs_and_matches_the_oracle():
             assert cnt[t].tolist() == exp['counters'].tolist()
         assert lib.dswx_batch_destroy(handle) == 0
     lib.dswx_ctx_destroy(ctx)
+
+
+def _build_c_example(tmp_path):
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    exe = str(tmp_path / 'resident_batch')
+    lib_dir = os.path.dirname(_capi.library_path())
+    _capi.load_library()                      # builds the library when missing or stale
+    subprocess.run(['gcc', '-std=c11', '-O2', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'examples', 'resident_batch.c'), '-L', lib_dir, '-ldswx_hip',
+                    f'-Wl,-rpath,{lib_dir}', '-o', exe], check=True)
+    return exe
+
+
+def test_c_example_builds_with_a_c_compiler_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/resident_batch.c: include/dswx_hip.h is a C header (gcc -std=c11 -Wall -Wextra -Werror), the library
+    links from C, and without a device the program stops at dswx_ctx_create -- there is no CPU fallback."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    if _capi.device_count() > 0:
+        pytest.skip('a GPU is present (the GPU test runs the program)')
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and 'no CPU fallback' in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_runs_and_matches_the_oracle(tmp_path):
+    """The same program on the GPU: counters and FNV-1a checksums of the seven layers of a placed, resident batch,
+    produced through the C-ABI from C alone, against the oracle on the same synthetic tiles."""
+    import subprocess
+    from oracle import c_oracle
+    from proteus_amd.synth import synth_tile
+    exe = _build_c_example(tmp_path)
+    n_tiles, size = 2, 96
+    r = subprocess.run([exe, str(n_tiles), str(size)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert f'tile stride {size * size} px' in lines[0] and '2 allocations' in lines[0]       # 9216 = 36 * 256: no padding
+    p = _capi.default_params()
+    exp = []
+    for t in range(n_tiles):
+        s = synth_tile(t, size, size, with_masks=True)
+        exp.append(c_oracle.classify(p, s['bands'], s['fmask'], land=s['land'], shad=s['shad'], ocean=s['ocean']))
+        c = exp[-1]['counters'].tolist()
+        assert f'counters {t}: n_valid {c[0]} n_cloud_and_valid {c[1]} n_not_ocean {c[2]}' in lines
+
+    def fnv(chunks):
+        h = 1469598103934665603
+        for chunk in chunks:
+            for byte in chunk.tobytes():
+                h = ((h ^ byte) * 1099511628211) & 0xffffffffffffffff
+        return h
+    for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+        assert f'checksum {key} {fnv([e[key] for e in exp]):016x}' in lines, key

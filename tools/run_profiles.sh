@@ -27,6 +27,12 @@ d=gpurun_out/prof_placed
 rm -rf "$d"; mkdir -p "$d"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -- python3 bench.py --tiles $TILES --no-cpu-baseline --no-single-tile --realloc-repeats 0 --steps 20 --warmup 3 > "$d/bench_trace.log" 2>&1
 fi
+if [[ "$WHAT" == *chain* ]]; then
+# bench.py --chain (BASELINE configs[4]'s per-pixel chain, device-resident): kernel trace of the three kernels of a step
+d=gpurun_out/prof_chain
+rm -rf "$d"; mkdir -p "$d"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -- python3 bench.py --chain --tiles $TILES --no-cpu-baseline --steps 20 --warmup 3 > "$d/bench_trace.log" 2>&1
+fi
 if [[ "$WHAT" == *next* ]]; then
 # the rows next to the hot path (shadow, cover, land-cover): kernel trace + the same three counter passes
 d=gpurun_out/prof_next

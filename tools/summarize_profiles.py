@@ -147,12 +147,60 @@ def summarize_placed(a, out):
     print(json.dumps({k: v for k, v in summary.items() if k != 'timed_dispatch_ns'}, indent=1))
 
 
+def summarize_chain(a, out):
+    """Kernel trace of `bench.py --chain`: the timed region = the last `steps` dispatches of each of the step's kernels
+    (the placement probes before it launch the classifier only).  Writes profiles/rNN_chain_kernel_stats.csv (stats over the
+    timed region) and profiles/rNN_chain_summary.json."""
+    tag = f'r{int(a.round):02d}_chain'
+    line = None
+    blog = os.path.join(a.src, 'bench_trace.log')
+    for l in open(blog):
+        if l.startswith('{"metric"'):
+            line = json.loads(l)
+    steps = line['steps']
+    trace = list(csv.DictReader(open(one(os.path.join(a.src, 'trace', '**', '*kernel_trace.csv')))))
+    trace.sort(key=lambda r: int(r['Start_Timestamp']))
+    # the last `steps` shadow-layer dispatches open the timed steps (warm-up comes before, the split timing after
+    # the timed region launches each kernel 11 more times: drop those by taking the window of `steps` steps that ends
+    # with the classifier dispatch closing the timed region)
+    shadow = [r for r in trace if 'dswx_shadow' in r['Kernel_Name']]
+    warm = line['warmup']
+    timed_shadow = shadow[warm:warm + steps]
+    t0 = int(timed_shadow[0]['Start_Timestamp'])
+    after = [r for r in trace if int(r['Start_Timestamp']) >= t0]
+    rows, counts = {}, {}
+    for r in after:
+        k = short(r['Kernel_Name'])
+        key = 'shadow' if 'shadow' in k else 'land' if 'landcover' in k else 'classify' if 'classify' in k else \
+            'counters' if 'counters' in k else None
+        if key is None or counts.get(key, 0) >= steps:
+            continue
+        counts[key] = counts.get(key, 0) + 1
+        rows.setdefault(r['Kernel_Name'], []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    total = sum(sum(v) for v in rows.values())
+    with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+        for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([name, len(v), sum(v), f'{sum(v) / len(v):.1f}', f'{100.0 * sum(v) / total:.4f}', min(v), max(v)])
+    summary = {'what': 'rocprofv3 --kernel-trace of `python3 bench.py --chain --tiles 256 --steps 20 --warmup 3`: the kernels of the '
+                       '20 timed steps', 'step_ms_from_trace': total / steps / 1e6,
+               'bench_line_ms_per_step': line['ms_per_step'], 'bench_line_value_Mpix_s': line['value'],
+               'bench_line_frac': line['roofline']['frac'], 'bench_line_chain_split_ms': line['roofline']['chain'],
+               'kernels_avg_ms': {short(k): sum(v) / len(v) / 1e6 for k, v in rows.items()},
+               'parity_check': line['parity_check']['result']}
+    json.dump(summary, open(os.path.join(out, f'{tag}_summary.json'), 'w'), indent=1)
+    shutil.copy(blog, os.path.join(out, f'{tag}_bench_under_rocprof.log'))
+    print(json.dumps(summary, indent=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('round')
     ap.add_argument('tiles', type=int)
     ap.add_argument('--masks', action='store_true')
     ap.add_argument('--next-rows', action='store_true', help='digest gpurun_out/prof_next instead of the hot kernel')
+    ap.add_argument('--chain', action='store_true', help='digest gpurun_out/prof_chain: the kernel trace of bench.py --chain')
     ap.add_argument('--placed', action='store_true',
                     help='digest gpurun_out/prof_placed: the kernel trace of the default (placed) bench configuration')
     ap.add_argument('--src', default=None)
@@ -161,11 +209,13 @@ def main():
     out = os.path.join(ROOT, 'profiles')
     os.makedirs(out, exist_ok=True)
     if a.src is None:
-        a.src = os.path.join(ROOT, 'gpurun_out', 'prof_placed' if a.placed else 'prof_next' if a.next_rows else ('prof_masks' if a.masks else 'prof'))
+        a.src = os.path.join(ROOT, 'gpurun_out', 'prof_chain' if a.chain else 'prof_placed' if a.placed else 'prof_next' if a.next_rows else ('prof_masks' if a.masks else 'prof'))
     if a.next_rows:
         return summarize_next_rows(a, out)
     if a.placed:
         return summarize_placed(a, out)
+    if a.chain:
+        return summarize_chain(a, out)
     tag = f'r{int(a.round):02d}' + ('_masks' if a.masks else '')
     stats = one(os.path.join(a.src, 'trace', '**', '*kernel_stats.csv'))
     shutil.copy(stats, os.path.join(out, f'{tag}_kernel_stats.csv'))
