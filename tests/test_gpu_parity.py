@@ -789,6 +789,59 @@ def test_offset_and_scale_inputs_vs_both_oracles(ctx, mode):
         ctx.classify_host(s1['bands'], s1['fmask'], p, layers=('diag', 'mndwi'))
 
 
+def test_contexts_on_concurrent_host_threads():
+    """'all functions thread-compatible, one context per device' -- the reference is single-threaded, a
+    service is not.  Four host threads, each with its OWN context (own stream, own tables, own scratch), classify
+    different tiles with different parameter sets concurrently and repeatedly (host entry, device batch, 'cover' mode
+    with its grow-only scratch); every result is the oracle's, and an error raised on one thread does not show up in
+    another's dswx_last_error()."""
+    import threading
+    errors, results = [], {}
+
+    def work(k):
+        try:
+            c = _capi.Context(0)
+            mode = ('mask', 'ignore', 'cover', 'mask')[k]
+            thr = dict(wigt=0.124 + 0.01 * k, pswt_1_nir=1500 - 37 * k)
+            p = _capi.make_params(dict(vars(o.Thresholds(**thr))), mask_adjacent_to_cloud_mode=mode)
+            for rep in range(6):
+                h, w = 120 + 31 * k + 7 * rep, 200 + 17 * k
+                s_ = synth_tile(700 + 10 * k + rep, h, w, with_masks=True)
+                got = c.classify_host(s_['bands'], s_['fmask'], p, land=s_['land'], shad=s_['shad'], ocean=s_['ocean'])
+                with np.errstate(all='ignore'):
+                    e = o.classify_tile(s_['bands'], s_['fmask'], o.Thresholds(**thr), landcover=s_['land'], shadow=s_['shad'],
+                                        ocean_mask=s_['ocean'], mask_adjacent_to_cloud_mode=mode)
+                for layer, key in NAME.items():
+                    assert np.array_equal(got[key], e[layer]), (k, rep, layer)
+                b = _capi.DeviceBatch(c, 2, 64 + 8 * k, 96, masks=bool(k % 2))
+                b.synth(SEED, tile0=50 * k + rep)
+                b.classify(p)
+                c.synchronize()
+                s1 = synth_tile(50 * k + rep + 1, 64 + 8 * k, 96, with_masks=bool(k % 2))
+                kw = dict(landcover=s1['land'], shadow=s1['shad'], ocean_mask=s1['ocean']) if k % 2 else {}
+                with np.errstate(all='ignore'):
+                    e1 = o.classify_tile(s1['bands'], s1['fmask'], o.Thresholds(**thr), mask_adjacent_to_cloud_mode=mode, **kw)
+                for layer, key in NAME.items():
+                    if key != 'wtr1_aerosol':
+                        assert np.array_equal(b.read_tile(key, 1), e1[layer]), (k, rep, layer, 'batch')
+                b.free()
+                if k == 0:              # this thread also provokes errors: they stay on this thread
+                    with pytest.raises(_capi.DswxError, match='tile_stride smaller'):
+                        _capi.batch_layout(1, 8, 8, tile_stride=3)
+            results[k] = c.lib.dswx_last_error().decode()
+            c.close()
+        except BaseException as e:      # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert 'tile_stride smaller' in results[0] and all('tile_stride' not in results[k] for k in (1, 2, 3))
+
+
 def test_output_region_in_a_sliding_range(ctx):
     """DeviceBatch(sliding_outputs=True) = dswx_batch_create(DSWX_BATCH_SLIDING_OUTPUTS): the output planes packed in a
     range of the virtual address space backed chunk by chunk, moved by dswx_batch_place_slide to the offset where the
