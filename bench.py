@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the DSWx-HLS per-pixel hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--tiles T] [--total-tiles M] [--masks]
+    python bench.py --gpus N --steps K --warmup W [--tiles T] [--total-tiles M] [--masks] [--chain] [--placement ...]
 
 One "step" = one pass of the fused classify kernel over the tiles a GPU owns: synthetic
 3660x3660 HLS.L30 tiles (6 int16 bands + Fmask; `--masks` adds LAND/SHAD/OCEAN), generated
@@ -10,9 +10,14 @@ in HBM before the timed region.
   --total-tiles M (strong)      BASELINE configs[3]: M (e.g. 4096) tiles split contiguously over the
                                 N ranks (proteus_amd.shard.tile_range); a rank walks its share in
                                 resident chunks of <= T tiles (default 512), so N = 1 works too
-The resident batch is PLACED before warm-up (--placement-trials): every output plane in the
-fastest of a few candidate allocations, the kernel itself as the probe; `roofline.frac_first_come_placement`
-and `roofline.realloc_spread` keep what unplaced allocations give in the same line.
+  --chain                       BASELINE configs[4]'s per-pixel chain per GPU: a step = terrain shadow layer from
+                                DEMs + LAND aggregation from WorldCover / CGLS, written straight into the batch's
+                                SHAD / LAND planes, + the classifier with SHAD + LAND + OCEAN
+The resident batch is allocated by the library (dswx_batch_create) and PLACED before warm-up (--placement, DESIGN.md
+sections 5 - 6): by default dswx_batch_place_slide times ~100 placements of the output planes inside a VMM-backed
+address range 48 GiB longer than they are and keeps the best; `roofline.frac_first_come_placement`,
+`roofline.frac_kept_placement_probe` and `roofline.realloc_spread` keep what unplaced allocations give in the same line.
+Every rank checks tiles of its own batch against the oracle after timing (`parity_check.ranks`).
 Tiles are independent: there is no data-path collective.  RCCL (torch.distributed 'nccl') carries
 only the barrier around the timed region and the MAX over ranks of the elapsed time.
 
