@@ -80,10 +80,18 @@ def parse_args():
                     help='strong scaling: after the timed region, generate every later chunk of the rank\'s share with '
                          'its own tile indices, classify it and check its first and last tile (the timed walk re-streams '
                          'the resident planes)')
+    ap.add_argument('--no-host-path', action='store_true',
+                    help='skip the end-to-end leg (dswx_classify_host on 4 tiles from page-locked and from pageable planes, '
+                         'all ranks at once; after the timed region)')
+    ap.add_argument('--no-strong', action='store_true',
+                    help='--gpus N > 1 without --tiles / --total-tiles measures the weak record AND BASELINE configs[3] '
+                         '(4096 tiles over the ranks, the `strong` sub-record of the line); this keeps the weak record only')
     ap.add_argument('--no-single-tile', action='store_true',
                     help='skip the configs[1] leg (profiling runs: keeps the kernel statistics to the batch launches)')
     ap.add_argument('--cpu-parallel-worker', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    # "plain": the command line names no workload -- what the driver runs (`bench.py --gpus N --steps K --warmup W`)
+    args.plain_command = args.tiles <= 0 and args.total_tiles <= 0 and not args.chain and not args.masks
     if args.chain:
         if args.total_tiles > 0:
             ap.error('--chain is a weak-scaling mode (one resident batch per GPU)')
@@ -464,32 +472,334 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def rank_plan(args, rank, world):
-    """What `rank` of `world` does in one step: (tiles it owns, first tile index, resident tiles,
-    launches as a list of tile counts).  Shared by the measurement and --plan-only."""
+def rank_plan(case, rank, world):
+    """What `rank` of `world` does in one step of `case` (total_tiles, tiles): (tiles it owns, first tile index,
+    resident tiles, launches as a list of tile counts).  Shared by the measurement and --plan-only."""
     from proteus_amd import shard
-    if args.total_tiles > 0:
-        lo, hi = shard.tile_range(args.total_tiles, rank, world)       # this rank's share of the job
+    if case.total_tiles > 0:
+        lo, hi = shard.tile_range(case.total_tiles, rank, world)       # this rank's share of the job
         my_tiles = hi - lo
-        n_tiles = max(1, min(args.tiles, my_tiles))                    # resident chunk
+        n_tiles = max(1, min(case.tiles, my_tiles))                    # resident chunk
         return my_tiles, lo, n_tiles, shard.chunk_sizes(my_tiles, n_tiles)
-    lo, _ = shard.weak_tile_range(args.tiles, rank)                    # rank r owns tiles [r*T, (r+1)*T)
-    return args.tiles, lo, args.tiles, [args.tiles]
+    lo, _ = shard.weak_tile_range(case.tiles, rank)                    # rank r owns tiles [r*T, (r+1)*T)
+    return case.tiles, lo, case.tiles, [case.tiles]
+
+
+STRONG_TOTAL_TILES = 4096          # BASELINE configs[3]
+STRONG_CHUNK_TILES = 512           # its per-GPU share at 8 GPUs, resident at once (89 GB + 55 GB)
+
+
+def cases_of(args, world):
+    """The measured configurations of this command line.  The first is the top-level record of the line.  A plain
+    `bench.py --gpus N` (N > 1, neither --tiles nor --total-tiles nor --chain) -- what the driver runs for the scaling
+    curve -- measures BOTH: the weak record (256 tiles per GPU = configs[2] x N) and, as the line's `strong` sub-record,
+    BASELINE configs[3]: 4096 tiles split over the ranks, walked in 512-tile chunks, every chunk classified once under a
+    parity check (--distinct-chunks)."""
+    first = argparse.Namespace(total_tiles=args.total_tiles, tiles=args.tiles, distinct_chunks=args.distinct_chunks,
+                               key=None)
+    cases = [first]
+    if world > 1 and args.plain_command and not args.no_strong:
+        cases.append(argparse.Namespace(total_tiles=STRONG_TOTAL_TILES, tiles=STRONG_CHUNK_TILES, distinct_chunks=True,
+                                        key='strong'))
+    return cases
 
 
 def plan_only(args, rank, world):
     from proteus_amd import shard
     cp = shard.ControlPlane(backend='gloo', device=None)
-    my_tiles, tile0, n_tiles, chunks = rank_plan(args, rank, world)
-    cp.barrier()
-    total = cp.sum_over_ranks(my_tiles)
-    plans = cp.gather_objects({'rank': rank, 'first_tile': tile0, 'tiles': my_tiles, 'resident_tiles': n_tiles,
-                               'launches': chunks})
+    out = None
+    for case in cases_of(args, world):
+        my_tiles, tile0, n_tiles, chunks = rank_plan(case, rank, world)
+        cp.barrier()
+        total = cp.sum_over_ranks(my_tiles)
+        plans = cp.gather_objects({'rank': rank, 'first_tile': tile0, 'tiles': my_tiles, 'resident_tiles': n_tiles,
+                                   'launches': chunks})
+        rec = {'plan_only': True, 'n_gpus': world, 'scaling': 'strong' if case.total_tiles else 'weak',
+               'tiles_per_step_all_ranks': total, 'control_plane': cp.backend, 'ranks': plans}
+        if case.key is None:
+            out = rec
+        else:
+            out[case.key] = rec
     if rank == 0:
-        print(json.dumps({'plan_only': True, 'n_gpus': world, 'scaling': 'strong' if args.total_tiles else 'weak',
-                          'tiles_per_step_all_ranks': total, 'control_plane': cp.backend, 'ranks': plans}), flush=True)
+        print(json.dumps(out), flush=True)
     cp.close()
     return 0
+
+
+def device_identity(torch, index):
+    """PCI address and UUID of the device a rank runs on: the line's n_gpus is the number of DISTINCT devices the ranks
+    report, not the number of ranks that were started."""
+    import socket
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        return f'{socket.gethostname()}/{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}/{pr.uuid}'
+    except Exception as e:              # noqa: BLE001
+        return f'{socket.gethostname()}/cuda:{index} ({type(e).__name__})'
+
+
+def host_path_leg(ctx, cp, params, check, n_tiles=4, reps=3):
+    """The END-TO-END (PCIe-inclusive) rate of the host-pointer entry dswx_classify_host, after the timed region and
+    never `value`: `n_tiles` 3660 x 3660 tiles (a) from planes in page-locked memory of dswx_host_alloc -- zero copy: the
+    kernels read the inputs and write the layers across PCIe themselves -- and (b) from pageable numpy arrays, as a
+    caller of the reference's seam holds them (staged copies).  With N ranks every rank runs the same calls AT ONCE
+    (barrier on both sides) and the rates are the SUM over ranks: this is north_star's "host scatter / gather" and the one
+    place where the GPUs of a node share something (the host's memory system)."""
+    import ctypes
+    import numpy as np
+    from proteus_amd import _capi
+    from proteus_amd.synth import synth_tile
+    layers = ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud')
+    s = synth_tile(3, TILE, TILE)
+    shape = (n_tiles, TILE, TILE)
+    px = n_tiles * TILE * TILE
+    rec = {'tiles_per_call': n_tiles, 'ranks': cp.world if cp.dist is not None else 1}
+    results = {}
+    for mode in ('zero_copy', 'pageable'):
+        alloc = ctx.pinned_empty if mode == 'zero_copy' else (lambda sh, dt: np.empty(sh, dtype=dt))
+        bands = [alloc(shape, np.int16) for _ in range(6)]
+        fm = alloc(shape, np.uint8)
+        for t in range(n_tiles):
+            for i in range(6):
+                bands[i][t] = s['bands'][i]
+            fm[t] = s['fmask']
+        outs = {k: alloc(shape, np.uint16 if k == 'diag' else np.uint8) for k in layers}
+        for a in outs.values():
+            a[...] = 0                          # pageable outputs: touched once, as a caller's arrays would be
+        pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
+        for i in range(6):
+            pin.band[i] = bands[i].ctypes.data
+        pin.fmask = fm.ctypes.data
+        for k in layers:
+            setattr(pout, k, outs[k].ctypes.data)
+        cnt = np.zeros((n_tiles, 3), np.int64)
+
+        def call():
+            _capi._check(ctx.lib.dswx_classify_host(ctx.handle, ctypes.byref(params), n_tiles, TILE, TILE,
+                                                    ctypes.byref(pin), ctypes.byref(pout), _capi._host_ptr(cnt)))
+        call()                                  # untimed: staging arena, tables
+        cp.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        mine = time.perf_counter() - t0
+        cp.barrier()
+        elapsed = cp.max_over_ranks(mine)
+        total_px = cp.sum_over_ranks(px) * reps
+        rec[f'{mode}_Gpx_s'] = round(total_px / elapsed / 1e9, 3)
+        rec[f'{mode}_ms_per_call'] = round(elapsed / reps * 1e3, 2)
+        rec[f'{mode}_kernel'] = ctx.last_kernel_info()
+        results[mode] = {k: np.array(v) for k, v in outs.items()}
+        results[mode]['counters'] = cnt.copy()
+        del bands, fm, outs
+    rec['pcie_GBps_in_plus_out'] = round(rec['zero_copy_Gpx_s'] * 21, 1)        # 13 B in + 8 B out per pixel, both ways at once
+    same = all(np.array_equal(results['zero_copy'][k], results['pageable'][k]) for k in results['zero_copy'])
+    verdict = 'both entries identical' if same else 'MISMATCH between the zero-copy and the staged entry'
+    if check and same:
+        from oracle import c_oracle
+        exp = c_oracle.classify(params, s['bands'], s['fmask'])
+        ok = all(np.array_equal(results['zero_copy'][k][n_tiles - 1], exp[k]) for k in layers) and \
+            results['zero_copy']['counters'][n_tiles - 1].tolist() == exp['counters'].tolist()
+        verdict += ', bit-exact vs the C oracle' if ok else ', MISMATCH vs the C oracle'
+    bad = [v for v in cp.gather_objects(verdict) if 'MISMATCH' in v]
+    rec['parity'] = bad[0] if bad else verdict
+    rec['note'] = ('dswx_classify_host, after the timed region (never `value`): page-locked planes of dswx_host_alloc = zero copy '
+                   'across PCIe; pageable numpy planes = staged copies; all ranks at once, rates summed over ranks')
+    return rec
+
+
+def measure_case(args, case, env):
+    """One measured configuration on every rank: place the resident batch, warm up, time K steps between barriers,
+    check parity on every rank.  Returns the record (complete on rank 0) and leaves nothing allocated, unless
+    `env.keep_batch` asks for the batch (the N = 1 legs after the headline case)."""
+    import torch
+    from proteus_amd import _capi
+    ctx, cp, rank, world, params = env.ctx, env.cp, env.rank, env.world, env.params
+    strong = case.total_tiles > 0
+    my_tiles, tile0, n_tiles, chunks = rank_plan(case, rank, world)
+    batch, placement = place_batch(ctx, params, n_tiles, tile0, args.masks,
+                                   'first' if env.share_device and args.placement != 'arena' else args.placement,
+                                   args.placement_trials, args.slide_refine, args.slide_slack_gib)
+    chain = ChainInputs(ctx, n_tiles, tile0) if args.chain else None
+
+    def one_step():
+        if chain:                   # terrain shadow + LAND aggregation into the batch's planes, then the classifier
+            chain.layers(batch)
+        for c in chunks:            # dswx_batch_classify: a partial last chunk = the first `c` resident tiles
+            batch.classify(params, n_tiles=c)
+
+    for _ in range(args.warmup):
+        one_step()
+    ctx.synchronize()
+    kernel_info = ctx.last_kernel_info()
+
+    starts = [ctx.event() for _ in range(args.steps)]
+    stops = [ctx.event() for _ in range(args.steps)]
+    cp.barrier()
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ctx.record(starts[k])
+        one_step()
+        ctx.record(stops[k])
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    cp.barrier()
+    elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
+
+    step_ms = [ctx.elapsed_ms(a, b) for a, b in zip(starts, stops)]
+    for e in starts + stops:
+        ctx.destroy_event(e)
+    chain_split = None
+    if chain and rank == 0:             # after the timed region: the three kernels of a step timed one by one
+        def ms_of(fn, reps=10):
+            fn()
+            ctx.synchronize()
+            e0, e1 = ctx.event(), ctx.event()
+            ctx.record(e0)
+            for _ in range(reps):
+                fn()
+            ctx.record(e1)
+            ctx.synchronize()
+            ms = ctx.elapsed_ms(e0, e1) / reps
+            ctx.destroy_event(e0)
+            ctx.destroy_event(e1)
+            return ms
+        both = ms_of(lambda: chain.layers(batch))
+        land_only = ms_of(lambda: ctx.landcover_mask_device(chain.d_wc.ptr, chain.d_cg.ptr, n_tiles, TILE, TILE, CHAIN_FOREST,
+                                                            batch.pin.land, out_tile_stride=batch.tile_stride))
+        chain_split = {'terrain_shadow_ms': round(both - land_only, 4), 'land_aggregation_ms': round(land_only, 4),
+                       'classify_ms': round(ms_of(lambda: batch.classify(params)), 4)}
+    elapsed = cp.max_over_ranks(elapsed)
+    total_px_per_step = cp.sum_over_ranks(my_tiles) * TILE * TILE
+
+    bytes_per_px = 24 if args.masks else 21      # SURVEY.md §8d: 13+8 (16+8 with masks)
+    if chain:       # + terrain shadow (4 B of DEM incl. its margin + 1 written) + LAND aggregation (9 + 1 + 1 written)
+        bytes_per_px = 24 + (4.0 * chain.H * chain.W / (TILE * TILE) + 1.0) + 11.0
+    # dominant kernel: one launch = one resident chunk; a step is len(chunks) launches
+    px_per_launch = n_tiles * TILE * TILE
+    my_px_per_step = my_tiles * TILE * TILE
+    avg_step_ms = sum(step_ms) / len(step_ms)
+    achieved = my_px_per_step * bytes_per_px / (avg_step_ms * 1e-3) / 1e9
+    avg_launch_ms = avg_step_ms * px_per_launch / my_px_per_step
+
+    def probe_frac(ms):
+        return round(px_per_launch * bytes_per_px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None
+
+    # what THIS rank saw: gathered into the line, the slowest rank named (value is bounded by it)
+    mine = {'rank': rank, 'device': env.device_id, 'tiles_per_step': my_tiles, 'launches_per_step': len(chunks),
+            'wall_ms_per_step': round(my_elapsed / args.steps * 1e3, 4),
+            'launch_ms_avg': round(avg_launch_ms, 4), 'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'placement': {'how': placement['how'], 'probes': placement.get('probes', 0),
+                          'first_come_launch_ms': placement.get('first_come_launch_ms'),
+                          'kept_launch_ms': placement.get('kept_launch_ms'),
+                          'frac_first_come_probe': probe_frac(placement.get('first_come_launch_ms')),
+                          'frac_kept_probe': probe_frac(placement.get('kept_launch_ms'))}}
+    for k in ('note', 'error', 'fallback'):
+        if placement.get(k):
+            mine['placement'][k] = placement[k]
+    per_rank = cp.gather_objects(mine)
+
+    parity = None
+    if not args.no_parity:              # EVERY rank checks its own tiles; the records are gathered into the line
+        try:
+            rec = chain_parity(ctx, batch, params, chain, rank, tile0, sorted({0, n_tiles - 1})) if chain else \
+                rank_parity(ctx, batch, params, rank, tile0, n_tiles, chunks, case.distinct_chunks)
+        except Exception as e:          # the checker failing is reported, not fatal to the measurement
+            rec = {'rank': rank, 'first_tile': tile0, 'result': f'not checked ({type(e).__name__}: {e})'[:300]}
+        records = cp.gather_objects(rec)
+        bad = [r['result'] for r in records if r['result'] != 'bit-exact']
+        parity = {'result': bad[0] if bad else 'bit-exact', 'ranks': records}
+
+    out = None
+    if rank == 0:
+        from proteus_amd import build as _build
+        traffic, pmc_note = pmc_traffic(args.masks, n_tiles)
+        if chain:
+            traffic, pmc_note = None, 'no PMC pass for the three-kernel chain'
+        if strong:
+            workload = (f'BASELINE configs[3]: {case.total_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles in all, split '
+                        f'contiguously over {world} rank(s); a rank walks its share ({my_tiles} tiles on rank 0) in '
+                        f'{len(chunks)} launch(es) over a resident chunk of {n_tiles} tiles (chunks after the first '
+                        f're-use the resident planes: same bytes streamed, the generator stays outside the timed region)')
+        else:
+            workload = (f'BASELINE configs[2]: {n_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles per GPU per step, '
+                        f'device-resident band-planar batch')
+        if chain:
+            workload = (f"BASELINE configs[4], one GPU's share, device-resident: {n_tiles} synthetic {TILE}x{TILE} tiles per step through "
+                        f'terrain shadow layer (DEM {chain.H}x{chain.W}, margin {CHAIN_MARGIN}) -> LAND aggregation (WorldCover '
+                        f'{3 * TILE}x{3 * TILE} + CGLS) -> fused classifier with SHAD + LAND + OCEAN, the two layers written straight into '
+                        f'the planes of the batch (a step = three kernels; L30 / S30 differ in host-side band mapping only)')
+        workload += (f' (tile stride {batch.tile_stride} px = 256-byte aligned tile starts)'
+                     + (', LAND+SHAD+OCEAN planes' if args.masks else ''))
+        devices = sorted({r['device'] for r in per_rank})
+        slowest = max(per_rank, key=lambda r: r['wall_ms_per_step'])
+        out = {
+            'metric': 'Mpixels/sec DSWx classify (3660^2 7-band HLS tiles)',
+            'value': round(total_px_per_step * args.steps / elapsed / 1e6, 1),
+            'unit': 'Mpixels/s',
+            # the number of DISTINCT devices the ranks report (PCI address + UUID), not the number of ranks started
+            'n_gpus': len(devices), 'n_ranks': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
+            'dtype': 'int16+f64', 'data': 'synthetic',
+            'config': {'workload': workload,
+                       'tiles_per_step_all_ranks': total_px_per_step // (TILE * TILE),
+                       'tiles_per_gpu_resident': n_tiles, 'launches_per_step': len(chunks),
+                       'tile': [TILE, TILE], 'tile_stride_px': batch.tile_stride,
+                       'planes_in': 10 if args.masks else 7, 'planes_out': 7,
+                       'sharding': f'tiles by rank x{world}, no collective',
+                       'control_plane': cp.backend,
+                       'arena_placement': dict(placement, note={
+                           'arena': 'all planes in one hipMalloc (dswx_batch_create without flags)',
+                           'first': 'inputs in one allocation, every output plane in its own, as they come',
+                           'slide': 'dswx_batch_place_slide (C-ABI): `positions` candidate placements of the output planes inside '
+                                    'a range 48 GiB longer than they are (packed at every 2 GiB, spread, then per-plane '
+                                    'refinement), the best kept, the rest of the range returned to the device; '
+                                    'first_come_launch_ms = the first-come range timed back to back with the kept one',
+                           'search': 'dswx_batch_place_search (C-ABI): every output plane in the fastest of `trials` candidate '
+                                     'allocations (one pass of coordinate descent, the kernel itself as the probe); '
+                                     'first_come_launch_ms = the first-come planes timed back to back with the kept ones',
+                       }[placement['how']] + '; before warm-up, outside the timed region; rank 0 (every rank: `ranks`); '
+                                             'roofline.realloc_spread shows what unplaced single-arena allocations give'
+                           + ('; library: ' + placement['note'] if placement.get('note') else '')),
+                       'kernel': kernel_info},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': traffic,
+                         'algorithmic_bytes_per_pixel': round(bytes_per_px, 3),
+                         'pixels_per_launch': px_per_launch,
+                         'launch_ms_avg': round(avg_launch_ms, 4),
+                         'launch_ms_min': round(min(step_ms) * px_per_launch / my_px_per_step, 4),
+                         'launch_ms_max': round(max(step_ms) * px_per_launch / my_px_per_step, 4),
+                         'launches_timed': args.steps * len(chunks),
+                         'read_frac_of_peak': round(achieved * (bytes_per_px - 8) / bytes_per_px
+                                                    / HBM_PEAK_GBS, 4),
+                         'traffic_source': pmc_note,
+                         'kernel_source_hash': _build.hot_kernel_hash(),
+                         'rank': 0},
+            'ranks': per_rank,
+            'slowest_rank': {'rank': slowest['rank'], 'device': slowest['device'],
+                             'wall_ms_per_step': slowest['wall_ms_per_step'], 'frac': slowest['frac']},
+            'parity_check': parity,
+        }
+        if len(devices) != world:
+            out['n_gpus_note'] = (f'{world} ranks ran on {len(devices)} distinct device(s)'
+                                  + (' (DSWX_BENCH_SHARE_DEVICE=1: a functional test, not a measurement)' if env.share_device else ''))
+        if chain:
+            out['roofline'].update(chain=chain_split, read_frac_of_peak=None,
+                                   note='achieved / frac = the algorithmic bytes of the three kernels of a step (24 + 5.22 + 11 '
+                                        'per pixel) over the step time')
+        if placement.get('first_come_launch_ms'):
+            # the first-come planes and the kept ones, timed back to back at the end of the placement (3-launch probes:
+            # compare THESE two with each other; sustained rates over the timed steps run 1.5 - 2 % below such probes)
+            out['roofline']['frac_first_come_placement'] = probe_frac(placement['first_come_launch_ms'])
+            out['roofline']['frac_kept_placement_probe'] = probe_frac(placement['kept_launch_ms'])
+    if chain:
+        chain.free()
+    batch.free()
+    return out, n_tiles
 
 
 def main():
@@ -519,7 +829,6 @@ def main():
                 break
             time.sleep(0.5)
     from proteus_amd import _capi, shard
-    from proteus_amd.synth import SEED
 
     share_device = os.environ.get('DSWX_BENCH_SHARE_DEVICE') == '1'
     if share_device:
@@ -529,177 +838,49 @@ def main():
         torch.cuda.set_device(0)
         cp = shard.ControlPlane(backend='gloo', device=None)
     else:
+        # N = 1 has no control plane (cp.backend None) unless DSWX_FORCE_DIST=1 asks for a world of one: the RCCL
+        # code path of an N > 1 run -- init with device_id, barrier, all_reduce on device tensors, all_gather_object,
+        # destroy -- on a box with one GPU (tests/test_gpu_multirank.py)
         torch.cuda.set_device(local_rank)
         cp = shard.ControlPlane(backend='nccl', device=torch.device('cuda', local_rank),
                                 allow_fallback=args.allow_gloo)
 
     ctx = _capi.Context(local_rank)        # raises if the HIP extension / GPU is missing
-    params = _capi.default_params()
-    strong = args.total_tiles > 0
-    my_tiles, tile0, n_tiles, chunks = rank_plan(args, rank, world)
-    batch, placement = place_batch(ctx, params, n_tiles, tile0, args.masks,
-                                   'first' if share_device and args.placement != 'arena' else args.placement,
-                                   args.placement_trials, args.slide_refine, args.slide_slack_gib)
-    barrier = cp.barrier
+    env = argparse.Namespace(ctx=ctx, cp=cp, rank=rank, world=world, params=_capi.default_params(),
+                             share_device=share_device, device_id=device_identity(torch, local_rank))
+    out = None
+    for case in cases_of(args, world):
+        rec, n_tiles = measure_case(args, case, env)
+        if rank == 0:
+            if case.key is None:
+                out = rec
+            else:           # a sub-record: the same fields, minus what only the top level carries
+                out[case.key] = {k: rec[k] for k in ('value', 'unit', 'n_gpus', 'n_ranks', 'steps', 'warmup', 'ms_per_step',
+                                                     'scaling', 'config', 'roofline', 'ranks', 'slowest_rank', 'parity_check')}
+        if case.key is None:
+            headline_tiles = n_tiles
 
-    chain = ChainInputs(ctx, n_tiles, tile0) if args.chain else None
-
-    def one_step():
-        if chain:                   # terrain shadow + LAND aggregation into the batch's planes, then the classifier
-            chain.layers(batch)
-        for c in chunks:            # dswx_batch_classify: a partial last chunk = the first `c` resident tiles
-            batch.classify(params, n_tiles=c)
-
-    for _ in range(args.warmup):
-        one_step()
-    ctx.synchronize()
-    kernel_info = ctx.last_kernel_info()
-
-    starts = [ctx.event() for _ in range(args.steps)]
-    stops = [ctx.event() for _ in range(args.steps)]
-    barrier()
-    torch.cuda.synchronize()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ctx.record(starts[k])
-        one_step()
-        ctx.record(stops[k])
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    step_ms = [ctx.elapsed_ms(a, b) for a, b in zip(starts, stops)]
-    for e in starts + stops:
-        ctx.destroy_event(e)
-    chain_split = None
-    if chain and rank == 0:             # after the timed region: the three kernels of a step timed one by one
-        def ms_of(fn, reps=10):
-            fn()
-            ctx.synchronize()
-            e0, e1 = ctx.event(), ctx.event()
-            ctx.record(e0)
-            for _ in range(reps):
-                fn()
-            ctx.record(e1)
-            ctx.synchronize()
-            ms = ctx.elapsed_ms(e0, e1) / reps
-            ctx.destroy_event(e0)
-            ctx.destroy_event(e1)
-            return ms
-        both = ms_of(lambda: chain.layers(batch))
-        land_only = ms_of(lambda: ctx.landcover_mask_device(chain.d_wc.ptr, chain.d_cg.ptr, n_tiles, TILE, TILE, CHAIN_FOREST,
-                                                            batch.pin.land, out_tile_stride=batch.tile_stride))
-        chain_split = {'terrain_shadow_ms': round(both - land_only, 4), 'land_aggregation_ms': round(land_only, 4),
-                       'classify_ms': round(ms_of(lambda: batch.classify(params)), 4)}
-    elapsed = cp.max_over_ranks(elapsed)
-    total_px_per_step = cp.sum_over_ranks(my_tiles) * TILE * TILE
-
-    parity = None
-    if not args.no_parity:              # EVERY rank checks its own tiles; the records are gathered into the line
-        try:
-            mine = chain_parity(ctx, batch, params, chain, rank, tile0, sorted({0, n_tiles - 1})) if chain else \
-                rank_parity(ctx, batch, params, rank, tile0, n_tiles, chunks, args.distinct_chunks)
-        except Exception as e:          # the checker failing is reported, not fatal to the measurement
-            mine = {'rank': rank, 'first_tile': tile0, 'result': f'not checked ({type(e).__name__}: {e})'[:300]}
-        records = cp.gather_objects(mine)
-        bad = [r['result'] for r in records if r['result'] != 'bit-exact']
-        parity = {'result': bad[0] if bad else 'bit-exact', 'ranks': records}
-
+    # ---- legs after the timed regions (none of them is `value`)
+    host_path = None
+    if not args.no_host_path and not args.chain:
+        try:                            # every rank takes part (all ranks at once, rates summed)
+            host_path = host_path_leg(ctx, cp, env.params, check=not args.no_parity)
+        except Exception as e:          # noqa: BLE001
+            host_path = {'error': f'{type(e).__name__}: {e}'[:300]}
+            if cp.dist is not None:
+                raise                   # a rank that leaves a collective leg strands the others: fail loudly instead
     if rank == 0:
-        bytes_per_px = 24 if args.masks else 21      # 13+8 (16+8 with masks)
-        if chain:       # + terrain shadow (4 B of DEM incl. its margin + 1 written) + LAND aggregation (9 + 1 + 1 written)
-            bytes_per_px = 24 + (4.0 * chain.H * chain.W / (TILE * TILE) + 1.0) + 11.0
-        # dominant kernel: one launch = one resident chunk; a step is len(chunks) launches
-        px_per_launch = n_tiles * TILE * TILE
-        my_px_per_step = my_tiles * TILE * TILE
-        avg_step_ms = sum(step_ms) / len(step_ms)
-        achieved = my_px_per_step * bytes_per_px / (avg_step_ms * 1e-3) / 1e9
-        avg_launch_ms = avg_step_ms * px_per_launch / my_px_per_step
-        traffic, pmc_note = pmc_traffic(args.masks, n_tiles)
-        if chain:
-            traffic, pmc_note = None, 'no PMC pass for the three-kernel chain'
-        if strong:
-            workload = (f'BASELINE configs[3]: {args.total_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles in all, split '
-                        f'contiguously over {world} rank(s); a rank walks its share ({my_tiles} tiles on rank 0) in '
-                        f'{len(chunks)} launch(es) over a resident chunk of {n_tiles} tiles (chunks after the first '
-                        f're-use the resident planes: same bytes streamed, the generator stays outside the timed region)')
-        else:
-            workload = (f'BASELINE configs[2]: {n_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles per GPU per step, '
-                        f'device-resident band-planar batch')
-        if chain:
-            workload = (f"BASELINE configs[4], one GPU's share, device-resident: {n_tiles} synthetic {TILE}x{TILE} tiles per step through "
-                        f'terrain shadow layer (DEM {chain.H}x{chain.W}, margin {CHAIN_MARGIN}) -> LAND aggregation (WorldCover '
-                        f'{3 * TILE}x{3 * TILE} + CGLS) -> fused classifier with SHAD + LAND + OCEAN, the two layers written straight into '
-                        f'the planes of the batch (a step = three kernels; L30 / S30 differ in host-side band mapping only)')
-        workload += (f' (tile stride {batch.tile_stride} px = 256-byte aligned tile starts)'
-                     + (', LAND+SHAD+OCEAN planes' if args.masks else ''))
-        out = {
-            'metric': 'Mpixels/sec DSWx classify (3660^2 7-band HLS tiles)',
-            'value': round(total_px_per_step * args.steps / elapsed / 1e6, 1),
-            'unit': 'Mpixels/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-            'dtype': 'int16+f64', 'data': 'synthetic',
-            'config': {'workload': workload,
-                       'tiles_per_step_all_ranks': total_px_per_step // (TILE * TILE),
-                       'tiles_per_gpu_resident': n_tiles, 'launches_per_step': len(chunks),
-                       'tile': [TILE, TILE], 'tile_stride_px': batch.tile_stride,
-                       'planes_in': 10 if args.masks else 7, 'planes_out': 7,
-                       'sharding': f'tiles by rank x{world}, no collective',
-                       'control_plane': cp.backend,
-                       'arena_placement': dict(placement, note={
-                           'arena': 'all planes in one hipMalloc (dswx_batch_create without flags)',
-                           'first': 'inputs in one allocation, every output plane in its own, as they come',
-                           'slide': 'dswx_batch_place_slide (C-ABI): `positions` candidate placements of the output planes inside '
-                                    'a range 48 GiB longer than they are (packed at every 2 GiB, spread, then per-plane '
-                                    'refinement), the best kept, the rest of the range returned to the device; '
-                                    'first_come_launch_ms = the first-come range timed back to back with the kept one',
-                           'search': 'dswx_batch_place_search (C-ABI): every output plane in the fastest of `trials` candidate '
-                                     'allocations (one pass of coordinate descent, the kernel itself as the probe); '
-                                     'first_come_launch_ms = the first-come planes timed back to back with the kept ones',
-                       }[placement['how']] + '; before warm-up, outside the timed region; roofline.realloc_spread shows what '
-                                             'unplaced single-arena allocations give'),
-                       'kernel': kernel_info},
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': traffic,
-                         'algorithmic_bytes_per_pixel': round(bytes_per_px, 3),
-                         'pixels_per_launch': px_per_launch,
-                         'launch_ms_avg': round(avg_launch_ms, 4),
-                         'launch_ms_min': round(min(step_ms) * px_per_launch / my_px_per_step, 4),
-                         'launch_ms_max': round(max(step_ms) * px_per_launch / my_px_per_step, 4),
-                         'launches_timed': args.steps * len(chunks),
-                         'read_frac_of_peak': round(achieved * (bytes_per_px - 8) / bytes_per_px
-                                                    / HBM_PEAK_GBS, 4),
-                         'traffic_source': pmc_note,
-                         'kernel_source_hash': _build.hot_kernel_hash()},
-            'parity_check': parity,
-        }
-        if chain:
-            out['roofline'].update(chain=chain_split, read_frac_of_peak=None,
-                                   note='achieved / frac = the algorithmic bytes of the three kernels of a step (24 + 5.22 + 11 '
-                                        'per pixel) over the step time')
-        if placement.get('first_come_launch_ms'):
-            # the first-come planes and the kept ones, timed back to back at the end of the placement (3-launch probes:
-            # compare THESE two with each other; sustained rates over the timed steps run 1.5 - 2 % below such probes)
-            def probe_frac(ms):
-                return round(px_per_launch * bytes_per_px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            out['roofline']['frac_first_come_placement'] = probe_frac(placement['first_come_launch_ms'])
-            out['roofline']['frac_kept_placement_probe'] = probe_frac(placement['kept_launch_ms'])
-        if world == 1 and args.realloc_repeats > 0 and not chain:
+        if host_path is not None:
+            out['host_path'] = host_path
+        if world == 1 and args.realloc_repeats > 0 and not args.chain:
             try:
-                batch.free()
-                batch = None
-                out['roofline']['realloc_spread'] = realloc_spread(ctx, params, n_tiles, args.masks,
+                out['roofline']['realloc_spread'] = realloc_spread(ctx, env.params, headline_tiles, args.masks,
                                                                    args.realloc_repeats)
             except Exception as e:
                 out['roofline']['realloc_spread'] = {'error': f'{type(e).__name__}: {e}'[:300]}
-        if world == 1 and not args.no_single_tile and not chain:
+        if world == 1 and not args.no_single_tile and not args.chain:
             try:
-                out['single_tile'] = single_tile_leg(ctx, params, args.masks)
+                out['single_tile'] = single_tile_leg(ctx, env.params, args.masks)
             except Exception as e:
                 out['single_tile'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         if world == 1 and not args.no_cpu_baseline:
@@ -711,10 +892,6 @@ def main():
             except Exception as e:      # a reported baseline must never cost the bench line
                 out['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         print(json.dumps(out), flush=True)
-    if chain:
-        chain.free()
-    if batch is not None:
-        batch.free()
     ctx.close()
     cp.close()
     return 0

@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
     CHECK(dswx_batch_synth(batch, 20251010u, 0, NULL));         /* a real caller uploads its tiles into the planes */
     /* place the output planes: 16 MiB of slack in 2 MiB steps is plenty for a toy batch (bench.py: 48 GiB / 2 GiB) */
     CHECK(dswx_batch_place_slide(batch, &params, 16u << 20, 2u << 20, 2, 1, 2, 0));
-    CHECK(dswx_batch_classify(batch, &params, 0, NULL));
+    CHECK(dswx_batch_classify(batch, &params, DSWX_BATCH_ALL_TILES, NULL));
     CHECK(dswx_stream_synchronize(ctx, NULL));
 
     dswx_planes_out_t out;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DSWX_ABI_VERSION 4
+#define DSWX_ABI_VERSION 5
 
 enum {
     DSWX_OK = 0,
@@ -354,7 +354,17 @@ typedef struct dswx_batch_info {
     int32_t search_probes;            /* probe measurements taken (each `launches` launches) */
     float first_come_launch_ms;       /* the planes as first allocated ... */
     float kept_launch_ms;             /* ... and as kept, timed back to back at the end of the search */
+    /* ABI v5: address space (DSWX_BATCH_SLIDING_OUTPUTS; see dswx_batch_va_budget) */
+    uint64_t va_reserved_bytes;       /* the reservation this batch's output range lives in (0: no range) */
+    uint64_t va_retired_bytes;        /* process-wide: address space of dropped ranges, retired for good */
+    uint64_t va_budget_bytes;         /* process-wide limit on reserved + retired address space */
+    char note[256];                   /* "" or why a sliding batch was allocated packed / why the last
+                                         dswx_batch_place_slide left the planes where they were */
 } dswx_batch_info_t;
+
+/* n_tiles of dswx_batch_classify: every resident tile (ABI v5; up to v4 this was spelled 0, which made an empty last
+ * chunk of a walk re-classify the whole batch -- 0 is now what it says: no tiles, no work) */
+#define DSWX_BATCH_ALL_TILES (-1)
 
 /* The layout rule alone (pure function, no device needed): where dswx_batch_create would put every
  * plane.  geom->tile_stride 0 = height*width rounded up to a multiple of 256 pixels (every tile of
@@ -362,18 +372,35 @@ typedef struct dswx_batch_info {
  * other value is taken as given (>= height*width).  Plane offsets are 256-byte aligned. */
 int dswx_batch_layout(const dswx_batch_geom_t* geom, uint32_t flags, dswx_batch_layout_t* out);
 
+/* DSWX_BATCH_SLIDING_OUTPUTS on a device without HIP virtual memory management: DSWX_ERR_UNSUPPORTED.  If the address
+ * range cannot be had -- hipMemAddressReserve refuses, or the library's address-space budget is spent
+ * (dswx_batch_va_budget) -- the batch is allocated PACKED (as without the flag) and dswx_batch_info_t.note says why;
+ * dswx_batch_info_t.flags shows the layout in effect.  dswx_batch_place_slide on such a batch times the planes where they
+ * are and succeeds (search_probes 0). */
 int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t flags,
                       dswx_batch_t** out);
 /* Frees every allocation of the batch.  A batch must not be USED after its context is destroyed; destroying it
  * afterwards is allowed. */
 int dswx_batch_destroy(dswx_batch_t* batch);
+/* Address space of the sliding ranges (ABI v5).  On ROCm 7.2 / gfx950 an address that a kernel has accessed through one
+ * mapping must never be mapped onto other physical memory: the kernel's translation stays stale and its stores go to the
+ * released memory (plain-HIP reproducer: tools/vmm_reuse_repro.hip).  The library therefore RETIRES
+ * the address range of every sliding range it drops -- all chunks unmapped and released, the addresses reserved for the
+ * life of the process -- and keeps count: `live_bytes` = reserved by ranges in use, `retired_bytes` = by dropped ones.
+ * Memory is never lost, address space is: about 100 GiB per dswx_batch_place_slide at 256 tiles of 3660 x 3660, so the
+ * default BUDGET of 64 TiB (half of the 47-bit space) lasts ~650 placements.  When live + retired + a new request would
+ * pass the budget the library reserves no more: sliding batches fall back as described at dswx_batch_create.
+ * new_budget_bytes 0 = leave the budget as it is; any output pointer may be NULL.  Process-wide, thread-safe. */
+int dswx_batch_va_budget(uint64_t new_budget_bytes, uint64_t* budget_bytes, uint64_t* live_bytes,
+                         uint64_t* retired_bytes);
 /* Device pointers of the planes (absent planes NULL), the resolved geometry and the counters array
  * ([n_tiles][3] int64); any output argument may be NULL.  Hand them to dswx_classify_batch /
  * dswx_synth_batch, or use the two conveniences below. */
 int dswx_batch_planes(const dswx_batch_t* batch, dswx_batch_geom_t* geom, dswx_planes_in_t* in,
                       dswx_planes_out_t* out, int64_t** counters);
 int dswx_batch_info(const dswx_batch_t* batch, dswx_batch_info_t* info);
-/* dswx_classify_batch over the first `n_tiles` resident tiles (0 = all), counters included. */
+/* dswx_classify_batch over the first `n_tiles` resident tiles (DSWX_BATCH_ALL_TILES = all, 0 = none), counters
+ * included. */
 int dswx_batch_classify(dswx_batch_t* batch, const dswx_params_t* params, int64_t n_tiles,
                         void* stream);
 /* dswx_synth_batch into the resident input planes: tiles tile0 .. tile0 + n_tiles - 1. */
@@ -400,8 +427,9 @@ int dswx_batch_place_search(dswx_batch_t* batch, const dswx_params_t* params, in
  * slack / step + 1 + spread_gaps probes without refinement (25 + 4 at 48 GiB / 2 GiB:
  * about 1 s for 256 tiles) and slack_bytes of transient memory, against 185 probes and five spare sets of planes
  * for dswx_batch_place_search.  Output pointers change: call dswx_batch_planes again.  Synchronous.
- * (Address ranges the library reserved are retired, not freed, when a range is dropped -- only address space, never
- * memory: re-reserving freed addresses proved unsafe on ROCm 7.2 / gfx950, see VmRange::destroy in dswx_batch.hip.) */
+ * (Every placement retires the address range it drops -- address space, never memory: see dswx_batch_va_budget.  When the
+ * wide range cannot be reserved or mapped the planes stay where they are, the call succeeds and dswx_batch_info_t.note
+ * says why.) */
 int dswx_batch_place_slide(dswx_batch_t* batch, const dswx_params_t* params, uint64_t slack_bytes,
                            uint64_t step_bytes, int32_t spread_gaps, int32_t refine_passes,
                            int32_t launches, uint64_t keep_free_bytes);

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import build as _build
 
-DSWX_ABI_VERSION = 4
+DSWX_ABI_VERSION = 5
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALIGN = 0, -1, -2, -3, -4, -5
 ADJ_MODES = {'mask': 0, 'ignore': 1, 'cover': 2}
 BAND_NAMES = ('blue', 'green', 'red', 'nir', 'swir1', 'swir2')
@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info',
     'dswx_batch_layout', 'dswx_batch_create', 'dswx_batch_destroy', 'dswx_batch_planes', 'dswx_batch_info',
     'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search', 'dswx_batch_place_slide',
+    'dswx_batch_va_budget',
     'dswx_shadow_layer_batch', 'dswx_landcover_mask_batch')
 
 
@@ -78,7 +79,8 @@ class PlanesOut(ctypes.Structure):
                 [(n, ctypes.c_void_p) for n in F64_LAYERS])
 
 
-# resident batches (include/dswx_hip.h, ABI v4)
+# resident batches (include/dswx_hip.h, ABI v4; v5: address-space accounting, DSWX_BATCH_ALL_TILES)
+BATCH_ALL_TILES = -1
 BATCH_MASKS, BATCH_WTR1_AEROSOL, BATCH_BROWSE, BATCH_SEPARATE_OUTPUTS, BATCH_SLIDING_OUTPUTS = 1, 2, 4, 1 << 10, 1 << 11
 BATCH_MAX_PLANES = 20
 PLANE_INDEX = dict(blue=0, green=1, red=2, nir=3, swir1=4, swir2=5, fmask=6, land=7, shad=8, ocean=9, diag=10,
@@ -96,7 +98,9 @@ class BatchInfo(ctypes.Structure):
     _fields_ = [('geom', BatchGeom), ('flags', ctypes.c_uint32), ('n_allocations', ctypes.c_int32),
                 ('bytes_allocated', ctypes.c_uint64), ('search_candidates', ctypes.c_int32),
                 ('search_probes', ctypes.c_int32), ('first_come_launch_ms', ctypes.c_float),
-                ('kept_launch_ms', ctypes.c_float)]
+                ('kept_launch_ms', ctypes.c_float), ('va_reserved_bytes', ctypes.c_uint64),
+                ('va_retired_bytes', ctypes.c_uint64), ('va_budget_bytes', ctypes.c_uint64),
+                ('note', ctypes.c_char * 256)]
 
 
 _lib = None
@@ -107,6 +111,13 @@ def library_path():
 
 
 _alt_libs = {}
+
+
+def va_budget(new_budget_bytes=0):
+    """dswx_batch_va_budget: the library's process-wide account of the address space its sliding ranges hold."""
+    v = [ctypes.c_uint64() for _ in range(3)]
+    _check(load_library().dswx_batch_va_budget(int(new_budget_bytes), *[ctypes.byref(x) for x in v]))
+    return dict(zip(('budget_bytes', 'live_bytes', 'retired_bytes'), (int(x.value) for x in v)))
 
 
 def load_library(path=None):
@@ -211,6 +222,7 @@ def load_library(path=None):
                                                    ctypes.c_uint64]),
         'dswx_batch_place_slide': (ctypes.c_int, [vp, ctypes.POINTER(Params), ctypes.c_uint64, ctypes.c_uint64,
                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64]),
+        'dswx_batch_va_budget': (ctypes.c_int, [ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_uint64)] * 3),
     }
     for name, (res, args) in sig.items():
         if alt and not hasattr(lib, name):
@@ -218,7 +230,9 @@ def load_library(path=None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.dswx_abi_version() != DSWX_ABI_VERSION:
+    if lib.dswx_abi_version() != DSWX_ABI_VERSION and not (alt and lib.dswx_abi_version() == DSWX_ABI_VERSION - 1):
+        # (an A/B partner may be the previous ABI: tools/ab_variants.py drives it through the classify entries only,
+        # whose signatures have not changed)
         raise RuntimeError('libdswx_hip.so ABI version mismatch; rebuild it')
     if alt:
         _alt_libs[path] = lib
@@ -774,6 +788,8 @@ class DeviceBatch:
         geom = BatchGeom(n_tiles, height, width, stride)
         if stride == 0:                 # an empty tile: let the library resolve the stride (0 stays 0)
             geom.tile_stride = 0
+        self._lib = ctx.lib             # kept for free(): the batch may outlive ctx.handle
+        self.handle = None
         _check(ctx.lib.dswx_batch_create(ctx.handle, ctypes.byref(geom), flags, ctypes.byref(h)))
         self.handle = h
         self.out_layers = ['wtr1'] + (['wtr1_aerosol'] if 'wtr1_aerosol' in extra_layers else []) + \
@@ -797,7 +813,9 @@ class DeviceBatch:
         return {'bytes_allocated': int(bi.bytes_allocated), 'n_allocations': int(bi.n_allocations),
                 'flags': int(bi.flags), 'search_candidates': int(bi.search_candidates),
                 'search_probes': int(bi.search_probes),
-                'first_come_launch_ms': float(bi.first_come_launch_ms), 'kept_launch_ms': float(bi.kept_launch_ms)}
+                'first_come_launch_ms': float(bi.first_come_launch_ms), 'kept_launch_ms': float(bi.kept_launch_ms),
+                'va_reserved_bytes': int(bi.va_reserved_bytes), 'va_retired_bytes': int(bi.va_retired_bytes),
+                'va_budget_bytes': int(bi.va_budget_bytes), 'note': bi.note.decode()}
 
     def place_search(self, params, candidates=6, launches=3, keep_free_bytes=8 << 30):
         """dswx_batch_place_search: measured placement of the output planes (separate_outputs batches whose inputs
@@ -822,30 +840,42 @@ class DeviceBatch:
                                                    int(keep_free_bytes)))
         self._rebind()
         i = self.info()
-        return {'positions': i['search_candidates'], 'probes': i['search_probes'],
-                'first_come_launch_ms': round(i['first_come_launch_ms'], 4),
-                'kept_launch_ms': round(i['kept_launch_ms'], 4)}
+        rec = {'positions': i['search_candidates'], 'probes': i['search_probes'],
+               'first_come_launch_ms': round(i['first_come_launch_ms'], 4),
+               'kept_launch_ms': round(i['kept_launch_ms'], 4), 'va_retired_gib': round(i['va_retired_bytes'] / 2 ** 30, 2)}
+        if i['note']:
+            rec['note'] = i['note']
+        return rec
 
     def synth(self, seed, tile0=0, stream=None):
         _check(self.ctx.lib.dswx_batch_synth(self.handle, int(seed), int(tile0),
                                              ctypes.c_void_p(stream) if stream else None))
 
-    def classify(self, params, stream=None, counters=True, n_tiles=0):
-        """The first `n_tiles` resident tiles (0 = all).  counters=False goes through dswx_classify_batch with a
-        NULL counters pointer (dswx_batch_classify always counts)."""
+    def classify(self, params, stream=None, counters=True, n_tiles=None):
+        """The first `n_tiles` resident tiles (None = all, DSWX_BATCH_ALL_TILES; 0 = none: an empty chunk is no work).
+        counters=False goes through dswx_classify_batch with a NULL counters pointer (dswx_batch_classify always counts)."""
+        if n_tiles is None:
+            n_tiles = BATCH_ALL_TILES
         if counters:
             _check(self.ctx.lib.dswx_batch_classify(self.handle, ctypes.byref(params), int(n_tiles),
                                                     ctypes.c_void_p(stream) if stream else None))
-        else:
-            geom = BatchGeom(n_tiles or self.n_tiles, self.height, self.width, self.tile_stride)
+        elif n_tiles != 0:
+            geom = BatchGeom(self.n_tiles if n_tiles == BATCH_ALL_TILES else n_tiles, self.height, self.width,
+                             self.tile_stride)
             self.ctx.classify_batch(params, geom, self.pin, self.pout, None, stream)
 
     def _plane(self, name):
         if name in BAND_NAMES:
-            return self.pin.band[BAND_NAMES.index(name)], np.int16
-        if name in ('fmask', 'land', 'shad', 'ocean'):
-            return getattr(self.pin, name), np.uint8
-        return getattr(self.pout, name), (np.uint16 if name == 'diag' else np.uint8)
+            ptr, dt = self.pin.band[BAND_NAMES.index(name)], np.int16
+        elif name in ('fmask', 'land', 'shad', 'ocean'):
+            ptr, dt = getattr(self.pin, name), np.uint8
+        elif name == 'diag' or name in U8_LAYERS:
+            ptr, dt = getattr(self.pout, name), (np.uint16 if name == 'diag' else np.uint8)
+        else:
+            raise ValueError(f'unknown plane {name!r}')
+        if not ptr:
+            raise ValueError(f'plane {name!r} is not part of this batch (masks / extra_layers of DeviceBatch)')
+        return ptr, dt
 
     def read_tile(self, name, tile):
         """Download one plane of one tile as [H,W]."""
@@ -874,13 +904,14 @@ class DeviceBatch:
         return out
 
     def free(self):
+        """dswx_batch_destroy: allowed after the context is gone (the batch remembers its device), so the HBM of a
+        batch that outlives its Context is still returned."""
         if self.handle:
-            self.ctx.lib.dswx_batch_destroy(self.handle)
+            self._lib.dswx_batch_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
         try:
-            if self.ctx.handle:
-                self.free()
+            self.free()
         except Exception:
             pass

@@ -6,8 +6,9 @@
 
 hipcc cross-compiles gfx950 without a GPU; the built .so files are git-ignored but travel with the
 gpurun snapshot.  `python -m proteus_amd.build` or __graft_entry__.build() call this.  Every entry
-(tests, bench.py, smoke) calls build(): it is a no-op when the libraries are newer than their sources,
-so an edited kernel can never be measured or tested through a stale binary.
+(tests, bench.py, smoke) calls build(): it is a no-op when the stamp beside a library (`*.so.srchash`) holds the
+content digest of its sources and compiler flags, so an edited kernel can never be measured or tested through a
+stale binary -- and a prebuilt library copied to a box without hipcc (mtimes reordered) is still recognised.
 """
 import contextlib
 import fcntl
@@ -45,19 +46,60 @@ def find_hipcc():
     return None
 
 
-def _stale(lib, deps):
-    if not os.path.exists(lib):
+def _digest(paths, extra=b''):
+    h = hashlib.sha256(extra)
+    for path in paths:
+        h.update(os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as f:
+            h.update(f.read())
+        h.update(b'\0')
+    return h.hexdigest()
+
+
+def _stamp(lib):
+    return lib + '.srchash'
+
+
+def _stale(lib, deps, extra=b''):
+    """A library is fresh when the stamp beside it holds the digest of the CONTENT of its sources and flags --
+    not when its mtime is newer: a checkout or an rsync reorders mtimes, and a box without hipcc must still be able
+    to tell a good prebuilt library from a stale one."""
+    if not os.path.exists(lib) or not os.path.exists(_stamp(lib)):
         return True
-    t = os.path.getmtime(lib)
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(_stamp(lib)) as f:
+            return f.read().strip() != _digest(deps, extra)
+    except OSError:
+        return True
+
+
+def _product_deps():
+    return SOURCES + HEADERS + [PUBLIC_HEADER]
+
+
+def _lab_deps():
+    return LAB_SOURCES + LAB_HEADERS + HEADERS + [PUBLIC_HEADER]
+
+
+def _flags_tag():
+    return ' '.join(HIPCC_FLAGS).encode()
 
 
 def is_stale():
-    return _stale(LIB_PATH, SOURCES + HEADERS + [PUBLIC_HEADER])
+    return _stale(LIB_PATH, _product_deps(), _flags_tag())
+
+
+def _product_stamp():
+    try:
+        with open(_stamp(LIB_PATH)) as f:
+            return f.read().strip().encode()
+    except OSError:
+        return b'missing'
 
 
 def lab_is_stale():
-    return _stale(LAB_PATH, LAB_SOURCES + LAB_HEADERS + HEADERS + [PUBLIC_HEADER, LIB_PATH])
+    # the lab library links against the product library: a new product build makes it stale too
+    return _stale(LAB_PATH, _lab_deps(), _flags_tag() + _product_stamp())
 
 
 def hot_kernel_hash():
@@ -80,9 +122,15 @@ def _run(cmd, verbose):
 @contextlib.contextmanager
 def _build_lock():
     """One builder at a time across processes (ranks, xdist workers, batch workers all call build()): the
-    others wait here and then find the library fresh."""
+    others wait here and then find the library fresh.  A directory that cannot be written (read-only install)
+    cannot be built into either: no lock then, and the compile step reports the real error."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as f:
+    try:
+        f = open(os.path.join(LIB_DIR, '.build.lock'), 'a')
+    except OSError:
+        yield
+        return
+    with f:
         fcntl.flock(f, fcntl.LOCK_EX)
         try:
             yield
@@ -90,12 +138,19 @@ def _build_lock():
             fcntl.flock(f, fcntl.LOCK_UN)
 
 
+def _write_stamp(lib, digest):
+    tmp = f'{_stamp(lib)}.{os.getpid()}.tmp'
+    with open(tmp, 'w') as f:
+        f.write(digest + '\n')
+    os.replace(tmp, _stamp(lib))
+
+
 def _need_hipcc(lib):
     hipcc = find_hipcc()
     if hipcc is None:
         # never a stale binary: a library older than its sources is not what the sources say
         raise RuntimeError(f'hipcc not found and {os.path.relpath(lib, ROOT)} is '
-                           + ('older than its sources' if os.path.exists(lib) else 'missing')
+                           + ('not the build of these sources (content digest differs)' if os.path.exists(lib) else 'missing')
                            + ' (need ROCm for the gfx950 build)')
     return hipcc
 
@@ -110,8 +165,12 @@ def build(force=False, verbose=False):
             return LIB_PATH
         hipcc = _need_hipcc(LIB_PATH)
         tmp = f'{LIB_PATH}.{os.getpid()}.tmp'
+        digest = _digest(_product_deps(), _flags_tag())         # of what is compiled now, read before the compile
         _run([hipcc] + HIPCC_FLAGS + ['-I', INCLUDE, '-I', CSRC] + SOURCES + ['-o', tmp], verbose)
+        if os.path.exists(_stamp(LIB_PATH)):
+            os.remove(_stamp(LIB_PATH))                         # never a new library beside an old stamp
         os.replace(tmp, LIB_PATH)
+        _write_stamp(LIB_PATH, digest)
     return LIB_PATH
 
 
@@ -125,9 +184,13 @@ def build_lab(force=False, verbose=False):
             return LAB_PATH
         hipcc = _need_hipcc(LAB_PATH)
         tmp = f'{LAB_PATH}.{os.getpid()}.tmp'
+        digest = _digest(_lab_deps(), _flags_tag() + _product_stamp())
         _run([hipcc] + HIPCC_FLAGS + ['-I', INCLUDE, '-I', CSRC, '-I', LAB] + LAB_SOURCES +
              ['-L', LIB_DIR, '-ldswx_hip', '-Wl,-rpath,$ORIGIN', '-o', tmp], verbose)
+        if os.path.exists(_stamp(LAB_PATH)):
+            os.remove(_stamp(LAB_PATH))
         os.replace(tmp, LAB_PATH)
+        _write_stamp(LAB_PATH, digest)
     return LAB_PATH
 
 

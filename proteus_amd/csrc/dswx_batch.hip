@@ -17,7 +17,10 @@
 // plane, each bound to the fastest of a few spare allocations).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -57,14 +60,48 @@ inline int elem_bytes(int plane) {
     return (plane <= DSWX_PLANE_BAND0 + 5 || plane == DSWX_PLANE_DIAG) ? 2 : 1;
 }
 
+// ---- address space ----------------------------------------------------------------------------------------------
+// An address that a kernel has accessed through one mapping must never be mapped onto other physical memory in this
+// process.  Measured in round 4 with plain HIP (tools/vmm_reuse_repro.hip, profiles/r04_vmm_reuse_repro.jsonl; ROCm 7.2,
+// gfx950): map chunk A at VA, a kernel fills it, hipMemUnmap + hipMemRelease, map a NEW chunk B at the same VA -- with or
+// without hipMemAddressFree / hipMemAddressReserve in between, with or without hipDeviceSynchronize before the unmap --
+// and in 31 of 200 iterations the next kernel's stores never arrive in B (B, seen through a fresh address, still holds
+// what a hipMemcpy put there) while hipMemcpy through VA reads and writes B: the KERNEL's translation of VA is stale
+// (it still points at A's released memory); the copy path resolves VA afresh.  Addresses that were mapped but never
+// touched by a kernel are safe to reuse (mode 3 of the reproducer: 0 of 200).  This is what round 3 saw as "layers read
+// back zeroed" (8 - 27 of 80 two-placement cases) and fenced by retiring ranges; the same library built with the
+// addresses freed (7 of 160 cases wrong), device-synchronised and freed (6 of 160) or kept in a free list and re-mapped
+// (9 of 160) fails, retired it does not (0 of 160): tests/vmm_policy_trial.py, profiles/r04_vmm_policy_trial.json.
+// So a dropped range is RETIRED: every chunk unmapped and released (the memory goes back to the device), the addresses
+// reserved for the life of the process and never mapped again.  That costs address space only -- about 100 GiB per
+// dswx_batch_place_slide at 256 tiles, of the 128 TiB a process has -- and the library keeps count of it
+// (dswx_batch_va_budget, dswx_batch_info_t.va_*): beyond a budget it reserves no more, dswx_batch_create(
+// DSWX_BATCH_SLIDING_OUTPUTS) falls back to the packed allocation and dswx_batch_place_slide leaves the planes where they
+// are, both with the reason in dswx_batch_info_t.note.
+// DSWX_VM_FREE_ADDRESSES (build-time, for tests/vmm_policy_trial.py only): 1 = hipMemAddressFree a dropped range,
+// 2 = hipDeviceSynchronize first -- the two unsafe forms, kept so that the trial can be repeated on a newer ROCm.
+#ifndef DSWX_VM_FREE_ADDRESSES
+#define DSWX_VM_FREE_ADDRESSES 0
+#endif
+
+struct VaPool {
+    std::mutex m;
+    uint64_t live = 0;                                  // reserved by ranges in use
+    uint64_t retired = 0;                               // reserved by dropped ranges: lost to the process for good
+    uint64_t budget = 64ull << 40;                      // live + retired may not pass this: half of the 47-bit space
+};
+VaPool& va_pool() { static VaPool* p = new VaPool; return *p; }     // never destroyed: frees may arrive during exit
+
 // A reserved range of the virtual address space backed chunk by chunk by physical allocations (HIP virtual
 // memory management): unlike a hipMalloc, it can give back the chunks it no longer needs.  The sliding
 // placement maps a range longer than the output planes, times the kernel with the planes at several offsets,
 // and keeps only the chunks under the best one.
 struct VmRange {
     char* va = nullptr;
-    size_t reserved = 0, chunk = 0;
+    size_t reserved = 0;       // the reservation = handle.size() * chunk
+    size_t chunk = 0;
     int device = 0;
+    std::string why;           // create() failed: the reason, for dswx_batch_info_t.note
     std::vector<hipMemGenericAllocationHandle_t> handle;
     std::vector<char> mapped;
 
@@ -74,6 +111,9 @@ struct VmRange {
         return n;
     }
     void destroy() {
+#if DSWX_VM_FREE_ADDRESSES == 2
+        (void)hipDeviceSynchronize();
+#endif
         for (size_t i = 0; i < handle.size(); ++i)
             if (mapped[i]) {
                 (void)hipMemUnmap(va + i * chunk, chunk);
@@ -81,11 +121,16 @@ struct VmRange {
             }
         handle.clear();
         mapped.clear();
-        // The address range itself is NOT handed back (hipMemAddressFree): on this stack (ROCm 7.2, gfx950) a later
-        // hipMemAddressReserve may return the same addresses, and kernels then wrote through stale translations of the
-        // old mapping -- layers came back zeroed in 8 - 27 of 80 two-slide cases of tests/test_gpu_parity.py::
-        // test_sliding_range_survives_repeated_placement, in none of 160 with the range kept reserved.  Every chunk is
-        // unmapped and released, so only address space (47 bits of it) is retired, never memory.
+        if (va) {
+            VaPool& pool = va_pool();
+            std::lock_guard<std::mutex> lock(pool.m);
+            pool.live -= reserved;
+#if DSWX_VM_FREE_ADDRESSES
+            (void)hipMemAddressFree(va, reserved);
+#else
+            pool.retired += reserved;       // never freed, never mapped again (see above)
+#endif
+        }
         va = nullptr;
         reserved = 0;
     }
@@ -94,15 +139,33 @@ struct VmRange {
         device = dev;
         chunk = chunk_bytes;
         const size_t n = (bytes + chunk - 1) / chunk;
+        const size_t need = n * chunk;
         hipMemAllocationProp prop = {};
         prop.type = hipMemAllocationTypePinned;
         prop.location.type = hipMemLocationTypeDevice;
         prop.location.id = dev;
-        void* base = nullptr;
-        hipError_t e = hipMemAddressReserve(&base, n * chunk, 0, nullptr, 0);
-        if (e != hipSuccess) return e;
-        va = static_cast<char*>(base);
-        reserved = n * chunk;
+        {
+            VaPool& pool = va_pool();
+            std::lock_guard<std::mutex> lock(pool.m);
+            if (pool.live + pool.retired + need > pool.budget) {
+                char buf[200];
+                snprintf(buf, sizeof buf, "address-space budget: %llu bytes reserved by live ranges + %llu retired + %llu "
+                         "wanted > %llu (dswx_batch_va_budget)", (unsigned long long)pool.live,
+                         (unsigned long long)pool.retired, (unsigned long long)need, (unsigned long long)pool.budget);
+                why = buf;
+                return hipErrorOutOfMemory;
+            }
+            void* base = nullptr;
+            const hipError_t e = hipMemAddressReserve(&base, need, 0, nullptr, 0);
+            if (e != hipSuccess) {
+                why = std::string("hipMemAddressReserve: ") + hipGetErrorString(e);
+                return e;
+            }
+            va = static_cast<char*>(base);
+            reserved = need;
+            pool.live += reserved;
+        }
+        hipError_t e = hipSuccess;
         for (size_t i = 0; i < n; ++i) {
             hipMemGenericAllocationHandle_t h;
             e = hipMemCreate(&h, chunk, &prop, 0);
@@ -110,7 +173,11 @@ struct VmRange {
                 e = hipMemMap(va + i * chunk, chunk, 0, h, 0);
                 if (e != hipSuccess) (void)hipMemRelease(h);
             }
-            if (e != hipSuccess) { destroy(); return e; }
+            if (e != hipSuccess) {
+                why = std::string("hipMemCreate / hipMemMap: ") + hipGetErrorString(e);
+                destroy();
+                return e;
+            }
             handle.push_back(h);
             mapped.push_back(1);
         }
@@ -118,7 +185,10 @@ struct VmRange {
         acc.location = prop.location;
         acc.flags = hipMemAccessFlagsProtReadWrite;
         e = hipMemSetAccess(va, reserved, &acc, 1);
-        if (e != hipSuccess) destroy();
+        if (e != hipSuccess) {
+            why = std::string("hipMemSetAccess: ") + hipGetErrorString(e);
+            destroy();
+        }
         return e;
     }
     // give back every chunk that touches none of the intervals [lo, hi)
@@ -156,7 +226,9 @@ struct dswx_batch {
     dswx_ctx* ctx = nullptr;
     int device = -1;                           // of ctx; kept here so that destroy works after the context is gone
     dswx_batch_geom_t geom = {};
-    uint32_t flags = 0;
+    uint32_t flags = 0;                        // as laid out (a sliding batch that fell back: without the sliding bit)
+    uint32_t requested_flags = 0;              // as asked for
+    std::string note;                          // why a sliding batch was allocated packed / a placement did nothing
     dswx_batch_layout_t lay = {};
     void* arena = nullptr;
     void* own[DSWX_BATCH_MAX_PLANES] = {};     // SEPARATE_OUTPUTS: the allocation an output plane lives in
@@ -166,6 +238,8 @@ struct dswx_batch {
     int search_candidates = 0, search_probes = 0;
     float first_ms = 0.f, kept_ms = 0.f;
 };
+
+static void set_note(dswx_batch* b, const std::string& text) { b->note = text; }
 
 static void bind_structs(const dswx_batch* b, dswx_planes_in_t* in, dswx_planes_out_t* out) {
     if (in) {
@@ -273,21 +347,34 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
     b->ctx = ctx;
     b->device = ctx->device;
     b->geom = *geom;
+    b->requested_flags = flags;
+    hipError_t e = hipSuccess;
+    if (mode == DSWX_BATCH_SLIDING_OUTPUTS) {
+        // the range first: if the address space cannot be had (the reservation refused, or the library's budget of
+        // retired addresses spent -- dswx_batch_va_budget), the batch is allocated PACKED instead, with the reason on
+        // record: a long-lived service degrades to the first-come rate, it does not fail
+        const size_t bytes = lay.write_span_bytes ? lay.write_span_bytes : kAlign;
+        b->range = new VmRange();
+        if (b->range->create(ctx->device, bytes, chunk_for(bytes)) != hipSuccess) {
+            (void)hipGetLastError();
+            set_note(b, "DSWX_BATCH_SLIDING_OUTPUTS not honoured, planes packed in one allocation: " + b->range->why);
+            delete b->range;
+            b->range = nullptr;
+            flags &= ~(uint32_t)DSWX_BATCH_SLIDING_OUTPUTS;
+            mode = 0;
+            if (int rc = dswx_batch_layout(geom, flags, &lay)) { delete b; return rc; }
+        }
+    }
     b->geom.tile_stride = lay.tile_stride;
     b->flags = flags;
     b->lay = lay;
-    hipError_t e = hipMalloc(&b->arena, lay.arena_bytes);
+    e = hipMalloc(&b->arena, lay.arena_bytes);
     const PlaneSet ps = planes_of(flags);
     if (e == hipSuccess && mode == DSWX_BATCH_SEPARATE_OUTPUTS)
         for (int k : ps.out) {
             e = hipMalloc(&b->own[k], lay.plane_bytes[k] ? lay.plane_bytes[k] : kAlign);
             if (e != hipSuccess) break;
         }
-    if (e == hipSuccess && mode == DSWX_BATCH_SLIDING_OUTPUTS) {
-        const size_t bytes = lay.write_span_bytes ? lay.write_span_bytes : kAlign;
-        b->range = new VmRange();
-        e = b->range->create(ctx->device, bytes, chunk_for(bytes));
-    }
     if (e != hipSuccess) {
         dswx_batch_destroy(b);
         return dswx_fail(DSWX_ERR_HIP, "dswx_batch_create: device allocation failed: %s (arena of %llu bytes)",
@@ -298,6 +385,16 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
         b->ptr[k] = b->own[k] ? b->own[k] : (b->range ? b->range->va : (char*)b->arena) + lay.plane_offset[k];
     b->ptr[DSWX_PLANE_COUNTERS] = (char*)b->arena + lay.plane_offset[DSWX_PLANE_COUNTERS];
     *out = b;
+    return DSWX_OK;
+}
+
+int dswx_batch_va_budget(uint64_t new_budget_bytes, uint64_t* budget_bytes, uint64_t* live_bytes, uint64_t* retired_bytes) {
+    VaPool& pool = va_pool();
+    std::lock_guard<std::mutex> lock(pool.m);
+    if (new_budget_bytes) pool.budget = new_budget_bytes;
+    if (budget_bytes) *budget_bytes = pool.budget;
+    if (live_bytes) *live_bytes = pool.live;
+    if (retired_bytes) *retired_bytes = pool.retired;
     return DSWX_OK;
 }
 
@@ -325,7 +422,15 @@ int dswx_batch_info(const dswx_batch_t* b, dswx_batch_info_t* info) {
     if (b->range) {
         ++info->n_allocations;
         info->bytes_allocated += b->range->mapped_bytes();
+        info->va_reserved_bytes = b->range->reserved;
     }
+    {
+        VaPool& pool = va_pool();
+        std::lock_guard<std::mutex> lock(pool.m);
+        info->va_retired_bytes = pool.retired;
+        info->va_budget_bytes = pool.budget;
+    }
+    snprintf(info->note, sizeof info->note, "%s", b->note.c_str());
     info->search_candidates = b->search_candidates;
     info->search_probes = b->search_probes;
     info->first_come_launch_ms = b->first_ms;
@@ -335,11 +440,13 @@ int dswx_batch_info(const dswx_batch_t* b, dswx_batch_info_t* info) {
 
 int dswx_batch_classify(dswx_batch_t* b, const dswx_params_t* params, int64_t n_tiles, void* stream) {
     if (!b) return dswx_fail(DSWX_ERR_ARG, "batch is NULL");
+    if (n_tiles == DSWX_BATCH_ALL_TILES) n_tiles = b->geom.n_tiles;
     if (n_tiles < 0 || n_tiles > b->geom.n_tiles)
         return dswx_fail(DSWX_ERR_ARG, "n_tiles %lld outside the batch (%lld resident)", (long long)n_tiles,
                          (long long)b->geom.n_tiles);
+    if (n_tiles == 0) return DSWX_OK;          // an empty chunk is no work (not "all": a walk's empty last chunk must not re-classify the batch)
     dswx_batch_geom_t g = b->geom;
-    if (n_tiles) g.n_tiles = n_tiles;
+    g.n_tiles = n_tiles;
     dswx_planes_in_t in;
     dswx_planes_out_t out;
     bind_structs(b, &in, &out);
@@ -356,11 +463,11 @@ int dswx_batch_synth(dswx_batch_t* b, uint64_t seed, int64_t tile0, void* stream
 // `launches` launches of the real kernel over the whole batch, after one untimed launch; ms per launch
 static int probe_ms(dswx_batch* b, const dswx_params_t* params, int launches, hipEvent_t e0, hipEvent_t e1, float* ms) {
     hipStream_t s = b->ctx->stream;
-    if (int rc = dswx_batch_classify(b, params, 0, nullptr)) return rc;
+    if (int rc = dswx_batch_classify(b, params, DSWX_BATCH_ALL_TILES, nullptr)) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipEventRecord(e0, s));
     for (int i = 0; i < launches; ++i)
-        if (int rc = dswx_batch_classify(b, params, 0, nullptr)) return rc;
+        if (int rc = dswx_batch_classify(b, params, DSWX_BATCH_ALL_TILES, nullptr)) return rc;
     HIP_TRY(hipEventRecord(e1, s));
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipEventElapsedTime(ms, e0, e1));
@@ -387,7 +494,8 @@ int dswx_batch_place_search(dswx_batch_t* b, const dswx_params_t* params, int32_
     if ((uint64_t)sets * out_bytes > room) sets = (int)(room / (out_bytes ? out_bytes : 1));
     std::vector<std::vector<void*>> spare(DSWX_BATCH_MAX_PLANES);      // per plane: candidates of ITS size
     bool full = true;
-    for (int sidx = 0; sidx < sets && full; ++sidx)
+    int complete_sets = 0;
+    for (int sidx = 0; sidx < sets && full; ++sidx) {
         for (int k : ps.out) {
             void* p = nullptr;
             if (hipMalloc(&p, b->lay.plane_bytes[k] ? b->lay.plane_bytes[k] : kAlign) != hipSuccess) {
@@ -397,6 +505,8 @@ int dswx_batch_place_search(dswx_batch_t* b, const dswx_params_t* params, int32_
             }
             spare[k].push_back(p);
         }
+        complete_sets += full ? 1 : 0;
+    }
     // planes of equal size share a pool: a candidate one plane did not take is a candidate for the next
     auto pool_of = [&](int k) -> std::vector<void*>& {
         for (int j : ps.out)
@@ -483,7 +593,7 @@ int dswx_batch_place_search(dswx_batch_t* b, const dswx_params_t* params, int32_
         if (!bound) (void)hipFree(p);
     }
     if (rc) return rc;
-    b->search_candidates = sets + 1;
+    b->search_candidates = complete_sets + 1;      // complete spare sets actually obtained + the first-come planes
     b->search_probes = probes;
     b->first_ms = first_ms;
     b->kept_ms = kept_ms;
@@ -494,11 +604,26 @@ int dswx_batch_place_search(dswx_batch_t* b, const dswx_params_t* params, int32_
 int dswx_batch_place_slide(dswx_batch_t* b, const dswx_params_t* params, uint64_t slack_bytes, uint64_t step_bytes,
                            int32_t spread_gaps, int32_t refine_passes, int32_t launches, uint64_t keep_free_bytes) {
     if (!b || !params) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
-    if (!(b->flags & DSWX_BATCH_SLIDING_OUTPUTS) || !b->range)
+    if (!(b->requested_flags & DSWX_BATCH_SLIDING_OUTPUTS))
         return dswx_fail(DSWX_ERR_ARG, "dswx_batch_place_slide needs a DSWX_BATCH_SLIDING_OUTPUTS batch");
     if (launches < 1 || step_bytes == 0 || spread_gaps < 0 || refine_passes < 0)
         return dswx_fail(DSWX_ERR_ARG, "launches and step_bytes must be positive, spread_gaps / refine_passes not negative");
     HIP_TRY(hipSetDevice(b->ctx->device));
+    if (!b->range) {
+        // the batch was asked for as a sliding one and allocated packed (dswx_batch_create's fallback): there is nothing
+        // to slide; time the planes as they are so that the record is complete, keep the note
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        int prc = DSWX_OK;
+        float ms = 0.f;
+        if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) prc = dswx_fail(DSWX_ERR_HIP, "hipEventCreate failed");
+        else prc = probe_ms(b, params, launches, t0, t1, &ms);
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        if (prc) return prc;
+        b->search_candidates = b->search_probes = 0;
+        b->first_ms = b->kept_ms = ms;
+        return DSWX_OK;
+    }
     const PlaneSet ps = planes_of(b->flags);
     const size_t region = b->lay.write_span_bytes ? b->lay.write_span_bytes : kAlign;
     const size_t step = (size_t)((step_bytes + 255) & ~(uint64_t)255);
@@ -527,12 +652,16 @@ int dswx_batch_place_slide(dswx_batch_t* b, const dswx_params_t* params, uint64_
         }
         if ((rc = probe_ms(b, params, launches, e0, e1, &first_ms))) break;
         kept_ms = first_ms;
-        if (slack == 0) break;                      // no room to slide in: the planes stay where they are
+        if (slack == 0) {                           // no room to slide in: the planes stay where they are
+            set_note(b, "dswx_batch_place_slide: no device memory to slide in, planes left where they are");
+            break;
+        }
         wide = new VmRange();
         const size_t chunk = chunk_for(region);
         hipError_t e = wide->create(b->ctx->device, region + slack, chunk);
         if (e != hipSuccess) {
             (void)hipGetLastError();
+            set_note(b, "dswx_batch_place_slide: planes left where they are: " + wide->why);
             delete wide;
             wide = nullptr;
             break;                                  // refused: nothing to choose from

@@ -3,7 +3,18 @@
 //
 // Block = 256 threads = 2048 consecutive pixels of one tile (grid.y = tile); each thread owns one
 // 8-pixel group: 6 x 16-B + 1 x 8-B non-temporal loads (+ 3 x 8 B with LAND / SHAD / OCEAN),
-// 1 x 16-B + 6 x 8-B non-temporal stores.  The tables (2 KiB; 2.5 KiB with masks; + 2 KiB in the EXTRAS
+// 1 x 16-B + 6 x 8-B non-temporal stores.
+//
+// Per-tile lead-in (round 4).  A wave's store to a u8 plane is 512 contiguous bytes; the memory system handles it as
+// whole 128-byte lines only if it STARTS on one.  With tile_stride % 256 != 0 -- the reference's natural layout, tiles
+// stacked contiguously: 3660 x 3660 = 144 (mod 256) -- tile t starts at pixel t * stride of every plane, so a fixed
+// thread -> group mapping puts every wave of every tile but the first across line boundaries on both ends (partial-line
+// writes: 3.7 - 4.2 TB/s on the store side instead of 6.3).  The kernel therefore shifts the
+// mapping PER TILE: thread i of the tile owns group i - lead, lead = (first pixel of the tile in the plane / 8) mod 32,
+// so that lane 0 of every wave sits on a 256-byte boundary of every u8 plane (512 of every int16 plane) whatever the
+// stride; the first `lead` threads of a tile idle and the grid carries up to 31 more groups per tile.  It needs all plane
+// base pointers 256-byte aligned (so that every plane has the same residue) and tile_stride % 8 == 0; lead is 0 for
+// the padded layout.  The tables (2 KiB; 2.5 KiB with masks; + 2 KiB in the EXTRAS
 // instantiations) are built on
 // the device by dswx_build_tables from the same px_w1 / px_chain / finish_px the scalar kernel
 // uses (rebuilt when the parameters change) and copied into LDS by every block.
@@ -51,14 +62,17 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
     const DevParams& P = a.P;
     const long long n_groups = a.n_pixels >> 3;
     const long long tile_base = (long long)blockIdx.y * a.tile_stride;
+    // groups between the last 256-byte boundary of the u8 planes and this tile's first pixel (wave-uniform, SALU)
+    const int lead = (int)((reinterpret_cast<uintptr_t>(a.in.fmask + tile_base) >> 3) & 31u);
     const bool has_l = MASKS && a.in.land, has_s = MASKS && a.in.shad, has_o = MASKS && a.in.ocean;
     uint32_t cnt = 0, t_ocean = 0;       // cnt: valid in the low half, cloud-and-valid in the high half
 
     for (int c = 0; c < LUT_CHUNKS; ++c) {
-        const long long grp = ((long long)blockIdx.x * LUT_CHUNKS + c) * 256 + threadIdx.x;
-        if ((grp - threadIdx.x) >= n_groups) break;                       // block-uniform
-        const bool in_range = grp < n_groups;
-        const long long off = tile_base + (in_range ? grp : n_groups - 1) * 8;
+        const long long grp0 = ((long long)blockIdx.x * LUT_CHUNKS + c) * 256 - lead;     // block-uniform
+        if (grp0 >= n_groups) break;
+        const long long grp = grp0 + threadIdx.x;
+        const bool in_range = (unsigned long long)grp < (unsigned long long)n_groups;
+        const long long off = tile_base + (in_range ? grp : (grp < 0 ? 0 : n_groups - 1)) * 8;
         u32x4 v[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
@@ -113,11 +127,12 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
     }
 }
 
-void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int* threads, long long* gx) {
+// `lead_max`: the largest per-tile lead-in of the launch (0 when every tile starts 256-byte aligned, else 31 groups)
+void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int lead_max, int* threads, long long* gx) {
     (void)ctx;
     const long long per_block = 256LL * (extras ? LUT_EXTRAS_CHUNKS : 1);
     *threads = 256;
-    *gx = (groups + per_block - 1) / per_block;
+    *gx = (groups + lead_max + per_block - 1) / per_block;
 }
 
 int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 block, hipStream_t s, char* info,

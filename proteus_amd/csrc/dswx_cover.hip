@@ -258,8 +258,13 @@ __global__ __launch_bounds__(256) void dswx_cover_finish(const KArgs a) {
         for (int k = 0; k < 4; ++k) { lo[k] = l4[k]; hi[k] = h4[k]; }
         lo[4] = br[0]; hi[4] = br[1];
     };
-    const long long grp0 = (long long)blockIdx.x * FIN_GROUPS * 256 + t;
-    if (VEC && (grp0 + (FIN_GROUPS - 1) * 256) * 8 + 8 <= a.n_pixels) {
+    // per-tile lead-in as in dswx_classify_lut: thread i of the tile owns group i - lead, so that lane 0 of every wave
+    // stores on a 256-byte boundary of the layers whatever the tile stride (contiguous tiles: 3660 x 3660 = 144 mod 256)
+    const uint8_t* const anchor = a.out.wtr ? a.out.wtr : a.out.bwtr ? a.out.bwtr : a.out.conf ? a.out.conf :
+                                  a.out.cloud ? a.out.cloud : a.out.browse ? a.out.browse : a.cover_state;
+    const int lead = VEC ? (int)((reinterpret_cast<uintptr_t>(anchor + tile_base) >> 3) & 31u) : 0;
+    const long long grp0 = (long long)blockIdx.x * FIN_GROUPS * 256 + t - lead;
+    if (VEC && grp0 >= 0 && (grp0 + (FIN_GROUPS - 1) * 256) * 8 + 8 <= a.n_pixels) {
         // every group of this thread is complete: straight-line code, all loads before the first use
         u32x2 st[FIN_GROUPS];
         uint32_t snow8[FIN_GROUPS];
@@ -285,6 +290,7 @@ __global__ __launch_bounds__(256) void dswx_cover_finish(const KArgs a) {
         const long long px0 = (grp0 + u * 256) * 8;
         const long long left = a.n_pixels - px0;
         if (left <= 0) break;
+        if (px0 < 0) continue;              // the lead-in threads of the tile's first block
         const int n = left >= 8 ? 8 : (int)left;
         const long long off = tile_base + px0;
         uint32_t st[2] = {0u, 0u};
@@ -319,7 +325,8 @@ int dswx_cover_stage2_launch(dswx_ctx* ctx, const KArgs& c2, long long n_tiles, 
         uint8_t* const outs[5] = {c2.out.wtr, c2.out.bwtr, c2.out.conf, c2.out.cloud, c2.out.browse};
         for (uint8_t* o : outs) vec = vec && (!o || aligned_to(o, 8));
         const long long groups = (c2.n_pixels + 7) / 8;
-        dim3 fgrid((unsigned)((groups + 256 * FIN_GROUPS - 1) / (256 * FIN_GROUPS)), (unsigned)n_tiles);
+        const long long lead_max = vec ? 31 : 0;
+        dim3 fgrid((unsigned)((groups + lead_max + 256 * FIN_GROUPS - 1) / (256 * FIN_GROUPS)), (unsigned)n_tiles);
         if (vec) hipLaunchKernelGGL(dswx_cover_finish<true>, fgrid, dim3(256), 0, s, c2);
         else hipLaunchKernelGGL(dswx_cover_finish<false>, fgrid, dim3(256), 0, s, c2);
         HIP_TRY(hipGetLastError());

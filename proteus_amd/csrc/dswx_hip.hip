@@ -550,8 +550,9 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     if (any_index && a.P.f32_mode)
         return dswx_fail(DSWX_ERR_UNSUPPORTED, "the float64 index planes describe the integer chain; not available with offset_and_scale_inputs");
     const bool masks = in->land || in->shad || in->ocean;
-    // the fused kernel needs every plane 16-byte aligned at every tile start
-    bool vec_ok = (tile_stride % 16 == 0) || n_tiles == 1;
+    // the fused kernels need every plane 16-byte aligned at every tile start (int16 planes: 8 pixels)
+    bool vec_ok = (tile_stride % 8 == 0) || n_tiles == 1;
+    const bool stride16 = (tile_stride % 16 == 0) || n_tiles == 1;     // the lab's LDS-DMA structures: 16 px per lane
     for (int k = 0; k < 6 && vec_ok; ++k) vec_ok = aligned_to(in->band[k], 16);
     vec_ok = vec_ok && aligned_to(in->fmask, 16) && (!in->land || aligned_to(in->land, 16)) &&
              (!in->shad || aligned_to(in->shad, 16)) && (!in->ocean || aligned_to(in->ocean, 16)) &&
@@ -559,13 +560,20 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     uint8_t* const u8outs[] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud,
                                out->browse};
     for (uint8_t* p : u8outs) vec_ok = vec_ok && (!p || aligned_to(p, 16));
-    // are all tile starts of all planes on 256-byte boundaries?
-    bool aligned256 = (tile_stride % 256 == 0) || n_tiles == 1;
-    for (int k = 0; k < 6 && aligned256; ++k) aligned256 = aligned_to(in->band[k], 256);
-    aligned256 = aligned256 && aligned_to(in->fmask, 256) && (!in->land || aligned_to(in->land, 256)) &&
-                 (!in->shad || aligned_to(in->shad, 256)) && (!in->ocean || aligned_to(in->ocean, 256)) &&
-                 (!out->diag || aligned_to(out->diag, 256));
-    for (uint8_t* p : u8outs) aligned256 = aligned256 && (!p || aligned_to(p, 256));
+    // Do all planes START on 256-byte boundaries?  Then every tile of every plane has the same residue modulo 256
+    // pixels and the table-driven kernel can put every wave access on a line boundary: directly when the tile stride
+    // is a multiple of 256 pixels (the padded batch layout), through its per-tile lead-in otherwise (contiguous
+    // [n_tiles][H * W] arrays, the reference's natural layout: 3660 x 3660 = 144 mod 256) -- dswx_classify_lut.hip.
+    bool bases256 = true;
+    for (int k = 0; k < 6 && bases256; ++k) bases256 = aligned_to(in->band[k], 256);
+    bases256 = bases256 && aligned_to(in->fmask, 256) && (!in->land || aligned_to(in->land, 256)) &&
+               (!in->shad || aligned_to(in->shad, 256)) && (!in->ocean || aligned_to(in->ocean, 256)) &&
+               (!out->diag || aligned_to(out->diag, 256));
+    for (uint8_t* p : u8outs) bases256 = bases256 && (!p || aligned_to(p, 256));
+    const bool stride256 = (tile_stride % 256 == 0) || n_tiles == 1;
+    const bool lut_ok = bases256 && (stride256 || tile_stride % 8 == 0);
+    // the lead-in is a property of the addresses (correct for any of them); 0 only when every tile start is aligned
+    const int lead_max = (bases256 && stride256) ? 0 : 31;  // groups: dswx_lut_geometry
 
     const int64_t max_y = 65535;
     char info[256];
@@ -604,16 +612,17 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             // 'cover' stage 1 and the browse plane: the direct kernel or the table-driven one (3), not
             // the experimental structures
             const bool plain_outputs = !cover && !b.out.browse;
-            // automatic choice: the table-driven kernel when every tile of every plane starts on
-            // a 256-byte boundary (6.1 vs 5.5 TB/s there), the direct kernel otherwise (5.4 vs 5.1)
+            // automatic choice: the table-driven kernel when every plane starts on a 256-byte boundary (its per-tile
+            // lead-in takes care of strides that are not multiples of 256 pixels), the direct kernel for planes at
+            // odd addresses (>= 16-byte aligned)
             int vsel = ctx->lab.fused_variant;
-            if (vsel < 0 || (vsel != 0 && vsel != 3 && !ctx->lab.launch)) vsel = aligned256 ? 3 : 0;
+            if (vsel < 0 || (vsel != 0 && vsel != 3 && (!ctx->lab.launch || !stride16))) vsel = lut_ok ? 3 : 0;
             // the LDS-DMA variants (2, 4, 5) move 16 pixels per lane of the u8 planes
             const bool dma16_ok = (n_pixels & 15) == 0 || vsel == 1 || vsel == 3;
             const bool variant = vsel != 0 && (plain_outputs || vsel == 3) && dma16_ok;
             int threads = 256;
             long long gx_ll = (groups + 255) / 256;
-            if (variant && vsel == 3) dswx_lut_geometry(ctx, groups, !plain_outputs, &threads, &gx_ll);
+            if (variant && vsel == 3) dswx_lut_geometry(ctx, groups, !plain_outputs, lead_max, &threads, &gx_ll);
             else if (variant) ctx->lab.geometry(ctx, vsel, groups, nt, &threads, &gx_ll);
             const int64_t gx = gx_ll;
             const int waves = threads / 64;

@@ -73,7 +73,7 @@ int dswx_make_dev_params(const dswx_params_t* p, DevParams* d);
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // ---- table-driven production kernel (dswx_classify_lut.hip)
-void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int* threads, long long* gx);
+void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int lead_max, int* threads, long long* gx);
 int dswx_lut_launch(dswx_ctx* ctx, const KArgs& args, bool masks, dim3 grid, dim3 block, hipStream_t stream,
                     char* info, size_t info_len);
 

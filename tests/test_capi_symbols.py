@@ -140,7 +140,9 @@ def test_struct_field_offsets_match_a_c_compiler(tmp_path):
     fields = {'dswx_params_t': [n for n, _ in _capi.Params._fields_],
               'dswx_planes_in_t': [n for n, _ in _capi.PlanesIn._fields_],
               'dswx_planes_out_t': [n for n, _ in _capi.PlanesOut._fields_],
-              'dswx_batch_geom_t': [n for n, _ in _capi.BatchGeom._fields_]}
+              'dswx_batch_geom_t': [n for n, _ in _capi.BatchGeom._fields_],
+              'dswx_batch_layout_t': [n for n, _ in _capi.BatchLayout._fields_],
+              'dswx_batch_info_t': [n for n, _ in _capi.BatchInfo._fields_]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dswx_hip.h"', 'int main(void) {']
     for st, names in fields.items():
         for n in names:
@@ -153,11 +155,48 @@ def test_struct_field_offsets_match_a_c_compiler(tmp_path):
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
     got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
     mirrors = {'dswx_params_t': _capi.Params, 'dswx_planes_in_t': _capi.PlanesIn,
-               'dswx_planes_out_t': _capi.PlanesOut, 'dswx_batch_geom_t': _capi.BatchGeom}
+               'dswx_planes_out_t': _capi.PlanesOut, 'dswx_batch_geom_t': _capi.BatchGeom,
+               'dswx_batch_layout_t': _capi.BatchLayout, 'dswx_batch_info_t': _capi.BatchInfo}
     for st, cls in mirrors.items():
         assert int(got[f'{st}.sizeof']) == ctypes.sizeof(cls), st
         for n in fields[st]:
             assert int(got[f'{st}.{n}']) == getattr(cls, n).offset, (st, n)
+
+
+def test_address_space_budget_account_needs_no_device():
+    """dswx_batch_va_budget (ABI v5): the process-wide account of the address space of the sliding ranges -- readable and
+    settable without a GPU; nothing is reserved before the first sliding batch."""
+    before = _capi.va_budget()
+    assert before['budget_bytes'] == 64 << 40 and before['live_bytes'] == 0 and before['retired_bytes'] == 0
+    try:
+        assert _capi.va_budget(1 << 30)['budget_bytes'] == 1 << 30
+        assert _capi.va_budget()['budget_bytes'] == 1 << 30            # 0 = leave as it is
+    finally:
+        _capi.va_budget(before['budget_bytes'])
+    assert _capi.BATCH_ALL_TILES == -1
+
+
+def test_library_freshness_is_decided_by_content_not_mtime(tmp_path, monkeypatch):
+    """a checkout or an rsync reorders mtimes; the stamp beside the library holds a digest of the sources'
+    CONTENT and the compiler flags, so a touched source does not make a good prebuilt library stale (a box without
+    hipcc would otherwise refuse it) and an edited one does."""
+    from proteus_amd import build
+    build.build()
+    assert not build.is_stale()
+    src = build.SOURCES[0]
+    st = os.stat(src)
+    try:
+        os.utime(src, (st.st_atime, st.st_mtime + 10 ** 6))            # "newer" than the library, same bytes
+        assert not build.is_stale()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    edited = tmp_path / 'edited.hip'
+    edited.write_bytes(open(src, 'rb').read() + b'\n// edited\n')
+    monkeypatch.setattr(build, 'SOURCES', [str(edited)] + build.SOURCES[1:])
+    assert build.is_stale()
+    monkeypatch.undo()
+    monkeypatch.setattr(build, 'HIPCC_FLAGS', build.HIPCC_FLAGS + ['-DSOMETHING'])
+    assert build.is_stale()                                            # other flags: another binary
 
 
 def test_bad_mode_raises_like_reference():
