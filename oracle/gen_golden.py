@@ -23,7 +23,9 @@ sys.path.insert(0, ROOT)
 from oracle._ref_import import import_reference  # noqa: E402
 from proteus_amd.synth import synth_tile          # noqa: E402
 
-GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+# DSWX_GOLDEN_OUT: write somewhere else (tests/test_oracle_golden.py::test_goldens_reproduce_from_reference regenerates
+# into a temporary directory and compares with the committed fixtures)
+GOLDEN = os.environ.get('DSWX_GOLDEN_OUT') or os.path.join(ROOT, 'tests', 'golden')
 
 ALT_THRESHOLDS = {
     'default': {},

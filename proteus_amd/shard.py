@@ -41,22 +41,29 @@ def env_rank():
 
 
 class ControlPlane:
-    """Barrier + max-over-ranks; a no-op object for world == 1."""
+    """Barrier + max-over-ranks; a no-op object for world == 1 -- unless DSWX_FORCE_DIST=1 asks for a process group of
+    ONE rank: the same init (RCCL with device_id), barrier, all_reduce on device tensors, all_gather_object and destroy
+    an N > 1 run goes through, on a box with a single GPU (tests/test_gpu_multirank.py)."""
 
     def __init__(self, backend=None, device=None, allow_fallback=False):
         self.rank, self.local_rank, self.world = env_rank()
         self.dist = None
         self.device = device
         self.backend = None
-        if self.world > 1:
+        if self.world > 1 or os.environ.get('DSWX_FORCE_DIST') == '1':
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             kw = {}
-            if backend == 'nccl' and device is not None:
-                kw['device_id'] = device
+            if 'MASTER_PORT' not in os.environ:            # a forced world of one outside torchrun: a private rendezvous
+                import socket
+                with socket.socket() as sock:
+                    sock.bind(('127.0.0.1', 0))
+                    port = sock.getsockname()[1]
+                kw.update(init_method=f'tcp://127.0.0.1:{port}', rank=self.rank, world_size=self.world)
+            dev_kw = {'device_id': device} if backend == 'nccl' and device is not None else {}
             if not dist.is_initialized():
                 try:
-                    dist.init_process_group(backend, **kw)
+                    dist.init_process_group(backend, **kw, **dev_kw)
                     self.backend = backend
                 except Exception as e:                      # noqa: BLE001
                     # RCCL could not come up.  A measurement must not quietly change its control plane:
@@ -67,7 +74,7 @@ class ControlPlane:
                         raise
                     if dist.is_initialized():
                         dist.destroy_process_group()
-                    dist.init_process_group('gloo')
+                    dist.init_process_group('gloo', **kw)
                     self.backend = f'gloo (fallback: {backend} init failed: {str(e)[:120]})'
                     self.device = None
             else:

@@ -14,11 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _bench(*argv):
+def _bench(*argv, share_device=True, force_dist=False):
     env = dict(os.environ)
-    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'DSWX_BENCH_SHARE_DEVICE', 'DSWX_FORCE_DIST'):
         env.pop(k, None)
-    env['DSWX_BENCH_SHARE_DEVICE'] = '1'
+    if share_device:
+        env['DSWX_BENCH_SHARE_DEVICE'] = '1'
+    if force_dist:
+        env['DSWX_FORCE_DIST'] = '1'
     # a child process (never exec from a process that touched the GPU); the parent bench process itself starts the
     # ranks with torch.distributed.run before it imports torch
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), capture_output=True, text=True,
@@ -30,7 +33,9 @@ def _bench(*argv):
 def test_two_ranks_strong_scaling_every_rank_checks_every_chunk():
     out = _bench('--gpus', '2', '--total-tiles', '16', '--tiles', '4', '--steps', '2', '--warmup', '1',
                  '--no-cpu-baseline', '--distinct-chunks')
-    assert out['n_gpus'] == 2 and out['scaling'] == 'strong'
+    # n_gpus counts DISTINCT devices (PCI address + UUID), not ranks: both ranks share device 0 here, and the line says so
+    assert out['n_ranks'] == 2 and out['n_gpus'] == 1 and 'DSWX_BENCH_SHARE_DEVICE' in out['n_gpus_note']
+    assert out['scaling'] == 'strong'
     assert out['config']['tiles_per_step_all_ranks'] == 16 and out['config']['launches_per_step'] == 2
     assert out['config']['control_plane'] == 'gloo'
     par = out['parity_check']
@@ -41,6 +46,19 @@ def test_two_ranks_strong_scaling_every_rank_checks_every_chunk():
     assert r0['tiles'] == [0, 2, 3, 4, 7] and r1['tiles'] == [8, 10, 11, 12, 15]
     assert r0['distinct_chunks'] == 2 and r1['distinct_chunks'] == 2
     assert out['value'] > 0 and out['roofline']['pixels_per_launch'] == 4 * 3660 * 3660
+    # every rank's own numbers are in the line, the slowest one is named (value is bounded by it)
+    ranks = out['ranks']
+    assert [r['rank'] for r in ranks] == [0, 1] and ranks[0]['device'] == ranks[1]['device']
+    for r in ranks:
+        assert r['tiles_per_step'] == 8 and r['launches_per_step'] == 2 and r['launch_ms_avg'] > 0 and 0 < r['frac'] < 1
+        assert r['placement']['how'] == 'first' and r['wall_ms_per_step'] > 0
+    assert out['slowest_rank']['rank'] in (0, 1)
+    assert out['slowest_rank']['wall_ms_per_step'] == max(r['wall_ms_per_step'] for r in ranks)
+    # the end-to-end leg: both ranks at once, rates summed
+    hp = out['host_path']
+    assert hp['ranks'] == 2 and hp['zero_copy_Gpx_s'] > 0 and hp['pageable_Gpx_s'] > 0
+    assert 'MISMATCH' not in hp['parity'] and 'bit-exact vs the C oracle' in hp['parity']
+    assert 'zero copy' in hp['zero_copy_kernel'] and 'dswx_classify_lut' in hp['zero_copy_kernel']
 
 
 def test_chain_mode_shadow_and_land_layers_into_the_batch():
@@ -48,8 +66,8 @@ def test_chain_mode_shadow_and_land_layers_into_the_batch():
     aggregation written straight into the SHAD / LAND planes of the resident batch (dswx_shadow_layer_batch,
     dswx_landcover_mask_batch with the batch's tile stride), then the classifier with SHAD + LAND + OCEAN.  The line's
     parity record compares SHAD and LAND with the numpy oracle's layers and everything downstream with the C oracle."""
-    out = _bench('--chain', '--tiles', '3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline')
-    assert out['n_gpus'] == 1 and 'configs[4]' in out['config']['workload'] and out['config']['planes_in'] == 10
+    out = _bench('--chain', '--tiles', '3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', share_device=False)
+    assert out['n_gpus'] == 1 and out['n_ranks'] == 1 and 'configs[4]' in out['config']['workload'] and out['config']['planes_in'] == 10
     assert out['parity_check']['result'] == 'bit-exact', out['parity_check']
     assert out['parity_check']['ranks'][0]['tiles'] == [0, 2]
     r = out['roofline']
@@ -58,9 +76,122 @@ def test_chain_mode_shadow_and_land_layers_into_the_batch():
 
 
 def test_two_ranks_weak_scaling_rank_offsets():
-    out = _bench('--gpus', '2', '--tiles', '3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--masks')
-    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['tiles_per_step_all_ranks'] == 6
+    out = _bench('--gpus', '2', '--tiles', '3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--masks',
+                 '--no-host-path')
+    assert out['n_ranks'] == 2 and out['scaling'] == 'weak' and out['config']['tiles_per_step_all_ranks'] == 6
+    assert 'host_path' not in out and 'strong' not in out
     par = out['parity_check']
     assert par['result'] == 'bit-exact', par
     assert [r['first_tile'] for r in par['ranks']] == [0, 3]
     assert [r['tiles'] for r in par['ranks']] == [[0, 1, 2], [3, 4, 5]]
+
+
+def test_rccl_control_plane_world_of_one():
+    """the RCCL code path of an N > 1 run had never executed (the two-rank tests above force gloo:
+    RCCL refuses two ranks on one GPU).  DSWX_FORCE_DIST=1 gives bench.py a process group of ONE rank over the 'nccl'
+    backend -- init_process_group with device_id, barrier, all_reduce MAX / SUM on device tensors, all_gather_object,
+    destroy -- around a real (small) measurement whose kernels run on the library's own stream beside torch's.  Every
+    record that an N > 1 line gathers through the control plane must come back through RCCL intact."""
+    out = _bench('--tiles', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-single-tile',
+                 '--realloc-repeats', '0', share_device=False, force_dist=True)
+    assert out['config']['control_plane'] == 'nccl'
+    assert out['n_gpus'] == 1 and out['n_ranks'] == 1 and out['config']['tiles_per_step_all_ranks'] == 2
+    assert out['parity_check']['result'] == 'bit-exact' and out['parity_check']['ranks'][0]['tiles'] == [0, 1]
+    assert [r['rank'] for r in out['ranks']] == [0] and out['ranks'][0]['placement']['how'] == 'slide'
+    assert out['value'] > 0 and out['ms_per_step'] > 0
+    hp = out['host_path']                       # barriers, MAX and SUM of the leg went through RCCL too
+    assert hp['ranks'] == 1 and hp['zero_copy_Gpx_s'] > 0 and 'MISMATCH' not in hp['parity']
+
+
+def test_rccl_control_plane_methods_beside_the_library_stream():
+    """The ControlPlane object itself over RCCL (world of one), every method, interleaved with launches of the library on
+    its own non-blocking stream: values survive the device round trip, close() leaves no process group behind."""
+    code = (
+        "import os, sys, json\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import numpy as np, torch\n"
+        "from proteus_amd import _capi, shard\n"
+        "from proteus_amd.synth import SEED\n"
+        "torch.cuda.set_device(0)\n"
+        "cp = shard.ControlPlane(backend='nccl', device=torch.device('cuda', 0))\n"
+        "assert cp.dist is not None and cp.backend == 'nccl'\n"
+        "ctx = _capi.Context(0)\n"
+        "b = _capi.DeviceBatch(ctx, 2, 200, 300)\n"
+        "b.synth(SEED)\n"
+        "p = _capi.default_params()\n"
+        "cp.barrier()\n"
+        "b.classify(p)\n"
+        "worst = cp.max_over_ranks(1.25)\n"
+        "b.classify(p)\n"
+        "total = cp.sum_over_ranks(2 ** 40 + 3)\n"
+        "ctx.synchronize()\n"
+        "objs = cp.gather_objects({'rank': cp.rank, 'nested': [1, 2.5, 'x']})\n"
+        "cnt = cp.gather_counters(b.read_counters())\n"
+        "cp.close()\n"
+        "import torch.distributed as dist\n"
+        "print(json.dumps({'worst': worst, 'total': total, 'objs': objs, 'cnt': np.asarray(cnt).tolist(), 'left': dist.is_initialized()}))\n"
+        "b.free(); ctx.close()\n")
+    env = dict(os.environ, DSWX_FORCE_DIST='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"worst"')][-1])
+    assert out['worst'] == 1.25 and out['total'] == 2 ** 40 + 3 and out['left'] is False
+    assert out['objs'] == [{'rank': 0, 'nested': [1, 2.5, 'x']}]
+    assert len(out['cnt']) == 2 and all(len(c) == 3 and c[0] > 0 for c in out['cnt'])
+
+
+def test_address_space_budget_spent_falls_back_to_packed_planes():
+    """ADVICE r03 (medium) / VERDICT r03 next-2: every sliding placement retires ~100 GiB of address space (addresses a
+    kernel has used must never be re-mapped on this stack: tools/vmm_reuse_repro.hip), so a long-lived service must not
+    die when that runs out.  With the library's address-space budget capped, dswx_batch_create(SLIDING) allocates the
+    planes PACKED and says why, dswx_batch_place_slide leaves them where they are and succeeds, and the results are
+    bit-exact.  A fresh process, so that the account starts at zero."""
+    code = (
+        "import sys, json\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import numpy as np\n"
+        "from oracle import c_oracle\n"
+        "from proteus_amd import _capi\n"
+        "from proteus_amd.synth import SEED, synth_tile\n"
+        "ctx = _capi.Context(0)\n"
+        "p = _capi.default_params()\n"
+        "rec = {}\n"
+        "def run(tag):\n"
+        "    b = _capi.DeviceBatch(ctx, 3, 300, 400, sliding_outputs=True)\n"
+        "    b.synth(SEED, tile0=40)\n"
+        "    r = b.place_slide(p, slack_bytes=8 << 20, step_bytes=1 << 20, launches=1)\n"
+        "    b.classify(p); ctx.synchronize()\n"
+        "    ok = True\n"
+        "    cnt = b.read_counters()\n"
+        "    for t in range(3):\n"
+        "        s = synth_tile(40 + t, 300, 400)\n"
+        "        e = c_oracle.classify(p, s['bands'], s['fmask'])\n"
+        "        ok = ok and all(np.array_equal(b.read_tile(k, t), e[k]) for k in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'))\n"
+        "        ok = ok and cnt[t].tolist() == e['counters'].tolist()\n"
+        "    rec[tag] = dict(place=r, info=b.info(), exact=ok, account=_capi.va_budget())\n"
+        "    b.free()\n"
+        "run('roomy')\n"
+        "acct = _capi.va_budget()\n"
+        "_capi.va_budget(acct['retired_bytes'] + (1 << 20))      # room for 1 MiB more: no range of this batch fits\n"
+        "run('capped')\n"
+        "_capi.va_budget(64 << 40)\n"
+        "run('restored')\n"
+        "print(json.dumps(rec))\n")
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rec = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"roomy"')][-1])
+    SLIDING = 1 << 11
+    roomy, capped, restored = rec['roomy'], rec['capped'], rec['restored']
+    assert roomy['exact'] and capped['exact'] and restored['exact']
+    assert roomy['info']['flags'] & SLIDING and roomy['place']['positions'] > 0 and roomy['info']['note'] == ''
+    assert roomy['info']['va_reserved_bytes'] > 0
+    # after the batch is gone its ranges are retired (address space, not memory), none is live
+    assert roomy['account']['live_bytes'] > 0 and capped['account']['live_bytes'] == 0
+    assert not capped['info']['flags'] & SLIDING and capped['info']['n_allocations'] == 1
+    assert 'address-space budget' in capped['info']['note'] and 'packed' in capped['info']['note']
+    assert capped['place']['positions'] == 0 and capped['place']['first_come_launch_ms'] > 0
+    assert capped['info']['va_reserved_bytes'] == 0
+    assert capped['account']['retired_bytes'] >= roomy['info']['va_reserved_bytes']      # the dropped ranges: retired, not freed
+    assert restored['info']['flags'] & SLIDING and restored['place']['positions'] > 0

@@ -733,10 +733,52 @@ def test_output_planes_in_separate_allocations(ctx):
     assert (sep.read_tile('wtr', 2) == 77).all() and np.array_equal(sep.read_tile('wtr', 1), one.read_tile('wtr', 1))
     with pytest.raises(_capi.DswxError):
         sep.classify(p, n_tiles=4)                     # more than resident
+    # ABI v5: an EMPTY chunk is no work -- it used to mean "all tiles", so that the empty last chunk of a
+    # walk re-classified the whole batch and overwrote its layers and counters
+    sep.write_tile('wtr', 0, np.full((h, w), 66, np.uint8))
+    sep.classify(p, n_tiles=0)
+    ctx.synchronize()
+    assert (sep.read_tile('wtr', 0) == 66).all() and (sep.read_tile('wtr', 2) == 77).all()
+    sep.classify(p)                                    # DSWX_BATCH_ALL_TILES
+    ctx.synchronize()
+    assert np.array_equal(sep.read_tile('wtr', 0), one.read_tile('wtr', 0))
+    assert np.array_equal(sep.read_tile('wtr', 2), one.read_tile('wtr', 2))
     with pytest.raises(_capi.DswxError):
         one.place_search(p)                            # one arena: nothing to re-bind
+    # planes the batch was not created with: a clear error, not None + int
+    plain = _capi.DeviceBatch(ctx, 1, 8, 8)
+    for absent in ('wtr1_aerosol', 'browse', 'land'):
+        with pytest.raises(ValueError, match='not part of this batch'):
+            plain.read_tile(absent, 0)
+    with pytest.raises(ValueError, match='unknown plane'):
+        plain.write_tile('nonsense', 0, np.zeros((8, 8), np.uint8))
+    plain.free()
     one.free()
     sep.free()
+
+
+def test_batch_outlives_its_context():
+    """the C ABI allows dswx_batch_destroy after the context is gone (the batch remembers its device); the
+    Python face used to skip the destroy then and leaked the batch's HBM until process exit."""
+    c2 = _capi.Context(0)
+    free_before = _free_device_bytes()
+    b = _capi.DeviceBatch(c2, 8, 1024, 1024, sliding_outputs=True)         # ~180 MB in an arena + a VMM range
+    assert _free_device_bytes() < free_before - (100 << 20)
+    c2.close()
+    assert b.handle is not None
+    b.free()
+    assert b.handle is None
+    assert _free_device_bytes() > free_before - (32 << 20)
+    b2 = _capi.DeviceBatch(_capi.Context(0), 2, 64, 64)
+    del b2                                             # __del__ after its context was collected: must not raise or leak
+
+
+def _free_device_bytes():
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    free_b, total_b = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) == 0
+    return free_b.value
 
 
 @pytest.mark.parametrize('mode', ['mask', 'ignore', 'cover'])

@@ -132,6 +132,57 @@ def test_bench_self_launch_weak_scaling_and_single_rank_plan():
     assert out['ranks'][0]['launches'] == [512] * 8 and out['tiles_per_step_all_ranks'] == 4096
 
 
+def test_plain_gpus_command_plans_the_weak_and_the_strong_record():
+    """`bench.py --gpus N` with nothing else -- what the driver runs for the scaling curve -- yields
+    BOTH records in its one line: the weak one at the top level (256 tiles per GPU = configs[2] x N) and BASELINE
+    configs[3] as the `strong` sub-record (4096 tiles split over the ranks, 512-tile resident chunks).  Naming a workload
+    (--tiles / --total-tiles / --masks / --chain) or --no-strong keeps the one record that was asked for."""
+    import json
+    res = _bench('--gpus', '2', '--plan-only')
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['scaling'] == 'weak' and out['tiles_per_step_all_ranks'] == 512
+    assert [(r['first_tile'], r['tiles'], r['launches']) for r in out['ranks']] == [(0, 256, [256]), (256, 256, [256])]
+    st = out['strong']
+    assert st['scaling'] == 'strong' and st['tiles_per_step_all_ranks'] == 4096 and st['n_gpus'] == 2
+    assert [(r['first_tile'], r['tiles'], r['launches']) for r in st['ranks']] == \
+        [(0, 2048, [512] * 4), (2048, 2048, [512] * 4)]
+    for extra in (['--no-strong'], ['--tiles', '8'], ['--masks']):
+        res = _bench('--gpus', '2', '--plan-only', *extra)
+        out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+        assert 'strong' not in out and out['scaling'] == 'weak', extra
+    res = _bench('--plan-only')                                     # N = 1: configs[2] alone
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    assert 'strong' not in out and out['tiles_per_step_all_ranks'] == 256
+
+
+def test_forced_world_of_one_goes_through_the_process_group(tmp_path):
+    """DSWX_FORCE_DIST=1: a process group of ONE rank outside torchrun (private tcp rendezvous), so that every call an
+    N > 1 run makes -- init, barrier, all_reduce MAX / SUM, all_gather_object, destroy -- runs on a single box; here
+    over gloo, on the GPU box over RCCL (tests/test_gpu_multirank.py)."""
+    script = tmp_path / 'one.py'
+    script.write_text(textwrap.dedent('''
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from proteus_amd import shard
+        cp = shard.ControlPlane(backend='gloo')
+        assert cp.dist is not None and cp.backend == 'gloo' and cp.world == 1
+        cp.barrier()
+        assert cp.max_over_ranks(2.5) == 2.5 and cp.sum_over_ranks(7) == 7
+        assert cp.gather_objects({'rank': 0}) == [{'rank': 0}]
+        assert cp.gather_counters(np.arange(6).reshape(2, 3)).tolist() == [[0, 1, 2], [3, 4, 5]]
+        cp.close()
+        assert cp.dist is None
+        print('OK')
+    ''') % ROOT)
+    e = dict(os.environ, DSWX_FORCE_DIST='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
+    assert res.returncode == 0 and 'OK' in res.stdout, res.stderr[-2000:]
+
+
 def test_bench_rank_without_a_gpu_fails_loudly():
     """A real (not --plan-only) run on a box without a GPU must fail, not fall back to anything."""
     from proteus_amd import _capi

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Engine / memory clocks and power while the fused kernel runs back to back (rocm-smi polled from a child process)."""
 import json, os, subprocess, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from proteus_amd import _capi
 from proteus_amd.synth import SEED
 

@@ -7,14 +7,14 @@ measured.  If the rate moves with base / gap inside ONE allocation, the placemen
 other (or to the part's channel / bank hashing) matters and a layout rule could fix it; if it only moves between
 allocations, it is the physical pages the driver handed out.
 
-    python tools/placement_probe.py [--tiles 64] [--reps 5]
+    python tools/lab/placement_probe.py [--tiles 64] [--reps 5]
 """
 import argparse
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from proteus_amd import _capi            # noqa: E402
 from proteus_amd.synth import SEED       # noqa: E402
 

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 3: placement in FRESH processes.  `bash tools/r03_trials.sh rules` = the ten-process table of
-# fixed layouts (profiles/r03_placement_rule_trials.json); `bash tools/r03_trials.sh slide` = the measured placements
+# round 3: placement in FRESH processes.  `bash tools/lab/r03_trials.sh rules` = the ten-process table of
+# fixed layouts (profiles/r03_placement_rule_trials.json); `bash tools/lab/r03_trials.sh slide` = the measured placements
 cd "$GRAFT_REPO_ROOT"
 B="timeout 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-single-tile --realloc-repeats 0 --no-parity"
 if [[ "${1:-rules}" == rules ]]; then

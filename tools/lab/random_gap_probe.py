@@ -2,11 +2,11 @@
 """Can the gain of scattered output planes (round 2's slab probe, profiles/r02_slab_probe.json) be had inside ONE allocation?
 
 One big allocation; the 14 planes of a T-tile batch are laid out with per-plane RANDOM gaps (multiples of `--quantum`)
-instead of the uniform gaps tools/placement_probe.py tried.  If random in-arena layouts reach what separately
+instead of the uniform gaps tools/lab/placement_probe.py tried.  If random in-arena layouts reach what separately
 allocated planes reach, the effect is the relative position of the streams and a layout rule can buy it; if
 they stay at the packed rate, it is the physical ranges.
 
-    python tools/random_gap_probe.py [--tiles 256] [--layouts 8]
+    python tools/lab/random_gap_probe.py [--tiles 256] [--layouts 8]
 """
 import argparse
 import json
@@ -14,7 +14,7 @@ import os
 import random
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from proteus_amd import _capi            # noqa: E402
 from proteus_amd.synth import SEED       # noqa: E402
 

@@ -2,7 +2,7 @@
 """Host-pointer entry from page-locked planes: zero copy (product) vs the staged three-stream pipeline (lab
 switch host_pipeline=1), the C entry timed with its outputs allocated beforehand.
 
-    python tools/zero_copy_probe.py [tiles]
+    python tools/lab/zero_copy_probe.py [tiles]
 """
 import ctypes
 import json
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from proteus_amd import _capi            # noqa: E402
 from proteus_amd.synth import synth_tile  # noqa: E402
 

@@ -20,8 +20,8 @@ for m in "" "--masks"; do
 done
 fi
 if [[ "$WHAT" == *placed* ]]; then
-# the DEFAULT bench configuration (every output plane placed by dswx_batch_place_search, --placement-trials 6) under the
-# kernel trace: the trace then holds the search's probe launches too; tools/summarize_profiles.py --placed keeps the last
+# the DEFAULT bench configuration (--placement slide: dswx_batch_place_slide, ~100 probe launches of the same kernel before warm-up) under the
+# kernel trace: the trace then holds the probe launches too; tools/summarize_profiles.py --placed keeps the last
 # `steps` full-batch dispatches = the timed region
 d=gpurun_out/prof_placed
 rm -rf "$d"; mkdir -p "$d"

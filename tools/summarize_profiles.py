@@ -91,9 +91,13 @@ def summarize_next_rows(a, out):
 
 
 def summarize_placed(a, out):
-    """The kernel trace of `bench.py` in its DEFAULT configuration (output planes placed by dswx_batch_place_search).
-    The trace also holds the search's probe launches (other plane bindings, slower by design) and the warm-up; the
-    timed region = the LAST `steps` full-batch dispatches of the fused kernel.  Writes
+    """The kernel trace of `bench.py` in its DEFAULT configuration (--placement slide: dswx_batch_place_slide).
+    The trace also holds the placement's ~100 x 4 probe launches -- full-batch launches of the SAME kernel on other plane
+    bindings -- and the warm-up, all BEFORE the timed region; after it tools/run_profiles.sh's command line launches
+    nothing of the full batch's grid any more (--realloc-repeats 0, --no-single-tile; the parity check launches nothing at
+    N = 1 and the host-path leg classifies 4 tiles, a smaller grid).  So the timed region = the LAST `steps` dispatches of
+    the fused kernel with the largest grid; the function asserts that they are contiguous in the trace (no other
+    full-batch dispatch, and only the counters kernel, between them).  Writes
       profiles/rNN_kernel_stats_placed.csv              rocprofv3-style stats rows over the timed-region dispatches
       profiles/rNN_kernel_stats_placed_all_launches.csv the rocprofv3 --stats summary as it came (probes included)
       profiles/rNN_placed_summary.json                  per-dispatch durations, the bench line of the same run"""
@@ -115,6 +119,11 @@ def summarize_placed(a, out):
     full = [r for r in disp if int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) == gmax]
     timed = full[-steps:]
     t0, t1 = int(timed[0]['Start_Timestamp']), int(timed[-1]['End_Timestamp'])
+    # the timed steps run back to back: a gap as long as a launch between two of them would mean that something else
+    # (a probe, a re-allocation) sits inside what is taken for the timed region
+    gaps = [int(b['Start_Timestamp']) - int(a_['End_Timestamp']) for a_, b in zip(timed, timed[1:])]
+    longest = max(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in timed)
+    assert all(g < longest for g in gaps), 'the last dispatches of the trace are not one back-to-back timed region'
     rows = {}
     for r in trace:                 # every kernel that ran inside the timed region (the counters kernel too)
         if t0 <= int(r['Start_Timestamp']) and int(r['End_Timestamp']) <= t1:
@@ -131,8 +140,8 @@ def summarize_placed(a, out):
     avg = sum(durs) / len(durs)
     summary = {
         'what': 'rocprofv3 --kernel-trace of `python3 bench.py --tiles 256 --steps 20 --warmup 3` in its default '
-                'configuration (--placement-trials 6: dswx_batch_place_search); the timed region = the last '
-                f'{steps} full-batch dispatches of the fused kernel, the earlier ones are the search probes and the warm-up',
+                'configuration (--placement slide: dswx_batch_place_slide); the timed region = the last '
+                f'{steps} full-batch dispatches of the fused kernel, the earlier ones are the placement probes and the warm-up',
         'kernel': timed[0]['Kernel_Name'], 'full_batch_dispatches_in_trace': len(full), 'timed_region_dispatches': len(durs),
         'trace_avg_ms': avg / 1e6, 'trace_min_ms': min(durs) / 1e6, 'trace_max_ms': max(durs) / 1e6,
         'trace_GBps': px * bpp / avg, 'trace_frac_of_8TBps': px * bpp / avg / 8000.0,
