@@ -38,6 +38,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 TILE = 3660
+STRONG_TOTAL_TILES = 4096          # BASELINE configs[3]
+STRONG_CHUNK_TILES = 512           # its per-GPU share at 8 GPUs, resident at once (89 GB + 55 GB)
 
 
 def parse_args():
@@ -89,6 +91,10 @@ def parse_args():
     ap.add_argument('--no-single-tile', action='store_true',
                     help='skip the configs[1] leg (profiling runs: keeps the kernel statistics to the batch launches)')
     ap.add_argument('--cpu-parallel-worker', type=int, default=0, help=argparse.SUPPRESS)
+    # the two-record plain command at toy sizes (tests/test_gpu_multirank.py: two ranks share one device there)
+    ap.add_argument('--plain-tiles', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--strong-total', type=int, default=STRONG_TOTAL_TILES, help=argparse.SUPPRESS)
+    ap.add_argument('--strong-chunk', type=int, default=STRONG_CHUNK_TILES, help=argparse.SUPPRESS)
     args = ap.parse_args()
     # "plain": the command line names no workload -- what the driver runs (`bench.py --gpus N --steps K --warmup W`)
     args.plain_command = args.tiles <= 0 and args.total_tiles <= 0 and not args.chain and not args.masks
@@ -97,7 +103,7 @@ def parse_args():
             ap.error('--chain is a weak-scaling mode (one resident batch per GPU)')
         args.masks = True
     if args.tiles <= 0:
-        args.tiles = 512 if args.total_tiles > 0 else 256
+        args.tiles = 512 if args.total_tiles > 0 else (args.plain_tiles or 256)
     if args.placement_trials is not None:
         args.placement = 'arena' if args.placement_trials <= 0 else 'first' if args.placement_trials == 1 else 'search'
     elif args.placement == 'search':
@@ -485,10 +491,6 @@ def rank_plan(case, rank, world):
     return case.tiles, lo, case.tiles, [case.tiles]
 
 
-STRONG_TOTAL_TILES = 4096          # BASELINE configs[3]
-STRONG_CHUNK_TILES = 512           # its per-GPU share at 8 GPUs, resident at once (89 GB + 55 GB)
-
-
 def cases_of(args, world):
     """The measured configurations of this command line.  The first is the top-level record of the line.  A plain
     `bench.py --gpus N` (N > 1, neither --tiles nor --total-tiles nor --chain) -- what the driver runs for the scaling
@@ -499,7 +501,7 @@ def cases_of(args, world):
                                key=None)
     cases = [first]
     if world > 1 and args.plain_command and not args.no_strong:
-        cases.append(argparse.Namespace(total_tiles=STRONG_TOTAL_TILES, tiles=STRONG_CHUNK_TILES, distinct_chunks=True,
+        cases.append(argparse.Namespace(total_tiles=args.strong_total, tiles=args.strong_chunk, distinct_chunks=True,
                                         key='strong'))
     return cases
 

@@ -115,9 +115,9 @@ _alt_libs = {}
 
 def va_budget(new_budget_bytes=0):
     """dswx_batch_va_budget: the library's process-wide account of the address space its sliding ranges hold."""
-    v = [ctypes.c_uint64() for _ in range(3)]
+    v = [ctypes.c_uint64() for _ in range(4)]
     _check(load_library().dswx_batch_va_budget(int(new_budget_bytes), *[ctypes.byref(x) for x in v]))
-    return dict(zip(('budget_bytes', 'live_bytes', 'retired_bytes'), (int(x.value) for x in v)))
+    return dict(zip(('budget_bytes', 'live_bytes', 'retired_bytes', 'loose_bytes'), (int(x.value) for x in v)))
 
 
 def load_library(path=None):
@@ -222,7 +222,7 @@ def load_library(path=None):
                                                    ctypes.c_uint64]),
         'dswx_batch_place_slide': (ctypes.c_int, [vp, ctypes.POINTER(Params), ctypes.c_uint64, ctypes.c_uint64,
                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64]),
-        'dswx_batch_va_budget': (ctypes.c_int, [ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_uint64)] * 3),
+        'dswx_batch_va_budget': (ctypes.c_int, [ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_uint64)] * 4),
     }
     for name, (res, args) in sig.items():
         if alt and not hasattr(lib, name):

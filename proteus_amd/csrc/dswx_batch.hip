@@ -72,12 +72,12 @@ inline int elem_bytes(int plane) {
 // back zeroed" (8 - 27 of 80 two-placement cases) and fenced by retiring ranges; the same library built with the
 // addresses freed (7 of 160 cases wrong), device-synchronised and freed (6 of 160) or kept in a free list and re-mapped
 // (9 of 160) fails, retired it does not (0 of 160): tests/vmm_policy_trial.py, profiles/r04_vmm_policy_trial.json.
-// So a dropped range is RETIRED: every chunk unmapped and released (the memory goes back to the device), the addresses
-// reserved for the life of the process and never mapped again.  That costs address space only -- about 100 GiB per
-// dswx_batch_place_slide at 256 tiles, of the 128 TiB a process has -- and the library keeps count of it
-// (dswx_batch_va_budget, dswx_batch_info_t.va_*): beyond a budget it reserves no more, dswx_batch_create(
-// DSWX_BATCH_SLIDING_OUTPUTS) falls back to the packed allocation and dswx_batch_place_slide leaves the planes where they
-// are, both with the reason in dswx_batch_info_t.note.
+// So the addresses of a dropped range are QUARANTINED for the life of the process (VmRange::destroy below: freed, which
+// is what returns the memory on this stack, and reserved again at once with nothing mapped).  That costs address space
+// only -- about 100 GiB per dswx_batch_place_slide at 256 tiles, of the 128 TiB a process has -- and the library keeps
+// count of it (dswx_batch_va_budget, dswx_batch_info_t.va_*): beyond a budget it reserves no more,
+// dswx_batch_create(DSWX_BATCH_SLIDING_OUTPUTS) falls back to the packed allocation and dswx_batch_place_slide leaves the
+// planes where they are, both with the reason in dswx_batch_info_t.note.
 // DSWX_VM_FREE_ADDRESSES (build-time, for tests/vmm_policy_trial.py only): 1 = hipMemAddressFree a dropped range,
 // 2 = hipDeviceSynchronize first -- the two unsafe forms, kept so that the trial can be repeated on a newer ROCm.
 #ifndef DSWX_VM_FREE_ADDRESSES
@@ -87,28 +87,51 @@ inline int elem_bytes(int plane) {
 struct VaPool {
     std::mutex m;
     uint64_t live = 0;                                  // reserved by ranges in use
-    uint64_t retired = 0;                               // reserved by dropped ranges: lost to the process for good
+    uint64_t retired = 0;                               // dropped ranges in quarantine: reserved, nothing mapped, for good
+    uint64_t loose = 0;                                 // dropped ranges whose addresses could not be taken back at once
     uint64_t budget = 64ull << 40;                      // live + retired may not pass this: half of the 47-bit space
 };
 VaPool& va_pool() { static VaPool* p = new VaPool; return *p; }     // never destroyed: frees may arrive during exit
 
-// A reserved range of the virtual address space backed chunk by chunk by physical allocations (HIP virtual
-// memory management): unlike a hipMalloc, it can give back the chunks it no longer needs.  The sliding
-// placement maps a range longer than the output planes, times the kernel with the planes at several offsets,
-// and keeps only the chunks under the best one.
+// A reserved range of the virtual address space backed chunk by chunk by physical allocations (HIP virtual memory
+// management).  The sliding placement maps a range longer than the output planes, times the kernel with the planes at
+// several places of it, and keeps only the chunks under the best one -- by moving those chunks (their physical memory,
+// hipMemGenericAllocationHandle_t) into a fresh range and dropping the wide one.
+// Two facts of this stack shape the life cycle (ROCm 7.2 / gfx950; tools/lab/vmm_meminfo.hip, profiles/r04_vmm_meminfo.json):
+//   * the physical memory of a chunk that was ever mapped returns to the device only when the RESERVATION it was mapped in
+//     is freed (hipMemAddressFree) -- hipMemUnmap + hipMemRelease alone keep it allocated (round 3's "trim" of the unused
+//     chunks of a live range therefore returned nothing, and its retired ranges kept their memory);
+//   * freed addresses must not come back (stale translations, above).
+// destroy() reconciles them: unmap, release, hipMemAddressFree -- the memory is back -- and at once
+// hipMemAddressReserve at the SAME address with nothing mapped: the addresses are quarantined for the life of the
+// process (32 of 32 GiB returned and the same address obtained in the probe; a second request for that address is sent
+// elsewhere).
 struct VmRange {
     char* va = nullptr;
     size_t reserved = 0;       // the reservation = handle.size() * chunk
     size_t chunk = 0;
     int device = 0;
-    std::string why;           // create() failed: the reason, for dswx_batch_info_t.note
+    std::string why;           // create() / rehome() failed: the reason, for dswx_batch_info_t.note
     std::vector<hipMemGenericAllocationHandle_t> handle;
-    std::vector<char> mapped;
+    std::vector<char> mapped;  // chunk i of the range is backed by handle[i]
 
     size_t mapped_bytes() const {
         size_t n = 0;
         for (char m : mapped) n += m ? chunk : 0;
         return n;
+    }
+    static hipMemAllocationProp prop_of(int dev) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        return prop;
+    }
+    hipError_t allow(size_t first_chunk, size_t n_chunks) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop_of(device).location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        return hipMemSetAccess(va + first_chunk * chunk, n_chunks * chunk, &acc, 1);
     }
     void destroy() {
 #if DSWX_VM_FREE_ADDRESSES == 2
@@ -125,47 +148,54 @@ struct VmRange {
             VaPool& pool = va_pool();
             std::lock_guard<std::mutex> lock(pool.m);
             pool.live -= reserved;
-#if DSWX_VM_FREE_ADDRESSES
-            (void)hipMemAddressFree(va, reserved);
-#else
-            pool.retired += reserved;       // never freed, never mapped again (see above)
+            (void)hipMemAddressFree(va, reserved);              // the memory of every chunk ever mapped here goes back NOW
+#if !DSWX_VM_FREE_ADDRESSES
+            void* again = nullptr;                              // ... and the addresses into quarantine
+            if (hipMemAddressReserve(&again, reserved, 0, va, 0) == hipSuccess && again == va) {
+                pool.retired += reserved;
+            } else {            // someone took them in between (another thread's allocation): they are out of our hands
+                if (again) (void)hipMemAddressFree(again, reserved);
+                (void)hipGetLastError();
+                pool.loose += reserved;
+            }
 #endif
         }
         va = nullptr;
         reserved = 0;
     }
-    // reserve `bytes` (rounded up to whole chunks), back all of it, make it accessible from `dev`
-    hipError_t create(int dev, size_t bytes, size_t chunk_bytes) {
+    // reserve `need` bytes of addresses (a multiple of the chunk size), nothing mapped
+    hipError_t reserve(int dev, size_t need, size_t chunk_bytes) {
         device = dev;
         chunk = chunk_bytes;
-        const size_t n = (bytes + chunk - 1) / chunk;
-        const size_t need = n * chunk;
-        hipMemAllocationProp prop = {};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = dev;
-        {
-            VaPool& pool = va_pool();
-            std::lock_guard<std::mutex> lock(pool.m);
-            if (pool.live + pool.retired + need > pool.budget) {
-                char buf[200];
-                snprintf(buf, sizeof buf, "address-space budget: %llu bytes reserved by live ranges + %llu retired + %llu "
-                         "wanted > %llu (dswx_batch_va_budget)", (unsigned long long)pool.live,
-                         (unsigned long long)pool.retired, (unsigned long long)need, (unsigned long long)pool.budget);
-                why = buf;
-                return hipErrorOutOfMemory;
-            }
-            void* base = nullptr;
-            const hipError_t e = hipMemAddressReserve(&base, need, 0, nullptr, 0);
-            if (e != hipSuccess) {
-                why = std::string("hipMemAddressReserve: ") + hipGetErrorString(e);
-                return e;
-            }
-            va = static_cast<char*>(base);
-            reserved = need;
-            pool.live += reserved;
+        VaPool& pool = va_pool();
+        std::lock_guard<std::mutex> lock(pool.m);
+        if (pool.live + pool.retired + need > pool.budget) {
+            char buf[200];
+            snprintf(buf, sizeof buf, "address-space budget: %llu bytes reserved by live ranges + %llu retired + %llu "
+                     "wanted > %llu (dswx_batch_va_budget)", (unsigned long long)pool.live,
+                     (unsigned long long)pool.retired, (unsigned long long)need, (unsigned long long)pool.budget);
+            why = buf;
+            return hipErrorOutOfMemory;
         }
-        hipError_t e = hipSuccess;
+        void* base = nullptr;
+        const hipError_t e = hipMemAddressReserve(&base, need, 0, nullptr, 0);
+        if (e != hipSuccess) {
+            why = std::string("hipMemAddressReserve: ") + hipGetErrorString(e);
+            return e;
+        }
+        va = static_cast<char*>(base);
+        reserved = need;
+        pool.live += reserved;
+        handle.assign(need / chunk, hipMemGenericAllocationHandle_t{});
+        mapped.assign(need / chunk, 0);
+        return hipSuccess;
+    }
+    // reserve `bytes` (rounded up to whole chunks), back all of it, make it accessible from `dev`
+    hipError_t create(int dev, size_t bytes, size_t chunk_bytes) {
+        const size_t n = (bytes + chunk_bytes - 1) / chunk_bytes;
+        hipError_t e = reserve(dev, n * chunk_bytes, chunk_bytes);
+        if (e != hipSuccess) return e;
+        const hipMemAllocationProp prop = prop_of(dev);
         for (size_t i = 0; i < n; ++i) {
             hipMemGenericAllocationHandle_t h;
             e = hipMemCreate(&h, chunk, &prop, 0);
@@ -178,31 +208,66 @@ struct VmRange {
                 destroy();
                 return e;
             }
-            handle.push_back(h);
-            mapped.push_back(1);
+            handle[i] = h;
+            mapped[i] = 1;
         }
-        hipMemAccessDesc acc = {};
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        e = hipMemSetAccess(va, reserved, &acc, 1);
+        e = allow(0, n);
         if (e != hipSuccess) {
             why = std::string("hipMemSetAccess: ") + hipGetErrorString(e);
             destroy();
         }
         return e;
     }
-    // give back every chunk that touches none of the intervals [lo, hi)
-    void trim(const std::vector<std::pair<size_t, size_t>>& keep) {
-        for (size_t i = 0; i < handle.size(); ++i) {
+    // The chunks that touch one of the intervals [lo, hi) of this range, moved -- the same physical memory -- into a
+    // fresh range that spans from the first to the last of them (holes stay unmapped); *base = offset of the new range's
+    // first byte in this one.  This range keeps its other chunks: destroy() it afterwards.  nullptr: nothing was moved
+    // (`why` says what failed).  The stream must be idle.
+    VmRange* rehome(const std::vector<std::pair<size_t, size_t>>& keep, size_t* base) {
+        const size_t n = handle.size();
+        std::vector<char> used(n, 0);
+        size_t first = n, last = 0;
+        for (size_t i = 0; i < n; ++i) {
             const size_t c0 = i * chunk, c1 = c0 + chunk;
-            bool used = false;
-            for (const auto& iv : keep) used = used || (c0 < iv.second && iv.first < c1);
-            if (mapped[i] && !used) {
-                (void)hipMemUnmap(va + c0, chunk);
-                (void)hipMemRelease(handle[i]);
-                mapped[i] = 0;
-            }
+            for (const auto& iv : keep) used[i] = used[i] || (c0 < iv.second && iv.first < c1);
+            if (used[i] && mapped[i]) { first = i < first ? i : first; last = i; }
         }
+        if (first == n) { why = "rehome: nothing to keep"; return nullptr; }
+        VmRange* home = new VmRange();
+        if (home->reserve(device, (last - first + 1) * chunk, chunk) != hipSuccess) {
+            why = home->why;
+            delete home;
+            return nullptr;
+        }
+        hipError_t e = hipSuccess;
+        size_t moved = first;
+        for (; moved <= last && e == hipSuccess; ++moved) {
+            if (!(used[moved] && mapped[moved])) continue;
+            e = hipMemUnmap(va + moved * chunk, chunk);
+            if (e != hipSuccess) break;
+            mapped[moved] = 0;
+            e = hipMemMap(home->va + (moved - first) * chunk, chunk, 0, handle[moved], 0);
+            if (e == hipSuccess) e = home->allow(moved - first, 1);
+            if (e != hipSuccess) break;
+            home->handle[moved - first] = handle[moved];
+            home->mapped[moved - first] = 1;
+        }
+        if (e != hipSuccess) {
+            // undo: every chunk back where it was (the addresses of THIS range have been used by kernels, but they get
+            // their own physical memory back: the translations that may linger are the right ones)
+            why = std::string("rehome: ") + hipGetErrorString(e);
+            (void)hipGetLastError();
+            for (size_t i = first; i <= last && i <= moved; ++i) {
+                if (!used[i] || mapped[i]) continue;
+                if (home->mapped[i - first]) { (void)hipMemUnmap(home->va + (i - first) * chunk, chunk); home->mapped[i - first] = 0; }
+                if (hipMemMap(va + i * chunk, chunk, 0, handle[i], 0) == hipSuccess && allow(i, 1) == hipSuccess) mapped[i] = 1;
+                else (void)hipMemRelease(handle[i]);            // lost: the planes over it are no longer valid (the caller fails)
+            }
+            home->destroy();
+            delete home;
+            return nullptr;
+        }
+        *base = first * chunk;
+        return home;
     }
 };
 
@@ -388,13 +453,15 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
     return DSWX_OK;
 }
 
-int dswx_batch_va_budget(uint64_t new_budget_bytes, uint64_t* budget_bytes, uint64_t* live_bytes, uint64_t* retired_bytes) {
+int dswx_batch_va_budget(uint64_t new_budget_bytes, uint64_t* budget_bytes, uint64_t* live_bytes, uint64_t* retired_bytes,
+                         uint64_t* loose_bytes) {
     VaPool& pool = va_pool();
     std::lock_guard<std::mutex> lock(pool.m);
     if (new_budget_bytes) pool.budget = new_budget_bytes;
     if (budget_bytes) *budget_bytes = pool.budget;
     if (live_bytes) *live_bytes = pool.live;
     if (retired_bytes) *retired_bytes = pool.retired;
+    if (loose_bytes) *loose_bytes = pool.loose;
     return DSWX_OK;
 }
 
@@ -737,17 +804,42 @@ int dswx_batch_place_slide(dswx_batch_t* b, const dswx_params_t* params, uint64_
         if ((rc = probe_ms(b, params, launches, e0, e1, &again_ms))) break;
         first_ms = again_ms;
         if (chosen_ms < again_ms) {
+            // keep the chosen placement: its chunks -- the physical memory -- move into a fresh range (addresses no kernel
+            // has used), the wide range is dropped whole, which is what gives its other chunks back to the device
             (void)hipStreamSynchronize(b->ctx->stream);
             std::vector<std::pair<size_t, size_t>> keep;
             for (size_t i = 0; i < n_out; ++i) keep.push_back({pos[i], pos[i] + len[i]});
-            wide->trim(keep);
-            b->range->destroy();
-            delete b->range;
-            b->range = wide;
-            wide = nullptr;
-            b->region_offset = pos[0];
-            bind_pos();
-            kept_ms = chosen_ms;
+            size_t base = 0;
+            VmRange* home = wide->rehome(keep, &base);
+            if (!home) {
+                set_note(b, "dswx_batch_place_slide: the chosen chunks could not be moved (" + wide->why + "), planes left where they were");
+                kept_ms = again_ms;
+            } else {
+                size_t n = 0;
+                for (int k : ps.out) b->ptr[k] = home->va + (pos[n++] - base);
+                float homed_ms;
+                if ((rc = probe_ms(b, params, launches, e0, e1, &homed_ms))) {
+                    memcpy(b->ptr, first_ptr, sizeof first_ptr);
+                    (void)hipStreamSynchronize(b->ctx->stream);
+                    home->destroy();
+                    delete home;
+                    break;
+                }
+                if (homed_ms < again_ms) {
+                    (void)hipStreamSynchronize(b->ctx->stream);
+                    b->range->destroy();
+                    delete b->range;
+                    b->range = home;
+                    b->region_offset = pos[0] - base;
+                    kept_ms = homed_ms;
+                } else {            // under its new addresses the placement is no better than the first-come one: drop it
+                    memcpy(b->ptr, first_ptr, sizeof first_ptr);
+                    (void)hipStreamSynchronize(b->ctx->stream);
+                    home->destroy();
+                    delete home;
+                    kept_ms = again_ms;
+                }
+            }
         } else {
             kept_ms = again_ms;
         }

@@ -20,6 +20,7 @@
 // uses (rebuilt when the parameters change) and copied into LDS by every block.
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "dswx_host.h"
 #include "dswx_tables.h"
@@ -33,6 +34,7 @@
 // scratch is placement-sensitive like every other plane).  The plain and masks instantiations
 // lose 3 - 8 % with more than one group per thread (5964 -> 5640 -> 5466 GB/s), as in round 1.
 constexpr int LUT_EXTRAS_CHUNKS = 4;
+constexpr int LUT_DEFAULT_INTERLEAVE = 0;      // see KArgs::tile_interleave and the measurements in DESIGN.md section 5
 
 template <bool MASKS, bool EXTRAS, int WPS>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
@@ -44,6 +46,17 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
     __shared__ uint16_t s_pre16[MASKS ? 128 : 2];
     __shared__ uint2 s_chain[128];
     __shared__ uint2 s_extra[EXTRAS ? 256 : 1];
+    const DevParams& P = a.P;
+    const long long n_groups = a.n_pixels >> 3;
+    // which tile, which block of it (block-uniform): see KArgs::tile_interleave
+    long long tile = blockIdx.y, blk = blockIdx.x;
+    if (a.tile_interleave > 1) {
+        const unsigned G = (unsigned)a.tile_interleave;
+        tile = (long long)blockIdx.y * G + blockIdx.x % G;
+        blk = blockIdx.x / G;
+        if (tile >= a.n_tiles_launch) return;           // the last group of tiles is partial (before any barrier)
+    }
+    const long long tile_base = tile * a.tile_stride;
     {   // 2 KiB of tables (2.5 KiB with masks) per block: one element per thread and table
         const int i = threadIdx.x;
         if (i < 128) {
@@ -59,16 +72,13 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
     if (EXTRAS) s_extra[threadIdx.x] = MASKS ? tabs->extram[threadIdx.x] : tabs->extra[threadIdx.x];
     __syncthreads();
 
-    const DevParams& P = a.P;
-    const long long n_groups = a.n_pixels >> 3;
-    const long long tile_base = (long long)blockIdx.y * a.tile_stride;
     // groups between the last 256-byte boundary of the u8 planes and this tile's first pixel (wave-uniform, SALU)
     const int lead = (int)((reinterpret_cast<uintptr_t>(a.in.fmask + tile_base) >> 3) & 31u);
     const bool has_l = MASKS && a.in.land, has_s = MASKS && a.in.shad, has_o = MASKS && a.in.ocean;
     uint32_t cnt = 0, t_ocean = 0;       // cnt: valid in the low half, cloud-and-valid in the high half
 
     for (int c = 0; c < LUT_CHUNKS; ++c) {
-        const long long grp0 = ((long long)blockIdx.x * LUT_CHUNKS + c) * 256 - lead;     // block-uniform
+        const long long grp0 = (blk * LUT_CHUNKS + c) * 256 - lead;     // block-uniform
         if (grp0 >= n_groups) break;
         const long long grp = grp0 + threadIdx.x;
         const bool in_range = (unsigned long long)grp < (unsigned long long)n_groups;
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
             transpose4(ex, pa); transpose4(ex + 4, pb);
             if (a.cover_state) {              // read back by stages 2 / 3 only after the whole batch: stream them out
                 stg<u32x2, true>(a.cover_state + off, u32x2{pa[0], pb[0]});
-                __builtin_nontemporal_store(bitmaps, a.cover_bits + (long long)blockIdx.y * a.cover_bits_stride + grp);
+                __builtin_nontemporal_store(bitmaps, a.cover_bits + tile * a.cover_bits_stride + grp);
             }
             if (a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{pa[2], pb[2]});
         }
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) { c0 += __shfl_xor(c0, sh); c2 += __shfl_xor(c2, sh); }
         if ((threadIdx.x & 63) == 0) {
-            const long long slot = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+            const long long slot = (tile * a.blocks_per_tile + blk) * 4 + (threadIdx.x >> 6);
             a.partials[slot] = make_uint2(c0, c2);
         }
     }
@@ -155,15 +165,25 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
     // and measure 0-2 % slower than 4)
     const int wps = ctx->tune_lut_wps > 0 ? ctx->tune_lut_wps : 4;
     const bool extras = b.out.browse || b.cover_state;
-#define LUT_LAUNCH(M, E, W) hipLaunchKernelGGL((dswx_classify_lut<M, E, W>), grid, block, 0, s, b, lc, tabs)
+    // block order (KArgs::tile_interleave): `grid` arrives as (blocks per tile, tiles)
+    KArgs k = b;
+    const long long nt = grid.y;
+    long long G = ctx->tune_lut_interleave >= 0 ? ctx->tune_lut_interleave : LUT_DEFAULT_INTERLEAVE;
+    if (G > nt) G = nt;
+    if (G > 1 && (long long)grid.x * G > 0x7fffffffLL) G = 1;
+    k.tile_interleave = (int)(G > 1 ? G : 0);
+    k.n_tiles_launch = (int)nt;
+    k.blocks_per_tile = grid.x;
+    if (G > 1) grid = dim3((unsigned)(grid.x * G), (unsigned)((nt + G - 1) / G));
+#define LUT_LAUNCH(M, E, W) hipLaunchKernelGGL((dswx_classify_lut<M, E, W>), grid, block, 0, s, k, lc, tabs)
 #define LUT_SEL_W(M, E) do { if (wps >= 6) LUT_LAUNCH(M, E, 6); else if (wps == 5) LUT_LAUNCH(M, E, 5); else LUT_LAUNCH(M, E, 4); } while (0)
     // masks + extras: 125 VGPRs at a bound of 4 (no spill) since the cover bitmaps come from the table; lab A/B: 3
     const bool ex3 = ctx->tune_lut_wps == 3;
     if (extras) { if (masks && ex3) LUT_LAUNCH(true, true, 3); else if (masks) LUT_LAUNCH(true, true, 4); else LUT_LAUNCH(false, true, 4); }
     else if (masks) LUT_SEL_W(true, false);
     else LUT_SEL_W(false, false);
-    snprintf(info, info_len, "dswx_classify_lut<%s%s> (table-driven) grid=(%lld,%lld) block=256 wps=%d",
-             masks ? "true" : "false", extras ? ",extras" : "", (long long)grid.x, (long long)grid.y,
-             extras ? (masks && ex3 ? 3 : 4) : wps);
+    snprintf(info, info_len, "dswx_classify_lut<%s%s> (table-driven) grid=(%lld,%lld) block=256 wps=%d%s",
+             masks ? "true" : "false", extras ? ",extras" : "", (long long)k.blocks_per_tile, nt,
+             extras ? (masks && ex3 ? 3 : 4) : wps, G > 1 ? (" tiles interleaved x" + std::to_string(G)).c_str() : "");
     return DSWX_OK;
 }

@@ -60,6 +60,12 @@ struct KArgs {
     long long n_pixels;             // per tile
     long long tile_stride;          // pixels between the starts of consecutive tiles in every plane
     long long px_begin;             // generic kernel: first pixel of the tile it covers
+    // table-driven kernel: block order.  0 / 1 = a tile's blocks are consecutive in dispatch order (grid = blocks x tiles);
+    // G > 1 = the blocks of G tiles interleaved (grid.x = blocks_per_tile * G, grid.y = ceil(tiles / G)), so that the
+    // blocks in flight at any moment -- and the 14 streams they read and write -- spread over G tiles of every plane
+    int tile_interleave;
+    int n_tiles_launch;             // tiles of this launch (interleaved order: the last group may be partial)
+    long long blocks_per_tile;      // partials are [tile][blocks_per_tile][wave] whatever the block order
 };
 
 // DIAG (5 bits) -> WTR-1 class, interpreted_dswx_band_dict :97-143, as three

@@ -40,6 +40,8 @@ struct dswx_ctx {
     int shadow_grid_pad = 1;               // dswx_shadow_v3: grid.x rounded up to a multiple of this (lab A/B, see the launch)
     std::string last_kernel;
     int tune_lut_wps = 0;    // table-driven kernel: launch bound (4, 5, 6; 0 = automatic)
+    int tune_lut_interleave = -1;   // table-driven kernel: tiles whose blocks are interleaved in dispatch order (-1 = the
+                                    // product default, dswx_lut_launch; 0 / 1 = none)
     int tune_wps = 6;        // launch bound of the direct kernel without masks (4, 6, 8)
     // Experiment hook, empty in production: libdswx_lab.so installs its fused-kernel structures here
     // (dswx_lab_attach) so that A/B tools can run them through the same entry points.

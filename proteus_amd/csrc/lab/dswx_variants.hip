@@ -679,6 +679,7 @@ int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value) {
         ctx->lab.fused_variant = value;
     } else if (k == "tune_wps") ctx->tune_wps = value;
     else if (k == "tune_lut_wps") ctx->tune_lut_wps = value;
+    else if (k == "tune_lut_interleave") ctx->tune_lut_interleave = value;
     else if (k == "tune_ablate") ctx->lab.tune_ablate = value;
     else if (k == "tune_pipe_blocks") ctx->lab.tune_pipe_blocks = value;
     else if (k == "cover_kernel") ctx->cover_kernel = value;

@@ -195,3 +195,21 @@ def test_address_space_budget_spent_falls_back_to_packed_planes():
     assert capped['info']['va_reserved_bytes'] == 0
     assert capped['account']['retired_bytes'] >= roomy['info']['va_reserved_bytes']      # the dropped ranges: retired, not freed
     assert restored['info']['flags'] & SLIDING and restored['place']['positions'] > 0
+
+
+def test_plain_gpus_command_yields_the_weak_and_the_strong_record():
+    """VERDICT r03 next-1b on the GPU, at toy sizes (hidden --plain-tiles / --strong-total / --strong-chunk; two ranks on
+    one device): `bench.py --gpus 2` with no workload named measures the weak record AND BASELINE configs[3]'s strong
+    walk in the one line -- the strong sub-record with --distinct-chunks parity on every rank and its own per-rank
+    records."""
+    out = _bench('--gpus', '2', '--plain-tiles', '3', '--strong-total', '16', '--strong-chunk', '4', '--steps', '2',
+                 '--warmup', '1', '--no-cpu-baseline', '--no-host-path')
+    assert out['scaling'] == 'weak' and out['config']['tiles_per_step_all_ranks'] == 6
+    assert out['parity_check']['result'] == 'bit-exact'
+    st = out['strong']
+    assert st['scaling'] == 'strong' and st['config']['tiles_per_step_all_ranks'] == 16 and st['config']['launches_per_step'] == 2
+    assert 'configs[3]' in st['config']['workload'] and st['value'] > 0 and st['ms_per_step'] > 0
+    assert st['parity_check']['result'] == 'bit-exact'
+    assert [r['tiles'] for r in st['parity_check']['ranks']] == [[0, 2, 3, 4, 7], [8, 10, 11, 12, 15]]
+    assert [r['tiles_per_step'] for r in st['ranks']] == [8, 8] and st['slowest_rank']['rank'] in (0, 1)
+    assert st['roofline']['pixels_per_launch'] == 4 * 3660 * 3660 and 0 < st['roofline']['frac'] < 1

@@ -773,6 +773,48 @@ def test_batch_outlives_its_context():
     del b2                                             # __del__ after its context was collected: must not raise or leak
 
 
+def test_sliding_placement_returns_its_memory(ctx):
+    """Round 4 finding (tools/lab/vmm_meminfo.hip): on this stack the physical memory of a VMM chunk goes back to the
+    device only when the address RESERVATION it was mapped in is freed -- unmap + release alone keep it -- so round 3's
+    placement, which unmapped the unused chunks of the wide range and retired dropped ranges without freeing them, held
+    on to all of it (48 GiB of slack + 25 GiB of old range per placement at 256 tiles).  Now the kept chunks move into a
+    fresh range, dropped ranges are freed and their addresses quarantined: after a placement the batch holds its planes
+    (+ chunk granularity), after its destruction nothing, and two placements in a row cost no more than one."""
+    n_tiles, h, w = 16, 1024, 1024
+    region = _capi.batch_layout(n_tiles, h, w, sliding_outputs=True)['write_span_bytes']           # 128 MiB
+    chunk = 16 << 20
+    p = _capi.default_params()
+    f0 = _free_device_bytes()
+    acct0 = _capi.va_budget()
+    b = _capi.DeviceBatch(ctx, n_tiles, h, w, sliding_outputs=True)
+    b.synth(SEED, tile0=60)
+    f1 = _free_device_bytes()
+    assert f0 - f1 >= b.nbytes - (4 << 20)
+    for rep in range(2):
+        rec = b.place_slide(p, slack_bytes=512 << 20, step_bytes=32 << 20, spread_gaps=2, refine_passes=1, launches=2)
+        assert rec['positions'] >= 17
+        f2 = _free_device_bytes()
+        # at most the planes' own chunks + one partial chunk per plane end (7 planes) more than before the placement --
+        # not the 512 MiB of slack, not the first-come range
+        assert f1 - f2 <= 9 * chunk, (rep, f1 - f2)
+        assert b.info()['bytes_allocated'] <= b.nbytes + 9 * chunk
+    b.classify(p)
+    ctx.synchronize()
+    cnt = b.read_counters()
+    for t in (0, 15):
+        s_ = synth_tile(60 + t, h, w)
+        exp = c_oracle.classify(p, s_['bands'], s_['fmask'])
+        for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+            assert np.array_equal(b.read_tile(key, t), exp[key]), (key, t)
+        assert cnt[t].tolist() == exp['counters'].tolist()
+    acct = _capi.va_budget()
+    assert acct['live_bytes'] - acct0['live_bytes'] == b.info()['va_reserved_bytes'] and acct['loose_bytes'] == acct0['loose_bytes']
+    assert acct['retired_bytes'] > acct0['retired_bytes']          # the dropped ranges: address space in quarantine
+    b.free()
+    assert f0 - _free_device_bytes() <= (8 << 20)
+    assert _capi.va_budget()['live_bytes'] == acct0['live_bytes']
+
+
 def _free_device_bytes():
     import ctypes
     hip = ctypes.CDLL('libamdhip64.so')

@@ -9,6 +9,7 @@
 //           allocation (8192 distinct 2-MiB translations): if the failures go away with it, what is stale is a cached
 //           translation (a TLB entry the unmap did not invalidate) that this traffic evicts
 //   mode 5: mode 1 with a 200 ms sleep in that place (the control for mode 4: time alone)
+//   mode 6: mode 1 without the hipMalloc / hipFree churn around the re-mapping (is the failure tied to it?)
 //   mode 3: the library's own pattern (dswx_batch_place_slide): a current range stays alive while a wider one is reserved
 //           and mapped beside it, written and checked; half of the wide range's chunks are unmapped ("trim"), the
 //           current range is unmapped + released + hipMemAddressFree'd, the wide one becomes current; sizes vary, so
@@ -93,7 +94,7 @@ int main(int argc, char** argv) {
     }
     for (int it = 0; it < iters; ++it) {
         const uint32_t a = 0xA5000000u + it, b = 0x5B000000u + it, c = 0xC3000000u + it;
-        void* junk = nullptr; CK(hipMalloc(&junk, (size_t)(1 + it % 7) << 20));          // allocation churn, as in the test
+        void* junk = nullptr; if (mode != 6) CK(hipMalloc(&junk, (size_t)(1 + it % 7) << 20));     // allocation churn, as in the test
         Range r; r.chunk = chunk;
         void* base = nullptr; CK(hipMemAddressReserve(&base, bytes, 0, nullptr, 0)); r.va = (char*)base;
         CK(map_all(r, 0, n));
@@ -104,9 +105,9 @@ int main(int argc, char** argv) {
         char* old_va = r.va;
         if (mode == 4) { thrash<<<256, 256, 0, s>>>(big, big_words, 16384, d_bad); CK(hipStreamSynchronize(s)); }
         if (mode == 5) { timespec ts = {0, 200000000}; nanosleep(&ts, nullptr); }
-        if (mode != 1 && mode != 4 && mode != 5) { CK(hipMemAddressFree(r.va, bytes)); CK(hipMemAddressReserve(&base, bytes, 0, old_va, 0)); r.va = (char*)base; }
+        if (mode != 1 && mode != 4 && mode != 5 && mode != 6) { CK(hipMemAddressFree(r.va, bytes)); CK(hipMemAddressReserve(&base, bytes, 0, old_va, 0)); r.va = (char*)base; }
         same_va += r.va == old_va;
-        CK(hipFree(junk));
+        if (junk) CK(hipFree(junk));
         CK(map_all(r, 0, n));
         fill<<<1024, 256, 0, s>>>((uint32_t*)r.va, words, b);
         CK(hipMemsetAsync(d_bad, 0, 8, s));
