@@ -14,13 +14,49 @@ LIB = os.environ.get('DSWX_ORACLE_LIB') or os.path.join(HERE, '_build', 'libdswx
 _lib = None
 
 
+def _digest():
+    import hashlib
+    h = hashlib.sha256()
+    for path in (os.path.join(HERE, 'dswx_oracle.c'), os.path.join(HERE, 'Makefile'),
+                 os.path.join(os.path.dirname(HERE), 'include', 'dswx_hip.h')):
+        with open(path, 'rb') as f:
+            h.update(f.read())
+        h.update(b'\0')
+    return h.hexdigest()
+
+
+def _fresh():
+    try:
+        with open(LIB + '.srchash') as f:
+            return os.path.exists(LIB) and f.read().strip() == _digest()
+    except OSError:
+        return False
+
+
 def build(force=False):
-    src = os.path.join(HERE, 'dswx_oracle.c')
+    """Compile the C oracle when the stamp beside it does not hold the digest of its sources (content, not mtime: a
+    copied tree reorders mtimes).  Safe when many processes call it at once -- every rank of `bench.py --gpus 8` checks
+    its tiles with it: one builder under a file lock, the library appears by an atomic rename."""
     if os.environ.get('DSWX_ORACLE_LIB'):
         return LIB
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.run(['make', '-C', HERE] + (['-B'] if force else []), check=True,
-                       capture_output=True)
+    if not force and _fresh():
+        return LIB
+    import fcntl
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    with open(os.path.join(os.path.dirname(LIB), '.build.lock'), 'a') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not _fresh():
+                digest = _digest()
+                tmp = f'_build/libdswx_oracle.so.{os.getpid()}.tmp'
+                subprocess.run(['make', '-C', HERE, '-B', f'OUT={tmp}'], check=True, capture_output=True)
+                if os.path.exists(LIB + '.srchash'):
+                    os.remove(LIB + '.srchash')
+                os.replace(os.path.join(HERE, tmp), LIB)
+                with open(LIB + '.srchash', 'w') as f:
+                    f.write(digest + '\n')
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
