@@ -88,6 +88,10 @@ def parse_args():
     ap.add_argument('--no-strong', action='store_true',
                     help='--gpus N > 1 without --tiles / --total-tiles measures the weak record AND BASELINE configs[3] '
                          '(4096 tiles over the ranks, the `strong` sub-record of the line); this keeps the weak record only')
+    ap.add_argument('--also-strong', action='store_true',
+                    help='measure the `strong` sub-record (BASELINE configs[3]) after the first record whatever N is: at N = 1 '
+                         'the one rank walks all 4096 tiles in 512-tile chunks (the weak batch is freed first: the same '
+                         'sequence an N > 1 rank goes through, at its real sizes)')
     ap.add_argument('--no-single-tile', action='store_true',
                     help='skip the configs[1] leg (profiling runs: keeps the kernel statistics to the batch launches)')
     ap.add_argument('--cpu-parallel-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -500,7 +504,7 @@ def cases_of(args, world):
     first = argparse.Namespace(total_tiles=args.total_tiles, tiles=args.tiles, distinct_chunks=args.distinct_chunks,
                                key=None)
     cases = [first]
-    if world > 1 and args.plain_command and not args.no_strong:
+    if (world > 1 and args.plain_command and not args.no_strong) or (args.also_strong and not args.total_tiles and not args.chain):
         cases.append(argparse.Namespace(total_tiles=args.strong_total, tiles=args.strong_chunk, distinct_chunks=True,
                                         key='strong'))
     return cases
@@ -871,6 +875,16 @@ def main():
             host_path = {'error': f'{type(e).__name__}: {e}'[:300]}
             if cp.dist is not None:
                 raise                   # a rank that leaves a collective leg strands the others: fail loudly instead
+    # RCCL prints a version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise
+    # come out at process exit, AFTER the JSON line: every rank empties its C buffers now, and rank 0 prints the line
+    # behind a barrier, so that it is the last thing on stdout
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:           # noqa: BLE001
+        pass
+    cp.barrier()
     if rank == 0:
         if host_path is not None:
             out['host_path'] = host_path

@@ -107,7 +107,9 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB_PATH
+    """The in-tree product library -- or another build of the same sources named by DSWX_HIP_LIB (tests: the build with
+    the host code under UBSan, proteus_amd.build.build_ubsan)."""
+    return os.environ.get('DSWX_HIP_LIB') or _build.LIB_PATH
 
 
 _alt_libs = {}
@@ -129,8 +131,8 @@ def load_library(path=None):
     if path is not None and path in _alt_libs:
         return _alt_libs[path]
     alt = path is not None
-    if not alt:
-        _build.build()        # no-op unless a source is newer than the library (never a stale binary)
+    if not alt and not os.environ.get('DSWX_HIP_LIB'):
+        _build.build()        # no-op unless the sources changed since the library was built (never a stale binary)
     path = path or library_path()
     if not os.path.exists(path):
         raise RuntimeError(

@@ -194,6 +194,51 @@ def build_lab(force=False, verbose=False):
     return LAB_PATH
 
 
+UBSAN_PATH = os.path.join(LIB_DIR, 'libdswx_hip_ubsan.so')
+
+
+def _ubsan_runtime_dir(hipcc):
+    """Directory of clang's shared UBSan runtime (the sanitised library links it, so that a plain `python` can dlopen it)."""
+    res = subprocess.run([hipcc, '--print-file-name=libclang_rt.ubsan_standalone-x86_64.so', '-print-runtime-dir'],
+                         capture_output=True, text=True)
+    for line in res.stdout.split():
+        d = line if os.path.isdir(line) else os.path.dirname(line)
+        if os.path.exists(os.path.join(d, 'libclang_rt.ubsan_standalone-x86_64.so')):
+            return d
+    import glob
+    hits = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so')
+    return os.path.dirname(hits[0]) if hits else None
+
+
+def build_ubsan(force=False, verbose=False):
+    """The product library with its HOST code under the undefined-behaviour sanitizer (-fsanitize=undefined,
+    -fno-sanitize-recover: the first finding aborts the process; clang ignores the flag for the gfx950 device code --
+    GPU sanitizers are not available on this pool).  Test infrastructure: tests/test_capi_symbols.py runs the host-only
+    entry points through it here, tests/test_gpu_parity.py the dispatch / batch / placement code on the GPU
+    (DSWX_HIP_LIB selects it in a child process)."""
+    deps, extra = _product_deps(), _flags_tag() + b' ubsan'
+    if not force and not _stale(UBSAN_PATH, deps, extra):
+        return UBSAN_PATH
+    with _build_lock():
+        if not force and not _stale(UBSAN_PATH, deps, extra):
+            return UBSAN_PATH
+        hipcc = _need_hipcc(UBSAN_PATH)
+        rt = _ubsan_runtime_dir(hipcc)
+        if rt is None:
+            raise RuntimeError('clang UBSan runtime not found beside hipcc')
+        flags = [f for f in HIPCC_FLAGS if f != '-O3'] + ['-O1', '-g', '-fsanitize=undefined',
+                                                          '-fno-sanitize-recover=undefined', '-shared-libsan',
+                                                          f'-Wl,-rpath,{rt}', '-Wno-option-ignored']
+        tmp = f'{UBSAN_PATH}.{os.getpid()}.tmp'
+        digest = _digest(deps, extra)
+        _run([hipcc] + flags + ['-I', INCLUDE, '-I', CSRC] + SOURCES + ['-o', tmp], verbose)
+        if os.path.exists(_stamp(UBSAN_PATH)):
+            os.remove(_stamp(UBSAN_PATH))
+        os.replace(tmp, UBSAN_PATH)
+        _write_stamp(UBSAN_PATH, digest)
+    return UBSAN_PATH
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
     print(build_lab(force='--force' in sys.argv, verbose=True))

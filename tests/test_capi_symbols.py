@@ -199,6 +199,54 @@ def test_library_freshness_is_decided_by_content_not_mtime(tmp_path, monkeypatch
     assert build.is_stale()                                            # other flags: another binary
 
 
+def test_host_entry_points_under_ubsan():
+    """SURVEY section 5 (sanitizers): the reference has none; here the C oracle has run under UBSan since round 1, and since
+    round 4 the HOST code of the product library does too (proteus_amd.build.build_ubsan: -fsanitize=undefined with
+    -fno-sanitize-recover, so the first finding aborts; clang ignores the flag for gfx950 device code).  On a box without
+    a GPU that covers the entry points that need none: parameter derivation, the layout rule at the edges of its range,
+    the shadow thresholds, the address-space account, the no-device failure.  (The dispatch, batch and placement code runs
+    under it on the GPU: tests/test_gpu_parity.py::test_host_code_under_ubsan_on_the_gpu.)"""
+    import subprocess
+    import sys
+    from proteus_amd import build
+    code = (
+        "import ctypes, itertools, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from proteus_amd import _capi\n"
+        "lib = _capi.load_library()\n"
+        "assert 'ubsan' in _capi.library_path()\n"
+        "p = _capi.default_params()\n"
+        "full = {k: getattr(p, k) for k in _capi.THRESHOLD_NAMES}\n"
+        "for thr in (None, dict(full, wigt=0.0, awgt=-1e9, pswt_1_nir=1e9, pswt_2_blue=-1e9, lcmask_nir=32767.5)):\n"
+        "    _capi.make_params(thr, band_fills=[None, 0.0, 1e6, -32768.0, 32767.0, -9999.5], fmask_fill=300.0,\n"
+        "                      aerosol_max_nir=-40000.0, offset_and_scale=[(1e-4, 0.0)] * 6)\n"
+        "n = 0\n"
+        "for nt, h, w, st, fl in itertools.product((0, 1, 256, 1 << 32, (1 << 32) + 1), (0, 1, 3660, 1 << 30, (1 << 30) + 1),\n"
+        "                                          (0, 7, 3660, 1 << 30), (0, 1, 13395600, 13395712, 1 << 46, (1 << 46) + 1),\n"
+        "                                          (0, 1, 7, 1 << 10, 1 << 11, 3 << 10, 1 << 20)):\n"
+        "    geom = _capi.BatchGeom(nt, h, w, st)\n"
+        "    lay = _capi.BatchLayout()\n"
+        "    rc = lib.dswx_batch_layout(ctypes.byref(geom), fl, ctypes.byref(lay))\n"
+        "    assert rc in (0, -1), rc\n"
+        "    n += rc == 0\n"
+        "assert n > 100\n"
+        "for ms, mi in ((-5, 40), (0, 90), (90, 180), (-91, -1), (1e-300, 1e-300), (89.999999, 179.999999)):\n"
+        "    _capi.shadow_thresholds(ms, mi); _capi.shadow_thresholds(ms, mi, float32=True)\n"
+        "    t, q = ctypes.c_double(), ctypes.c_double()\n"
+        "    lib.dswx_shadow_thresholds(float(ms), float(mi), ctypes.byref(t), ctypes.byref(q))\n"
+        "_capi.va_budget(1 << 40); _capi.va_budget((1 << 64) - 1); _capi.va_budget(64 << 40)\n"
+        "if _capi.device_count() == 0:\n"
+        "    try:\n"
+        "        _capi.Context(0)\n"
+        "    except _capi.DswxError as e:\n"
+        "        assert e.code == _capi.ERR_NO_DEVICE\n"
+        "print('UBSAN-CLEAN', n)\n")
+    env = dict(os.environ, DSWX_HIP_LIB=build.build_ubsan(), UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1')
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0 and 'UBSAN-CLEAN' in res.stdout, (res.stdout[-500:], res.stderr[-3000:])
+    assert 'runtime error' not in res.stderr
+
+
 def test_bad_mode_raises_like_reference():
     with pytest.raises(Exception, match='ERROR mask adjacent to cloud/cloud-shadow mode'):
         _capi.make_params(mask_adjacent_to_cloud_mode='bogus')

@@ -815,6 +815,24 @@ def test_sliding_placement_returns_its_memory(ctx):
     assert _capi.va_budget()['live_bytes'] == acct0['live_bytes']
 
 
+def test_host_code_under_ubsan_on_the_gpu():
+    """The HOST side of the library -- dispatch, launch geometry, the batch layer, both placements, the host-pointer entries --
+    under the undefined-behaviour sanitizer while it drives real launches (proteus_amd.build.build_ubsan; GPU sanitizers
+    are not available on this pool, clang ignores the flag for device code).  Three soaks of tests/fuzz_parity.py in child
+    processes with DSWX_HIP_LIB pointing at the sanitised build: any finding aborts the child (-fno-sanitize-recover)."""
+    import subprocess
+    import sys
+    from proteus_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSWX_HIP_LIB=build.build_ubsan(), UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1')
+    for argv in (['--iters', '120', '--seed', '7'], ['--device-batch', '--iters', '200', '--seed', '8'],
+                 ['--pinned', '--iters', '80', '--seed', '9']):
+        res = subprocess.run([sys.executable, os.path.join(root, 'tests', 'fuzz_parity.py')] + argv, capture_output=True,
+                             text=True, timeout=900, env=env, cwd=root)
+        assert res.returncode == 0, (argv, res.stdout[-500:], res.stderr[-3000:])
+        assert '"ok": true' in res.stdout and 'runtime error' not in res.stderr, (argv, res.stderr[-2000:])
+
+
 def _free_device_bytes():
     import ctypes
     hip = ctypes.CDLL('libamdhip64.so')
