@@ -16,11 +16,15 @@
  *
  * Plane layout ("band-planar batch"): every plane is [n_tiles][tile_stride] with
  * the tile's H*W pixels row-major at the start of its slot.  tile_stride defaults
- * to H*W (contiguous tiles); for full HBM write rate make it a multiple of 256
- * pixels so that every tile starts on a 256-byte boundary in every plane -- a
- * 3660 x 3660 tile is 13,395,600 pixels = 144 mod 256, and with contiguous tiles
- * every 1 KiB wave store of tiles 1.. then straddles partial 128-byte lines
- * (measured: 4.9 vs 6.0 TB/s for the same kernel).
+ * to H*W (contiguous tiles, what the reference's seam holds).  For the full HBM rate
+ * make every plane BASE 256-byte aligned (a hipMalloc pointer is) and the tile stride
+ * a multiple of 8 pixels: the table-driven kernel then keeps every wave access on a
+ * 128-byte line boundary on any such stride -- a 3660 x 3660 tile is 13,395,600
+ * pixels = 144 mod 256, and a fixed thread -> pixel mapping would put every 1 KiB wave
+ * store of tiles 1.. across partial lines (5.1 - 5.6 vs 5.7 - 6.3 TB/s, DESIGN.md
+ * section 5); since ABI v5 the kernel shifts the mapping per tile instead, and a
+ * stride padded to 256 pixels (dswx_batch_create's default) is no longer needed
+ * for speed.  Planes at odd addresses and ragged strides remain legal (slower kernels).
  */
 #ifndef DSWX_HIP_H
 #define DSWX_HIP_H

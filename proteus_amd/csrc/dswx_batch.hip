@@ -246,10 +246,11 @@ struct VmRange {
             if (e != hipSuccess) break;
             mapped[moved] = 0;
             e = hipMemMap(home->va + (moved - first) * chunk, chunk, 0, handle[moved], 0);
-            if (e == hipSuccess) e = home->allow(moved - first, 1);
             if (e != hipSuccess) break;
             home->handle[moved - first] = handle[moved];
             home->mapped[moved - first] = 1;
+            e = home->allow(moved - first, 1);
+            if (e != hipSuccess) break;
         }
         if (e != hipSuccess) {
             // undo: every chunk back where it was (the addresses of THIS range have been used by kernels, but they get
@@ -262,6 +263,7 @@ struct VmRange {
                 if (hipMemMap(va + i * chunk, chunk, 0, handle[i], 0) == hipSuccess && allow(i, 1) == hipSuccess) mapped[i] = 1;
                 else (void)hipMemRelease(handle[i]);            // lost: the planes over it are no longer valid (the caller fails)
             }
+            std::fill(home->mapped.begin(), home->mapped.end(), 0);     // its chunks went back: destroy() must not release them
             home->destroy();
             delete home;
             return nullptr;

@@ -41,7 +41,12 @@ struct dswx_ctx {
     std::string last_kernel;
     int tune_lut_wps = 0;    // table-driven kernel: launch bound (4, 5, 6; 0 = automatic)
     int tune_lut_interleave = -1;   // table-driven kernel: tiles whose blocks are interleaved in dispatch order (-1 = the
-                                    // product default, dswx_lut_launch; 0 / 1 = none)
+                                    // product default, dswx_lut_launch: none; 0 / 1 = none).  Measured in round 4 on
+                                    // three first-come arenas, 256 tiles, GB/s: none 5976 / 5618 / 6292, G = 4 6006 /
+                                    // 5633 / 6397, G = 8 5941 / 5623 / 6354, G = 16 5731 / 5352 / 6285, G = 64 5624 /
+                                    // 5201 / 6290, G = 256 5606 / 5214 / 6187 (profiles/r04_ab_interleave.json): spreading
+                                    // the 14 streams over many tiles does not lift a badly placed arena and costs 2 - 7 %
+                                    // beyond G = 8; kept as a lab switch only
     int tune_wps = 6;        // launch bound of the direct kernel without masks (4, 6, 8)
     // Experiment hook, empty in production: libdswx_lab.so installs its fused-kernel structures here
     // (dswx_lab_attach) so that A/B tools can run them through the same entry points.
