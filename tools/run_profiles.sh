@@ -12,7 +12,7 @@ if [[ "$WHAT" == *hot* ]]; then
 for m in "" "--masks"; do
   d=gpurun_out/prof$( [ -n "$m" ] && echo _masks )
   rm -rf "$d"; mkdir -p "$d"
-  B="python3 bench.py --tiles $TILES $m --no-cpu-baseline --no-single-tile --realloc-repeats 0 --placement-trials 0"
+  B="python3 bench.py --tiles $TILES $m --no-cpu-baseline --no-single-tile --no-host-path --realloc-repeats 0 --placement-trials 0"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -- $B --steps 20 --warmup 3 > "$d/bench_trace.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/pmc_fetch" -- $B --steps 3 --warmup 1 --no-parity > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/pmc_write" -- $B --steps 3 --warmup 1 --no-parity > /dev/null 2>&1
@@ -25,13 +25,13 @@ if [[ "$WHAT" == *placed* ]]; then
 # `steps` full-batch dispatches = the timed region
 d=gpurun_out/prof_placed
 rm -rf "$d"; mkdir -p "$d"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -- python3 bench.py --tiles $TILES --no-cpu-baseline --no-single-tile --realloc-repeats 0 --steps 20 --warmup 3 > "$d/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -- python3 bench.py --tiles $TILES --no-cpu-baseline --no-single-tile --no-host-path --realloc-repeats 0 --steps 20 --warmup 3 > "$d/bench_trace.log" 2>&1
 fi
 if [[ "$WHAT" == *chain* ]]; then
 # bench.py --chain (BASELINE configs[4]'s per-pixel chain, device-resident): kernel trace of the three kernels of a step
 d=gpurun_out/prof_chain
 rm -rf "$d"; mkdir -p "$d"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -- python3 bench.py --chain --tiles $TILES --no-cpu-baseline --steps 20 --warmup 3 > "$d/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -- python3 bench.py --chain --tiles $TILES --no-cpu-baseline --no-host-path --steps 20 --warmup 3 > "$d/bench_trace.log" 2>&1
 fi
 if [[ "$WHAT" == *next* ]]; then
 # the rows next to the hot path (shadow, cover, land-cover): kernel trace + the same three counter passes
