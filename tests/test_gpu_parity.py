@@ -269,16 +269,19 @@ def test_device_batch_and_synth(ctx, geom, tile_align):
     batch.free()
 
 
-@pytest.mark.parametrize('tile_align', [256, 1])
-def test_more_tiles_than_one_grid_dimension(ctx, tile_align):
+@pytest.mark.parametrize('tile_align,h,w', [(256, 7, 11), (1, 7, 11), (1, 8, 11), (1, 8, 13)])
+def test_more_tiles_than_one_grid_dimension(ctx, tile_align, h, w):
     """70,000 small tiles: the launch is split at 65,535 tiles (grid.y limit); tiles and counters
-    either side of the split match the oracle."""
-    n_tiles, h, w = 70000, 7, 11          # 77 px: nine 8-pixel groups + a 5-pixel tail
+    either side of the split match the oracle.  7 x 11 = 77 px: nine 8-pixel groups + a 5-pixel tail (contiguous: the
+    generic kernel); 8 x 11 = 88 and 8 x 13 = 104 px contiguous: the table-driven kernel's per-tile lead-in, whose second
+    launch starts at a tile whose residue modulo 256 is not the batch's (65,535 x 88 = 0xC8 mod 256)."""
+    n_tiles = 70000
     batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, tile_align=tile_align)
     batch.synth(SEED, tile0=5)
     p = _capi.default_params()
     batch.classify(p)
     ctx.synchronize()
+    assert ('dswx_classify_lut' in ctx.last_kernel_info()) == (batch.tile_stride % 8 == 0)
     cnt = batch.read_counters()
     for t in (0, 1, 65534, 65535, 65536, 69999):
         s = synth_tile(5 + t, h, w, with_masks=True)
