@@ -416,11 +416,16 @@ def test_zero_copy_writes_stay_inside_the_planes(ctx, align):
     assert any(want in k for k in kinds), kinds
 
 
-def test_full_size_batch_properties(ctx):
+@pytest.mark.parametrize('tile_align', [256, 1], ids=['padded', 'contiguous'])
+def test_full_size_batch_properties(ctx, tile_align):
     """BASELINE.json configs[2]-like batch (8 full tiles with masks, device-resident):
-    C-oracle spot checks on two tiles + size-independent properties on all."""
+    C-oracle spot checks on two tiles + size-independent properties on all.  `contiguous`: the same with
+    tile_stride = H * W (the per-tile lead-in of the table-driven kernel at full tile size, masks instantiation); the
+    last property -- a tile's layers do not depend on where it sits, nor on the layout of the batch around it -- then
+    compares a contiguous batch with a single padded tile."""
     n_tiles, h, w = 8, 3660, 3660
-    batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, extra_layers=('wtr1_aerosol',))
+    batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, extra_layers=('wtr1_aerosol',), tile_align=tile_align)
+    assert batch.tile_stride == (h * w if tile_align == 1 else 13395712)
     batch.synth(SEED, tile0=100)
     p = _capi.default_params()
     batch.classify(p)
