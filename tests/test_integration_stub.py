@@ -153,6 +153,7 @@ def test_c_example_runs_and_matches_the_oracle(tmp_path):
     assert r.returncode == 0, r.stderr
     lines = r.stdout.splitlines()
     assert f'tile stride {size * size} px' in lines[0] and '2 allocations' in lines[0]       # 9216 = 36 * 256: no padding
+    assert lines[1].startswith('address space: ') and ' 0 loose' in lines[1] and 'note' not in lines[1]     # ABI v5 from C
     p = _capi.default_params()
     exp = []
     for t in range(n_tiles):
