@@ -8,6 +8,8 @@
 //   mode 4: mode 1, and between the unmap and the new mapping a kernel reads one word of every 64 KiB of a 16 GiB
 //           allocation (8192 distinct 2-MiB translations): if the failures go away with it, what is stale is a cached
 //           translation (a TLB entry the unmap did not invalidate) that this traffic evicts
+//   mode 7: mode 1, and in that place a kernel reads a word of each of 6144 SEPARATE 2-MiB VMM chunks (one translation
+//           each, unlike the large fragments of a single hipMalloc) three times over
 //   mode 5: mode 1 with a 200 ms sleep in that place (the control for mode 4: time alone)
 //   mode 6: mode 1 without the hipMalloc / hipFree churn around the re-mapping (is the failure tied to it?)
 //   mode 3: the library's own pattern (dswx_batch_place_slide): a current range stays alive while a wider one is reserved
@@ -59,6 +61,8 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> host(words);
     uint32_t* big = nullptr; const size_t big_words = (size_t)16 << 28;      // mode 4: 16 GiB
     if (mode == 4) { CK(hipMalloc(&big, big_words * 4)); CK(hipMemset(big, 0, big_words * 4)); }
+    Range many; many.chunk = (size_t)2 << 20; const size_t many_n = 6144;      // mode 7: 12 GiB in 6144 chunks of their own
+    if (mode == 7) { void* b7 = nullptr; CK(hipMemAddressReserve(&b7, many_n * many.chunk, 0, nullptr, 0)); many.va = (char*)b7; CK(map_all(many, 0, many_n)); CK(hipMemset(many.va, 0, many_n * many.chunk)); }
     int same_va = 0, bad_kernel = 0, bad_d2h = 0, bad_after_h2d = 0, first_bad = -1, third = 0, third_kernel_ok = 0, third_copy_ok = 0;
     if (mode == 3) {
         Range cur; cur.chunk = chunk; size_t cur_n = n;
@@ -104,8 +108,9 @@ int main(int argc, char** argv) {
         unmap_all(r);
         char* old_va = r.va;
         if (mode == 4) { thrash<<<256, 256, 0, s>>>(big, big_words, 16384, d_bad); CK(hipStreamSynchronize(s)); }
+        if (mode == 7) { for (int r3 = 0; r3 < 3; ++r3) thrash<<<256, 256, 0, s>>>((const uint32_t*)many.va, many_n * many.chunk / 4, many.chunk / 4, d_bad); CK(hipStreamSynchronize(s)); }
         if (mode == 5) { timespec ts = {0, 200000000}; nanosleep(&ts, nullptr); }
-        if (mode != 1 && mode != 4 && mode != 5 && mode != 6) { CK(hipMemAddressFree(r.va, bytes)); CK(hipMemAddressReserve(&base, bytes, 0, old_va, 0)); r.va = (char*)base; }
+        if (mode != 1 && mode != 4 && mode != 5 && mode != 6 && mode != 7) { CK(hipMemAddressFree(r.va, bytes)); CK(hipMemAddressReserve(&base, bytes, 0, old_va, 0)); r.va = (char*)base; }
         same_va += r.va == old_va;
         if (junk) CK(hipFree(junk));
         CK(map_all(r, 0, n));
