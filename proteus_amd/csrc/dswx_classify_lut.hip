@@ -36,7 +36,11 @@
 constexpr int LUT_EXTRAS_CHUNKS = 4;
 constexpr int LUT_DEFAULT_INTERLEAVE = 0;      // see KArgs::tile_interleave and the measurements in DESIGN.md section 5
 
-template <bool MASKS, bool EXTRAS, int WPS>
+// FLEX: the per-tile lead-in and the block-order switch.  Off for launches whose every tile starts 256-byte aligned in
+// tile-by-tile order (the padded batch layout: the code of rounds 1 - 3, instruction for instruction); with the few scalar
+// instructions of FLEX compiled in unconditionally that layout measured 0.1 % (plain) and 1.0 % (LAND / SHAD / OCEAN:
+// 107 VGPRs, the tightest instantiation) slower in a same-process A/B against the round-3 build.
+template <bool MASKS, bool EXTRAS, int WPS, bool FLEX>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
                                                              const Tables* __restrict__ tabs) {
     constexpr int LUT_CHUNKS = EXTRAS ? LUT_EXTRAS_CHUNKS : 1;     // 8-pixel groups per thread
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
     const long long n_groups = a.n_pixels >> 3;
     // which tile, which block of it (block-uniform): see KArgs::tile_interleave
     long long tile = blockIdx.y, blk = blockIdx.x;
-    if (a.tile_interleave > 1) {
+    if (FLEX && a.tile_interleave > 1) {
         const unsigned G = (unsigned)a.tile_interleave;
         tile = (long long)blockIdx.y * G + blockIdx.x % G;
         blk = blockIdx.x / G;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
     __syncthreads();
 
     // groups between the last 256-byte boundary of the u8 planes and this tile's first pixel (wave-uniform, SALU)
-    const int lead = (int)((reinterpret_cast<uintptr_t>(a.in.fmask + tile_base) >> 3) & 31u);
+    const int lead = FLEX ? (int)((reinterpret_cast<uintptr_t>(a.in.fmask + tile_base) >> 3) & 31u) : 0;
     const bool has_l = MASKS && a.in.land, has_s = MASKS && a.in.shad, has_o = MASKS && a.in.ocean;
     uint32_t cnt = 0, t_ocean = 0;       // cnt: valid in the low half, cloud-and-valid in the high half
 
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         const long long grp0 = (blk * LUT_CHUNKS + c) * 256 - lead;     // block-uniform
         if (grp0 >= n_groups) break;
         const long long grp = grp0 + threadIdx.x;
-        const bool in_range = (unsigned long long)grp < (unsigned long long)n_groups;
-        const long long off = tile_base + (in_range ? grp : (grp < 0 ? 0 : n_groups - 1)) * 8;
+        const bool in_range = FLEX ? (unsigned long long)grp < (unsigned long long)n_groups : grp < n_groups;
+        const long long off = tile_base + (in_range ? grp : (FLEX && grp < 0 ? 0 : n_groups - 1)) * 8;
         u32x4 v[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
@@ -175,15 +179,19 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
     k.n_tiles_launch = (int)nt;
     k.blocks_per_tile = grid.x;
     if (G > 1) grid = dim3((unsigned)(grid.x * G), (unsigned)((nt + G - 1) / G));
-#define LUT_LAUNCH(M, E, W) hipLaunchKernelGGL((dswx_classify_lut<M, E, W>), grid, block, 0, s, k, lc, tabs)
+    // FLEX unless every tile of the launch starts on a 256-byte boundary (then every lead-in is 0) in tile-by-tile order
+    const bool flex = G > 1 || (reinterpret_cast<uintptr_t>(b.in.fmask) & 255u) != 0 || (nt > 1 && b.tile_stride % 256 != 0);
+#define LUT_LAUNCH(M, E, W) do { if (flex) hipLaunchKernelGGL((dswx_classify_lut<M, E, W, true>), grid, block, 0, s, k, lc, tabs); \
+                                 else hipLaunchKernelGGL((dswx_classify_lut<M, E, W, false>), grid, block, 0, s, k, lc, tabs); } while (0)
 #define LUT_SEL_W(M, E) do { if (wps >= 6) LUT_LAUNCH(M, E, 6); else if (wps == 5) LUT_LAUNCH(M, E, 5); else LUT_LAUNCH(M, E, 4); } while (0)
     // masks + extras: 125 VGPRs at a bound of 4 (no spill) since the cover bitmaps come from the table; lab A/B: 3
     const bool ex3 = ctx->tune_lut_wps == 3;
     if (extras) { if (masks && ex3) LUT_LAUNCH(true, true, 3); else if (masks) LUT_LAUNCH(true, true, 4); else LUT_LAUNCH(false, true, 4); }
     else if (masks) LUT_SEL_W(true, false);
     else LUT_SEL_W(false, false);
-    snprintf(info, info_len, "dswx_classify_lut<%s%s> (table-driven) grid=(%lld,%lld) block=256 wps=%d%s",
+    snprintf(info, info_len, "dswx_classify_lut<%s%s> (table-driven) grid=(%lld,%lld) block=256 wps=%d%s%s",
              masks ? "true" : "false", extras ? ",extras" : "", (long long)k.blocks_per_tile, nt,
-             extras ? (masks && ex3 ? 3 : 4) : wps, G > 1 ? (" tiles interleaved x" + std::to_string(G)).c_str() : "");
+             extras ? (masks && ex3 ? 3 : 4) : wps, flex && G <= 1 ? " per-tile lead-in" : "",
+             G > 1 ? (" tiles interleaved x" + std::to_string(G)).c_str() : "");
     return DSWX_OK;
 }
