@@ -847,6 +847,12 @@ def main():
         # N = 1 has no control plane (cp.backend None) unless DSWX_FORCE_DIST=1 asks for a world of one: the RCCL
         # code path of an N > 1 run -- init with device_id, barrier, all_reduce on device tensors, all_gather_object,
         # destroy -- on a box with one GPU (tests/test_gpu_multirank.py)
+        # LOCAL_RANK is the device index when every rank sees all GPUs (torchrun's default); a launcher that narrows every
+        # rank's view to its own GPU (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per rank) leaves one device, index 0
+        visible = torch.cuda.device_count()
+        if visible < 1:
+            raise SystemExit('no GPU visible to this rank: the DSWx HIP path has no CPU fallback')
+        local_rank = local_rank % visible
         torch.cuda.set_device(local_rank)
         cp = shard.ControlPlane(backend='nccl', device=torch.device('cuda', local_rank),
                                 allow_fallback=args.allow_gloo)
