@@ -762,7 +762,7 @@ def measure_case(args, case, env):
                            'first': 'inputs in one allocation, every output plane in its own, as they come',
                            'slide': 'dswx_batch_place_slide (C-ABI): `positions` candidate placements of the output planes inside '
                                     'a range 48 GiB longer than they are (packed at every 2 GiB, spread, then per-plane '
-                                    'refinement), the best kept, the rest of the range returned to the device; '
+                                    'refinement), the chunks under the best one moved into a range of their own and kept, the wide range freed; '
                                     'first_come_launch_ms = the first-come range timed back to back with the kept one',
                            'search': 'dswx_batch_place_search (C-ABI): every output plane in the fastest of `trials` candidate '
                                      'allocations (one pass of coordinate descent, the kernel itself as the probe); '
