@@ -241,7 +241,11 @@ def test_host_entry_points_under_ubsan():
         "    except _capi.DswxError as e:\n"
         "        assert e.code == _capi.ERR_NO_DEVICE\n"
         "print('UBSAN-CLEAN', n)\n")
-    env = dict(os.environ, DSWX_HIP_LIB=build.build_ubsan(), UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1')
+    try:
+        ubsan_lib = build.build_ubsan()
+    except RuntimeError as e:
+        pytest.skip(f'no sanitised build on this box: {e}')
+    env = dict(os.environ, DSWX_HIP_LIB=ubsan_lib, UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1')
     res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0 and 'UBSAN-CLEAN' in res.stdout, (res.stdout[-500:], res.stderr[-3000:])
     assert 'runtime error' not in res.stderr
