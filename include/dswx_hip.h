@@ -394,8 +394,9 @@ int dswx_batch_destroy(dswx_batch_t* batch);
  * mapped, for the life of the process.  It keeps count: `live_bytes` = reserved by ranges in use, `retired_bytes` = in
  * quarantine, `loose_bytes` = ranges whose addresses another thread's allocation took in the instant between the free and
  * the new reservation (0 in a single-threaded caller; such addresses are no longer under the library's control).
- * Memory is never lost, address space is: about 100 GiB per dswx_batch_place_slide at 256 tiles of 3660 x 3660, so the
- * default BUDGET of 64 TiB (half of the 47-bit space) lasts ~650 placements.  When live + retired + a new request would
+ * Memory is never lost, address space is: 100 - 160 GiB per placed batch at 256 tiles of 3660 x 3660 (the first-come range,
+ * the wide range and, when the batch goes, the range of the kept chunks), so the default BUDGET of 64 TiB (half of the 47-bit
+ * space) lasts 400 - 650 placements.  When live + retired + a new request would
  * pass the budget the library reserves no more: sliding batches fall back as described at dswx_batch_create.
  * new_budget_bytes 0 = leave the budget as it is; any output pointer may be NULL.  Process-wide, thread-safe. */
 int dswx_batch_va_budget(uint64_t new_budget_bytes, uint64_t* budget_bytes, uint64_t* live_bytes,

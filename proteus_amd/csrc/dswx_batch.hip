@@ -74,7 +74,7 @@ inline int elem_bytes(int plane) {
 // (9 of 160) fails, retired it does not (0 of 160): tests/vmm_policy_trial.py, profiles/r04_vmm_policy_trial.json.
 // So the addresses of a dropped range are QUARANTINED for the life of the process (VmRange::destroy below: freed, which
 // is what returns the memory on this stack, and reserved again at once with nothing mapped).  That costs address space
-// only -- about 100 GiB per dswx_batch_place_slide at 256 tiles, of the 128 TiB a process has -- and the library keeps
+// only -- 100 - 160 GiB per placed batch at 256 tiles, of the 128 TiB a process has -- and the library keeps
 // count of it (dswx_batch_va_budget, dswx_batch_info_t.va_*): beyond a budget it reserves no more,
 // dswx_batch_create(DSWX_BATCH_SLIDING_OUTPUTS) falls back to the packed allocation and dswx_batch_place_slide leaves the
 // planes where they are, both with the reason in dswx_batch_info_t.note.
