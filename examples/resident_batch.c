@@ -67,10 +67,11 @@ int main(int argc, char** argv) {
            " bytes, %d placements probed\n", geom.n_tiles, geom.height, geom.width, geom.tile_stride, info.n_allocations,
            info.bytes_allocated, info.search_probes);
     /* ABI v5: what the placement cost in ADDRESS SPACE (never memory), and why it did nothing if it did nothing */
-    uint64_t budget = 0, live = 0, retired = 0, loose = 0;
-    CHECK(dswx_batch_va_budget(0, &budget, &live, &retired, &loose));
-    printf("address space: %" PRIu64 " bytes reserved by this batch, %" PRIu64 " in quarantine, %" PRIu64 " loose, budget %" PRIu64
-           "%s%s\n", info.va_reserved_bytes, retired, loose, budget, info.note[0] ? "; note: " : "", info.note);
+    uint64_t budget = 0, live = 0, retired = 0, loose = 0, pooled = 0;
+    CHECK(dswx_batch_va_budget(0, &budget, &live, &retired, &loose, &pooled));
+    printf("address space: %" PRIu64 " bytes reserved by this batch, %" PRIu64 " retired, %" PRIu64 " loose, budget %" PRIu64
+           "; %" PRIu64 " bytes of memory pooled%s%s\n", info.va_reserved_bytes, retired, loose, budget, pooled,
+           info.note[0] ? "; note: " : "", info.note);
 
     int64_t* counters = malloc((size_t)n_tiles * DSWX_N_COUNTERS * sizeof *counters);
     if (!counters) return 1;
@@ -94,6 +95,7 @@ int main(int argc, char** argv) {
     free(host);
     free(counters);
     CHECK(dswx_batch_destroy(batch));
+    CHECK(dswx_batch_pool_trim(NULL));             /* single-threaded here: the pooled chunks back to the device */
     CHECK(dswx_ctx_destroy(ctx));
     return 0;
 }

@@ -360,8 +360,9 @@ typedef struct dswx_batch_info {
     float kept_launch_ms;             /* ... and as kept, timed back to back at the end of the search */
     /* ABI v5: address space (DSWX_BATCH_SLIDING_OUTPUTS; see dswx_batch_va_budget) */
     uint64_t va_reserved_bytes;       /* the reservation this batch's output range lives in (0: no range) */
-    uint64_t va_retired_bytes;        /* process-wide: address space of dropped ranges, in quarantine for good */
+    uint64_t va_retired_bytes;        /* process-wide: address space of dropped ranges, reserved and empty for good */
     uint64_t va_budget_bytes;         /* process-wide limit on reserved + retired address space */
+    uint64_t va_pooled_bytes;         /* process-wide: physical chunks of dropped ranges kept for later ranges */
     char note[256];                   /* "" or why a sliding batch was allocated packed / why the last
                                          dswx_batch_place_slide left the planes where they were */
 } dswx_batch_info_t;
@@ -386,21 +387,28 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
 /* Frees every allocation of the batch.  A batch must not be USED after its context is destroyed; destroying it
  * afterwards is allowed. */
 int dswx_batch_destroy(dswx_batch_t* batch);
-/* Address space of the sliding ranges (ABI v5).  On ROCm 7.2 / gfx950 an address that a kernel has accessed through one
- * mapping must never be mapped onto other physical memory: the kernel's translation stays stale and its stores go to the
- * released memory (plain-HIP reproducer: tools/vmm_reuse_repro.hip).  The library therefore
- * QUARANTINES the address range of every sliding range it drops: all chunks unmapped and released, the addresses freed
- * -- on this stack that is what returns the physical memory to the device -- and reserved again at once with nothing
- * mapped, for the life of the process.  It keeps count: `live_bytes` = reserved by ranges in use, `retired_bytes` = in
- * quarantine, `loose_bytes` = ranges whose addresses another thread's allocation took in the instant between the free and
- * the new reservation (0 in a single-threaded caller; such addresses are no longer under the library's control).
- * Memory is never lost, address space is: 100 - 160 GiB per placed batch at 256 tiles of 3660 x 3660 (the first-come range,
- * the wide range and, when the batch goes, the range of the kept chunks), so the default BUDGET of 64 TiB (half of the 47-bit
- * space) lasts 400 - 650 placements.  When live + retired + a new request would
- * pass the budget the library reserves no more: sliding batches fall back as described at dswx_batch_create.
+/* Address space and memory of the sliding ranges (ABI v5).  Two properties of HIP virtual memory management on ROCm 7.2 /
+ * gfx950 (plain-HIP reproducers: tools/vmm_reuse_repro.hip, tools/lab/vmm_meminfo.hip):
+ *   (1) an address that a kernel has accessed through one mapping must never be mapped onto other physical memory -- the
+ *       kernel's translation stays stale and its stores go to the released memory;
+ *   (2) the physical memory of a chunk that was ever mapped returns to the device only when the address RESERVATION it was
+ *       mapped in is freed.
+ * By default the library therefore RETIRES every sliding range it drops: the addresses stay reserved, empty, for the life
+ * of the process (`retired_bytes`; `live_bytes` = reserved by ranges in use), and the physical chunks go into a process-wide
+ * POOL (`pooled_bytes`) from which later batches and placements of the same chunk size are built before new memory is
+ * created -- nothing is ever exposed to reuse, and a service that re-creates or re-places batches reuses its own memory.
+ * dswx_batch_pool_trim() gives the pooled memory back to the device: it releases the chunks, frees every retired
+ * reservation -- which is what returns the memory -- and reserves the same addresses again at once, empty.  Between those
+ * two calls the addresses are up for grabs by other threads of the process: call it when none of them allocates (a range
+ * lost that way is counted in `loose_bytes` and is out of the library's control).
+ * Address space is consumed for good: 100 - 160 GiB per placed batch at 256 tiles of 3660 x 3660 (the first-come range, the
+ * wide range and, when the batch goes, the range of the kept chunks), so the default BUDGET of 64 TiB (half of the 47-bit
+ * space) lasts 400 - 650 placements.  When live + retired + a new request would pass the budget the library reserves no
+ * more: sliding batches fall back as described at dswx_batch_create.
  * new_budget_bytes 0 = leave the budget as it is; any output pointer may be NULL.  Process-wide, thread-safe. */
 int dswx_batch_va_budget(uint64_t new_budget_bytes, uint64_t* budget_bytes, uint64_t* live_bytes,
-                         uint64_t* retired_bytes, uint64_t* loose_bytes);
+                         uint64_t* retired_bytes, uint64_t* loose_bytes, uint64_t* pooled_bytes);
+int dswx_batch_pool_trim(uint64_t* released_bytes);
 /* Device pointers of the planes (absent planes NULL), the resolved geometry and the counters array
  * ([n_tiles][3] int64); any output argument may be NULL.  Hand them to dswx_classify_batch /
  * dswx_synth_batch, or use the two conveniences below. */
@@ -427,8 +435,9 @@ int dswx_batch_place_search(dswx_batch_t* batch, const dswx_params_t* params, in
  * (bounded so that `keep_free_bytes` of device memory stay free), the kernel is timed (`launches` launches) with the
  * output region at offsets 0, step_bytes, 2 step_bytes, ... of it, the best position and the first-come range are
  * then timed back to back, and the better one is kept: the chunks (physical memory) under the chosen position move into a
- * fresh address range of their own, the wide range is dropped and everything else goes back to the device at once; the
- * moved planes are timed once more and kept only if they still beat the first-come range.  After the packed positions `spread_gaps` more
+ * fresh address range of their own, the wide range is dropped (its other chunks go to the library's pool, see
+ * dswx_batch_va_budget / dswx_batch_pool_trim); the moved planes are timed once more and kept only if they still beat the
+ * first-come range.  After the packed positions `spread_gaps` more
  * candidates are tried: the planes spread over the range with equal gaps of 1/spread_gaps ... 1 x the largest gap that
  * fits (0 = packed positions only).  `refine_passes` passes of refinement follow: from the best candidate, every
  * plane in turn (DIAG first) tries the other free places of the range on a grid of 2 step_bytes and keeps the best
@@ -436,7 +445,7 @@ int dswx_batch_place_search(dswx_batch_t* batch, const dswx_params_t* params, in
  * slack / step + 1 + spread_gaps probes without refinement (25 + 4 at 48 GiB / 2 GiB:
  * about 1 s for 256 tiles) and slack_bytes of transient memory, against 185 probes and five spare sets of planes
  * for dswx_batch_place_search.  Output pointers change: call dswx_batch_planes again.  Synchronous.
- * (Every placement quarantines the address ranges it drops -- address space, never memory: see dswx_batch_va_budget.  When the
+ * (Every placement retires the address ranges it drops: see dswx_batch_va_budget.  When the
  * wide range cannot be reserved or mapped the planes stay where they are, the call succeeds and dswx_batch_info_t.note
  * says why.) */
 int dswx_batch_place_slide(dswx_batch_t* batch, const dswx_params_t* params, uint64_t slack_bytes,

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     'dswx_event_record', 'dswx_event_elapsed_ms', 'dswx_last_kernel_info',
     'dswx_batch_layout', 'dswx_batch_create', 'dswx_batch_destroy', 'dswx_batch_planes', 'dswx_batch_info',
     'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search', 'dswx_batch_place_slide',
-    'dswx_batch_va_budget',
+    'dswx_batch_va_budget', 'dswx_batch_pool_trim',
     'dswx_shadow_layer_batch', 'dswx_landcover_mask_batch')
 
 
@@ -100,7 +100,7 @@ class BatchInfo(ctypes.Structure):
                 ('search_probes', ctypes.c_int32), ('first_come_launch_ms', ctypes.c_float),
                 ('kept_launch_ms', ctypes.c_float), ('va_reserved_bytes', ctypes.c_uint64),
                 ('va_retired_bytes', ctypes.c_uint64), ('va_budget_bytes', ctypes.c_uint64),
-                ('note', ctypes.c_char * 256)]
+                ('va_pooled_bytes', ctypes.c_uint64), ('note', ctypes.c_char * 256)]
 
 
 _lib = None
@@ -117,9 +117,17 @@ _alt_libs = {}
 
 def va_budget(new_budget_bytes=0):
     """dswx_batch_va_budget: the library's process-wide account of the address space its sliding ranges hold."""
-    v = [ctypes.c_uint64() for _ in range(4)]
+    v = [ctypes.c_uint64() for _ in range(5)]
     _check(load_library().dswx_batch_va_budget(int(new_budget_bytes), *[ctypes.byref(x) for x in v]))
-    return dict(zip(('budget_bytes', 'live_bytes', 'retired_bytes', 'loose_bytes'), (int(x.value) for x in v)))
+    return dict(zip(('budget_bytes', 'live_bytes', 'retired_bytes', 'loose_bytes', 'pooled_bytes'), (int(x.value) for x in v)))
+
+
+def pool_trim():
+    """dswx_batch_pool_trim: the pooled chunks of dropped sliding ranges back to the device (call when no other thread of
+    the process allocates: the retired reservations are freed and re-reserved empty).  Returns the bytes released."""
+    v = ctypes.c_uint64()
+    _check(load_library().dswx_batch_pool_trim(ctypes.byref(v)))
+    return int(v.value)
 
 
 def load_library(path=None):
@@ -224,7 +232,8 @@ def load_library(path=None):
                                                    ctypes.c_uint64]),
         'dswx_batch_place_slide': (ctypes.c_int, [vp, ctypes.POINTER(Params), ctypes.c_uint64, ctypes.c_uint64,
                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64]),
-        'dswx_batch_va_budget': (ctypes.c_int, [ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_uint64)] * 4),
+        'dswx_batch_va_budget': (ctypes.c_int, [ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_uint64)] * 5),
+        'dswx_batch_pool_trim': (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         if alt and not hasattr(lib, name):
@@ -817,7 +826,8 @@ class DeviceBatch:
                 'search_probes': int(bi.search_probes),
                 'first_come_launch_ms': float(bi.first_come_launch_ms), 'kept_launch_ms': float(bi.kept_launch_ms),
                 'va_reserved_bytes': int(bi.va_reserved_bytes), 'va_retired_bytes': int(bi.va_retired_bytes),
-                'va_budget_bytes': int(bi.va_budget_bytes), 'note': bi.note.decode()}
+                'va_budget_bytes': int(bi.va_budget_bytes), 'va_pooled_bytes': int(bi.va_pooled_bytes),
+                'note': bi.note.decode()}
 
     def place_search(self, params, candidates=6, launches=3, keep_free_bytes=8 << 30):
         """dswx_batch_place_search: measured placement of the output planes (separate_outputs batches whose inputs

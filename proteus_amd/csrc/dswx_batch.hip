@@ -72,24 +72,41 @@ inline int elem_bytes(int plane) {
 // back zeroed" (8 - 27 of 80 two-placement cases) and fenced by retiring ranges; the same library built with the
 // addresses freed (7 of 160 cases wrong), device-synchronised and freed (6 of 160) or kept in a free list and re-mapped
 // (9 of 160) fails, retired it does not (0 of 160): tests/vmm_policy_trial.py, profiles/r04_vmm_policy_trial.json.
-// So the addresses of a dropped range are QUARANTINED for the life of the process (VmRange::destroy below: freed, which
-// is what returns the memory on this stack, and reserved again at once with nothing mapped).  That costs address space
-// only -- 100 - 160 GiB per placed batch at 256 tiles, of the 128 TiB a process has -- and the library keeps
-// count of it (dswx_batch_va_budget, dswx_batch_info_t.va_*): beyond a budget it reserves no more,
+// So the addresses of a dropped range are never mapped again.  What happens to them and to the memory they held is shaped by
+// a second property of this stack (tools/lab/vmm_meminfo.hip, profiles/r04_vmm_meminfo.json): the physical memory of a chunk
+// that was ever mapped returns to the device only when the RESERVATION it was mapped in is freed (hipMemAddressFree) --
+// hipMemUnmap + hipMemRelease alone keep it allocated.  Freeing the addresses and reserving them again at once, empty
+// (a quarantine) returns the memory and gets the same addresses back (32 of 32 GiB in the probe) -- but between the two
+// calls the addresses are up for grabs by any other thread of the process (a four-thread stress lost one range in a few
+// hundred to an allocation the library cannot fence: the runtime's own, numpy's mmap, ...), and whoever maps GPU memory
+// there inherits the stale translations.  Hence two steps:
+//   * by default a dropped range is RETIRED: its chunks are unmapped and their physical memory goes into a process-wide
+//     POOL (per device and chunk size) from which later ranges are built before any new memory is created; its addresses
+//     stay reserved, empty.  Nothing is ever exposed; the memory stays with the library (dswx_batch_va_budget reports
+//     pooled_bytes) and is reused by the next batch or placement of the same chunk size;
+//   * dswx_batch_pool_trim() -- the caller's decision, for a moment when no other thread of the process allocates --
+//     releases the pooled chunks and does the free + quarantine of every retired range: the memory goes back to the
+//     device, the addresses stay out of circulation (a range whose addresses were lost in that instant is counted as
+//     `loose`).
+// Address space is consumed for good either way -- 100 - 160 GiB per placed batch at 256 tiles, of the 128 TiB a process
+// has -- and the library keeps count (dswx_batch_va_budget, dswx_batch_info_t.va_*): beyond a budget it reserves no more,
 // dswx_batch_create(DSWX_BATCH_SLIDING_OUTPUTS) falls back to the packed allocation and dswx_batch_place_slide leaves the
 // planes where they are, both with the reason in dswx_batch_info_t.note.
-// DSWX_VM_FREE_ADDRESSES (build-time, for tests/vmm_policy_trial.py only): 1 = hipMemAddressFree a dropped range,
-// 2 = hipDeviceSynchronize first -- the two unsafe forms, kept so that the trial can be repeated on a newer ROCm.
+// DSWX_VM_FREE_ADDRESSES (build-time, for tests/vmm_policy_trial.py only): 1 = release the chunks and hipMemAddressFree a
+// dropped range, 2 = hipDeviceSynchronize first -- the two unsafe forms, kept so that the trial can be repeated on a newer ROCm.
 #ifndef DSWX_VM_FREE_ADDRESSES
 #define DSWX_VM_FREE_ADDRESSES 0
 #endif
 
-struct VaPool {
-    std::mutex m;
+struct VaPool {                                         // guarded by dswx_va_mutex()
     uint64_t live = 0;                                  // reserved by ranges in use
-    uint64_t retired = 0;                               // dropped ranges in quarantine: reserved, nothing mapped, for good
-    uint64_t loose = 0;                                 // dropped ranges whose addresses could not be taken back at once
+    uint64_t retired = 0;                               // reserved by dropped ranges (empty, for good)
+    uint64_t loose = 0;                                 // dropped ranges whose addresses were lost during a trim
     uint64_t budget = 64ull << 40;                      // live + retired may not pass this: half of the 47-bit space
+    struct Spare { int device; size_t chunk; hipMemGenericAllocationHandle_t handle; };
+    std::vector<Spare> spare;                           // physical chunks of dropped ranges, unmapped, for later ranges
+    uint64_t pooled = 0;                                // their bytes
+    std::vector<std::pair<char*, size_t>> untrimmed;    // retired ranges whose reservation still pins released memory
 };
 VaPool& va_pool() { static VaPool* p = new VaPool; return *p; }     // never destroyed: frees may arrive during exit
 
@@ -97,15 +114,7 @@ VaPool& va_pool() { static VaPool* p = new VaPool; return *p; }     // never des
 // management).  The sliding placement maps a range longer than the output planes, times the kernel with the planes at
 // several places of it, and keeps only the chunks under the best one -- by moving those chunks (their physical memory,
 // hipMemGenericAllocationHandle_t) into a fresh range and dropping the wide one.
-// Two facts of this stack shape the life cycle (ROCm 7.2 / gfx950; tools/lab/vmm_meminfo.hip, profiles/r04_vmm_meminfo.json):
-//   * the physical memory of a chunk that was ever mapped returns to the device only when the RESERVATION it was mapped in
-//     is freed (hipMemAddressFree) -- hipMemUnmap + hipMemRelease alone keep it allocated (round 3's "trim" of the unused
-//     chunks of a live range therefore returned nothing, and its retired ranges kept their memory);
-//   * freed addresses must not come back (stale translations, above).
-// destroy() reconciles them: unmap, release, hipMemAddressFree -- the memory is back -- and at once
-// hipMemAddressReserve at the SAME address with nothing mapped: the addresses are quarantined for the life of the
-// process (32 of 32 GiB returned and the same address obtained in the probe; a second request for that address is sent
-// elsewhere).
+// Life cycle: see "address space" above (retire + pool by default, dswx_batch_pool_trim for the memory).
 struct VmRange {
     char* va = nullptr;
     size_t reserved = 0;       // the reservation = handle.size() * chunk
@@ -137,27 +146,27 @@ struct VmRange {
 #if DSWX_VM_FREE_ADDRESSES == 2
         (void)hipDeviceSynchronize();
 #endif
+        std::lock_guard<std::mutex> lock(dswx_va_mutex());
+        VaPool& pool = va_pool();
         for (size_t i = 0; i < handle.size(); ++i)
             if (mapped[i]) {
                 (void)hipMemUnmap(va + i * chunk, chunk);
+#if DSWX_VM_FREE_ADDRESSES
                 (void)hipMemRelease(handle[i]);
+#else
+                pool.spare.push_back({device, chunk, handle[i]});       // the memory stays with the library: the next range's
+                pool.pooled += chunk;
+#endif
             }
         handle.clear();
         mapped.clear();
         if (va) {
-            VaPool& pool = va_pool();
-            std::lock_guard<std::mutex> lock(pool.m);
             pool.live -= reserved;
-            (void)hipMemAddressFree(va, reserved);              // the memory of every chunk ever mapped here goes back NOW
-#if !DSWX_VM_FREE_ADDRESSES
-            void* again = nullptr;                              // ... and the addresses into quarantine
-            if (hipMemAddressReserve(&again, reserved, 0, va, 0) == hipSuccess && again == va) {
-                pool.retired += reserved;
-            } else {            // someone took them in between (another thread's allocation): they are out of our hands
-                if (again) (void)hipMemAddressFree(again, reserved);
-                (void)hipGetLastError();
-                pool.loose += reserved;
-            }
+#if DSWX_VM_FREE_ADDRESSES
+            (void)hipMemAddressFree(va, reserved);
+#else
+            pool.retired += reserved;                                   // reserved, empty, for good
+            pool.untrimmed.push_back({va, reserved});
 #endif
         }
         va = nullptr;
@@ -168,7 +177,7 @@ struct VmRange {
         device = dev;
         chunk = chunk_bytes;
         VaPool& pool = va_pool();
-        std::lock_guard<std::mutex> lock(pool.m);
+        std::lock_guard<std::mutex> lock(dswx_va_mutex());
         if (pool.live + pool.retired + need > pool.budget) {
             char buf[200];
             snprintf(buf, sizeof buf, "address-space budget: %llu bytes reserved by live ranges + %llu retired + %llu "
@@ -198,7 +207,20 @@ struct VmRange {
         const hipMemAllocationProp prop = prop_of(dev);
         for (size_t i = 0; i < n; ++i) {
             hipMemGenericAllocationHandle_t h;
-            e = hipMemCreate(&h, chunk, &prop, 0);
+            bool from_pool = false;
+            {
+                std::lock_guard<std::mutex> lock(dswx_va_mutex());
+                VaPool& pool = va_pool();
+                for (size_t k = pool.spare.size(); k-- > 0;)
+                    if (pool.spare[k].device == dev && pool.spare[k].chunk == chunk) {
+                        h = pool.spare[k].handle;
+                        pool.spare.erase(pool.spare.begin() + (long)k);
+                        pool.pooled -= chunk;
+                        from_pool = true;
+                        break;
+                    }
+            }
+            e = from_pool ? hipSuccess : hipMemCreate(&h, chunk, &prop, 0);
             if (e == hipSuccess) {
                 e = hipMemMap(va + i * chunk, chunk, 0, h, 0);
                 if (e != hipSuccess) (void)hipMemRelease(h);
@@ -435,11 +457,11 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
     b->geom.tile_stride = lay.tile_stride;
     b->flags = flags;
     b->lay = lay;
-    e = hipMalloc(&b->arena, lay.arena_bytes);
+    e = dswx_locked_malloc(&b->arena, lay.arena_bytes);
     const PlaneSet ps = planes_of(flags);
     if (e == hipSuccess && mode == DSWX_BATCH_SEPARATE_OUTPUTS)
         for (int k : ps.out) {
-            e = hipMalloc(&b->own[k], lay.plane_bytes[k] ? lay.plane_bytes[k] : kAlign);
+            e = dswx_locked_malloc(&b->own[k], lay.plane_bytes[k] ? lay.plane_bytes[k] : kAlign);
             if (e != hipSuccess) break;
         }
     if (e != hipSuccess) {
@@ -456,14 +478,42 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
 }
 
 int dswx_batch_va_budget(uint64_t new_budget_bytes, uint64_t* budget_bytes, uint64_t* live_bytes, uint64_t* retired_bytes,
-                         uint64_t* loose_bytes) {
+                         uint64_t* loose_bytes, uint64_t* pooled_bytes) {
     VaPool& pool = va_pool();
-    std::lock_guard<std::mutex> lock(pool.m);
+    std::lock_guard<std::mutex> lock(dswx_va_mutex());
     if (new_budget_bytes) pool.budget = new_budget_bytes;
     if (budget_bytes) *budget_bytes = pool.budget;
     if (live_bytes) *live_bytes = pool.live;
     if (retired_bytes) *retired_bytes = pool.retired;
     if (loose_bytes) *loose_bytes = pool.loose;
+    if (pooled_bytes) *pooled_bytes = pool.pooled;
+    return DSWX_OK;
+}
+
+int dswx_batch_pool_trim(uint64_t* released_bytes) {
+    VaPool& pool = va_pool();
+    std::lock_guard<std::mutex> lock(dswx_va_mutex());
+    uint64_t released = 0;
+    for (const VaPool::Spare& sp : pool.spare) {
+        (void)hipSetDevice(sp.device);
+        (void)hipMemRelease(sp.handle);
+        released += sp.chunk;
+    }
+    pool.spare.clear();
+    pool.pooled = 0;
+    // the reservations of the retired ranges still pin that memory: free each and take its addresses back at once, empty
+    for (const auto& r : pool.untrimmed) {
+        (void)hipMemAddressFree(r.first, r.second);
+        void* again = nullptr;
+        if (hipMemAddressReserve(&again, r.second, 0, r.first, 0) != hipSuccess || again != r.first) {
+            if (again) (void)hipMemAddressFree(again, r.second);       // another thread took them in that instant
+            (void)hipGetLastError();
+            pool.retired -= r.second;
+            pool.loose += r.second;
+        }
+    }
+    pool.untrimmed.clear();
+    if (released_bytes) *released_bytes = released;
     return DSWX_OK;
 }
 
@@ -495,9 +545,10 @@ int dswx_batch_info(const dswx_batch_t* b, dswx_batch_info_t* info) {
     }
     {
         VaPool& pool = va_pool();
-        std::lock_guard<std::mutex> lock(pool.m);
+        std::lock_guard<std::mutex> lock(dswx_va_mutex());
         info->va_retired_bytes = pool.retired;
         info->va_budget_bytes = pool.budget;
+        info->va_pooled_bytes = pool.pooled;
     }
     snprintf(info->note, sizeof info->note, "%s", b->note.c_str());
     info->search_candidates = b->search_candidates;
@@ -567,7 +618,7 @@ int dswx_batch_place_search(dswx_batch_t* b, const dswx_params_t* params, int32_
     for (int sidx = 0; sidx < sets && full; ++sidx) {
         for (int k : ps.out) {
             void* p = nullptr;
-            if (hipMalloc(&p, b->lay.plane_bytes[k] ? b->lay.plane_bytes[k] : kAlign) != hipSuccess) {
+            if (dswx_locked_malloc(&p, b->lay.plane_bytes[k] ? b->lay.plane_bytes[k] : kAlign) != hipSuccess) {
                 (void)hipGetLastError();        // refused: search among what there is
                 full = false;
                 break;
@@ -699,7 +750,13 @@ int dswx_batch_place_slide(dswx_batch_t* b, const dswx_params_t* params, uint64_
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     // the wider range is held BESIDE the current one while the search runs
-    const uint64_t room = free_b > keep_free_bytes + region ? free_b - keep_free_bytes - region : 0;
+    uint64_t usable = free_b;          // + the pooled chunks of the size the wide range is built from
+    {
+        std::lock_guard<std::mutex> lock(dswx_va_mutex());
+        for (const VaPool::Spare& sp : va_pool().spare)
+            if (sp.device == b->ctx->device && sp.chunk == chunk_for(region)) usable += sp.chunk;
+    }
+    const uint64_t room = usable > keep_free_bytes + region ? usable - keep_free_bytes - region : 0;
     size_t slack = (size_t)(slack_bytes < room ? slack_bytes : room);
     slack = slack / step * step;
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -406,6 +406,8 @@ int dswx_make_dev_params(const dswx_params_t* p, DevParams* d) {
 }
 
 
+std::mutex& dswx_va_mutex() { static std::mutex* m = new std::mutex; return *m; }      // never destroyed: frees may arrive during exit
+
 extern "C" {
 
 int dswx_abi_version(void) { return DSWX_ABI_VERSION; }
@@ -534,7 +536,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             HIP_TRY(hipStreamSynchronize(s));
             if (ctx->cover) HIP_TRY(hipFree(ctx->cover));
             ctx->cover = nullptr; ctx->cover_bytes = 0;
-            HIP_TRY(hipMalloc(&ctx->cover, need));
+            HIP_TRY(dswx_locked_malloc(&ctx->cover, need));
             ctx->cover_bytes = need;
         }
         a.cover_state = static_cast<uint8_t*>(ctx->cover);
@@ -633,7 +635,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
                     HIP_TRY(hipStreamSynchronize(s));
                     if (ctx->partials) HIP_TRY(hipFree(ctx->partials));
                     ctx->partials = nullptr; ctx->partials_bytes = 0;
-                    HIP_TRY(hipMalloc(&ctx->partials, need));
+                    HIP_TRY(dswx_locked_malloc(&ctx->partials, need));
                     ctx->partials_bytes = need;
                 }
                 b.partials = static_cast<uint2*>(ctx->partials);
@@ -724,7 +726,7 @@ int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out) {
     if (!ctx || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    HIP_TRY(dswx_locked_malloc(out, bytes ? bytes : 1));
     return DSWX_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <string>
 
 #include "dswx_device.h"
@@ -76,6 +77,18 @@ int dswx_make_dev_params(const dswx_params_t* p, DevParams* d);
             return dswx_fail(DSWX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
                              __FILE__, __LINE__);                                                  \
     } while (0)
+
+// Device allocations of the library go through ONE mutex, the one the sliding ranges hold while they free a dropped range's
+// addresses and reserve them again (VmRange::destroy, dswx_batch.hip): between those two calls the addresses are up for
+// grabs, and an allocation of another thread of THIS library must not be the one that takes them (a stress of four
+// threads creating and placing batches lost one range in two hundred that way).  Allocations of the caller's own threads
+// cannot be fenced; the account reports them (dswx_batch_va_budget: loose_bytes).
+std::mutex& dswx_va_mutex();
+template <typename T>
+static inline hipError_t dswx_locked_malloc(T** p, size_t n) {
+    std::lock_guard<std::mutex> lock(dswx_va_mutex());
+    return hipMalloc(reinterpret_cast<void**>(p), n);
+}
 
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 

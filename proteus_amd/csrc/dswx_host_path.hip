@@ -163,7 +163,7 @@ static int classify_host_pipelined(dswx_ctx_t* ctx, const dswx_params_t* params,
         HIP_TRY(hipDeviceSynchronize());
         if (ctx->stage) HIP_TRY(hipFree(ctx->stage));
         ctx->stage = nullptr; ctx->stage_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->stage, slot_bytes * NSLOT));
+        HIP_TRY(dswx_locked_malloc(&ctx->stage, slot_bytes * NSLOT));
         ctx->stage_bytes = slot_bytes * NSLOT;
     }
     char* const arena = static_cast<char*>(ctx->stage);
@@ -292,7 +292,7 @@ int dswx_classify_host(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_t
     if (off > ctx->stage_bytes) {
         if (ctx->stage) HIP_TRY(hipFree(ctx->stage));
         ctx->stage = nullptr; ctx->stage_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->stage, off));
+        HIP_TRY(dswx_locked_malloc(&ctx->stage, off));
         ctx->stage_bytes = off;
     }
     char* base = static_cast<char*>(ctx->stage);

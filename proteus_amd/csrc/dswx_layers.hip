@@ -455,8 +455,8 @@ int dswx_interpret_layer_host(dswx_ctx_t* ctx, const int64_t* diag_decimal, int6
     HIP_TRY(hipSetDevice(ctx->device));
     void* d_in = nullptr;
     void* d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_in, (size_t)n * 8));
-    hipError_t e = hipMalloc(&d_out, (size_t)n);
+    HIP_TRY(dswx_locked_malloc(&d_in, (size_t)n * 8));
+    hipError_t e = dswx_locked_malloc(&d_out, (size_t)n);
     if (e != hipSuccess) { (void)hipFree(d_in); return dswx_fail(DSWX_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     hipStream_t s = ctx->stream;
     e = hipMemcpyAsync(d_in, diag_decimal, (size_t)n * 8, hipMemcpyHostToDevice, s);
@@ -677,8 +677,8 @@ static int shadow_host_impl(dswx_ctx_t* ctx, const float* dem, int64_t height, i
     const size_t out_px = (size_t)(height - 2 * margin) * (size_t)(width - 2 * margin);
     void* d_dem = nullptr;
     void* d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_dem, in_bytes));
-    hipError_t e = hipMalloc(&d_out, out_px);
+    HIP_TRY(dswx_locked_malloc(&d_dem, in_bytes));
+    hipError_t e = dswx_locked_malloc(&d_out, out_px);
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemcpyAsync(d_dem, dem, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
@@ -818,9 +818,9 @@ int dswx_landcover_mask_host(dswx_ctx_t* ctx, const uint8_t* worldcover_up3, con
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t)height * (size_t)width;
     void* d_wc = nullptr; void* d_cg = nullptr; void* d_out = nullptr;
-    hipError_t e = hipMalloc(&d_wc, 9 * n);
-    if (e == hipSuccess) e = hipMalloc(&d_cg, n);
-    if (e == hipSuccess) e = hipMalloc(&d_out, n);
+    hipError_t e = dswx_locked_malloc(&d_wc, 9 * n);
+    if (e == hipSuccess) e = dswx_locked_malloc(&d_cg, n);
+    if (e == hipSuccess) e = dswx_locked_malloc(&d_out, n);
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemcpyAsync(d_wc, worldcover_up3, 9 * n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_cg, copernicus, n, hipMemcpyHostToDevice, s);

@@ -2,8 +2,9 @@
 """What a long-lived service does to the device: `--cycles` times create a sliding batch of
 `--tiles` 3660 x 3660 tiles, generate, place (dswx_batch_place_slide), classify, check one tile against the C oracle,
 destroy -- and after every cycle record the device's free memory and the library's address-space account.  Memory must
-come back every time (the dropped ranges are freed and their addresses quarantined); address space is consumed at
-~100 GiB per cycle at 256 tiles until the budget is reached, after which batches are allocated packed (the note says
+stay bounded (the chunks of dropped ranges go into the library's pool and are what the next cycle's ranges are built from;
+dswx_batch_pool_trim at the end gives the pool back); address space is consumed at 100 - 160 GiB per cycle at 256 tiles
+until the budget is reached, after which batches are allocated packed (the note says
 so) and the service keeps running.  `--budget-gib` caps the budget so that the fallback is reached inside the run.
 
     python tests/service_cycles_soak.py --tiles 256 --cycles 12 --budget-gib 800
@@ -76,13 +77,20 @@ def main():
                      'frac_of_8TBps': round(px * 21 / (ms * 1e-3) / 8e12, 4), 'bit_exact': bool(exact),
                      'held_with_batch_GiB': round(held / 2 ** 30, 2), 'batch_GiB': round(info['bytes_allocated'] / 2 ** 30, 2),
                      'free_lost_after_destroy_MiB': round((f_start - free_bytes()) / 2 ** 20, 1),
+                     'pooled_GiB': round(acct['pooled_bytes'] / 2 ** 30, 2),
                      'va_quarantined_GiB': round(acct['retired_bytes'] / 2 ** 30, 1), 'va_loose_GiB': round(acct['loose_bytes'] / 2 ** 30, 1),
                      'note': info['note'][:120], 'seconds': round(time.perf_counter() - t0, 1)})
         print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
-    # (a constant remainder after the first cycle is the context's own grow-only scratch -- partial counters, tables --, not a leak)
-    ok = all(r['bit_exact'] for r in rows) and rows[-1]['free_lost_after_destroy_MiB'] - rows[0]['free_lost_after_destroy_MiB'] < 16
+    # memory not back on the device after a destroy = the pool (reused by the next cycle) + the context's own scratch; it
+    # must stop growing once the pool holds what one cycle needs
+    unaccounted = [r['free_lost_after_destroy_MiB'] - r['pooled_GiB'] * 1024 for r in rows]
+    released = _capi.pool_trim()
+    after_trim = (f_start - free_bytes()) / 2 ** 20
+    ok = all(r['bit_exact'] for r in rows) and max(unaccounted) - min(unaccounted) < 64 and after_trim < 128 and \
+        max(r['free_lost_after_destroy_MiB'] for r in rows[1:]) <= rows[1]['free_lost_after_destroy_MiB'] + 4096
     print(json.dumps({'ok': bool(ok), 'tiles': a.tiles, 'cycles': a.cycles, 'budget_GiB': a.budget_gib or 65536,
-                      'free_at_start_GiB': round(f_start / 2 ** 30, 2), 'rows': rows}))
+                      'free_at_start_GiB': round(f_start / 2 ** 30, 2), 'pool_trim_released_GiB': round(released / 2 ** 30, 2),
+                      'free_lost_after_trim_MiB': round(after_trim, 1), 'account_after_trim': _capi.va_budget(), 'rows': rows}))
     ctx.close()
     return 0 if ok else 1
 

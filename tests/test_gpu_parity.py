@@ -769,6 +769,7 @@ def test_batch_outlives_its_context():
     """the C ABI allows dswx_batch_destroy after the context is gone (the batch remembers its device); the
     Python face used to skip the destroy then and leaked the batch's HBM until process exit."""
     c2 = _capi.Context(0)
+    _capi.pool_trim()
     free_before = _free_device_bytes()
     b = _capi.DeviceBatch(c2, 8, 1024, 1024, sliding_outputs=True)         # ~180 MB in an arena + a VMM range
     assert _free_device_bytes() < free_before - (100 << 20)
@@ -776,36 +777,43 @@ def test_batch_outlives_its_context():
     assert b.handle is not None
     b.free()
     assert b.handle is None
+    _capi.pool_trim()                                  # the chunks of its sliding range sit in the library's pool
     assert _free_device_bytes() > free_before - (32 << 20)
     b2 = _capi.DeviceBatch(_capi.Context(0), 2, 64, 64)
     del b2                                             # __del__ after its context was collected: must not raise or leak
 
 
-def test_sliding_placement_returns_its_memory(ctx):
-    """Round 4 finding (tools/lab/vmm_meminfo.hip): on this stack the physical memory of a VMM chunk goes back to the
-    device only when the address RESERVATION it was mapped in is freed -- unmap + release alone keep it -- so round 3's
-    placement, which unmapped the unused chunks of the wide range and retired dropped ranges without freeing them, held
-    on to all of it (48 GiB of slack + 25 GiB of old range per placement at 256 tiles).  Now the kept chunks move into a
-    fresh range, dropped ranges are freed and their addresses quarantined: after a placement the batch holds its planes
-    (+ chunk granularity), after its destruction nothing, and two placements in a row cost no more than one."""
+def test_sliding_placement_pools_its_memory_and_trim_returns_it(ctx):
+    """Round 4 findings (tools/lab/vmm_meminfo.hip, tools/vmm_reuse_repro.hip): on this stack the physical memory of a VMM
+    chunk goes back to the device only when the address RESERVATION it was mapped in is freed, and freed addresses that a
+    kernel has used must not be mapped again.  Round 3's placement therefore held on to everything it had ever mapped
+    (48 GiB of slack + the 25 GiB first-come range per placement at 256 tiles) without knowing it.  Now the chunks of
+    dropped ranges go into the library's POOL and are what the next range is built from -- a second placement costs the
+    device nothing -- and dswx_batch_pool_trim() gives the pool back (free + re-reserve of the retired addresses)."""
     n_tiles, h, w = 16, 1024, 1024
-    region = _capi.batch_layout(n_tiles, h, w, sliding_outputs=True)['write_span_bytes']           # 128 MiB
-    chunk = 16 << 20
+    chunk = 16 << 20                                   # chunk_for(128 MiB of output planes)
     p = _capi.default_params()
+    _capi.pool_trim()
     f0 = _free_device_bytes()
     acct0 = _capi.va_budget()
+    assert acct0['pooled_bytes'] == 0
     b = _capi.DeviceBatch(ctx, n_tiles, h, w, sliding_outputs=True)
     b.synth(SEED, tile0=60)
     f1 = _free_device_bytes()
     assert f0 - f1 >= b.nbytes - (4 << 20)
-    for rep in range(2):
-        rec = b.place_slide(p, slack_bytes=512 << 20, step_bytes=32 << 20, spread_gaps=2, refine_passes=1, launches=2)
-        assert rec['positions'] >= 17
-        f2 = _free_device_bytes()
-        # at most the planes' own chunks + one partial chunk per plane end (7 planes) more than before the placement --
-        # not the 512 MiB of slack, not the first-come range
-        assert f1 - f2 <= 9 * chunk, (rep, f1 - f2)
-        assert b.info()['bytes_allocated'] <= b.nbytes + 9 * chunk
+    rec = b.place_slide(p, slack_bytes=512 << 20, step_bytes=32 << 20, spread_gaps=2, refine_passes=1, launches=2)
+    assert rec['positions'] >= 17
+    f2 = _free_device_bytes()
+    pooled = _capi.va_budget()['pooled_bytes']
+    # the device gave the wide range (planes + 512 MiB); what the batch does not keep is in the pool, not lost
+    assert 500 << 20 <= f1 - f2 <= (640 << 20) + 9 * chunk
+    assert pooled >= 480 << 20 and b.info()['bytes_allocated'] <= b.nbytes + 9 * chunk
+    assert abs((f1 - f2) - (pooled + b.info()['bytes_allocated'] - b.nbytes)) <= 2 * chunk
+    # a second placement is built from the pool: the device's free memory does not move
+    rec = b.place_slide(p, slack_bytes=512 << 20, step_bytes=32 << 20, spread_gaps=2, refine_passes=1, launches=2)
+    assert rec['positions'] >= 17
+    f3 = _free_device_bytes()
+    assert abs(f2 - f3) <= 9 * chunk, (f2 - f3)
     b.classify(p)
     ctx.synchronize()
     cnt = b.read_counters()
@@ -817,10 +825,14 @@ def test_sliding_placement_returns_its_memory(ctx):
         assert cnt[t].tolist() == exp['counters'].tolist()
     acct = _capi.va_budget()
     assert acct['live_bytes'] - acct0['live_bytes'] == b.info()['va_reserved_bytes'] and acct['loose_bytes'] == acct0['loose_bytes']
-    assert acct['retired_bytes'] > acct0['retired_bytes']          # the dropped ranges: address space in quarantine
+    assert acct['retired_bytes'] > acct0['retired_bytes']          # the dropped ranges: address space, reserved and empty
     b.free()
-    assert f0 - _free_device_bytes() <= (8 << 20)
     assert _capi.va_budget()['live_bytes'] == acct0['live_bytes']
+    # everything the batch's ranges held is in the pool now; trim gives it back to the device
+    released = _capi.pool_trim()
+    assert released >= (512 << 20) and _capi.va_budget()['pooled_bytes'] == 0
+    assert f0 - _free_device_bytes() <= (8 << 20)
+    assert _capi.va_budget()['loose_bytes'] == acct0['loose_bytes']            # single-threaded: every range taken back
 
 
 def test_host_code_under_ubsan_on_the_gpu():
