@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from proteus_amd import build as _build            # noqa: E402
 
 TRIAL_DIR = os.path.join(_build.LIB_DIR, 'trial')
-POLICIES = {1: 'hipMemAddressFree', 2: 'hipDeviceSynchronize + hipMemAddressFree', 0: 'retire, never reuse (product)'}
+POLICIES = {1: 'release + hipMemAddressFree', 2: 'hipDeviceSynchronize + release + hipMemAddressFree', 0: 'retire the addresses, pool the chunks (product)'}
 
 
 def lib_of(policy):
