@@ -494,8 +494,7 @@ int dswx_batch_pool_trim(uint64_t* released_bytes) {
     VaPool& pool = va_pool();
     std::lock_guard<std::mutex> lock(dswx_va_mutex());
     uint64_t released = 0;
-    for (const VaPool::Spare& sp : pool.spare) {
-        (void)hipSetDevice(sp.device);
+    for (const VaPool::Spare& sp : pool.spare) {            // (a handle carries its device: no current-device switch needed)
         (void)hipMemRelease(sp.handle);
         released += sp.chunk;
     }
