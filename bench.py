@@ -896,6 +896,10 @@ def main():
             out['host_path'] = host_path
         if world == 1 and args.realloc_repeats > 0 and not args.chain:
             try:
+                # the legs below allocate whole batches with hipMalloc: hand the library's pool (the chunks of the placed
+                # batch's dropped ranges, ~100 GiB at 256 tiles) back to the device first -- this process has no other
+                # thread that allocates
+                out['roofline']['pool_trimmed_GiB'] = round(_capi.pool_trim() / 2 ** 30, 2)
                 out['roofline']['realloc_spread'] = realloc_spread(ctx, env.params, headline_tiles, args.masks,
                                                                    args.realloc_repeats)
             except Exception as e:
