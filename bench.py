@@ -452,6 +452,8 @@ def place_batch(ctx, params, n_tiles, tile0, masks, how, trials, refine=1, slack
         rec = {'how': how, 'probes': 0, 'fallback': str(e)[:200]}
         b = _capi.DeviceBatch(ctx, n_tiles, TILE, TILE, masks=masks, separate_outputs=True)
     b.synth(SEED, tile0=tile0)
+    ctx.synchronize()
+    t_place = time.perf_counter()
     try:
         if how == 'slide':
             rec.update(b.place_slide(params, slack_bytes=int(slack_gib * (1 << 30)), refine_passes=refine))
@@ -459,6 +461,7 @@ def place_batch(ctx, params, n_tiles, tile0, masks, how, trials, refine=1, slack
             rec.update(b.place_search(params, candidates=trials))
     except Exception as e:          # the placement is an optimisation: the planes bound now are valid whatever happened
         rec['error'] = f'{type(e).__name__}: {e}'[:300]
+    rec['seconds'] = round(time.perf_counter() - t_place, 2)
     return b, rec
 
 
