@@ -154,6 +154,9 @@ def test_plain_gpus_command_plans_the_weak_and_the_strong_record():
     res = _bench('--plan-only')                                     # N = 1: configs[2] alone
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
     assert 'strong' not in out and out['tiles_per_step_all_ranks'] == 256
+    res = _bench('--plan-only', '--also-strong')                    # ... unless asked for: the one rank walks all 4096 tiles
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['tiles_per_step_all_ranks'] == 256 and out['strong']['ranks'][0]['launches'] == [512] * 8
 
 
 def test_forced_world_of_one_goes_through_the_process_group(tmp_path):
