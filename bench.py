@@ -52,8 +52,15 @@ def parse_args():
                          'strong: the chunk size, default 512 = the per-GPU share of configs[3] at 8 GPUs)')
     ap.add_argument('--total-tiles', type=int, default=0,
                     help='strong scaling: tiles of the whole job, split over the ranks (BASELINE configs[3]: 4096)')
-    ap.add_argument('--allow-gloo', action='store_true',
-                    help='let the control plane fall back to gloo if RCCL cannot initialise (default: fail)')
+    ap.add_argument('--require-rccl', action='store_true',
+                    help='fail (every rank, no line) if the RCCL control plane cannot come up on every rank.  Default: fall '
+                         'back to gloo LOUDLY -- `config.control_plane` says why and `rccl_ranks` is 0; RCCL carries only the '
+                         'barriers and the MAX / SUM of a few scalars here, tiles are independent')
+    ap.add_argument('--allow-gloo', action='store_true', help=argparse.SUPPRESS)       # r04 spelling: now the default
+    ap.add_argument('--preflight', action='store_true',
+                    help='bring the ranks up, print the preflight record (per rank: device PCI address + UUID, free HBM vs '
+                         'what the resident chunk needs, control-plane round trip) as JSON and exit.  The same record is '
+                         'taken before every N > 1 measurement and stored in the line as `preflight`')
     ap.add_argument('--realloc-repeats', type=int, default=5,
                     help='N = 1: after the timed region, re-allocate the batch this many times and report the '
                          'spread of the kernel rate (it depends on where the arena lands, DESIGN.md section 5)')
@@ -546,177 +553,260 @@ def device_identity(torch, index):
         return f'{socket.gethostname()}/cuda:{index} ({type(e).__name__})'
 
 
-def host_path_leg(ctx, cp, params, check, n_tiles=4, reps=3):
+class RankGuard:
+    """one rank's exception must not cost the line.  Every piece of LOCAL work of a rank (allocate,
+    place, warm up, the timed loop, the parity check, ...) runs through `run`; the first exception becomes this rank's
+    error record and the rest of the rank's local work in this case is skipped -- but the rank keeps walking the same
+    sequence of collectives as the others (barriers, MAX, SUM, gathers: they sit OUTSIDE `run`), so nobody is stranded
+    and rank 0 still prints the line, with `value: null` for the case a rank failed in and the failure named.
+    DSWX_BENCH_INJECT='<rank>:<case index>:<phase>' raises inside that phase (tests/: the injected failure)."""
+
+    def __init__(self, rank, case_index, boot_error=None):
+        self.rank, self.case_index = rank, case_index
+        self.error = dict(boot_error) if boot_error else None
+        self.inject = None
+        spec = os.environ.get('DSWX_BENCH_INJECT', '')
+        if spec:
+            r, c, phase = spec.split(':', 2)
+            if int(r) == rank and int(c) == case_index:
+                self.inject = phase
+
+    @property
+    def ok(self):
+        return self.error is None
+
+    def run(self, phase, fn, default=None):
+        if self.error is not None:
+            return default
+        try:
+            if self.inject == phase:
+                raise RuntimeError(f'injected failure in phase {phase!r} (DSWX_BENCH_INJECT)')
+            return fn()
+        except Exception as e:                              # noqa: BLE001
+            import traceback
+            self.error = {'phase': phase, 'error': f'{type(e).__name__}: {e}'[:400]}
+            print(f'[bench rank {self.rank}] case {self.case_index}: {phase} failed: {self.error["error"]}\n'
+                  + traceback.format_exc(limit=6), file=sys.stderr, flush=True)
+            return default
+
+
+def host_path_leg(ctx, cp, params, check, rank=0, n_tiles=4, reps=3):
     """The END-TO-END (PCIe-inclusive) rate of the host-pointer entry dswx_classify_host, after the timed region and
     never `value`: `n_tiles` 3660 x 3660 tiles (a) from planes in page-locked memory of dswx_host_alloc -- zero copy: the
     kernels read the inputs and write the layers across PCIe themselves -- and (b) from pageable numpy arrays, as a
     caller of the reference's seam holds them (staged copies).  With N ranks every rank runs the same calls AT ONCE
     (barrier on both sides) and the rates are the SUM over ranks: this is north_star's "host scatter / gather" and the one
-    place where the GPUs of a node share something (the host's memory system)."""
+    place where the GPUs of a node share something (the host's memory system).  A rank whose local work fails keeps
+    walking the leg's collectives (RankGuard) and the leg reports the error instead of rates."""
     import ctypes
     import numpy as np
     from proteus_amd import _capi
     from proteus_amd.synth import synth_tile
     layers = ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud')
-    s = synth_tile(3, TILE, TILE)
+    guard = RankGuard(rank, 99)
     shape = (n_tiles, TILE, TILE)
     px = n_tiles * TILE * TILE
     rec = {'tiles_per_call': n_tiles, 'ranks': cp.world if cp.dist is not None else 1}
     results = {}
+    s = guard.run('host path: generator', lambda: synth_tile(3, TILE, TILE))
     for mode in ('zero_copy', 'pageable'):
-        alloc = ctx.pinned_empty if mode == 'zero_copy' else (lambda sh, dt: np.empty(sh, dtype=dt))
-        bands = [alloc(shape, np.int16) for _ in range(6)]
-        fm = alloc(shape, np.uint8)
-        for t in range(n_tiles):
+        st = {}
+
+        def prepare():
+            alloc = ctx.pinned_empty if mode == 'zero_copy' else (lambda sh, dt: np.empty(sh, dtype=dt))
+            bands = [alloc(shape, np.int16) for _ in range(6)]
+            fm = alloc(shape, np.uint8)
+            for t in range(n_tiles):
+                for i in range(6):
+                    bands[i][t] = s['bands'][i]
+                fm[t] = s['fmask']
+            outs = {k: alloc(shape, np.uint16 if k == 'diag' else np.uint8) for k in layers}
+            for a in outs.values():
+                a[...] = 0                          # pageable outputs: touched once, as a caller's arrays would be
+            pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
             for i in range(6):
-                bands[i][t] = s['bands'][i]
-            fm[t] = s['fmask']
-        outs = {k: alloc(shape, np.uint16 if k == 'diag' else np.uint8) for k in layers}
-        for a in outs.values():
-            a[...] = 0                          # pageable outputs: touched once, as a caller's arrays would be
-        pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
-        for i in range(6):
-            pin.band[i] = bands[i].ctypes.data
-        pin.fmask = fm.ctypes.data
-        for k in layers:
-            setattr(pout, k, outs[k].ctypes.data)
-        cnt = np.zeros((n_tiles, 3), np.int64)
+                pin.band[i] = bands[i].ctypes.data
+            pin.fmask = fm.ctypes.data
+            for k in layers:
+                setattr(pout, k, outs[k].ctypes.data)
+            st.update(bands=bands, fm=fm, outs=outs, pin=pin, pout=pout, cnt=np.zeros((n_tiles, 3), np.int64))
+            call()                                  # untimed: staging arena, tables
 
         def call():
             _capi._check(ctx.lib.dswx_classify_host(ctx.handle, ctypes.byref(params), n_tiles, TILE, TILE,
-                                                    ctypes.byref(pin), ctypes.byref(pout), _capi._host_ptr(cnt)))
-        call()                                  # untimed: staging arena, tables
+                                                    ctypes.byref(st['pin']), ctypes.byref(st['pout']),
+                                                    _capi._host_ptr(st['cnt'])))
+
+        guard.run(f'host path: {mode} setup', prepare)
         cp.barrier()
         t0 = time.perf_counter()
-        for _ in range(reps):
-            call()
+        guard.run(f'host path: {mode} calls', lambda: [call() for _ in range(reps)])
         mine = time.perf_counter() - t0
         cp.barrier()
         elapsed = cp.max_over_ranks(mine)
         total_px = cp.sum_over_ranks(px) * reps
-        rec[f'{mode}_Gpx_s'] = round(total_px / elapsed / 1e9, 3)
-        rec[f'{mode}_ms_per_call'] = round(elapsed / reps * 1e3, 2)
-        rec[f'{mode}_kernel'] = ctx.last_kernel_info()
-        results[mode] = {k: np.array(v) for k, v in outs.items()}
-        results[mode]['counters'] = cnt.copy()
-        del bands, fm, outs
+        if guard.ok:
+            rec[f'{mode}_Gpx_s'] = round(total_px / elapsed / 1e9, 3)
+            rec[f'{mode}_ms_per_call'] = round(elapsed / reps * 1e3, 2)
+            rec[f'{mode}_kernel'] = ctx.last_kernel_info()
+            results[mode] = {k: np.array(v) for k, v in st['outs'].items()}
+            results[mode]['counters'] = st['cnt'].copy()
+        st.clear()
+
+    def verdict_of():
+        same = all(np.array_equal(results['zero_copy'][k], results['pageable'][k]) for k in results['zero_copy'])
+        verdict = 'both entries identical' if same else 'MISMATCH between the zero-copy and the staged entry'
+        if check and same:
+            from oracle import c_oracle
+            exp = c_oracle.classify(params, s['bands'], s['fmask'])
+            ok = all(np.array_equal(results['zero_copy'][k][n_tiles - 1], exp[k]) for k in layers) and \
+                results['zero_copy']['counters'][n_tiles - 1].tolist() == exp['counters'].tolist()
+            verdict += ', bit-exact vs the C oracle' if ok else ', MISMATCH vs the C oracle'
+        return verdict
+    verdict = guard.run('host path: parity', verdict_of)
+    mine = {'rank': rank, 'verdict': verdict, 'error': guard.error}
+    every = cp.gather_objects(mine)
+    failed = [r for r in every if r['error']]
+    if failed:          # the rates above are sums over ranks of which one did no work: not rates
+        return {'error': f"rank {failed[0]['rank']} failed in {failed[0]['error']['phase']}: {failed[0]['error']['error']}",
+                'failed_ranks': [r['rank'] for r in failed], 'tiles_per_call': n_tiles, 'ranks': rec['ranks']}
     rec['pcie_GBps_in_plus_out'] = round(rec['zero_copy_Gpx_s'] * 21, 1)        # 13 B in + 8 B out per pixel, both ways at once
-    same = all(np.array_equal(results['zero_copy'][k], results['pageable'][k]) for k in results['zero_copy'])
-    verdict = 'both entries identical' if same else 'MISMATCH between the zero-copy and the staged entry'
-    if check and same:
-        from oracle import c_oracle
-        exp = c_oracle.classify(params, s['bands'], s['fmask'])
-        ok = all(np.array_equal(results['zero_copy'][k][n_tiles - 1], exp[k]) for k in layers) and \
-            results['zero_copy']['counters'][n_tiles - 1].tolist() == exp['counters'].tolist()
-        verdict += ', bit-exact vs the C oracle' if ok else ', MISMATCH vs the C oracle'
-    bad = [v for v in cp.gather_objects(verdict) if 'MISMATCH' in v]
+    bad = [r['verdict'] for r in every if 'MISMATCH' in r['verdict']]
     rec['parity'] = bad[0] if bad else verdict
     rec['note'] = ('dswx_classify_host, after the timed region (never `value`): page-locked planes of dswx_host_alloc = zero copy '
                    'across PCIe; pageable numpy planes = staged copies; all ranks at once, rates summed over ranks')
     return rec
 
 
-def measure_case(args, case, env):
+def measure_case(args, case, env, case_index=0):
     """One measured configuration on every rank: place the resident batch, warm up, time K steps between barriers,
-    check parity on every rank.  Returns the record (complete on rank 0) and leaves nothing allocated, unless
-    `env.keep_batch` asks for the batch (the N = 1 legs after the headline case)."""
-    import torch
+    check parity on every rank.  Returns (record -- complete on rank 0 --, resident tiles, ranks that failed) and leaves
+    nothing allocated.  All local work runs under a RankGuard; the collectives do not (see there)."""
     from proteus_amd import _capi
     ctx, cp, rank, world, params = env.ctx, env.cp, env.rank, env.world, env.params
+    guard = RankGuard(rank, case_index, env.boot_error)
     strong = case.total_tiles > 0
     my_tiles, tile0, n_tiles, chunks = rank_plan(case, rank, world)
-    batch, placement = place_batch(ctx, params, n_tiles, tile0, args.masks,
-                                   'first' if env.share_device and args.placement != 'arena' else args.placement,
-                                   args.placement_trials, args.slide_refine, args.slide_slack_gib)
-    chain = ChainInputs(ctx, n_tiles, tile0) if args.chain else None
+    how = 'first' if env.share_device and args.placement != 'arena' else args.placement
+    st = argparse.Namespace(batch=None, chain=None, placement={'how': how, 'probes': 0}, kernel_info=None,
+                            starts=[], stops=[], step_ms=[], chain_split=None)
+
+    def place():
+        st.batch, st.placement = place_batch(ctx, params, n_tiles, tile0, args.masks, how, args.placement_trials,
+                                             args.slide_refine, env.slack_gib)
+    guard.run('place', place)
+    if args.chain:
+        def chain_inputs():
+            st.chain = ChainInputs(ctx, n_tiles, tile0)
+        guard.run('chain inputs', chain_inputs)
 
     def one_step():
-        if chain:                   # terrain shadow + LAND aggregation into the batch's planes, then the classifier
-            chain.layers(batch)
+        if st.chain:                # terrain shadow + LAND aggregation into the batch's planes, then the classifier
+            st.chain.layers(st.batch)
         for c in chunks:            # dswx_batch_classify: a partial last chunk = the first `c` resident tiles
-            batch.classify(params, n_tiles=c)
+            st.batch.classify(params, n_tiles=c)
 
-    for _ in range(args.warmup):
-        one_step()
-    ctx.synchronize()
-    kernel_info = ctx.last_kernel_info()
+    def warm_up():
+        for _ in range(args.warmup):
+            one_step()
+        ctx.synchronize()
+        st.kernel_info = ctx.last_kernel_info()
+        st.starts = [ctx.event() for _ in range(args.steps)]
+        st.stops = [ctx.event() for _ in range(args.steps)]
+    guard.run('warm-up', warm_up)
 
-    starts = [ctx.event() for _ in range(args.steps)]
-    stops = [ctx.event() for _ in range(args.steps)]
+    def timed():
+        for k in range(args.steps):
+            ctx.record(st.starts[k])
+            one_step()
+            ctx.record(st.stops[k])
+        ctx.synchronize()
+        env.device_synchronize()
+
     cp.barrier()
-    torch.cuda.synchronize()
-    ctx.synchronize()
+    guard.run('sync before the timed region', lambda: (env.device_synchronize(), ctx.synchronize()))
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ctx.record(starts[k])
-        one_step()
-        ctx.record(stops[k])
-    ctx.synchronize()
-    torch.cuda.synchronize()
+    guard.run('timed region', timed)
     cp.barrier()
     elapsed = time.perf_counter() - t0
     my_elapsed = elapsed
 
-    step_ms = [ctx.elapsed_ms(a, b) for a, b in zip(starts, stops)]
-    for e in starts + stops:
-        ctx.destroy_event(e)
-    chain_split = None
-    if chain and rank == 0:             # after the timed region: the three kernels of a step timed one by one
-        def ms_of(fn, reps=10):
-            fn()
-            ctx.synchronize()
-            e0, e1 = ctx.event(), ctx.event()
-            ctx.record(e0)
-            for _ in range(reps):
+    def after():
+        st.step_ms = [ctx.elapsed_ms(a, b) for a, b in zip(st.starts, st.stops)]
+        for e in st.starts + st.stops:
+            ctx.destroy_event(e)
+        st.starts, st.stops = [], []
+        if st.chain and rank == 0:          # after the timed region: the three kernels of a step timed one by one
+            chain, batch = st.chain, st.batch
+
+            def ms_of(fn, reps=10):
                 fn()
-            ctx.record(e1)
-            ctx.synchronize()
-            ms = ctx.elapsed_ms(e0, e1) / reps
-            ctx.destroy_event(e0)
-            ctx.destroy_event(e1)
-            return ms
-        both = ms_of(lambda: chain.layers(batch))
-        land_only = ms_of(lambda: ctx.landcover_mask_device(chain.d_wc.ptr, chain.d_cg.ptr, n_tiles, TILE, TILE, CHAIN_FOREST,
-                                                            batch.pin.land, out_tile_stride=batch.tile_stride))
-        chain_split = {'terrain_shadow_ms': round(both - land_only, 4), 'land_aggregation_ms': round(land_only, 4),
-                       'classify_ms': round(ms_of(lambda: batch.classify(params)), 4)}
+                ctx.synchronize()
+                e0, e1 = ctx.event(), ctx.event()
+                ctx.record(e0)
+                for _ in range(reps):
+                    fn()
+                ctx.record(e1)
+                ctx.synchronize()
+                ms = ctx.elapsed_ms(e0, e1) / reps
+                ctx.destroy_event(e0)
+                ctx.destroy_event(e1)
+                return ms
+            both = ms_of(lambda: chain.layers(batch))
+            land_only = ms_of(lambda: ctx.landcover_mask_device(chain.d_wc.ptr, chain.d_cg.ptr, n_tiles, TILE, TILE,
+                                                                CHAIN_FOREST, batch.pin.land,
+                                                                out_tile_stride=batch.tile_stride))
+            st.chain_split = {'terrain_shadow_ms': round(both - land_only, 4), 'land_aggregation_ms': round(land_only, 4),
+                              'classify_ms': round(ms_of(lambda: batch.classify(params)), 4)}
+    guard.run('read the step timers', after)
     elapsed = cp.max_over_ranks(elapsed)
     total_px_per_step = cp.sum_over_ranks(my_tiles) * TILE * TILE
 
     bytes_per_px = 24 if args.masks else 21      # SURVEY.md §8d: 13+8 (16+8 with masks)
-    if chain:       # + terrain shadow (4 B of DEM incl. its margin + 1 written) + LAND aggregation (9 + 1 + 1 written)
-        bytes_per_px = 24 + (4.0 * chain.H * chain.W / (TILE * TILE) + 1.0) + 11.0
+    if args.chain:  # + terrain shadow (4 B of DEM incl. its margin + 1 written) + LAND aggregation (9 + 1 + 1 written)
+        side = TILE + 2 * CHAIN_MARGIN
+        bytes_per_px = 24 + (4.0 * side * side / (TILE * TILE) + 1.0) + 11.0
     # dominant kernel: one launch = one resident chunk; a step is len(chunks) launches
     px_per_launch = n_tiles * TILE * TILE
     my_px_per_step = my_tiles * TILE * TILE
-    avg_step_ms = sum(step_ms) / len(step_ms)
-    achieved = my_px_per_step * bytes_per_px / (avg_step_ms * 1e-3) / 1e9
-    avg_launch_ms = avg_step_ms * px_per_launch / my_px_per_step
+    placement = st.placement
 
     def probe_frac(ms):
         return round(px_per_launch * bytes_per_px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None
 
     # what THIS rank saw: gathered into the line, the slowest rank named (value is bounded by it)
-    mine = {'rank': rank, 'device': env.device_id, 'tiles_per_step': my_tiles, 'launches_per_step': len(chunks),
-            'wall_ms_per_step': round(my_elapsed / args.steps * 1e3, 4),
-            'launch_ms_avg': round(avg_launch_ms, 4), 'frac': round(achieved / HBM_PEAK_GBS, 4),
-            'placement': {'how': placement['how'], 'probes': placement.get('probes', 0),
-                          'first_come_launch_ms': placement.get('first_come_launch_ms'),
-                          'kept_launch_ms': placement.get('kept_launch_ms'),
-                          'frac_first_come_probe': probe_frac(placement.get('first_come_launch_ms')),
-                          'frac_kept_probe': probe_frac(placement.get('kept_launch_ms'))}}
-    for k in ('note', 'error', 'fallback'):
-        if placement.get(k):
-            mine['placement'][k] = placement[k]
+    mine = {'rank': rank, 'device': env.device_id, 'tiles_per_step': my_tiles, 'launches_per_step': len(chunks)}
+    achieved = avg_launch_ms = None
+    if guard.ok:
+        avg_step_ms = sum(st.step_ms) / len(st.step_ms)
+        achieved = my_px_per_step * bytes_per_px / (avg_step_ms * 1e-3) / 1e9
+        avg_launch_ms = avg_step_ms * px_per_launch / my_px_per_step
+        mine.update({'wall_ms_per_step': round(my_elapsed / args.steps * 1e3, 4),
+                     'launch_ms_avg': round(avg_launch_ms, 4), 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                     'placement': {'how': placement['how'], 'probes': placement.get('probes', 0),
+                                   'first_come_launch_ms': placement.get('first_come_launch_ms'),
+                                   'kept_launch_ms': placement.get('kept_launch_ms'),
+                                   'frac_first_come_probe': probe_frac(placement.get('first_come_launch_ms')),
+                                   'frac_kept_probe': probe_frac(placement.get('kept_launch_ms'))}})
+        for k in ('note', 'error', 'fallback'):
+            if placement.get(k):
+                mine['placement'][k] = placement[k]
+    else:
+        mine.update(error=guard.error['error'], phase=guard.error['phase'])
     per_rank = cp.gather_objects(mine)
+    failed = [r for r in per_rank if 'error' in r]
 
     parity = None
     if not args.no_parity:              # EVERY rank checks its own tiles; the records are gathered into the line
-        try:
-            rec = chain_parity(ctx, batch, params, chain, rank, tile0, sorted({0, n_tiles - 1})) if chain else \
-                rank_parity(ctx, batch, params, rank, tile0, n_tiles, chunks, case.distinct_chunks)
-        except Exception as e:          # the checker failing is reported, not fatal to the measurement
-            rec = {'rank': rank, 'first_tile': tile0, 'result': f'not checked ({type(e).__name__}: {e})'[:300]}
+        rec = None
+        if guard.ok:                    # (the checker failing is reported, not fatal to the measurement)
+            try:
+                rec = chain_parity(ctx, st.batch, params, st.chain, rank, tile0, sorted({0, n_tiles - 1})) if st.chain else \
+                    rank_parity(ctx, st.batch, params, rank, tile0, n_tiles, chunks, case.distinct_chunks)
+            except Exception as e:      # noqa: BLE001
+                rec = {'rank': rank, 'first_tile': tile0, 'result': f'not checked ({type(e).__name__}: {e})'[:300]}
+        else:
+            rec = {'rank': rank, 'first_tile': tile0, 'result': f"not checked (the rank failed in {guard.error['phase']})"}
         records = cp.gather_objects(rec)
         bad = [r['result'] for r in records if r['result'] != 'bit-exact']
         parity = {'result': bad[0] if bad else 'bit-exact', 'ranks': records}
@@ -724,9 +814,8 @@ def measure_case(args, case, env):
     out = None
     if rank == 0:
         from proteus_amd import build as _build
-        traffic, pmc_note = pmc_traffic(args.masks, n_tiles)
-        if chain:
-            traffic, pmc_note = None, 'no PMC pass for the three-kernel chain'
+        batch, chain = st.batch, st.chain
+        stride = batch.tile_stride if batch is not None else -(-TILE * TILE // 256) * 256
         if strong:
             workload = (f'BASELINE configs[3]: {case.total_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles in all, split '
                         f'contiguously over {world} rank(s); a rank walks its share ({my_tiles} tiles on rank 0) in '
@@ -735,80 +824,218 @@ def measure_case(args, case, env):
         else:
             workload = (f'BASELINE configs[2]: {n_tiles} synthetic {TILE}x{TILE} HLS.L30 tiles per GPU per step, '
                         f'device-resident band-planar batch')
-        if chain:
+        if args.chain:
+            side = TILE + 2 * CHAIN_MARGIN
             workload = (f"BASELINE configs[4], one GPU's share, device-resident: {n_tiles} synthetic {TILE}x{TILE} tiles per step through "
-                        f'terrain shadow layer (DEM {chain.H}x{chain.W}, margin {CHAIN_MARGIN}) -> LAND aggregation (WorldCover '
+                        f'terrain shadow layer (DEM {side}x{side}, margin {CHAIN_MARGIN}) -> LAND aggregation (WorldCover '
                         f'{3 * TILE}x{3 * TILE} + CGLS) -> fused classifier with SHAD + LAND + OCEAN, the two layers written straight into '
                         f'the planes of the batch (a step = three kernels; L30 / S30 differ in host-side band mapping only)')
-        workload += (f' (tile stride {batch.tile_stride} px = 256-byte aligned tile starts)'
+        workload += (f' (tile stride {stride} px = 256-byte aligned tile starts)'
                      + (', LAND+SHAD+OCEAN planes' if args.masks else ''))
         devices = sorted({r['device'] for r in per_rank})
-        slowest = max(per_rank, key=lambda r: r['wall_ms_per_step'])
+        good = [r for r in per_rank if 'error' not in r]
         out = {
             'metric': 'Mpixels/sec DSWx classify (3660^2 7-band HLS tiles)',
-            'value': round(total_px_per_step * args.steps / elapsed / 1e6, 1),
+            # a case in which ANY rank failed has no whole-job rate: null, with the failure named (`error`, `ranks`)
+            'value': None if failed else round(total_px_per_step * args.steps / elapsed / 1e6, 1),
             'unit': 'Mpixels/s',
             # the number of DISTINCT devices the ranks report (PCI address + UUID), not the number of ranks started
             'n_gpus': len(devices), 'n_ranks': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'ms_per_step': None if failed else round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'int16+f64', 'data': 'synthetic',
+            'rccl_ranks': cp.rccl_ranks,
             'config': {'workload': workload,
                        'tiles_per_step_all_ranks': total_px_per_step // (TILE * TILE),
                        'tiles_per_gpu_resident': n_tiles, 'launches_per_step': len(chunks),
-                       'tile': [TILE, TILE], 'tile_stride_px': batch.tile_stride,
+                       'tile': [TILE, TILE], 'tile_stride_px': stride,
                        'planes_in': 10 if args.masks else 7, 'planes_out': 7,
                        'sharding': f'tiles by rank x{world}, no collective',
                        'control_plane': cp.backend,
-                       'arena_placement': dict(placement, note={
-                           'arena': 'all planes in one hipMalloc (dswx_batch_create without flags)',
-                           'first': 'inputs in one allocation, every output plane in its own, as they come',
-                           'slide': 'dswx_batch_place_slide (C-ABI): `positions` candidate placements of the output planes inside '
-                                    'a range 48 GiB longer than they are (packed at every 2 GiB, spread, then per-plane '
-                                    'refinement), the chunks under the best one moved into a range of their own and kept, the wide range freed; '
-                                    'first_come_launch_ms = the first-come range timed back to back with the kept one',
-                           'search': 'dswx_batch_place_search (C-ABI): every output plane in the fastest of `trials` candidate '
-                                     'allocations (one pass of coordinate descent, the kernel itself as the probe); '
-                                     'first_come_launch_ms = the first-come planes timed back to back with the kept ones',
-                       }[placement['how']] + '; before warm-up, outside the timed region; rank 0 (every rank: `ranks`); '
-                                             'roofline.realloc_spread shows what unplaced single-arena allocations give'
-                           + ('; library: ' + placement['note'] if placement.get('note') else '')),
-                       'kernel': kernel_info},
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': traffic,
-                         'algorithmic_bytes_per_pixel': round(bytes_per_px, 3),
-                         'pixels_per_launch': px_per_launch,
-                         'launch_ms_avg': round(avg_launch_ms, 4),
-                         'launch_ms_min': round(min(step_ms) * px_per_launch / my_px_per_step, 4),
-                         'launch_ms_max': round(max(step_ms) * px_per_launch / my_px_per_step, 4),
-                         'launches_timed': args.steps * len(chunks),
-                         'read_frac_of_peak': round(achieved * (bytes_per_px - 8) / bytes_per_px
-                                                    / HBM_PEAK_GBS, 4),
-                         'traffic_source': pmc_note,
-                         'kernel_source_hash': _build.hot_kernel_hash(),
-                         'rank': 0},
+                       'kernel': st.kernel_info},
             'ranks': per_rank,
-            'slowest_rank': {'rank': slowest['rank'], 'device': slowest['device'],
-                             'wall_ms_per_step': slowest['wall_ms_per_step'], 'frac': slowest['frac']},
             'parity_check': parity,
         }
+        if failed:
+            out['error'] = '; '.join(f"rank {r['rank']} failed in {r['phase']}: {r['error']}" for r in failed)[:1200]
+            out['failed_ranks'] = [r['rank'] for r in failed]
+        if good:
+            slowest = max(good, key=lambda r: r['wall_ms_per_step'])
+            out['slowest_rank'] = {'rank': slowest['rank'], 'device': slowest['device'],
+                                   'wall_ms_per_step': slowest['wall_ms_per_step'], 'frac': slowest['frac']}
         if len(devices) != world:
             out['n_gpus_note'] = (f'{world} ranks ran on {len(devices)} distinct device(s)'
                                   + (' (DSWX_BENCH_SHARE_DEVICE=1: a functional test, not a measurement)' if env.share_device else ''))
-        if chain:
-            out['roofline'].update(chain=chain_split, read_frac_of_peak=None,
-                                   note='achieved / frac = the algorithmic bytes of the three kernels of a step (24 + 5.22 + 11 '
-                                        'per pixel) over the step time')
-        if placement.get('first_come_launch_ms'):
-            # the first-come planes and the kept ones, timed back to back at the end of the placement (3-launch probes:
-            # compare THESE two with each other; sustained rates over the timed steps run 1.5 - 2 % below such probes)
-            out['roofline']['frac_first_come_placement'] = probe_frac(placement['first_come_launch_ms'])
-            out['roofline']['frac_kept_placement_probe'] = probe_frac(placement['kept_launch_ms'])
-    if chain:
-        chain.free()
-    batch.free()
-    return out, n_tiles
+        if guard.ok:            # rank 0's own kernel figures
+            traffic, pmc_note = pmc_traffic(args.masks, n_tiles)
+            if chain:
+                traffic, pmc_note = None, 'no PMC pass for the three-kernel chain'
+            out['config']['arena_placement'] = dict(placement, note={
+                'arena': 'all planes in one hipMalloc (dswx_batch_create without flags)',
+                'first': 'inputs in one allocation, every output plane in its own, as they come',
+                'slide': 'dswx_batch_place_slide (C-ABI): `positions` candidate placements of the output planes inside '
+                         'a range 48 GiB longer than they are (packed at every 2 GiB, spread, then per-plane '
+                         'refinement), the chunks under the best one moved into a range of their own and kept, the wide range freed; '
+                         'first_come_launch_ms = the first-come range timed back to back with the kept one',
+                'search': 'dswx_batch_place_search (C-ABI): every output plane in the fastest of `trials` candidate '
+                          'allocations (one pass of coordinate descent, the kernel itself as the probe); '
+                          'first_come_launch_ms = the first-come planes timed back to back with the kept ones',
+            }[placement['how']] + '; before warm-up, outside the timed region; rank 0 (every rank: `ranks`); '
+                                  'roofline.realloc_spread shows what unplaced single-arena allocations give'
+                + ('; library: ' + placement['note'] if placement.get('note') else ''))
+            step_ms = st.step_ms
+            out['roofline'] = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                               'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                               'traffic': traffic,
+                               'algorithmic_bytes_per_pixel': round(bytes_per_px, 3),
+                               'pixels_per_launch': px_per_launch,
+                               'launch_ms_avg': round(avg_launch_ms, 4),
+                               'launch_ms_min': round(min(step_ms) * px_per_launch / my_px_per_step, 4),
+                               'launch_ms_max': round(max(step_ms) * px_per_launch / my_px_per_step, 4),
+                               'launches_timed': args.steps * len(chunks),
+                               'read_frac_of_peak': round(achieved * (bytes_per_px - 8) / bytes_per_px
+                                                          / HBM_PEAK_GBS, 4),
+                               'traffic_source': pmc_note,
+                               'kernel_source_hash': _build.hot_kernel_hash(),
+                               'rank': 0}
+            if chain:
+                out['roofline'].update(chain=st.chain_split, read_frac_of_peak=None,
+                                       note='achieved / frac = the algorithmic bytes of the three kernels of a step (24 + 5.22 + 11 '
+                                            'per pixel) over the step time')
+            if placement.get('first_come_launch_ms'):
+                # the first-come planes and the kept ones, timed back to back at the end of the placement (3-launch probes:
+                # compare THESE two with each other; sustained rates over the timed steps run 1.5 - 2 % below such probes)
+                out['roofline']['frac_first_come_placement'] = probe_frac(placement['first_come_launch_ms'])
+                out['roofline']['frac_kept_placement_probe'] = probe_frac(placement['kept_launch_ms'])
+        else:
+            out['roofline'] = None
+    # nothing stays allocated, whatever happened above
+    for obj in (st.chain, st.batch):
+        if obj is not None:
+            try:
+                obj.free()
+            except Exception as e:      # noqa: BLE001
+                print(f'[bench rank {rank}] free failed: {e}', file=sys.stderr, flush=True)
+    return out, n_tiles, [r['rank'] for r in failed]
+
+
+def resident_bytes(n_tiles, masks):
+    """HBM the resident planes of `n_tiles` tiles take (256-byte aligned tile starts; + the counters, negligible)."""
+    stride = -(-TILE * TILE // 256) * 256
+    return n_tiles * stride * (24 if masks else 21)
+
+
+def preflight(args, env, cases):
+    """VERDICT r04 next-1c, < 10 s, before any big allocation, on every rank: which device (PCI address + UUID), how
+    much of its HBM is free against what the largest resident chunk of this command line needs (+ the placement range's
+    slack; a rank that is short shrinks ITS slack and says so -- the slack is a per-rank optimisation, no agreement is
+    needed), and one control-plane round trip (barrier + MAX).  Gathered; the distinctness of the devices is judged on
+    the gathered list.  Returns the record (same on all ranks) and sets env.slack_gib."""
+    margin = 6 << 30                                        # probes of the placement keep 8 GiB free themselves
+    need = 0
+    for case in cases:
+        _, _, n_tiles, _ = rank_plan(case, env.rank, env.world)
+        need = max(need, resident_bytes(n_tiles, args.masks))
+    if args.chain:
+        side = TILE + 2 * CHAIN_MARGIN
+        need += args.tiles * (4 * side * side + 10 * TILE * TILE)
+    mine = {'rank': env.rank, 'device': env.device_id, 'resident_chunk_GiB': round(need / 2 ** 30, 2)}
+    env.slack_gib = args.slide_slack_gib
+    if env.boot_error:
+        mine['error'] = f"{env.boot_error['phase']}: {env.boot_error['error']}"
+    else:
+        try:
+            free, total = env.mem_info()
+            mine.update(hbm_free_GiB=round(free / 2 ** 30, 2), hbm_total_GiB=round(total / 2 ** 30, 2))
+            slide = args.placement == 'slide' and not env.share_device
+            if free < need + margin:
+                mine['warning'] = (f'free HBM {free / 2 ** 30:.1f} GiB < resident chunk {need / 2 ** 30:.1f} GiB + '
+                                   f'{margin >> 30} GiB: the allocation is likely to fail')
+                env.slack_gib = 0.0
+            elif slide and free < need + margin + int(args.slide_slack_gib * 2 ** 30):
+                env.slack_gib = float(max(0, (free - need - margin) >> 30))
+                mine['adjusted'] = f'--slide-slack-gib {args.slide_slack_gib:g} -> {env.slack_gib:g} (free HBM)'
+            if slide:
+                mine['slide_slack_GiB'] = env.slack_gib
+        except Exception as e:                              # noqa: BLE001
+            mine['error'] = f'mem info: {type(e).__name__}: {e}'[:300]
+    t0 = time.perf_counter()
+    env.cp.barrier()
+    env.cp.max_over_ranks(0.0)
+    mine['control_plane_round_trip_ms'] = round((time.perf_counter() - t0) * 1e3, 3)
+    ranks = env.cp.gather_objects(mine)
+    devices = [r['device'] for r in ranks]
+    rec = {'ranks': ranks, 'distinct_devices': len(set(devices)), 'control_plane': env.cp.backend,
+           'rccl_ranks': env.cp.rccl_ranks,
+           'ok': len(set(devices)) == len(devices) and not any('error' in r or 'warning' in r for r in ranks)}
+    if len(set(devices)) != len(devices):
+        rec['note'] = 'two ranks report the same device' + (' (DSWX_BENCH_SHARE_DEVICE=1)' if env.share_device else
+                                                             ': the launcher did not give every rank its own GPU')
+    return rec
+
+
+def bring_up(args, rank, local_rank, world):
+    """This rank's device, control plane and library context.  The control plane comes first and does not depend on
+    the GPU working (gloo underneath, RCCL probed beside it: proteus_amd.shard.ControlPlane), so a rank whose device or
+    library fails still takes part in every collective and its failure is a record in the line (`boot_error`)."""
+    import torch
+    from proteus_amd import build as _build
+    boot_error = None
+    try:
+        # compile when missing or stale (never a CPU fallback, never an old binary); one rank builds
+        if local_rank == 0:
+            _build.build()                  # os.replace at the end: the file appears complete or not at all
+        else:
+            for _ in range(1200):
+                if not _build.is_stale():
+                    break
+                time.sleep(0.5)
+    except Exception as e:                                  # noqa: BLE001
+        boot_error = {'phase': 'build', 'error': f'{type(e).__name__}: {e}'[:400]}
+    from proteus_amd import _capi, shard
+
+    share_device = os.environ.get('DSWX_BENCH_SHARE_DEVICE') == '1'
+    visible = torch.cuda.device_count()
+    if visible < 1 and boot_error is None:
+        boot_error = {'phase': 'device', 'error': 'no GPU visible to this rank: the DSWx HIP path has no CPU fallback'}
+    if share_device:
+        # functional test of the N > 1 code path on a 1-GPU box: every rank on device 0, gloo as
+        # the control plane (RCCL refuses two ranks on one GPU).  Not a measurement.
+        local_rank = 0
+    else:
+        # LOCAL_RANK is the device index when every rank sees all GPUs (torchrun's default); a launcher that narrows every
+        # rank's view to its own GPU (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per rank) leaves one device, index 0
+        local_rank = local_rank % max(visible, 1)
+    device = torch.device('cuda', local_rank)
+    if visible >= 1:
+        try:
+            torch.cuda.set_device(local_rank)
+        except Exception as e:                              # noqa: BLE001
+            boot_error = boot_error or {'phase': 'device', 'error': f'{type(e).__name__}: {e}'[:400]}
+    # N = 1 has no control plane (cp.backend None) unless DSWX_FORCE_DIST=1 asks for a world of one: the RCCL code path
+    # of an N > 1 run -- bring-up with device_id, barrier, all_reduce on device tensors, gathers, destroy -- on a box with
+    # one GPU (tests/test_gpu_multirank.py)
+    cp = shard.ControlPlane(backend='gloo' if share_device else 'nccl', device=None if share_device else device,
+                            require=args.require_rccl)
+    ctx = None
+    if boot_error is None:
+        try:
+            ctx = _capi.Context(local_rank)        # raises if the HIP extension / GPU is missing
+        except Exception as e:                              # noqa: BLE001
+            boot_error = {'phase': 'library context', 'error': f'{type(e).__name__}: {e}'[:400]}
+
+    def device_synchronize():
+        torch.cuda.synchronize()
+
+    return argparse.Namespace(ctx=ctx, cp=cp, rank=rank, world=world, params=_capi.default_params(),
+                              share_device=share_device, boot_error=boot_error, slack_gib=args.slide_slack_gib,
+                              device_id=device_identity(torch, local_rank) if visible >= 1 else f'none (rank {rank})',
+                              device_synchronize=device_synchronize,
+                              mem_info=lambda: torch.cuda.mem_get_info(local_rank))
+
+
+SUB_RECORD_KEYS = ('value', 'unit', 'n_gpus', 'n_ranks', 'steps', 'warmup', 'ms_per_step', 'scaling', 'config', 'roofline',
+                   'ranks', 'slowest_rank', 'parity_check', 'error', 'failed_ranks')
 
 
 def main():
@@ -818,6 +1045,7 @@ def main():
         return 0
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_launch(args)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # RCCL on this host driver needs dmabuf IPC
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -827,63 +1055,46 @@ def main():
     if args.plan_only:
         return plan_only(args, rank, world)
 
-    import torch
-    from proteus_amd import build as _build
-    # compile when missing or stale (never a CPU fallback, never an old binary); one rank builds
-    if local_rank == 0:
-        _build.build()                      # os.replace at the end: the file appears complete or not at all
-    else:
-        for _ in range(1200):
-            if not _build.is_stale():
-                break
-            time.sleep(0.5)
-    from proteus_amd import _capi, shard
+    env = bring_up(args, rank, local_rank, world)
+    ctx, cp = env.ctx, env.cp
+    cases = cases_of(args, world)
+    pre = None
+    if world > 1 or args.preflight or cp.dist is not None:
+        pre = preflight(args, env, cases)
+        if args.preflight:
+            if rank == 0:
+                print(json.dumps({'preflight': pre}), flush=True)
+            if ctx is not None:
+                ctx.close()
+            cp.close()
+            return 0 if pre['ok'] else 1
 
-    share_device = os.environ.get('DSWX_BENCH_SHARE_DEVICE') == '1'
-    if share_device:
-        # functional test of the N > 1 code path on a 1-GPU box: every rank on device 0, gloo as
-        # the control plane (RCCL refuses two ranks on one GPU).  Not a measurement.
-        local_rank = 0
-        torch.cuda.set_device(0)
-        cp = shard.ControlPlane(backend='gloo', device=None)
-    else:
-        # N = 1 has no control plane (cp.backend None) unless DSWX_FORCE_DIST=1 asks for a world of one: the RCCL
-        # code path of an N > 1 run -- init with device_id, barrier, all_reduce on device tensors, all_gather_object,
-        # destroy -- on a box with one GPU (tests/test_gpu_multirank.py)
-        # LOCAL_RANK is the device index when every rank sees all GPUs (torchrun's default); a launcher that narrows every
-        # rank's view to its own GPU (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per rank) leaves one device, index 0
-        visible = torch.cuda.device_count()
-        if visible < 1:
-            raise SystemExit('no GPU visible to this rank: the DSWx HIP path has no CPU fallback')
-        local_rank = local_rank % visible
-        torch.cuda.set_device(local_rank)
-        cp = shard.ControlPlane(backend='nccl', device=torch.device('cuda', local_rank),
-                                allow_fallback=args.allow_gloo)
-
-    ctx = _capi.Context(local_rank)        # raises if the HIP extension / GPU is missing
-    env = argparse.Namespace(ctx=ctx, cp=cp, rank=rank, world=world, params=_capi.default_params(),
-                             share_device=share_device, device_id=device_identity(torch, local_rank))
     out = None
-    for case in cases_of(args, world):
-        rec, n_tiles = measure_case(args, case, env)
+    failed_any = []
+    headline_tiles = args.tiles
+    for index, case in enumerate(cases):
+        rec, n_tiles, failed = measure_case(args, case, env, index)
+        failed_any += failed
         if rank == 0:
             if case.key is None:
                 out = rec
+                if pre is not None:
+                    out['preflight'] = pre
             else:           # a sub-record: the same fields, minus what only the top level carries
-                out[case.key] = {k: rec[k] for k in ('value', 'unit', 'n_gpus', 'n_ranks', 'steps', 'warmup', 'ms_per_step',
-                                                     'scaling', 'config', 'roofline', 'ranks', 'slowest_rank', 'parity_check')}
+                out[case.key] = {k: rec[k] for k in SUB_RECORD_KEYS if k in rec}
+            # what is known so far goes to stderr: a rank that dies HARD in a later case (a signal, not an exception)
+            # takes the line with it, this copy stays in the log
+            print('[bench partial] ' + json.dumps({k: out.get(k) for k in ('value', 'ms_per_step', 'n_gpus', 'error')}
+                                                  | ({case.key: {'value': rec['value']}} if case.key else {})),
+                  file=sys.stderr, flush=True)
         if case.key is None:
             headline_tiles = n_tiles
 
     # ---- legs after the timed regions (none of them is `value`)
     host_path = None
-    if not args.no_host_path and not args.chain:
-        try:                            # every rank takes part (all ranks at once, rates summed)
-            host_path = host_path_leg(ctx, cp, env.params, check=not args.no_parity)
-        except Exception as e:          # noqa: BLE001
-            host_path = {'error': f'{type(e).__name__}: {e}'[:300]}
-            if cp.dist is not None:
-                raise                   # a rank that leaves a collective leg strands the others: fail loudly instead
+    if not args.no_host_path and not args.chain and not failed_any:       # (every rank knows `failed_any`: gathered)
+        # every rank takes part (all ranks at once, rates summed); a rank's failure is a record, not an exit
+        host_path = host_path_leg(ctx, cp, env.params, check=not args.no_parity, rank=rank)
     # RCCL prints a version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise
     # come out at process exit, AFTER the JSON line: every rank empties its C buffers now, and rank 0 prints the line
     # behind a barrier, so that it is the last thing on stdout
@@ -895,9 +1106,13 @@ def main():
         pass
     cp.barrier()
     if rank == 0:
+        from proteus_amd import _capi
+        out['rccl_ranks'] = cp.rccl_ranks               # as it stands at the END of the run (a late fallback shows)
+        out['config']['control_plane'] = cp.backend
         if host_path is not None:
             out['host_path'] = host_path
-        if world == 1 and args.realloc_repeats > 0 and not args.chain:
+        solo = world == 1 and not failed_any
+        if solo and args.realloc_repeats > 0 and not args.chain:
             try:
                 # the legs below allocate whole batches with hipMalloc: hand the library's pool (the chunks of the placed
                 # batch's dropped ranges, ~100 GiB at 256 tiles) back to the device first -- this process has no other
@@ -907,12 +1122,12 @@ def main():
                                                                    args.realloc_repeats)
             except Exception as e:
                 out['roofline']['realloc_spread'] = {'error': f'{type(e).__name__}: {e}'[:300]}
-        if world == 1 and not args.no_single_tile and not args.chain:
+        if solo and not args.no_single_tile and not args.chain:
             try:
                 out['single_tile'] = single_tile_leg(ctx, env.params, args.masks)
             except Exception as e:
                 out['single_tile'] = {'error': f'{type(e).__name__}: {e}'[:300]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not failed_any:
             try:
                 out['cpu_baseline'] = cpu_baseline_sample()
                 par = cpu_baseline_parallel()
@@ -921,9 +1136,18 @@ def main():
             except Exception as e:      # a reported baseline must never cost the bench line
                 out['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         print(json.dumps(out), flush=True)
-    ctx.close()
-    cp.close()
-    return 0
+    code = 1 if failed_any else 0           # non-zero AFTER the line
+    try:
+        if ctx is not None:
+            ctx.close()
+        cp.close()
+    except Exception as e:                  # noqa: BLE001
+        print(f'[bench rank {rank}] shutdown: {e}', file=sys.stderr, flush=True)
+    if cp.hung:                             # a helper thread is still inside RCCL: do not wait for it at interpreter exit
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(code)
+    return code
 
 
 if __name__ == '__main__':

@@ -2,7 +2,7 @@
 
 Every pixel -- hence every tile -- is independent in the 'mask' / 'ignore' modes, so
 the batch is split statically and contiguously over ranks and no data-path
-collective exists.  torch.distributed (RCCL on the GPU box, gloo in the CPU tests)
+collective exists.  torch.distributed (gloo always, RCCL beside it on the GPU box)
 is used only as the control plane: a barrier around the timed region and a MAX
 over ranks of the elapsed time.
 """
@@ -42,70 +42,179 @@ def env_rank():
 
 class ControlPlane:
     """Barrier + max-over-ranks; a no-op object for world == 1 -- unless DSWX_FORCE_DIST=1 asks for a process group of
-    ONE rank: the same init (RCCL with device_id), barrier, all_reduce on device tensors, all_gather_object and destroy
-    an N > 1 run goes through, on a box with a single GPU (tests/test_gpu_multirank.py)."""
+    ONE rank: the same bring-up, barrier, all_reduce on device tensors, all_gather_object and destroy an N > 1 run goes
+    through, on a box with a single GPU (tests/test_gpu_multirank.py).
 
-    def __init__(self, backend=None, device=None, allow_fallback=False):
+    Bring-up.  The default process group is ALWAYS gloo over the launcher's TCP rendezvous: it
+    carries the pickled per-rank records and is the channel on which the ranks AGREE about everything else.  With
+    backend='nccl' an RCCL group is created beside it and probed (barrier + all_reduce of a device tensor, inside a
+    helper thread with a time limit); the ranks then take the MIN of their verdicts over gloo.  All ranks good: the
+    barriers and the MAX / SUM reductions run over RCCL on device tensors.  Any rank bad: EVERY rank uses gloo, loudly --
+    `backend` becomes 'gloo (fallback: nccl ... failed on rank(s) [..]: <first error>)' and `rccl_ranks` is 0 -- unless
+    `require=True` (bench.py --require-rccl), which raises on every rank.  RCCL is not on the data path (tiles are
+    independent), so the fallback loses nothing of the measurement.  A reduction that fails over RCCL later in the run
+    is caught the same way: every reduction is followed by a one-integer agreement over gloo, and one bad rank moves all
+    ranks to gloo, where the reduction is repeated.  Barriers carry no agreement (they bracket the timed region)."""
+
+    PROBE_TIMEOUT_S = 120.0
+
+    def __init__(self, backend=None, device=None, allow_fallback=True, require=False):
         self.rank, self.local_rank, self.world = env_rank()
         self.dist = None
         self.device = device
         self.backend = None
-        if self.world > 1 or os.environ.get('DSWX_FORCE_DIST') == '1':
-            import torch.distributed as dist
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            kw = {}
-            if 'MASTER_PORT' not in os.environ:            # a forced world of one outside torchrun: a private rendezvous
-                import socket
-                with socket.socket() as sock:
-                    sock.bind(('127.0.0.1', 0))
-                    port = sock.getsockname()[1]
-                kw.update(init_method=f'tcp://127.0.0.1:{port}', rank=self.rank, world_size=self.world)
-            dev_kw = {'device_id': device} if backend == 'nccl' and device is not None else {}
-            if not dist.is_initialized():
-                try:
-                    dist.init_process_group(backend, **kw, **dev_kw)
-                    self.backend = backend
-                except Exception as e:                      # noqa: BLE001
-                    # RCCL could not come up.  A measurement must not quietly change its control plane:
-                    # fail unless the caller opted in (bench.py --allow-gloo).  With the opt-in, gloo
-                    # carries the same barrier and MAX of one double (there is no data-path collective
-                    # to lose) and the backend string records what happened.
-                    if backend == 'gloo' or not allow_fallback:
-                        raise
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                    dist.init_process_group('gloo', **kw)
-                    self.backend = f'gloo (fallback: {backend} init failed: {str(e)[:120]})'
-                    self.device = None
+        self.rccl_ranks = 0
+        self.fast = None                # the RCCL group, when every rank's probe passed
+        self.hung = False               # an RCCL call never returned: leave with os._exit, never through destroy
+        self._pending = None            # an RCCL failure seen by a barrier, folded into the next agreement
+        if not (self.world > 1 or os.environ.get('DSWX_FORCE_DIST') == '1'):
+            return
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        kw = {}
+        if self.world == 1 and 'MASTER_PORT' not in os.environ:
+            # a forced world of one outside torchrun: a private rendezvous.  A world > 1 keeps env:// so that a launcher
+            # which forgot MASTER_PORT fails at once instead of every rank waiting on its own port (ADVICE r04)
+            import socket
+            with socket.socket() as sock:
+                sock.bind(('127.0.0.1', 0))
+                port = sock.getsockname()[1]
+            kw.update(init_method=f'tcp://127.0.0.1:{port}', rank=self.rank, world_size=self.world)
+        if not dist.is_initialized():
+            dist.init_process_group('gloo', **kw)
+        self.dist = dist
+        self.backend = 'gloo'
+        if backend == 'nccl':
+            err = self._bring_up_rccl()
+            verdicts = self.gather_objects(err)
+            bad = [(r, e) for r, e in enumerate(verdicts) if e]
+            if not bad:
+                self.backend, self.rccl_ranks = 'nccl', self.world
             else:
-                self.backend = dist.get_backend()
-            self.dist = dist
+                self.fast = None
+                why = f'nccl bring-up failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}'
+                if require or not allow_fallback:
+                    raise RuntimeError(why + ' (and the strict control plane was asked for)')
+                self._fall_back(why)
 
+    # ---- RCCL beside gloo
+    def _timed_call(self, fn, what):
+        """(result, None) or (None, why): `fn` in a helper thread with a time limit, so that an RCCL call which never
+        returns (a peer that raised before entering the collective, a wedged link) becomes an error on this rank after
+        DSWX_RCCL_PROBE_TIMEOUT_S instead of the end of the run.  After a timeout the thread is abandoned inside RCCL
+        (`hung`: the process must leave through os._exit) and the RCCL group is not used again."""
+        import threading
+        box = {}
+
+        def body():
+            try:
+                box['result'] = fn()
+            except BaseException as e:                      # noqa: BLE001
+                box['error'] = f'{type(e).__name__}: {e}'[:300]
+
+        limit = float(os.environ.get('DSWX_RCCL_PROBE_TIMEOUT_S', self.PROBE_TIMEOUT_S))
+        th = threading.Thread(target=body, daemon=True, name='dswx-rccl-call')
+        th.start()
+        th.join(limit)
+        if th.is_alive():
+            self.hung = True
+            self.fast = None
+            return None, f'RCCL {what} did not return within {limit:.0f} s'
+        if 'error' in box:
+            return None, box['error']
+        return box.get('result'), None
+
+    def _bring_up_rccl(self):
+        """None, or why RCCL is not usable on THIS rank: group creation, a barrier and an all_reduce whose value is
+        checked."""
+        def probe():
+            import torch
+            dist = self.dist
+            kw = {'device_id': self.device} if self.device is not None else {}
+            group = dist.new_group(backend='nccl', **kw)
+            dev = self.device if self.device is not None else torch.device('cuda', self.local_rank)
+            dist.barrier(group=group, device_ids=[dev.index if dev.index is not None else 0])
+            t = torch.full((1,), float(self.rank), dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            if float(t.item()) != float(self.world - 1):
+                raise RuntimeError(f'all_reduce MAX of the ranks gave {float(t.item())}, not {self.world - 1}')
+            return group
+
+        group, err = self._timed_call(probe, 'bring-up')
+        if err is None:
+            self.fast = group
+        return err
+
+    def _fall_back(self, why):
+        import sys
+        self.fast = None
+        self.rccl_ranks = 0
+        self.backend = f'gloo (fallback: {why})'[:400]
+        if self.rank == 0:
+            print(f'[dswx control plane] {self.backend}', file=sys.stderr, flush=True)
+
+    def _agree(self, my_error):
+        """After a reduction over RCCL: did it work on EVERY rank?  One int64 MIN over gloo; if not, all ranks move to
+        gloo (the caller repeats its reduction there)."""
+        import torch
+        err = my_error or self._pending
+        self._pending = None
+        ok = torch.tensor([0 if err else 1], dtype=torch.int64)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return True
+        errs = self.gather_objects(err)
+        bad = [(r, e) for r, e in enumerate(errs) if e]
+        self._fall_back(f'nccl collective failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}')
+        return False
+
+    def _reduce(self, value, dtype, op_name):
+        import torch
+        op = getattr(self.dist.ReduceOp, op_name)
+        if self.fast is not None or self._pending:
+            out, err = None, self._pending
+            if self.fast is not None:
+                group = self.fast
+
+                def over_rccl():
+                    t = torch.tensor([value], dtype=dtype, device=self.device)
+                    self.dist.all_reduce(t, op=op, group=group)
+                    return t.item()
+                out, err = self._timed_call(over_rccl, f'all_reduce {op_name}')
+            if self._agree(err):
+                return out
+        t = torch.tensor([value], dtype=dtype)
+        self.dist.all_reduce(t, op=op)
+        return t.item()
+
+    # ---- what bench.py calls
     def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
+        if self.dist is None:
+            return
+        if self.fast is not None:
+            group = self.fast
+            idx = self.device.index if self.device is not None and self.device.index is not None else 0
+            _, err = self._timed_call(lambda: self.dist.barrier(group=group, device_ids=[idx]), 'barrier')
+            if err is None:
+                return
+            self._pending = err             # reported by the next agreement; this rank meets the others on gloo
+        self.dist.barrier()
 
     def max_over_ranks(self, value):
         if self.dist is None:
             return float(value)
         import torch
-        t = torch.tensor([float(value)], dtype=torch.float64,
-                         device=self.device if self.device is not None else 'cpu')
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(self._reduce(float(value), torch.float64, 'MAX'))
 
     def sum_over_ranks(self, value):
         """Integer sum over ranks (e.g. tiles processed per step by the whole job)."""
         if self.dist is None:
             return int(value)
         import torch
-        t = torch.tensor([int(value)], dtype=torch.int64,
-                         device=self.device if self.device is not None else 'cpu')
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return int(t.item())
+        return int(self._reduce(int(value), torch.int64, 'SUM'))
 
     def gather_objects(self, obj):
-        """Every rank's small Python object, in rank order, on every rank."""
+        """Every rank's small Python object, in rank order, on every rank (pickled, over gloo)."""
         if self.dist is None:
             return [obj]
         out = [None] * self.world
@@ -117,14 +226,15 @@ class ControlPlane:
         (Host-side metadata only; 24 bytes per tile.)"""
         if self.dist is None:
             return local
-        import torch
-        out = [None] * self.world
-        self.dist.all_gather_object(out, local)
         import numpy as np
-        return np.concatenate(out, axis=0)
+        return np.concatenate(self.gather_objects(local), axis=0)
 
     def close(self):
         if self.dist is not None:
-            self.dist.barrier()
+            self.barrier()              # (over gloo on a rank whose RCCL group is gone: the others wait here too)
+            if self.hung:               # a thread is still inside RCCL: destroy_process_group would wait for it
+                self.dist = None
+                return
             self.dist.destroy_process_group()
             self.dist = None
+            self.fast = None

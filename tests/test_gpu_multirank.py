@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _bench(*argv, share_device=True, force_dist=False):
+def _bench(*argv, share_device=True, force_dist=False, extra_env=None, expect_rc=0):
     env = dict(os.environ)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'DSWX_BENCH_SHARE_DEVICE', 'DSWX_FORCE_DIST'):
         env.pop(k, None)
@@ -22,12 +22,16 @@ def _bench(*argv, share_device=True, force_dist=False):
         env['DSWX_BENCH_SHARE_DEVICE'] = '1'
     if force_dist:
         env['DSWX_FORCE_DIST'] = '1'
+    env.pop('DSWX_BENCH_INJECT', None)
+    env.update(extra_env or {})
     # a child process (never exec from a process that touched the GPU); the parent bench process itself starts the
     # ranks with torch.distributed.run before it imports torch
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), capture_output=True, text=True,
                          timeout=1500, cwd=ROOT, env=env)
-    assert res.returncode == 0, res.stderr[-3000:]
-    return json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert (res.returncode == 0) == (expect_rc == 0), res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, (res.stdout[-2000:], res.stderr[-3000:])
+    return json.loads(lines[0])
 
 
 def test_two_ranks_strong_scaling_every_rank_checks_every_chunk():
@@ -94,7 +98,9 @@ def test_rccl_control_plane_world_of_one():
     record that an N > 1 line gathers through the control plane must come back through RCCL intact."""
     out = _bench('--tiles', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-single-tile',
                  '--realloc-repeats', '0', share_device=False, force_dist=True)
-    assert out['config']['control_plane'] == 'nccl'
+    assert out['config']['control_plane'] == 'nccl' and out['rccl_ranks'] == 1
+    pre = out['preflight']                      # taken whenever a process group exists
+    assert pre['ok'] and pre['rccl_ranks'] == 1 and pre['ranks'][0]['hbm_free_GiB'] > 100 and pre['ranks'][0]['slide_slack_GiB'] == 48.0
     assert out['n_gpus'] == 1 and out['n_ranks'] == 1 and out['config']['tiles_per_step_all_ranks'] == 2
     assert out['parity_check']['result'] == 'bit-exact' and out['parity_check']['ranks'][0]['tiles'] == [0, 1]
     assert [r['rank'] for r in out['ranks']] == [0] and out['ranks'][0]['placement']['how'] == 'slide'
@@ -233,3 +239,32 @@ def test_four_ranks_on_one_device_plain_command():
     assert [r['tiles'] for r in st['parity_check']['ranks']] == [list(range(5 * r, 5 * r + 5)) for r in range(4)]
     assert all(r['distinct_chunks'] == 3 for r in st['parity_check']['ranks'])
     assert [r['tiles_per_step'] for r in st['ranks']] == [5] * 4
+
+
+def test_a_failing_rank_is_a_record_in_the_line_real_kernels():
+    """VERDICT r04 next-1b on the GPU: two ranks on one device, the plain two-record command at toy sizes, and rank 1
+    raises inside the timed region of the FIRST case (DSWX_BENCH_INJECT).  Rank 0's kernels and parity check are real.
+    The line is printed, names the failure, has no whole-job value for that case, keeps rank 0's own roofline, and the
+    second case -- measured after the failure by BOTH ranks, on real kernels -- is intact and bit-exact; the exit code
+    is non-zero, after the line."""
+    out = _bench('--gpus', '2', '--plain-tiles', '3', '--strong-total', '16', '--strong-chunk', '4', '--steps', '2',
+                 '--warmup', '1', '--no-cpu-baseline', extra_env={'DSWX_BENCH_INJECT': '1:0:timed region'}, expect_rc=1)
+    assert out['value'] is None and out['failed_ranks'] == [1] and 'rank 1 failed in timed region' in out['error']
+    assert out['roofline']['frac'] > 0 and out['ranks'][0]['frac'] > 0 and 'injected' in out['ranks'][1]['error']
+    assert out['parity_check']['ranks'][0]['result'] == 'bit-exact'
+    assert out['parity_check']['ranks'][1]['result'].startswith('not checked')
+    assert 'host_path' not in out                   # the collective legs after a failure are skipped by every rank
+    st = out['strong']
+    assert st['value'] > 0 and 'error' not in st and st['parity_check']['result'] == 'bit-exact'
+    assert [r['tiles'] for r in st['parity_check']['ranks']] == [[0, 2, 3, 4, 7], [8, 10, 11, 12, 15]]
+    assert out['preflight']['distinct_devices'] == 1 and not out['preflight']['ok']      # both ranks on device 0: said
+
+
+def test_a_rank_whose_allocation_fails_is_a_record_and_the_memory_comes_back():
+    """The failure VERDICT r04 names: the resident chunk does not fit (here: 40 000 tiles = 10 TB asked of the library).
+    Both ranks fail in 'place' with the library's own error, the line says so, nothing is left allocated, exit non-zero."""
+    out = _bench('--gpus', '2', '--tiles', '40000', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-host-path',
+                 expect_rc=1)
+    assert out['value'] is None and out['failed_ranks'] == [0, 1] and out['roofline'] is None
+    assert all(r['phase'] == 'place' and 'DswxError' in r['error'] for r in out['ranks'])
+    assert any('likely to fail' in r.get('warning', '') for r in out['preflight']['ranks'])

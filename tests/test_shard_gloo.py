@@ -187,18 +187,23 @@ def test_forced_world_of_one_goes_through_the_process_group(tmp_path):
 
 
 def test_bench_rank_without_a_gpu_fails_loudly():
-    """A real (not --plan-only) run on a box without a GPU must fail, not fall back to anything."""
+    """A real (not --plan-only) run on a box without a GPU must fail, not fall back to anything: exit code non-zero,
+    and the line it still prints (a failure is a record) carries no number, only the reason."""
+    import json
     from proteus_amd import _capi
     if _capi.device_count() > 0:
         pytest.skip('a GPU is present')
-    res = _bench('--steps', '1', '--warmup', '0', '--tiles', '1', '--no-cpu-baseline')
+    res = _bench('--steps', '1', '--warmup', '0', '--tiles', '1')
     assert res.returncode != 0
-    assert '{"metric"' not in res.stdout
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert out['value'] is None and out['ms_per_step'] is None and out['roofline'] is None
+    assert 'no GPU visible to this rank: the DSWx HIP path has no CPU fallback' in out['error']
+    assert 'cpu_baseline' not in out and 'single_tile' not in out and 'host_path' not in out
 
 
 def test_control_plane_does_not_fall_back_to_gloo_silently(tmp_path):
-    """RCCL cannot come up here (no GPU): without allow_fallback the control plane raises; with it the
-    backend string says what happened."""
+    """RCCL cannot come up here (no GPU): with allow_fallback=False (or require=True) the control plane raises on every
+    rank; by default the backend string says what happened (more cases: tests/test_bench_survival.py)."""
     script = tmp_path / 'cp.py'
     script.write_text(textwrap.dedent('''
         import sys
@@ -225,7 +230,7 @@ def test_control_plane_does_not_fall_back_to_gloo_silently(tmp_path):
             assert res.returncode != 0 and 'RAISED' in res.stdout
         else:
             assert res.returncode == 0, res.stderr[-2000:]
-            assert 'BACKEND gloo (fallback: nccl init failed' in res.stdout
+            assert 'BACKEND gloo (fallback: nccl bring-up failed on rank(s) [0, 1]' in res.stdout
 
 
 def test_batch_plan():
