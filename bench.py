@@ -83,6 +83,9 @@ def parse_args():
                          'layer from DEMs and the LAND layer from WorldCover + CGLS maps straight into the SHAD / LAND planes of '
                          'the batch (dswx_shadow_layer_batch, dswx_landcover_mask_batch) and classifies with SHAD + LAND + '
                          'OCEAN on; weak scaling only')
+    ap.add_argument('--scaled', action='store_true',
+                    help="the reference's flag_offset_and_scale_inputs (dswx_hls.py:2300-2302): the chain on float32 "
+                         'reflectances 0.0001 * x, thresholds in those units -- the float32 instantiation of the fused kernel')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--distinct-chunks', action='store_true',
@@ -108,7 +111,7 @@ def parse_args():
     ap.add_argument('--strong-chunk', type=int, default=STRONG_CHUNK_TILES, help=argparse.SUPPRESS)
     args = ap.parse_args()
     # "plain": the command line names no workload -- what the driver runs (`bench.py --gpus N --steps K --warmup W`)
-    args.plain_command = args.tiles <= 0 and args.total_tiles <= 0 and not args.chain and not args.masks
+    args.plain_command = args.tiles <= 0 and args.total_tiles <= 0 and not args.chain and not args.masks and not args.scaled
     if args.chain:
         if args.total_tiles > 0:
             ap.error('--chain is a weak-scaling mode (one resident batch per GPU)')
@@ -120,6 +123,19 @@ def parse_args():
     elif args.placement == 'search':
         args.placement_trials = 6
     return args
+
+
+SCALED_UNITS = 1e-4            # --scaled: HLS scale_factor; the reflectance thresholds below are the defaults x 1e-4
+SCALED_THRESHOLDS = dict(wigt=0.124, awgt=0.0, pswt_1_mndwi=-0.44, pswt_1_nir=0.15, pswt_1_swir1=0.09, pswt_1_ndvi=0.7,
+                         pswt_2_mndwi=-0.5, pswt_2_blue=0.1, pswt_2_nir=0.25, pswt_2_swir1=0.3, pswt_2_swir2=0.1,
+                         lcmask_nir=0.12)
+
+
+def bench_params(args):
+    from proteus_amd import _capi
+    if not args.scaled:
+        return _capi.default_params()
+    return _capi.make_params(SCALED_THRESHOLDS, offset_and_scale=[(SCALED_UNITS, 0.0)] * 6, aerosol_max_nir=1000 * SCALED_UNITS)
 
 
 def cpu_baseline_sample(n_tiles=4):
@@ -830,6 +846,8 @@ def measure_case(args, case, env, case_index=0):
                         f'terrain shadow layer (DEM {side}x{side}, margin {CHAIN_MARGIN}) -> LAND aggregation (WorldCover '
                         f'{3 * TILE}x{3 * TILE} + CGLS) -> fused classifier with SHAD + LAND + OCEAN, the two layers written straight into '
                         f'the planes of the batch (a step = three kernels; L30 / S30 differ in host-side band mapping only)')
+        if args.scaled:
+            workload += ' -- flag_offset_and_scale_inputs: the chain on float32 reflectances (0.0001 x), thresholds in those units'
         workload += (f' (tile stride {stride} px = 256-byte aligned tile starts)'
                      + (', LAND+SHAD+OCEAN planes' if args.masks else ''))
         devices = sorted({r['device'] for r in per_rank})
@@ -843,7 +861,7 @@ def measure_case(args, case, env, case_index=0):
             'n_gpus': len(devices), 'n_ranks': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': None if failed else round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-            'dtype': 'int16+f64', 'data': 'synthetic',
+            'dtype': 'int16+f32' if args.scaled else 'int16+f64', 'data': 'synthetic',
             'rccl_ranks': cp.rccl_ranks,
             'config': {'workload': workload,
                        'tiles_per_step_all_ranks': total_px_per_step // (TILE * TILE),
@@ -1027,7 +1045,7 @@ def bring_up(args, rank, local_rank, world):
     def device_synchronize():
         torch.cuda.synchronize()
 
-    return argparse.Namespace(ctx=ctx, cp=cp, rank=rank, world=world, params=_capi.default_params(),
+    return argparse.Namespace(ctx=ctx, cp=cp, rank=rank, world=world, params=bench_params(args),
                               share_device=share_device, boot_error=boot_error, slack_gib=args.slide_slack_gib,
                               device_id=device_identity(torch, local_rank) if visible >= 1 else f'none (rank {rank})',
                               device_synchronize=device_synchronize,

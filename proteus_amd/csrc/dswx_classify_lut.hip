@@ -40,7 +40,8 @@ constexpr int LUT_DEFAULT_INTERLEAVE = 0;      // see KArgs::tile_interleave and
 // tile-by-tile order (the padded batch layout: the code of rounds 1 - 3, instruction for instruction); with the few scalar
 // instructions of FLEX compiled in unconditionally that layout measured 0.1 % (plain) and 1.0 % (LAND / SHAD / OCEAN:
 // 107 VGPRs, the tightest instantiation) slower in a same-process A/B against the round-3 build.
-template <bool MASKS, bool EXTRAS, int WPS, bool FLEX>
+// F32: the float32 chain of flag_offset_and_scale_inputs (lut_group<.., F32>): same loads, tables, packing and stores.
+template <bool MASKS, bool EXTRAS, int WPS, bool FLEX, bool F32 = false>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, const LutConsts C,
                                                              const Tables* __restrict__ tabs) {
     constexpr int LUT_CHUNKS = EXTRAS ? LUT_EXTRAS_CHUNKS : 1;     // 8-pixel groups per thread
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         if (grp0 >= n_groups) break;
         const long long grp = grp0 + threadIdx.x;
         const bool in_range = FLEX ? (unsigned long long)grp < (unsigned long long)n_groups : grp < n_groups;
-        const long long off = tile_base + (in_range ? grp : (FLEX && grp < 0 ? 0 : n_groups - 1)) * 8;
+        // (threads outside the tile redo its first / last group; max(): safe even for a launch without groups)
+        const long long off = tile_base + (in_range ? grp : (FLEX && grp < 0 ? 0 : max(n_groups - 1, 0LL))) * 8;
         u32x4 v[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         }
         uint32_t w1w[8], chx[8], chy[8];      // per-pixel table words
         uint32_t idx2[EXTRAS ? 8 : 1];
-        lut_group<MASKS, EXTRAS>(P, C, s_lut1, s_fm16, s_land8, s_chain, s_pre16, v, vf, vl, vs, vo, has_l, in_range,
+        lut_group<MASKS, EXTRAS, F32>(P, C, s_lut1, s_fm16, s_land8, s_chain, s_pre16, v, vf, vl, vs, vo, has_l, in_range,
                                  w1w, chx, chy, cnt, idx2);
         if (EXTRAS && in_range) {
             uint32_t ex[8], pa[4], pb[4];     // byte 0 cover state (adjacent bit included), byte 2 browse
@@ -186,6 +188,18 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
 #define LUT_SEL_W(M, E) do { if (wps >= 6) LUT_LAUNCH(M, E, 6); else if (wps == 5) LUT_LAUNCH(M, E, 5); else LUT_LAUNCH(M, E, 4); } while (0)
     // masks + extras: 125 VGPRs at a bound of 4 (no spill) since the cover bitmaps come from the table; lab A/B: 3
     const bool ex3 = ctx->tune_lut_wps == 3;
+    if (b.P.f32_mode) {
+        // flag_offset_and_scale_inputs: one instantiation per plane set (launch bound 4, FLEX: the per-tile lead-in is free
+        // when every lead is 0)
+        if (extras && masks) hipLaunchKernelGGL((dswx_classify_lut<true, true, 4, true, true>), grid, block, 0, s, k, lc, tabs);
+        else if (extras) hipLaunchKernelGGL((dswx_classify_lut<false, true, 4, true, true>), grid, block, 0, s, k, lc, tabs);
+        else if (masks) hipLaunchKernelGGL((dswx_classify_lut<true, false, 4, true, true>), grid, block, 0, s, k, lc, tabs);
+        else hipLaunchKernelGGL((dswx_classify_lut<false, false, 4, true, true>), grid, block, 0, s, k, lc, tabs);
+        snprintf(info, info_len, "dswx_classify_lut<%s%s,f32> (table-driven, float32 chain) grid=(%lld,%lld) block=256 wps=4%s",
+                 masks ? "true" : "false", extras ? ",extras" : "", (long long)k.blocks_per_tile, nt,
+                 G > 1 ? (" tiles interleaved x" + std::to_string(G)).c_str() : "");
+        return DSWX_OK;
+    }
     if (extras) { if (masks && ex3) LUT_LAUNCH(true, true, 3); else if (masks) LUT_LAUNCH(true, true, 4); else LUT_LAUNCH(false, true, 4); }
     else if (masks) LUT_SEL_W(true, false);
     else LUT_SEL_W(false, false);

@@ -32,7 +32,7 @@ struct DevParams {
                             // (0,1,2,3,4,252,253,254,255), _compute_browse_array :3057-3129
     uint32_t aer_lut[64];   // byte v: bit c set <=> Fmask v remaps WTR-1 class c
                             // (all zero when aerosol remapping is disabled)
-    // flag_offset_and_scale_inputs (:2300-2302): the chain on float32 reflectances (generic kernel only)
+    // flag_offset_and_scale_inputs (:2300-2302): the chain on float32 reflectances (classify_px_f32, lut_group<.., F32>)
     int32_t f32_mode;
     float f_scale[6], f_offset[6];
     float f_thr[12];        // the twelve thresholds in dswx_params_t order, rounded to float32

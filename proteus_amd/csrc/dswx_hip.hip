@@ -60,7 +60,7 @@
 // EXTRAS: also produce the browse plane and the two scratch planes of 'cover' stage 1
 // (kept out of the default instantiation so that its register and instruction budget
 // is untouched)
-template <bool MASKS, bool EXTRAS, int WPS = 4>
+template <bool MASKS, bool EXTRAS, int WPS = 4, bool F32 = false>
 __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
     const DevParams& P = a.P;
     // aerosol table: 256 bytes = one dword per lane of a wave, looked up with
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
                 ((uint32_t)__builtin_amdgcn_ds_bpermute((fm >> 2) << 2, (int)lut_reg) >> (8 * (fm & 3))) & 0xffu;
             PxOut o;
             bool ok, cv;
-            classify_px(P, aer_bits, b, g, r, n, s1, s2, fm, land, shad, ocean, o, ok, cv);
+            if (F32) classify_px_f32(P, aer_bits, b, g, r, n, s1, s2, fm, land, shad, ocean, o, ok, cv);
+            else classify_px(P, aer_bits, b, g, r, n, s1, s2, fm, land, shad, ocean, o, ok, cv);
             w_valid += (uint32_t)__popcll(__ballot(ok & in_range));
             w_cloud += (uint32_t)__popcll(__ballot(cv & in_range));
             q_diag[wd] |= o.diag << (16 * hf);
@@ -604,8 +605,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         if (b.cover_state) { b.cover_state += shift; b.cover_bits += t0 * b.cover_bits_stride; b.cover_snow += t0 * b.cover_snow_stride; }
         b.px_begin = 0;
         b.partials = nullptr;
-        // the float32 chain (flag_offset_and_scale_inputs) exists in the generic kernel only
-        const int64_t groups = (vec_ok && !a.P.f32_mode) ? (n_pixels >> 3) : 0;
+        const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
         // the finishing kernel of the vector path WRITES the counters; only the generic kernel
         // alone (atomic adds) needs them zeroed first
         if (groups == 0 && b.counters)
@@ -618,7 +618,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             // lead-in takes care of strides that are not multiples of 256 pixels), the direct kernel for planes at
             // odd addresses (>= 16-byte aligned)
             int vsel = ctx->lab.fused_variant;
-            if (vsel < 0 || (vsel != 0 && vsel != 3 && (!ctx->lab.launch || !stride16))) vsel = lut_ok ? 3 : 0;
+            if (vsel < 0 || (vsel != 0 && vsel != 3 && (!ctx->lab.launch || !stride16 || a.P.f32_mode))) vsel = lut_ok ? 3 : 0;
             // the LDS-DMA variants (2, 4, 5) move 16 pixels per lane of the u8 planes
             const bool dma16_ok = (n_pixels & 15) == 0 || vsel == 1 || vsel == 3;
             const bool variant = vsel != 0 && (plain_outputs || vsel == 3) && dma16_ok;
@@ -651,14 +651,21 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
                 if (vrc) return vrc;
             } else {
                 const bool extras = b.out.browse || b.cover_state;
-                if (masks && extras) hipLaunchKernelGGL((dswx_classify_v8<true, true>), grid, block, 0, s, b);
+                if (b.P.f32_mode) {         // flag_offset_and_scale_inputs
+                    if (masks && extras) hipLaunchKernelGGL((dswx_classify_v8<true, true, 4, true>), grid, block, 0, s, b);
+                    else if (masks) hipLaunchKernelGGL((dswx_classify_v8<true, false, 4, true>), grid, block, 0, s, b);
+                    else if (extras) hipLaunchKernelGGL((dswx_classify_v8<false, true, 4, true>), grid, block, 0, s, b);
+                    else hipLaunchKernelGGL((dswx_classify_v8<false, false, 4, true>), grid, block, 0, s, b);
+                }
+                else if (masks && extras) hipLaunchKernelGGL((dswx_classify_v8<true, true>), grid, block, 0, s, b);
                 else if (masks) hipLaunchKernelGGL((dswx_classify_v8<true, false>), grid, block, 0, s, b);
                 else if (extras) hipLaunchKernelGGL((dswx_classify_v8<false, true>), grid, block, 0, s, b);
                 else if (ctx->tune_wps == 6) hipLaunchKernelGGL((dswx_classify_v8<false, false, 6>), grid, block, 0, s, b);
                 else if (ctx->tune_wps == 8) hipLaunchKernelGGL((dswx_classify_v8<false, false, 8>), grid, block, 0, s, b);
                 else hipLaunchKernelGGL((dswx_classify_v8<false, false, 4>), grid, block, 0, s, b);
-                snprintf(info, sizeof info, "dswx_classify_v8<%s,%s> (fused, direct stores) grid=(%lld,%lld) block=256",
-                         masks ? "true" : "false", extras ? "true" : "false", (long long)gx, (long long)nt);
+                snprintf(info, sizeof info, "dswx_classify_v8<%s,%s%s> (fused, direct stores) grid=(%lld,%lld) block=256",
+                         masks ? "true" : "false", extras ? "true" : "false", b.P.f32_mode ? ",f32" : "", (long long)gx,
+                         (long long)nt);
             }
             HIP_TRY(hipGetLastError());
             if (b.counters) {

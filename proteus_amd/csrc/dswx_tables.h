@@ -128,7 +128,10 @@ __device__ __forceinline__ void transpose4(const uint32_t a[4], uint32_t out[4])
 // The table-driven classification of one 8-pixel group held in registers.  Leaves, per
 // pixel j, the three table words (w1w: DIAG | code | WTR-1; chx: WTR-1-AEROSOL, WTR-2, WTR,
 // BWTR; chy: CONF, CLOUD) and adds the group's coverage counts to `cnt`.
-template <bool MASKS, bool WANT_IDX = false>
+// F32 (flag_offset_and_scale_inputs, :2300-2302): the five tests and the two nir comparisons of A9 / A10 on float32
+// reflectances scale * (float32(x) - offset), operation by operation as classify_px_f32 (dswx_device.h) and numpy
+// evaluate them (-ffp-contract=off, IEEE division); fill test, clip, tables and packing are the integer path's.
+template <bool MASKS, bool WANT_IDX = false, bool F32 = false>
 __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C, const uint32_t* __restrict__ s_lut1,
                                           const uint16_t* __restrict__ s_fm16, const uint8_t* __restrict__ s_land8,
                                           const uint2* __restrict__ s_chain, const uint16_t* __restrict__ s_pre16,
@@ -148,35 +151,63 @@ __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C
 #pragma unroll
             for (int k = 0; k < 6; ++k) x[k] = pk_max_i(x[k], C.clip_pk);   // A0 clip
             const uint32_t b = x[0], g = x[1], r = x[2], n = x[3], s1 = x[4], s2 = x[5];
-            const uint32_t d1 = pk_add(g, s1), n1 = pk_sub(g, s1), mv = pk_add(g, r), mn = pk_add(n, s1);
-            const uint32_t n2 = pk_sub(n, r), d2 = pk_add(n, r);
-            // sign bit (15 / 31) set  <=>  ...
-            const uint32_t t2s = pk_sub_sat(mn, mv);                                            // T2 true
-            const uint32_t viol4 = pk_sub_sat(C.k_p1_swir1, s1) | pk_sub_sat(C.k_p1_nir, n) | C.force4;   // T4 ints fail
-            const uint32_t viol5 = pk_sub_sat(C.k_p2_blue, b) | pk_sub_sat(C.k_p2_swir1, s1) |
-                                   pk_sub_sat(C.k_p2_swir2, s2) | pk_sub_sat(C.k_p2_nir, n) | C.force5;   // T5 ints fail
-            const uint32_t dark = pk_sub_sat(n, C.k_lc_nir) | C.force_dark;                     // nir NOT > lcmask_nir
-            const uint32_t noaer = pk_sub_sat(C.k_aer_nir, n) | C.force_noaer;                  // nir NOT <= 1000
+            uint32_t d1 = 0, n1 = 0, mn = 0, n2 = 0, d2 = 0, t2s = 0, viol4 = 0, viol5 = 0, dark = 0, noaer = 0;
+            if (!F32) {
+                d1 = pk_add(g, s1); n1 = pk_sub(g, s1); mn = pk_add(n, s1);
+                n2 = pk_sub(n, r); d2 = pk_add(n, r);
+                // sign bit (15 / 31) set  <=>  ...
+                t2s = pk_sub_sat(mn, pk_add(g, r));                                                 // T2 true
+                viol4 = pk_sub_sat(C.k_p1_swir1, s1) | pk_sub_sat(C.k_p1_nir, n) | C.force4;        // T4 ints fail
+                viol5 = pk_sub_sat(C.k_p2_blue, b) | pk_sub_sat(C.k_p2_swir1, s1) |
+                        pk_sub_sat(C.k_p2_swir2, s2) | pk_sub_sat(C.k_p2_nir, n) | C.force5;        // T5 ints fail
+                dark = pk_sub_sat(n, C.k_lc_nir) | C.force_dark;                                    // nir NOT > lcmask_nir
+                noaer = pk_sub_sat(C.k_aer_nir, n) | C.force_noaer;                                 // nir NOT <= 1000
+            }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int j = wd * 2 + hf, sh = 16 * hf;
                 const int bw = j >> 2, bk = j & 3;
-                // ---- A4 quotient tests, sign-bit form (see the header comment)
-                const int in1 = s16_of(n1, hf), id1 = s16_of(d1, hf), in2 = s16_of(n2, hf), id2 = s16_of(d2, hf);
-                const double dn1 = (double)in1, dd1 = (double)id1, dn2 = (double)in2, dd2 = (double)id2;
-                const double r0 = __builtin_fma(-P.qt[0], dd1, dn1), r1 = __builtin_fma(-P.qt[1], dd1, dn1),
-                             r2 = __builtin_fma(-P.qt[2], dd1, dn1), r3 = __builtin_fma(-P.qt[3], dd2, dn2);
-                // sign(h*d - r) = 1  <=>  r > h*d ;  sign(r - hneg*d) = 1  <=>  r < hneg*d ; exact zero -> +0
-                const uint32_t g0 = hi32(__builtin_fma(P.qh[0], dd1, -r0)) >> 31, g1 = hi32(__builtin_fma(P.qh[1], dd1, -r1)) >> 31,
-                               g2 = hi32(__builtin_fma(P.qh[2], dd1, -r2)) >> 31, l3 = hi32(__builtin_fma(-P.qh[3], dd2, r3)) >> 31;
-                const uint32_t neg1 = (uint32_t)id1 >> 31, neg2 = (uint32_t)id2 >> 31;
-                const uint32_t t1 = g0 ^ neg1, m_p1 = g1 ^ neg1, m_p2 = g2 ^ neg1, v_p1 = l3 ^ neg2;
-                // ---- AWESH as int32: sign set <=> 4*awesh < awesh4_min  (T3 false)
-                const int aw = C.awesh_init + 4 * s16_of(b, hf) + 10 * s16_of(g, hf) - 6 * s16_of(mn, hf) - s16_of(s2, hf);
-                const uint32_t t3n = (uint32_t)aw >> 31;
-                const uint32_t t2 = (t2s >> (15 + sh)) & 1u;
-                const uint32_t t4 = m_p1 & v_p1 & ~(viol4 >> (15 + sh)) & 1u;
-                const uint32_t t5 = m_p2 & ~(viol5 >> (15 + sh)) & 1u;
+                uint32_t t1, t2, t3n, t4, t5, dark1, noaer1;
+                if (F32) {
+                    const float fb = P.f_scale[0] * ((float)s16_of(b, hf) - P.f_offset[0]);
+                    const float fg = P.f_scale[1] * ((float)s16_of(g, hf) - P.f_offset[1]);
+                    const float fr = P.f_scale[2] * ((float)s16_of(r, hf) - P.f_offset[2]);
+                    const float fn = P.f_scale[3] * ((float)s16_of(n, hf) - P.f_offset[3]);
+                    const float fs1 = P.f_scale[4] * ((float)s16_of(s1, hf) - P.f_offset[4]);
+                    const float fs2 = P.f_scale[5] * ((float)s16_of(s2, hf) - P.f_offset[5]);
+                    const float mndwi = (fg - fs1) / (fg + fs1);
+                    const float mbsrv = fg + fr, mbsrn = fn + fs1;
+                    const float awesh = ((fb + 2.5f * fg) - 1.5f * mbsrn) - 0.25f * fs2;
+                    const float ndvi = (fn - fr) / (fn + fr);
+                    const float* T = P.f_thr;   // wigt awgt p1_mndwi p1_nir p1_swir1 p1_ndvi p2_mndwi p2_blue p2_nir p2_swir1 p2_swir2 lcmask_nir
+                    t1 = mndwi > T[0] ? 1u : 0u;
+                    t2 = mbsrv > mbsrn ? 1u : 0u;
+                    t3n = awesh > T[1] ? 0u : 1u;
+                    t4 = ((mndwi > T[2]) & (fs1 < T[4]) & (fn < T[3]) & (ndvi < T[5])) ? 1u : 0u;
+                    t5 = ((mndwi > T[6]) & (fb < T[7]) & (fs1 < T[9]) & (fs2 < T[10]) & (fn < T[8])) ? 1u : 0u;
+                    dark1 = fn > T[11] ? 0u : 1u;
+                    noaer1 = fn <= P.f_aer_nir ? 0u : 1u;
+                } else {
+                    // ---- A4 quotient tests, sign-bit form (see the header comment)
+                    const int in1 = s16_of(n1, hf), id1 = s16_of(d1, hf), in2 = s16_of(n2, hf), id2 = s16_of(d2, hf);
+                    const double dn1 = (double)in1, dd1 = (double)id1, dn2 = (double)in2, dd2 = (double)id2;
+                    const double r0 = __builtin_fma(-P.qt[0], dd1, dn1), r1 = __builtin_fma(-P.qt[1], dd1, dn1),
+                                 r2 = __builtin_fma(-P.qt[2], dd1, dn1), r3 = __builtin_fma(-P.qt[3], dd2, dn2);
+                    // sign(h*d - r) = 1  <=>  r > h*d ;  sign(r - hneg*d) = 1  <=>  r < hneg*d ; exact zero -> +0
+                    const uint32_t g0 = hi32(__builtin_fma(P.qh[0], dd1, -r0)) >> 31, g1 = hi32(__builtin_fma(P.qh[1], dd1, -r1)) >> 31,
+                                   g2 = hi32(__builtin_fma(P.qh[2], dd1, -r2)) >> 31, l3 = hi32(__builtin_fma(-P.qh[3], dd2, r3)) >> 31;
+                    const uint32_t neg1 = (uint32_t)id1 >> 31, neg2 = (uint32_t)id2 >> 31;
+                    const uint32_t m_p1 = g1 ^ neg1, m_p2 = g2 ^ neg1, v_p1 = l3 ^ neg2;
+                    t1 = g0 ^ neg1;
+                    // ---- AWESH as int32: sign set <=> 4*awesh < awesh4_min  (T3 false)
+                    const int aw = C.awesh_init + 4 * s16_of(b, hf) + 10 * s16_of(g, hf) - 6 * s16_of(mn, hf) - s16_of(s2, hf);
+                    t3n = (uint32_t)aw >> 31;
+                    t2 = (t2s >> (15 + sh)) & 1u;
+                    t4 = m_p1 & v_p1 & ~(viol4 >> (15 + sh)) & 1u;
+                    t5 = m_p2 & ~(viol5 >> (15 + sh)) & 1u;
+                    dark1 = (dark >> (15 + sh)) & 1u;
+                    noaer1 = (noaer >> (15 + sh)) & 1u;
+                }
                 const uint32_t fm = (vf[bw] >> (8 * bk)) & 0xffu;
                 const uint32_t F = s_fm16[fm];
                 const uint32_t band_ok = (bandvalid >> sh) & 1u;
@@ -190,13 +221,13 @@ __device__ __forceinline__ void lut_group(const DevParams& P, const LutConsts& C
                 const uint32_t idx1 = t1 | t2 << 1 | t3n << 2 | t4 << 3 | t5 << 4 | invalid << 5 | (ocean_nz ^ 1u) << 6;
                 const uint32_t word1 = s_lut1[idx1];
                 const uint32_t code = (word1 >> 16) & 7u;
-                const uint32_t remap = (F >> code) & ~(noaer >> (15 + sh)) & 1u;
+                const uint32_t remap = (F >> code) & ~noaer1 & 1u;
                 uint32_t idx2 = code | remap << 3 | ((F >> 5) & 7u) << 4;
                 uint32_t w1a = 0;
                 if (MASKS) {
                     // first factor (LAND / SHAD rules): WTR-1-AEROSOL and the WTR-2 code that indexes the second
                     const uint32_t shadrule = (shad_nz ^ 1u) & ~lbits & 1u;
-                    const uint32_t lcpsw = (lbits >> 1) & ~(dark >> (15 + sh)) & 1u;
+                    const uint32_t lcpsw = (lbits >> 1) & ~dark1 & 1u;
                     const uint32_t pre = s_pre16[code | remap << 3 | shadrule << 4 | lcpsw << 5 | ((lbits >> 2) & 1u) << 6];
                     w1a = pre & 0xffu;
                     idx2 = (pre >> 8) | remap << 3 | ((F >> 5) & 7u) << 4;

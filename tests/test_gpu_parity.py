@@ -867,9 +867,10 @@ def _free_device_bytes():
 
 @pytest.mark.parametrize('mode', ['mask', 'ignore', 'cover'])
 def test_offset_and_scale_inputs_vs_both_oracles(ctx, mode):
-    """flag_offset_and_scale_inputs (:2300-2302): the float32 chain of the generic kernel against the numpy oracle and
-    the scalar C oracle (both pinned to the reference-made `*_scaled_*` goldens), over random scales / offsets /
-    thresholds near the data, host entry and device batch, with and without masks."""
+    """flag_offset_and_scale_inputs (:2300-2302): the float32 chain -- since round 5 the 8-pixel-per-thread kernels
+    (table-driven on aligned planes, direct otherwise; the generic kernel only behind them for a ragged tail) -- against
+    the numpy oracle and the scalar C oracle (both pinned to the reference-made `*_scaled_*` goldens), over random
+    scales / offsets / thresholds near the data, host entry and device batch, with and without masks."""
     rng = np.random.default_rng({'mask': 1, 'ignore': 2, 'cover': 3}[mode])
     for it in range(6):
         h, w = int(rng.integers(20, 300)), int(rng.integers(20, 300))
@@ -885,7 +886,7 @@ def test_offset_and_scale_inputs_vs_both_oracles(ctx, mode):
         p = _capi.make_params(thr, mask_adjacent_to_cloud_mode=mode, offset_and_scale=scale,
                               aerosol_max_nir=None if mode == 'cover' else 1000 * k)
         got = ctx.classify_host(s['bands'], s['fmask'], p, **kw)
-        assert 'dswx_classify_v1' in ctx.last_kernel_info()
+        assert 'f32>' in ctx.last_kernel_info() and 'dswx_classify_v1' not in ctx.last_kernel_info()
         with np.errstate(all='ignore'):
             exp = o.classify_tile(s['bands'], s['fmask'], o.Thresholds(**thr), landcover=kw.get('land'),
                                   shadow=kw.get('shad'), ocean_mask=kw.get('ocean'), mask_adjacent_to_cloud_mode=mode,
@@ -906,14 +907,14 @@ def test_offset_and_scale_inputs_vs_both_oracles(ctx, mode):
             got2 = ctx.classify_host(s['bands'], s['fmask'], p1000, **kw)
             for layer, key in NAME.items():
                 assert np.array_equal(got2[key], expn[layer]), (layer, it)
-    # a device batch too (aligned tiles would take the table-driven kernel: the float chain must not)
+    # a device batch too: aligned tiles take the table-driven kernel's float32 instantiation
     b = _capi.DeviceBatch(ctx, 2, 64, 128)
     b.synth(SEED, tile0=5)
     scale = [(0.0001, 0.0)] * 6
     p = _capi.make_params(mask_adjacent_to_cloud_mode=mode, offset_and_scale=scale)
     b.classify(p)
     ctx.synchronize()
-    assert 'dswx_classify_v1' in ctx.last_kernel_info()
+    assert 'dswx_classify_lut<false' in ctx.last_kernel_info() and ',f32>' in ctx.last_kernel_info()
     s1 = synth_tile(6, 64, 128)
     with np.errstate(all='ignore'):
         e1 = o.classify_tile(s1['bands'], s1['fmask'], mask_adjacent_to_cloud_mode=mode, offset_and_scale=scale)
@@ -923,6 +924,42 @@ def test_offset_and_scale_inputs_vs_both_oracles(ctx, mode):
     b.free()
     with pytest.raises(_capi.DswxError):                  # the float64 index planes describe the integer chain
         ctx.classify_host(s1['bands'], s1['fmask'], p, layers=('diag', 'mndwi'))
+
+
+@pytest.mark.parametrize('masks', [False, True])
+def test_offset_and_scale_full_size_tile_and_contiguous_batch(ctx, masks):
+    """a 3660 x 3660 tile through the float32 chain's vector kernel against the numpy oracle (every
+    layer, the counters), and a contiguous [n][H*W] batch whose tiles start off the 256-byte grid (per-tile lead-in)
+    against the scalar C oracle tile by tile."""
+    scale = [(1e-4, 0.0), (1e-4, 0.0), (2e-4, -3.0), (1e-4, 0.0), (1e-4, 5.0), (1e-4, 0.0)]
+    p = _capi.make_params(offset_and_scale=scale)
+    s = synth_tile(11, 3660, 3660, with_masks=masks)
+    kw = dict(land=s['land'], shad=s['shad'], ocean=s['ocean']) if masks else {}
+    got = ctx.classify_host(s['bands'], s['fmask'], p, **kw)
+    assert f"dswx_classify_lut<{'true' if masks else 'false'},f32>" in ctx.last_kernel_info()
+    with np.errstate(all='ignore'):
+        exp = o.classify_tile(s['bands'], s['fmask'], landcover=kw.get('land'), shadow=kw.get('shad'),
+                              ocean_mask=kw.get('ocean'), offset_and_scale=scale)
+    for layer, key in NAME.items():
+        assert np.array_equal(got[key], exp[layer]), layer
+    c = exp['counters']
+    assert got['counters'][0].tolist() == [c['n_valid'], c['n_cloud_and_valid'], c['n_not_ocean']]
+    # contiguous tiles of 200 x 126 = 25200 px (112 mod 256): tiles 1.. start off the 256-byte grid
+    b = _capi.DeviceBatch(ctx, 5, 200, 126, masks=masks, tile_align=1)
+    assert b.tile_stride == 25200
+    b.synth(SEED, tile0=20)
+    b.classify(p)
+    ctx.synchronize()
+    assert ',f32>' in ctx.last_kernel_info()
+    cnt = b.read_counters()
+    for t in range(5):
+        st = synth_tile(20 + t, 200, 126, with_masks=masks)
+        kwt = dict(land=st['land'], shad=st['shad'], ocean=st['ocean']) if masks else {}
+        e = c_oracle.classify(p, st['bands'], st['fmask'], **kwt)
+        for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+            assert np.array_equal(b.read_tile(key, t), e[key]), (key, t)
+        assert cnt[t].tolist() == e['counters'].tolist()
+    b.free()
 
 
 def test_contexts_on_concurrent_host_threads():
