@@ -915,6 +915,13 @@ class DeviceBatch:
                                                 ctypes.c_void_p(self.counters_ptr), out.nbytes))
         return out
 
+    def write_counters_sentinel(self, value):
+        """Fill the counters plane with `value` (tests: which tiles did a launch write?)."""
+        arr = np.full((self.n_tiles, 3), value, dtype=np.int64)
+        if arr.nbytes:
+            _check(self.ctx.lib.dswx_memcpy_h2d(self.ctx.handle, ctypes.c_void_p(self.counters_ptr), _host_ptr(arr),
+                                                arr.nbytes))
+
     def free(self):
         """dswx_batch_destroy: allowed after the context is gone (the batch remembers its device), so the HBM of a
         batch that outlives its Context is still returned."""

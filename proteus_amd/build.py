@@ -1,7 +1,7 @@
 """Builds the HIP shared libraries in-tree (proteus_amd/_lib/).
 
   libdswx_hip.so   the product: production kernels + the C-ABI of include/dswx_hip.h
-  libdswx_lab.so   experiments only (csrc/lab/: losing kernel structures, roofline probes, A/B switches);
+  libdswx_lab.so   experiments only (csrc/lab/: roofline probes, A/B switches of the dispatch);
                    links against libdswx_hip.so; loaded by tools/ and the variant tests, never by the product
 
 hipcc cross-compiles gfx950 without a GPU; the built .so files are git-ignored but travel with the
@@ -25,7 +25,7 @@ LAB = os.path.join(CSRC, 'lab')
 SOURCES = [os.path.join(CSRC, n) for n in ('dswx_hip.hip', 'dswx_classify_lut.hip', 'dswx_cover.hip',
                                            'dswx_layers.hip', 'dswx_host_path.hip', 'dswx_batch.hip')]
 HEADERS = [os.path.join(CSRC, n) for n in ('dswx_device.h', 'dswx_host.h', 'dswx_tables.h')]
-LAB_SOURCES = [os.path.join(LAB, n) for n in ('dswx_variants.hip', 'dswx_probes.hip')]
+LAB_SOURCES = [os.path.join(LAB, n) for n in ('dswx_lab.hip', 'dswx_probes.hip')]
 LAB_HEADERS = [os.path.join(LAB, 'dswx_lab.h')]
 INCLUDE = os.path.join(ROOT, 'include')
 PUBLIC_HEADER = os.path.join(INCLUDE, 'dswx_hip.h')

@@ -71,7 +71,7 @@ inline int elem_bytes(int plane) {
 // touched by a kernel are safe to reuse (mode 3 of the reproducer: 0 of 200).  This is what round 3 saw as "layers read
 // back zeroed" (8 - 27 of 80 two-placement cases) and fenced by retiring ranges; the same library built with the
 // addresses freed (7 of 160 cases wrong), device-synchronised and freed (6 of 160) or kept in a free list and re-mapped
-// (9 of 160) fails, retired it does not (0 of 160): tests/vmm_policy_trial.py, profiles/r04_vmm_policy_trial.json.
+// (9 of 160) fails, retired it does not (0 of 160): tests/helpers/vmm_policy_trial.py, profiles/r04_vmm_policy_trial.json.
 // So the addresses of a dropped range are never mapped again.  What happens to them and to the memory they held is shaped by
 // a second property of this stack (tools/lab/vmm_meminfo.hip, profiles/r04_vmm_meminfo.json): the physical memory of a chunk
 // that was ever mapped returns to the device only when the RESERVATION it was mapped in is freed (hipMemAddressFree) --
@@ -92,7 +92,7 @@ inline int elem_bytes(int plane) {
 // has -- and the library keeps count (dswx_batch_va_budget, dswx_batch_info_t.va_*): beyond a budget it reserves no more,
 // dswx_batch_create(DSWX_BATCH_SLIDING_OUTPUTS) falls back to the packed allocation and dswx_batch_place_slide leaves the
 // planes where they are, both with the reason in dswx_batch_info_t.note.
-// DSWX_VM_FREE_ADDRESSES (build-time, for tests/vmm_policy_trial.py only): 1 = release the chunks and hipMemAddressFree a
+// DSWX_VM_FREE_ADDRESSES (build-time, for tests/helpers/vmm_policy_trial.py only): 1 = release the chunks and hipMemAddressFree a
 // dropped range, 2 = hipDeviceSynchronize first -- the two unsafe forms, kept so that the trial can be repeated on a newer ROCm.
 #ifndef DSWX_VM_FREE_ADDRESSES
 #define DSWX_VM_FREE_ADDRESSES 0

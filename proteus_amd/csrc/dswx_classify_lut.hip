@@ -132,11 +132,40 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
             if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{gp.cl[0], gp.cl[1]});
         }
     }
-    if (a.partials) {
+    if (a.partials || a.fold_acc) {
         uint32_t c0 = cnt, c2 = t_ocean;
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) { c0 += __shfl_xor(c0, sh); c2 += __shfl_xor(c2, sh); }
-        if ((threadIdx.x & 63) == 0) {
+        if (a.fold_acc) {
+            // Counters folded into this kernel (launches of a few tiles).  One 64-bit atomic per block carries the block's
+            // valid count (bits 0-23), cloud-and-valid count (24-47) and ONE TICKET (48-63): the returned value tells the
+            // block whether it drew the tile's last ticket, and if so it also holds the tile's complete sums -- no fence, no
+            // second pass.  n_not_ocean goes through a second accumulator, added BEFORE the ticket is drawn (fence in
+            // between), so the last block finds it complete.  The last block writes counters[tile] and leaves both
+            // accumulators zero for the next launch.  (The host folds only tiles < 2^24 pixels in < 2^16 blocks.)
+            __shared__ uint2 s_red[4];
+            if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = make_uint2(c0, c2);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long v = 0, cl = 0, oc = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { v += s_red[w].x & 0xffffu; cl += s_red[w].x >> 16; oc += s_red[w].y; }
+                unsigned long long* acc = a.fold_acc + tile * 2;
+                if (has_o) {
+                    if (oc) atomicAdd(acc + 1, oc);
+                    __threadfence();
+                }
+                const unsigned long long add = v | cl << 24 | 1ull << 48;
+                const unsigned long long now = atomicAdd(acc, add) + add;
+                if ((long long)(now >> 48) == a.blocks_per_tile) {
+                    unsigned long long* out = a.counters + tile * 3;
+                    out[0] = now & 0xffffffull;
+                    out[1] = (now >> 24) & 0xffffffull;
+                    out[2] = has_o ? atomicExch(acc + 1, 0ull) : (unsigned long long)(n_groups * 8);
+                    acc[0] = 0ull;
+                }
+            }
+        } else if ((threadIdx.x & 63) == 0) {
             const long long slot = (tile * a.blocks_per_tile + blk) * 4 + (threadIdx.x >> 6);
             a.partials[slot] = make_uint2(c0, c2);
         }
@@ -195,17 +224,17 @@ int dswx_lut_launch(dswx_ctx* ctx, const KArgs& b, bool masks, dim3 grid, dim3 b
         else if (extras) hipLaunchKernelGGL((dswx_classify_lut<false, true, 4, true, true>), grid, block, 0, s, k, lc, tabs);
         else if (masks) hipLaunchKernelGGL((dswx_classify_lut<true, false, 4, true, true>), grid, block, 0, s, k, lc, tabs);
         else hipLaunchKernelGGL((dswx_classify_lut<false, false, 4, true, true>), grid, block, 0, s, k, lc, tabs);
-        snprintf(info, info_len, "dswx_classify_lut<%s%s,f32> (table-driven, float32 chain) grid=(%lld,%lld) block=256 wps=4%s",
+        snprintf(info, info_len, "dswx_classify_lut<%s%s,f32> (table-driven, float32 chain) grid=(%lld,%lld) block=256 wps=4%s%s",
                  masks ? "true" : "false", extras ? ",extras" : "", (long long)k.blocks_per_tile, nt,
-                 G > 1 ? (" tiles interleaved x" + std::to_string(G)).c_str() : "");
+                 G > 1 ? (" tiles interleaved x" + std::to_string(G)).c_str() : "", b.fold_acc ? " counters folded" : "");
         return DSWX_OK;
     }
     if (extras) { if (masks && ex3) LUT_LAUNCH(true, true, 3); else if (masks) LUT_LAUNCH(true, true, 4); else LUT_LAUNCH(false, true, 4); }
     else if (masks) LUT_SEL_W(true, false);
     else LUT_SEL_W(false, false);
-    snprintf(info, info_len, "dswx_classify_lut<%s%s> (table-driven) grid=(%lld,%lld) block=256 wps=%d%s%s",
+    snprintf(info, info_len, "dswx_classify_lut<%s%s> (table-driven) grid=(%lld,%lld) block=256 wps=%d%s%s%s",
              masks ? "true" : "false", extras ? ",extras" : "", (long long)k.blocks_per_tile, nt,
              extras ? (masks && ex3 ? 3 : 4) : wps, flex && G <= 1 ? " per-tile lead-in" : "",
-             G > 1 ? (" tiles interleaved x" + std::to_string(G)).c_str() : "");
+             G > 1 ? (" tiles interleaved x" + std::to_string(G)).c_str() : "", b.fold_acc ? " counters folded" : "");
     return DSWX_OK;
 }

@@ -43,11 +43,9 @@ struct KArgs {
     DevParams P;
     dswx_planes_in_t in;
     dswx_planes_out_t out;
-    uint2* partials;                // fused kernel: per-wave counts, [tile][block][wave]
-    uint8_t* u8_out[7];             // fused kernel: the wanted u8 layers, compacted,
-    int u8_region[7];               //   and the LDS staging region each one lives in
-    int n_u8_out;
-    int n_diag_pieces;              // 8 if DIAG is wanted, else 0
+    uint2* partials;                // fused kernel: per-wave counts, [tile][block][wave] (summed by dswx_counters_finish) ...
+    unsigned long long* fold_acc;   // ... or, for launches of a few tiles, [tile][2] accumulators the blocks add to; the block
+                                    //   that draws a tile's last ticket writes counters[tile] itself (dswx_classify_lut.hip)
     uint8_t* cover_state;           // 'cover' mode: stage 1 parks one state byte per pixel here
                                     //   (cover_state_of) ...
     uint32_t* cover_bits;           //   ... and the four dilation predicates of every 8-pixel group as one

@@ -5,7 +5,7 @@
 //   dswx_classify_lut.hip table-driven production kernel (+ dswx_tables.h)
 //   dswx_host_path.hip    dswx_classify_host (synchronous and pipelined), page-locked memory
 //   dswx_layers.hip       shadow layer, LAND aggregation, interpret-alone, synthetic tiles
-//   (experimental data-movement structures and roofline probes: libdswx_lab.so, csrc/lab/)
+//   (roofline probes and A/B switches: libdswx_lab.so, csrc/lab/)
 //
 // One fused streaming kernel computes, per pixel, everything the reference does
 // in ~100 whole-array numpy passes between src/proteus/dswx_hls.py:5088 and :5369:
@@ -468,6 +468,7 @@ int dswx_ctx_destroy(dswx_ctx_t* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->fold_acc) (void)hipFree(ctx->fold_acc);
     if (ctx->cover) (void)hipFree(ctx->cover);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -605,6 +606,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         if (b.cover_state) { b.cover_state += shift; b.cover_bits += t0 * b.cover_bits_stride; b.cover_snow += t0 * b.cover_snow_stride; }
         b.px_begin = 0;
         b.partials = nullptr;
+        b.fold_acc = nullptr;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
         // the finishing kernel of the vector path WRITES the counters; only the generic kernel
         // alone (atomic adds) needs them zeroed first
@@ -617,19 +619,29 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             // automatic choice: the table-driven kernel when every plane starts on a 256-byte boundary (its per-tile
             // lead-in takes care of strides that are not multiples of 256 pixels), the direct kernel for planes at
             // odd addresses (>= 16-byte aligned)
-            int vsel = ctx->lab.fused_variant;
-            if (vsel < 0 || (vsel != 0 && vsel != 3 && (!ctx->lab.launch || !stride16 || a.P.f32_mode))) vsel = lut_ok ? 3 : 0;
-            // the LDS-DMA variants (2, 4, 5) move 16 pixels per lane of the u8 planes
-            const bool dma16_ok = (n_pixels & 15) == 0 || vsel == 1 || vsel == 3;
-            const bool variant = vsel != 0 && (plain_outputs || vsel == 3) && dma16_ok;
+            int vsel = ctx->fused_variant;
+            if (vsel != 0 && vsel != 3) vsel = lut_ok ? 3 : 0;
+            const bool variant = vsel == 3;
             int threads = 256;
             long long gx_ll = (groups + 255) / 256;
-            if (variant && vsel == 3) dswx_lut_geometry(ctx, groups, !plain_outputs, lead_max, &threads, &gx_ll);
-            else if (variant) ctx->lab.geometry(ctx, vsel, groups, nt, &threads, &gx_ll);
+            if (variant) dswx_lut_geometry(ctx, groups, !plain_outputs, lead_max, &threads, &gx_ll);
             const int64_t gx = gx_ll;
             const int waves = threads / 64;
             dim3 grid((unsigned)gx, (unsigned)nt), block(threads);
-            if (b.counters) {
+            // few tiles: the table-driven kernel sums the counters itself (dswx_host.h: DSWX_FOLD_MAX_TILES)
+            const bool fold = variant && b.counters && nt <= DSWX_FOLD_MAX_TILES && n_pixels < (1LL << 24) && gx < 65536 &&
+                              ctx->tune_fold != 0;
+            if (fold) {
+                if (!ctx->fold_acc) {
+                    HIP_TRY(dswx_locked_malloc(&ctx->fold_acc, (size_t)DSWX_FOLD_MAX_TILES * 2 * sizeof(unsigned long long)));
+                    ctx->fold_clean = false;
+                }
+                if (!ctx->fold_clean) {
+                    HIP_TRY(hipMemsetAsync(ctx->fold_acc, 0, (size_t)DSWX_FOLD_MAX_TILES * 2 * sizeof(unsigned long long), s));
+                    ctx->fold_clean = true;
+                }
+                b.fold_acc = ctx->fold_acc;
+            } else if (b.counters) {
                 const size_t need = (size_t)nt * (size_t)gx * waves * sizeof(uint2);
                 if (need > ctx->partials_bytes) {
                     HIP_TRY(hipStreamSynchronize(s));
@@ -640,14 +652,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
                 }
                 b.partials = static_cast<uint2*>(ctx->partials);
             }
-            uint8_t* const u8p[7] = {b.out.wtr1, b.out.wtr1_aerosol, b.out.wtr2, b.out.wtr, b.out.bwtr, b.out.conf, b.out.cloud};
-            b.n_u8_out = 0;
-            for (int i = 0; i < 7; ++i)
-                if (u8p[i]) { b.u8_out[b.n_u8_out] = u8p[i]; b.u8_region[b.n_u8_out] = i; ++b.n_u8_out; }
-            b.n_diag_pieces = b.out.diag ? 8 : 0;
             if (variant) {
-                const int vrc = vsel == 3 ? dswx_lut_launch(ctx, b, masks, grid, block, s, info, sizeof info)
-                                          : ctx->lab.launch(ctx, vsel, b, masks, grid, block, s, info, sizeof info);
+                const int vrc = dswx_lut_launch(ctx, b, masks, grid, block, s, info, sizeof info);
                 if (vrc) return vrc;
             } else {
                 const bool extras = b.out.browse || b.cover_state;
@@ -667,8 +673,11 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
                          masks ? "true" : "false", extras ? "true" : "false", b.P.f32_mode ? ",f32" : "", (long long)gx,
                          (long long)nt);
             }
-            HIP_TRY(hipGetLastError());
-            if (b.counters) {
+            if (hipError_t le = hipGetLastError(); le != hipSuccess) {
+                ctx->fold_clean = false;
+                return dswx_fail(DSWX_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
+            }
+            if (b.counters && !fold) {
                 hipLaunchKernelGGL(dswx_counters_finish, dim3((unsigned)nt), dim3(1024), 0, s, b.partials,
                                    b.counters, (long long)gx * waves, in->ocean ? 1 : 0, (long long)groups * 8);
                 HIP_TRY(hipGetLastError());

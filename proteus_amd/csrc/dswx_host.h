@@ -18,6 +18,10 @@ struct dswx_ctx {
     // grow-only workspace for the vector kernel's per-wave counter partials
     void* partials = nullptr;
     size_t partials_bytes = 0;
+    // [DSWX_FOLD_MAX_TILES][2] accumulators of the folded counters (launches of a few tiles): zeroed once, left zero by
+    // every launch that completes; a launch path that fails marks them dirty
+    unsigned long long* fold_acc = nullptr;
+    bool fold_clean = false;
     // device copy of the lookup tables of the table-driven kernel (rebuilt per call)
     void* tables = nullptr;
     bool tables_valid = false;             // the device tables match tables_params, built on tables_stream
@@ -49,19 +53,9 @@ struct dswx_ctx {
                                     // the 14 streams over many tiles does not lift a badly placed arena and costs 2 - 7 %
                                     // beyond G = 8; kept as a lab switch only
     int tune_wps = 6;        // launch bound of the direct kernel without masks (4, 6, 8)
-    // Experiment hook, empty in production: libdswx_lab.so installs its fused-kernel structures here
-    // (dswx_lab_attach) so that A/B tools can run them through the same entry points.
-    struct lab_hooks {
-        int fused_variant = -1;  // -1 automatic (table-driven kernel when every tile starts on a 256-byte
-                                 // boundary in every plane, else the direct kernel); 0 / 3 force those two;
-                                 // 1, 2, 4, 5 = the lab's LDS-staged / warp-specialised / pipelined structures
-        int tune_pipe_blocks = 512;   // persistent pipeline: total blocks
-        int tune_ablate = 0;          // diagnostic ablation level of variant 4 (outputs invalid)
-        void (*geometry)(const dswx_ctx* ctx, int variant, long long groups, long long n_tiles, int* threads,
-                         long long* gx) = nullptr;
-        int (*launch)(dswx_ctx* ctx, int variant, const KArgs& args, bool masks, dim3 grid, dim3 block,
-                      hipStream_t stream, char* info, size_t info_len) = nullptr;
-    } lab;
+    int tune_fold = 1;       // 0: always the separate dswx_counters_finish launch (lab A/B of the folded counters)
+    int fused_variant = -1;  // -1 automatic (table-driven kernel when every plane starts on a 256-byte boundary, else the
+                             // direct kernel); 0 / 3 force those two (lab A/B and the variant parity tests)
 };
 
 // records a printf-style message for dswx_last_error() and returns `code`
@@ -91,6 +85,11 @@ static inline hipError_t dswx_locked_malloc(T** p, size_t n) {
 }
 
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// Launches of at most this many tiles sum the coverage counters inside the fused kernel (last-block-done) instead of in
+// the separate dswx_counters_finish launch, which is ~10 us + a kernel boundary: a quarter of a single-tile call, 0.09 % of
+// a 256-tile one (measurements in DESIGN.md section 5).
+constexpr int DSWX_FOLD_MAX_TILES = 16;
 
 // ---- table-driven production kernel (dswx_classify_lut.hip)
 void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int lead_max, int* threads, long long* gx);

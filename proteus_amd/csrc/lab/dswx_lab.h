@@ -3,8 +3,8 @@
  * the DSWx-HLS classifier.  NOT part of the drop-in boundary (include/dswx_hip.h): nothing here is
  * needed to run the product, and the product library (libdswx_hip.so) carries none of these kernels.
  * libdswx_lab.so links against libdswx_hip.so and works on the same dswx_ctx_t.  Users:
- * tools/roofline_probe.py, tools/ab_variants.py, tests/test_gpu_parity.py (variant parity),
- * tests/fuzz_parity.py.
+ * tools/roofline_probe.py, tools/ab_variants.py, tests/helpers/fuzz_parity.py, tests/test_gpu_parity.py (both product
+ * kernels forced).
  */
 #ifndef DSWX_LAB_H
 #define DSWX_LAB_H
@@ -15,14 +15,12 @@
 extern "C" {
 #endif
 
-/* Installs the lab's fused-kernel structures (1 LDS-staged stores, 2 warp-specialised LDS-DMA,
- * 4 warp-specialised + table-driven, 5 persistent pipeline) as candidates of this context's
- * dispatch; they run only after dswx_lab_configure(ctx, "fused_variant", v). */
+/* No-op since round 5 (it used to install four experimental kernel structures); kept so that tools written against
+ * the earlier lab ABI keep working. */
 int dswx_lab_attach(dswx_ctx_t* ctx);
 
 /* A/B switches (what round 1 read from DSWX_* environment variables): "fused_variant" (-1 automatic,
- * 0 direct kernel, 3 table-driven kernel, 1/2/4/5 lab structures), "tune_wps", "tune_lut_wps",
- * "tune_ablate", "tune_pipe_blocks", "cover_kernel", "host_pipeline", "host_chunks", "shadow_grid_pad". */
+ * 0 direct kernel, 3 table-driven kernel), "tune_wps", "tune_lut_wps", "tune_lut_interleave", "cover_kernel", "host_pipeline", "host_chunks", "shadow_grid_pad". */
 int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value);
 
 /* Roofline probe: streams exactly the bytes dswx_classify_device streams for the same arguments

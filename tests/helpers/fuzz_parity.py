@@ -3,7 +3,7 @@
 hugging the thresholds) through dswx_classify_host, every layer and the counters compared with
 the scalar C oracle.  Exit code 1 and a JSON description of the first mismatch on failure.
 
-    python tests/fuzz_parity.py [--iters 300] [--seed 1] [--variant N] [--device-batch] [--pinned]
+    python tests/helpers/fuzz_parity.py [--iters 300] [--seed 1] [--variant N] [--device-batch] [--pinned]
 
 (Lives under tests/ because it uses the oracle, which only tests/, smoke() and bench.py's CPU baseline may do;
 its name keeps pytest from collecting it.)
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import c_oracle                         # noqa: E402  (checker)
 from proteus_amd import _capi                       # noqa: E402
@@ -94,7 +94,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=300)
     ap.add_argument('--seed', type=int, default=1)
-    ap.add_argument('--variant', default=None, help='fused-kernel structure for this run (libdswx_lab.so switch: 0..5)')
+    ap.add_argument('--variant', default=None, help='force a product kernel for this run (libdswx_lab.so switch: 0 direct, 3 table-driven)')
     ap.add_argument('--device-batch', action='store_true', help='soak the device-resident batch entry instead')
     ap.add_argument('--pinned', action='store_true', help='inputs in page-locked arrays: the zero-copy host path')
     a = ap.parse_args()

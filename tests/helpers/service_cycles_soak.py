@@ -7,7 +7,7 @@ dswx_batch_pool_trim at the end gives the pool back); address space is consumed 
 until the budget is reached, after which batches are allocated packed (the note says
 so) and the service keeps running.  `--budget-gib` caps the budget so that the fallback is reached inside the run.
 
-    python tests/service_cycles_soak.py --tiles 256 --cycles 12 --budget-gib 800
+    python tests/helpers/service_cycles_soak.py --tiles 256 --cycles 12 --budget-gib 800
 
 (Lives under tests/ because it uses the oracle as its checker; its name keeps pytest from collecting it.)
 """
@@ -20,7 +20,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import c_oracle                         # noqa: E402  (checker)
 from proteus_amd import _capi                       # noqa: E402

@@ -7,8 +7,8 @@ tests/test_gpu_parity.py::test_sliding_range_survives_repeated_placement against
 churn, two sliding placements per batch, every layer of every tile against the C oracle.  Prints one JSON object:
 per policy the number of (batch, placement) cases with a wrong layer and what the wrong layer looked like.
 
-    python tests/vmm_policy_trial.py --build          # here (CPU container): compile the three variants in-tree
-    python tests/vmm_policy_trial.py --cases 80       # on the GPU box: run them (one child process per policy)
+    python tests/helpers/vmm_policy_trial.py --build          # here (CPU container): compile the three variants in-tree
+    python tests/helpers/vmm_policy_trial.py --cases 80       # on the GPU box: run them (one child process per policy)
 """
 import argparse
 import json
@@ -16,7 +16,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from proteus_amd import build as _build            # noqa: E402
 
