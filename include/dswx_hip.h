@@ -400,7 +400,12 @@ int dswx_batch_destroy(dswx_batch_t* batch);
  * dswx_batch_pool_trim() gives the pooled memory back to the device: it releases the chunks, frees every retired
  * reservation -- which is what returns the memory -- and reserves the same addresses again at once, empty.  Between those
  * two calls the addresses are up for grabs by other threads of the process: call it when none of them allocates (a range
- * lost that way is counted in `loose_bytes` and is out of the library's control).
+ * lost that way is counted in `loose_bytes` and is out of the library's control).  Batches may be LIVE during a trim,
+ * placed ones included: a kept placement's chunks were once mapped in the (now retired) wide range whose reservation the trim
+ * frees, and that was measured to be harmless (tests/test_gpu_parity.py::test_pool_trim_while_a_placed_batch_is_live;
+ * profiles/r05_trim_live_probe.json).  The library never trims by itself, not even when an allocation fails: the error
+ * text of dswx_batch_create then says how many bytes the pool holds.  Chunk sizes are powers of two (2 MiB ... 1 GiB), so
+ * batches of different geometry share the pool.
  * Address space is consumed for good: 100 - 160 GiB per placed batch at 256 tiles of 3660 x 3660 (the first-come range, the
  * wide range and, when the batch goes, the range of the kept chunks), so the default BUDGET of 64 TiB (half of the 47-bit
  * space) lasts 400 - 650 placements.  When live + retired + a new request would pass the budget the library reserves no

@@ -24,7 +24,7 @@ CSRC = os.path.join(PKG, 'csrc')
 LAB = os.path.join(CSRC, 'lab')
 SOURCES = [os.path.join(CSRC, n) for n in ('dswx_hip.hip', 'dswx_classify_lut.hip', 'dswx_cover.hip',
                                            'dswx_layers.hip', 'dswx_host_path.hip', 'dswx_batch.hip')]
-HEADERS = [os.path.join(CSRC, n) for n in ('dswx_device.h', 'dswx_host.h', 'dswx_tables.h')]
+HEADERS = [os.path.join(CSRC, n) for n in ('dswx_device.h', 'dswx_host.h', 'dswx_tables.h', 'dswx_vmm.h')]
 LAB_SOURCES = [os.path.join(LAB, n) for n in ('dswx_lab.hip', 'dswx_probes.hip')]
 LAB_HEADERS = [os.path.join(LAB, 'dswx_lab.h')]
 INCLUDE = os.path.join(ROOT, 'include')

@@ -25,6 +25,12 @@
 #include <vector>
 
 #include "dswx_host.h"
+#include "dswx_vmm.h"
+
+using dswx_vmm::VaPool;
+using dswx_vmm::VmRange;
+using dswx_vmm::chunk_for;
+using dswx_vmm::va_pool;
 
 namespace {
 
@@ -58,248 +64,6 @@ PlaneSet planes_of(uint32_t flags) {
 
 inline int elem_bytes(int plane) {
     return (plane <= DSWX_PLANE_BAND0 + 5 || plane == DSWX_PLANE_DIAG) ? 2 : 1;
-}
-
-// ---- address space ----------------------------------------------------------------------------------------------
-// An address that a kernel has accessed through one mapping must never be mapped onto other physical memory in this
-// process.  Measured in round 4 with plain HIP (tools/vmm_reuse_repro.hip, profiles/r04_vmm_reuse_repro.jsonl; ROCm 7.2,
-// gfx950): map chunk A at VA, a kernel fills it, hipMemUnmap + hipMemRelease, map a NEW chunk B at the same VA -- with or
-// without hipMemAddressFree / hipMemAddressReserve in between, with or without hipDeviceSynchronize before the unmap --
-// and in 31 of 200 iterations the next kernel's stores never arrive in B (B, seen through a fresh address, still holds
-// what a hipMemcpy put there) while hipMemcpy through VA reads and writes B: the KERNEL's translation of VA is stale
-// (it still points at A's released memory); the copy path resolves VA afresh.  Addresses that were mapped but never
-// touched by a kernel are safe to reuse (mode 3 of the reproducer: 0 of 200).  This is what round 3 saw as "layers read
-// back zeroed" (8 - 27 of 80 two-placement cases) and fenced by retiring ranges; the same library built with the
-// addresses freed (7 of 160 cases wrong), device-synchronised and freed (6 of 160) or kept in a free list and re-mapped
-// (9 of 160) fails, retired it does not (0 of 160): tests/helpers/vmm_policy_trial.py, profiles/r04_vmm_policy_trial.json.
-// So the addresses of a dropped range are never mapped again.  What happens to them and to the memory they held is shaped by
-// a second property of this stack (tools/lab/vmm_meminfo.hip, profiles/r04_vmm_meminfo.json): the physical memory of a chunk
-// that was ever mapped returns to the device only when the RESERVATION it was mapped in is freed (hipMemAddressFree) --
-// hipMemUnmap + hipMemRelease alone keep it allocated.  Freeing the addresses and reserving them again at once, empty
-// (a quarantine) returns the memory and gets the same addresses back (32 of 32 GiB in the probe) -- but between the two
-// calls the addresses are up for grabs by any other thread of the process (a four-thread stress lost one range in a few
-// hundred to an allocation the library cannot fence: the runtime's own, numpy's mmap, ...), and whoever maps GPU memory
-// there inherits the stale translations.  Hence two steps:
-//   * by default a dropped range is RETIRED: its chunks are unmapped and their physical memory goes into a process-wide
-//     POOL (per device and chunk size) from which later ranges are built before any new memory is created; its addresses
-//     stay reserved, empty.  Nothing is ever exposed; the memory stays with the library (dswx_batch_va_budget reports
-//     pooled_bytes) and is reused by the next batch or placement of the same chunk size;
-//   * dswx_batch_pool_trim() -- the caller's decision, for a moment when no other thread of the process allocates --
-//     releases the pooled chunks and does the free + quarantine of every retired range: the memory goes back to the
-//     device, the addresses stay out of circulation (a range whose addresses were lost in that instant is counted as
-//     `loose`).
-// Address space is consumed for good either way -- 100 - 160 GiB per placed batch at 256 tiles, of the 128 TiB a process
-// has -- and the library keeps count (dswx_batch_va_budget, dswx_batch_info_t.va_*): beyond a budget it reserves no more,
-// dswx_batch_create(DSWX_BATCH_SLIDING_OUTPUTS) falls back to the packed allocation and dswx_batch_place_slide leaves the
-// planes where they are, both with the reason in dswx_batch_info_t.note.
-// DSWX_VM_FREE_ADDRESSES (build-time, for tests/helpers/vmm_policy_trial.py only): 1 = release the chunks and hipMemAddressFree a
-// dropped range, 2 = hipDeviceSynchronize first -- the two unsafe forms, kept so that the trial can be repeated on a newer ROCm.
-#ifndef DSWX_VM_FREE_ADDRESSES
-#define DSWX_VM_FREE_ADDRESSES 0
-#endif
-
-struct VaPool {                                         // guarded by dswx_va_mutex()
-    uint64_t live = 0;                                  // reserved by ranges in use
-    uint64_t retired = 0;                               // reserved by dropped ranges (empty, for good)
-    uint64_t loose = 0;                                 // dropped ranges whose addresses were lost during a trim
-    uint64_t budget = 64ull << 40;                      // live + retired may not pass this: half of the 47-bit space
-    struct Spare { int device; size_t chunk; hipMemGenericAllocationHandle_t handle; };
-    std::vector<Spare> spare;                           // physical chunks of dropped ranges, unmapped, for later ranges
-    uint64_t pooled = 0;                                // their bytes
-    std::vector<std::pair<char*, size_t>> untrimmed;    // retired ranges whose reservation still pins released memory
-};
-VaPool& va_pool() { static VaPool* p = new VaPool; return *p; }     // never destroyed: frees may arrive during exit
-
-// A reserved range of the virtual address space backed chunk by chunk by physical allocations (HIP virtual memory
-// management).  The sliding placement maps a range longer than the output planes, times the kernel with the planes at
-// several places of it, and keeps only the chunks under the best one -- by moving those chunks (their physical memory,
-// hipMemGenericAllocationHandle_t) into a fresh range and dropping the wide one.
-// Life cycle: see "address space" above (retire + pool by default, dswx_batch_pool_trim for the memory).
-struct VmRange {
-    char* va = nullptr;
-    size_t reserved = 0;       // the reservation = handle.size() * chunk
-    size_t chunk = 0;
-    int device = 0;
-    std::string why;           // create() / rehome() failed: the reason, for dswx_batch_info_t.note
-    std::vector<hipMemGenericAllocationHandle_t> handle;
-    std::vector<char> mapped;  // chunk i of the range is backed by handle[i]
-
-    size_t mapped_bytes() const {
-        size_t n = 0;
-        for (char m : mapped) n += m ? chunk : 0;
-        return n;
-    }
-    static hipMemAllocationProp prop_of(int dev) {
-        hipMemAllocationProp prop = {};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = dev;
-        return prop;
-    }
-    hipError_t allow(size_t first_chunk, size_t n_chunks) {
-        hipMemAccessDesc acc = {};
-        acc.location = prop_of(device).location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        return hipMemSetAccess(va + first_chunk * chunk, n_chunks * chunk, &acc, 1);
-    }
-    void destroy() {
-#if DSWX_VM_FREE_ADDRESSES == 2
-        (void)hipDeviceSynchronize();
-#endif
-        std::lock_guard<std::mutex> lock(dswx_va_mutex());
-        VaPool& pool = va_pool();
-        for (size_t i = 0; i < handle.size(); ++i)
-            if (mapped[i]) {
-                (void)hipMemUnmap(va + i * chunk, chunk);
-#if DSWX_VM_FREE_ADDRESSES
-                (void)hipMemRelease(handle[i]);
-#else
-                pool.spare.push_back({device, chunk, handle[i]});       // the memory stays with the library: the next range's
-                pool.pooled += chunk;
-#endif
-            }
-        handle.clear();
-        mapped.clear();
-        if (va) {
-            pool.live -= reserved;
-#if DSWX_VM_FREE_ADDRESSES
-            (void)hipMemAddressFree(va, reserved);
-#else
-            pool.retired += reserved;                                   // reserved, empty, for good
-            pool.untrimmed.push_back({va, reserved});
-#endif
-        }
-        va = nullptr;
-        reserved = 0;
-    }
-    // reserve `need` bytes of addresses (a multiple of the chunk size), nothing mapped
-    hipError_t reserve(int dev, size_t need, size_t chunk_bytes) {
-        device = dev;
-        chunk = chunk_bytes;
-        VaPool& pool = va_pool();
-        std::lock_guard<std::mutex> lock(dswx_va_mutex());
-        if (pool.live + pool.retired + need > pool.budget) {
-            char buf[200];
-            snprintf(buf, sizeof buf, "address-space budget: %llu bytes reserved by live ranges + %llu retired + %llu "
-                     "wanted > %llu (dswx_batch_va_budget)", (unsigned long long)pool.live,
-                     (unsigned long long)pool.retired, (unsigned long long)need, (unsigned long long)pool.budget);
-            why = buf;
-            return hipErrorOutOfMemory;
-        }
-        void* base = nullptr;
-        const hipError_t e = hipMemAddressReserve(&base, need, 0, nullptr, 0);
-        if (e != hipSuccess) {
-            why = std::string("hipMemAddressReserve: ") + hipGetErrorString(e);
-            return e;
-        }
-        va = static_cast<char*>(base);
-        reserved = need;
-        pool.live += reserved;
-        handle.assign(need / chunk, hipMemGenericAllocationHandle_t{});
-        mapped.assign(need / chunk, 0);
-        return hipSuccess;
-    }
-    // reserve `bytes` (rounded up to whole chunks), back all of it, make it accessible from `dev`
-    hipError_t create(int dev, size_t bytes, size_t chunk_bytes) {
-        const size_t n = (bytes + chunk_bytes - 1) / chunk_bytes;
-        hipError_t e = reserve(dev, n * chunk_bytes, chunk_bytes);
-        if (e != hipSuccess) return e;
-        const hipMemAllocationProp prop = prop_of(dev);
-        for (size_t i = 0; i < n; ++i) {
-            hipMemGenericAllocationHandle_t h;
-            bool from_pool = false;
-            {
-                std::lock_guard<std::mutex> lock(dswx_va_mutex());
-                VaPool& pool = va_pool();
-                for (size_t k = pool.spare.size(); k-- > 0;)
-                    if (pool.spare[k].device == dev && pool.spare[k].chunk == chunk) {
-                        h = pool.spare[k].handle;
-                        pool.spare.erase(pool.spare.begin() + (long)k);
-                        pool.pooled -= chunk;
-                        from_pool = true;
-                        break;
-                    }
-            }
-            e = from_pool ? hipSuccess : hipMemCreate(&h, chunk, &prop, 0);
-            if (e == hipSuccess) {
-                e = hipMemMap(va + i * chunk, chunk, 0, h, 0);
-                if (e != hipSuccess) (void)hipMemRelease(h);
-            }
-            if (e != hipSuccess) {
-                why = std::string("hipMemCreate / hipMemMap: ") + hipGetErrorString(e);
-                destroy();
-                return e;
-            }
-            handle[i] = h;
-            mapped[i] = 1;
-        }
-        e = allow(0, n);
-        if (e != hipSuccess) {
-            why = std::string("hipMemSetAccess: ") + hipGetErrorString(e);
-            destroy();
-        }
-        return e;
-    }
-    // The chunks that touch one of the intervals [lo, hi) of this range, moved -- the same physical memory -- into a
-    // fresh range that spans from the first to the last of them (holes stay unmapped); *base = offset of the new range's
-    // first byte in this one.  This range keeps its other chunks: destroy() it afterwards.  nullptr: nothing was moved
-    // (`why` says what failed).  The stream must be idle.
-    VmRange* rehome(const std::vector<std::pair<size_t, size_t>>& keep, size_t* base) {
-        const size_t n = handle.size();
-        std::vector<char> used(n, 0);
-        size_t first = n, last = 0;
-        for (size_t i = 0; i < n; ++i) {
-            const size_t c0 = i * chunk, c1 = c0 + chunk;
-            for (const auto& iv : keep) used[i] = used[i] || (c0 < iv.second && iv.first < c1);
-            if (used[i] && mapped[i]) { first = i < first ? i : first; last = i; }
-        }
-        if (first == n) { why = "rehome: nothing to keep"; return nullptr; }
-        VmRange* home = new VmRange();
-        if (home->reserve(device, (last - first + 1) * chunk, chunk) != hipSuccess) {
-            why = home->why;
-            delete home;
-            return nullptr;
-        }
-        hipError_t e = hipSuccess;
-        size_t moved = first;
-        for (; moved <= last && e == hipSuccess; ++moved) {
-            if (!(used[moved] && mapped[moved])) continue;
-            e = hipMemUnmap(va + moved * chunk, chunk);
-            if (e != hipSuccess) break;
-            mapped[moved] = 0;
-            e = hipMemMap(home->va + (moved - first) * chunk, chunk, 0, handle[moved], 0);
-            if (e != hipSuccess) break;
-            home->handle[moved - first] = handle[moved];
-            home->mapped[moved - first] = 1;
-            e = home->allow(moved - first, 1);
-            if (e != hipSuccess) break;
-        }
-        if (e != hipSuccess) {
-            // undo: every chunk back where it was (the addresses of THIS range have been used by kernels, but they get
-            // their own physical memory back: the translations that may linger are the right ones)
-            why = std::string("rehome: ") + hipGetErrorString(e);
-            (void)hipGetLastError();
-            for (size_t i = first; i <= last && i <= moved; ++i) {
-                if (!used[i] || mapped[i]) continue;
-                if (home->mapped[i - first]) { (void)hipMemUnmap(home->va + (i - first) * chunk, chunk); home->mapped[i - first] = 0; }
-                if (hipMemMap(va + i * chunk, chunk, 0, handle[i], 0) == hipSuccess && allow(i, 1) == hipSuccess) mapped[i] = 1;
-                else (void)hipMemRelease(handle[i]);            // lost: the planes over it are no longer valid (the caller fails)
-            }
-            std::fill(home->mapped.begin(), home->mapped.end(), 0);     // its chunks went back: destroy() must not release them
-            home->destroy();
-            delete home;
-            return nullptr;
-        }
-        *base = first * chunk;
-        return home;
-    }
-};
-
-// chunk size of a range that holds `bytes` of planes: 2 MiB ... 1 GiB, about an eighth of the planes
-size_t chunk_for(size_t bytes) {
-    const size_t mib2 = size_t(2) << 20, gib = size_t(1) << 30;
-    size_t c = (bytes / 8 + mib2 - 1) / mib2 * mib2;
-    return c < mib2 ? mib2 : (c > gib ? gib : c);
 }
 
 int layout_mode(uint32_t flags, uint32_t* mode) {
@@ -466,8 +230,13 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
         }
     if (e != hipSuccess) {
         dswx_batch_destroy(b);
-        return dswx_fail(DSWX_ERR_HIP, "dswx_batch_create: device allocation failed: %s (arena of %llu bytes)",
-                         hipGetErrorString(e), (unsigned long long)lay.arena_bytes);
+        (void)hipGetLastError();
+        uint64_t pooled = 0;
+        dswx_vmm::account(0, nullptr, nullptr, nullptr, nullptr, &pooled);
+        // (the library does not trim by itself: dswx_batch_pool_trim has a window in which other threads must not allocate)
+        return dswx_fail(DSWX_ERR_HIP, "dswx_batch_create: device allocation failed: %s (arena of %llu bytes; the library's pool of "
+                         "placement chunks holds %llu bytes that dswx_batch_pool_trim() returns to the device)",
+                         hipGetErrorString(e), (unsigned long long)lay.arena_bytes, (unsigned long long)pooled);
     }
     for (int k : ps.in) b->ptr[k] = (char*)b->arena + lay.plane_offset[k];
     for (int k : ps.out)
@@ -479,39 +248,12 @@ int dswx_batch_create(dswx_ctx_t* ctx, const dswx_batch_geom_t* geom, uint32_t f
 
 int dswx_batch_va_budget(uint64_t new_budget_bytes, uint64_t* budget_bytes, uint64_t* live_bytes, uint64_t* retired_bytes,
                          uint64_t* loose_bytes, uint64_t* pooled_bytes) {
-    VaPool& pool = va_pool();
-    std::lock_guard<std::mutex> lock(dswx_va_mutex());
-    if (new_budget_bytes) pool.budget = new_budget_bytes;
-    if (budget_bytes) *budget_bytes = pool.budget;
-    if (live_bytes) *live_bytes = pool.live;
-    if (retired_bytes) *retired_bytes = pool.retired;
-    if (loose_bytes) *loose_bytes = pool.loose;
-    if (pooled_bytes) *pooled_bytes = pool.pooled;
+    dswx_vmm::account(new_budget_bytes, budget_bytes, live_bytes, retired_bytes, loose_bytes, pooled_bytes);
     return DSWX_OK;
 }
 
 int dswx_batch_pool_trim(uint64_t* released_bytes) {
-    VaPool& pool = va_pool();
-    std::lock_guard<std::mutex> lock(dswx_va_mutex());
-    uint64_t released = 0;
-    for (const VaPool::Spare& sp : pool.spare) {            // (a handle carries its device: no current-device switch needed)
-        (void)hipMemRelease(sp.handle);
-        released += sp.chunk;
-    }
-    pool.spare.clear();
-    pool.pooled = 0;
-    // the reservations of the retired ranges still pin that memory: free each and take its addresses back at once, empty
-    for (const auto& r : pool.untrimmed) {
-        (void)hipMemAddressFree(r.first, r.second);
-        void* again = nullptr;
-        if (hipMemAddressReserve(&again, r.second, 0, r.first, 0) != hipSuccess || again != r.first) {
-            if (again) (void)hipMemAddressFree(again, r.second);       // another thread took them in that instant
-            (void)hipGetLastError();
-            pool.retired -= r.second;
-            pool.loose += r.second;
-        }
-    }
-    pool.untrimmed.clear();
+    const uint64_t released = dswx_vmm::pool_trim();
     if (released_bytes) *released_bytes = released;
     return DSWX_OK;
 }

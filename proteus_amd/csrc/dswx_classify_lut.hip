@@ -62,21 +62,6 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         if (tile >= a.n_tiles_launch) return;           // the last group of tiles is partial (before any barrier)
     }
     const long long tile_base = tile * a.tile_stride;
-    {   // 2 KiB of tables (2.5 KiB with masks) per block: one element per thread and table
-        const int i = threadIdx.x;
-        if (i < 128) {
-            s_lut1[i] = tabs->lut1[i];
-            reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
-            s_chain[i] = MASKS ? tabs->chainm[i] : tabs->chain[i];
-        } else if (MASKS) {
-            const int k = i - 128;
-            if (k < 64) reinterpret_cast<uint32_t*>(s_land8)[k] = reinterpret_cast<const uint32_t*>(tabs->land8)[k];
-            else reinterpret_cast<uint32_t*>(s_pre16)[k - 64] = reinterpret_cast<const uint32_t*>(tabs->pre16)[k - 64];
-        }
-    }
-    if (EXTRAS) s_extra[threadIdx.x] = MASKS ? tabs->extram[threadIdx.x] : tabs->extra[threadIdx.x];
-    __syncthreads();
-
     // groups between the last 256-byte boundary of the u8 planes and this tile's first pixel (wave-uniform, SALU)
     const int lead = FLEX ? (int)((reinterpret_cast<uintptr_t>(a.in.fmask + tile_base) >> 3) & 31u) : 0;
     const bool has_l = MASKS && a.in.land, has_s = MASKS && a.in.shad, has_o = MASKS && a.in.ocean;
@@ -102,6 +87,25 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
                 const uint32_t so = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
                 t_ocean += in_range ? so : 0u;
             }
+        }
+        if (c == 0) {
+            // The tables (block-uniform: every thread of the block is here) AFTER the first group's loads have been issued:
+            // the table fill and its barrier then overlap the HBM latency of those loads instead of preceding it -- nothing
+            // in a batch launch, where other resident waves cover it, but 3 us of a single-tile launch's 50 (round 5 A/B)
+            {   // 2 KiB of tables (2.5 KiB with masks) per block: one element per thread and table
+                const int i = threadIdx.x;
+                if (i < 128) {
+                    s_lut1[i] = tabs->lut1[i];
+                    reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
+                    s_chain[i] = MASKS ? tabs->chainm[i] : tabs->chain[i];
+                } else if (MASKS) {
+                    const int k = i - 128;
+                    if (k < 64) reinterpret_cast<uint32_t*>(s_land8)[k] = reinterpret_cast<const uint32_t*>(tabs->land8)[k];
+                    else reinterpret_cast<uint32_t*>(s_pre16)[k - 64] = reinterpret_cast<const uint32_t*>(tabs->pre16)[k - 64];
+                }
+            }
+            if (EXTRAS) s_extra[threadIdx.x] = MASKS ? tabs->extram[threadIdx.x] : tabs->extra[threadIdx.x];
+            __syncthreads();
         }
         uint32_t w1w[8], chx[8], chy[8];      // per-pixel table words
         uint32_t idx2[EXTRAS ? 8 : 1];
@@ -137,12 +141,17 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) { c0 += __shfl_xor(c0, sh); c2 += __shfl_xor(c2, sh); }
         if (a.fold_acc) {
-            // Counters folded into this kernel (launches of a few tiles).  One 64-bit atomic per block carries the block's
-            // valid count (bits 0-23), cloud-and-valid count (24-47) and ONE TICKET (48-63): the returned value tells the
-            // block whether it drew the tile's last ticket, and if so it also holds the tile's complete sums -- no fence, no
-            // second pass.  n_not_ocean goes through a second accumulator, added BEFORE the ticket is drawn (fence in
-            // between), so the last block finds it complete.  The last block writes counters[tile] and leaves both
-            // accumulators zero for the next launch.  (The host folds only tiles < 2^24 pixels in < 2^16 blocks.)
+            // Counters folded into this kernel (launches of a few tiles): two levels of last-block-done, ONE atomic per block,
+            // no fence.  The blocks of a tile form groups of a.fold_group blocks (<= 2^17 pixels); every group and every
+            // tile has an accumulator on a 128-byte line of its own, so that the groups' atomics spread over the memory
+            // channels (one accumulator per tile serialised 6,541 same-address atomics and cost a 3660 x 3660 launch 35 us,
+            // and a __threadfence per block -- an L2 write-back on this part -- cost six times the kernel: both measured
+            // in round 5).  A block adds  valid | cloud_and_valid << 19 | not_ocean << 38 | ONE TICKET << 57  to its group:
+            // the value the atomic returns tells the block whether it drew the group's last ticket, and if so it also holds
+            // the group's complete sums.  That block forwards them to the tile: n_not_ocean first (its own word; the atomic
+            // RETURNS, so it has been performed), then valid | cloud << 24 | one ticket << 48 -- made data-dependent on that
+            // return -- and whoever draws the tile's last ticket reads the n_not_ocean word complete, writes counters[tile]
+            // and leaves every accumulator zero for the next launch.  (The host folds only tiles < 2^24 pixels.)
             __shared__ uint2 s_red[4];
             if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = make_uint2(c0, c2);
             __syncthreads();
@@ -150,19 +159,28 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
                 unsigned long long v = 0, cl = 0, oc = 0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { v += s_red[w].x & 0xffffu; cl += s_red[w].x >> 16; oc += s_red[w].y; }
-                unsigned long long* acc = a.fold_acc + tile * 2;
-                if (has_o) {
-                    if (oc) atomicAdd(acc + 1, oc);
-                    __threadfence();
-                }
-                const unsigned long long add = v | cl << 24 | 1ull << 48;
-                const unsigned long long now = atomicAdd(acc, add) + add;
-                if ((long long)(now >> 48) == a.blocks_per_tile) {
-                    unsigned long long* out = a.counters + tile * 3;
-                    out[0] = now & 0xffffffull;
-                    out[1] = (now >> 24) & 0xffffffull;
-                    out[2] = has_o ? atomicExch(acc + 1, 0ull) : (unsigned long long)(n_groups * 8);
-                    acc[0] = 0ull;
+                const long long gb = a.fold_group, G = (a.blocks_per_tile + gb - 1) / gb, g = blk / gb;
+                const long long in_group = min(gb, a.blocks_per_tile - g * gb);
+                unsigned long long* tacc = a.fold_acc + tile * (G + 1) * 16;        // [tile][1 + G] lines of 16 u64
+                unsigned long long* gacc = tacc + (1 + g) * 16;
+                const unsigned long long add = v | cl << 19 | oc << 38 | 1ull << 57;
+                const unsigned long long now = atomicAdd(gacc, add) + add;
+                if ((long long)(now >> 57) == in_group) {               // the group's last block: `now` holds the group's sums
+                    atomicExch(gacc, 0ull);
+                    unsigned long long tadd = (now & 0x7ffffull) | ((now >> 19) & 0x7ffffull) << 24 | 1ull << 48;
+                    if (has_o) {
+                        unsigned long long seen = atomicAdd(tacc + 1, (now >> 38) & 0x7ffffull);
+                        asm volatile("" : "+v"(seen));                  // (opaque: the ticket below waits for this return)
+                        tadd += seen >> 63;                             // always 0
+                    }
+                    const unsigned long long tnow = atomicAdd(tacc, tadd) + tadd;
+                    if ((long long)(tnow >> 48) == G) {                 // the tile's last group
+                        unsigned long long* out = a.counters + tile * 3;
+                        out[0] = tnow & 0xffffffull;
+                        out[1] = (tnow >> 24) & 0xffffffull;
+                        out[2] = has_o ? atomicExch(tacc + 1, 0ull) : (unsigned long long)(n_groups * 8);
+                        atomicExch(tacc, 0ull);
+                    }
                 }
             }
         } else if ((threadIdx.x & 63) == 0) {
@@ -173,6 +191,9 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
 }
 
 // `lead_max`: the largest per-tile lead-in of the launch (0 when every tile starts 256-byte aligned, else 31 groups)
+// blocks per group of the folded counters: at most 2^17 pixels per group (19-bit fields of the group accumulator)
+int dswx_lut_fold_group(bool extras) { return 64 / (extras ? LUT_EXTRAS_CHUNKS : 1); }
+
 void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int lead_max, int* threads, long long* gx) {
     (void)ctx;
     const long long per_block = 256LL * (extras ? LUT_EXTRAS_CHUNKS : 1);

@@ -607,6 +607,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         b.px_begin = 0;
         b.partials = nullptr;
         b.fold_acc = nullptr;
+        b.fold_group = 0;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
         // the finishing kernel of the vector path WRITES the counters; only the generic kernel
         // alone (atomic adds) needs them zeroed first
@@ -632,15 +633,24 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             const bool fold = variant && b.counters && nt <= DSWX_FOLD_MAX_TILES && n_pixels < (1LL << 24) && gx < 65536 &&
                               ctx->tune_fold != 0;
             if (fold) {
-                if (!ctx->fold_acc) {
-                    HIP_TRY(dswx_locked_malloc(&ctx->fold_acc, (size_t)DSWX_FOLD_MAX_TILES * 2 * sizeof(unsigned long long)));
+                // [tile][1 + groups of 64 blocks] accumulators, one 128-byte line each: zeroed when (re)allocated or after a
+                // failed launch, left zero by every launch that completes
+                const int gb = dswx_lut_fold_group(!plain_outputs);
+                const size_t need = (size_t)nt * (size_t)(1 + (gx + gb - 1) / gb) * 128;
+                if (need > ctx->fold_bytes) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    if (ctx->fold_acc) HIP_TRY(hipFree(ctx->fold_acc));
+                    ctx->fold_acc = nullptr; ctx->fold_bytes = 0;
+                    HIP_TRY(dswx_locked_malloc(&ctx->fold_acc, need));
+                    ctx->fold_bytes = need;
                     ctx->fold_clean = false;
                 }
                 if (!ctx->fold_clean) {
-                    HIP_TRY(hipMemsetAsync(ctx->fold_acc, 0, (size_t)DSWX_FOLD_MAX_TILES * 2 * sizeof(unsigned long long), s));
+                    HIP_TRY(hipMemsetAsync(ctx->fold_acc, 0, ctx->fold_bytes, s));
                     ctx->fold_clean = true;
                 }
                 b.fold_acc = ctx->fold_acc;
+                b.fold_group = gb;
             } else if (b.counters) {
                 const size_t need = (size_t)nt * (size_t)gx * waves * sizeof(uint2);
                 if (need > ctx->partials_bytes) {

@@ -18,9 +18,10 @@ struct dswx_ctx {
     // grow-only workspace for the vector kernel's per-wave counter partials
     void* partials = nullptr;
     size_t partials_bytes = 0;
-    // [DSWX_FOLD_MAX_TILES][2] accumulators of the folded counters (launches of a few tiles): zeroed once, left zero by
-    // every launch that completes; a launch path that fails marks them dirty
+    // grow-only accumulators of the folded counters (launches of a few tiles, dswx_classify_lut.hip): zeroed when
+    // allocated, left zero by every launch that completes; a launch path that fails marks them dirty
     unsigned long long* fold_acc = nullptr;
+    size_t fold_bytes = 0;
     bool fold_clean = false;
     // device copy of the lookup tables of the table-driven kernel (rebuilt per call)
     void* tables = nullptr;
@@ -72,11 +73,13 @@ int dswx_make_dev_params(const dswx_params_t* p, DevParams* d);
                              __FILE__, __LINE__);                                                  \
     } while (0)
 
-// Device allocations of the library go through ONE mutex, the one the sliding ranges hold while they free a dropped range's
-// addresses and reserve them again (VmRange::destroy, dswx_batch.hip): between those two calls the addresses are up for
-// grabs, and an allocation of another thread of THIS library must not be the one that takes them (a stress of four
-// threads creating and placing batches lost one range in two hundred that way).  Allocations of the caller's own threads
-// cannot be fenced; the account reports them (dswx_batch_va_budget: loose_bytes).
+// The hipMalloc calls of THIS library go through one mutex, the one dswx_batch_pool_trim (dswx_vmm.h) holds while it frees a
+// retired range's addresses and reserves them again: between those two calls the addresses are up for grabs, and an
+// allocation of another thread of this library must not be the one that takes them (a stress of four threads creating and
+// placing batches lost one range in two hundred that way).  The fence covers nothing else: hipHostMalloc, stream and event
+// creation, the runtime's own allocations (module load, first launch of a kernel) and every allocation of the caller's
+// threads can still land there -- the account reports such a loss (dswx_batch_va_budget: loose_bytes), and the header asks
+// callers to trim when nothing else in the process allocates.  (VmRange::destroy itself only retires a range.)
 std::mutex& dswx_va_mutex();
 template <typename T>
 static inline hipError_t dswx_locked_malloc(T** p, size_t n) {
@@ -92,6 +95,7 @@ static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cas
 constexpr int DSWX_FOLD_MAX_TILES = 16;
 
 // ---- table-driven production kernel (dswx_classify_lut.hip)
+int dswx_lut_fold_group(bool extras);
 void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int lead_max, int* threads, long long* gx);
 int dswx_lut_launch(dswx_ctx* ctx, const KArgs& args, bool masks, dim3 grid, dim3 block, hipStream_t stream,
                     char* info, size_t info_len);

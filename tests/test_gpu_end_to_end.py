@@ -3,6 +3,7 @@
 unit test (tests/test_dswx_hls_units.py) restated against this package."""
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -168,6 +169,35 @@ def test_runconfig_entry_point(tmp_path, sensor):
     assert 'per-pixel chain on GPU: dswx_classify' in (tmp_path / 'run.log').read_text()
     wtr = str(out_dir / 'dswx_hls_synth_v1.0_B01_WTR.tif')
     assert D.compare_dswx_hls_products(wtr, wtr)
+
+
+def test_runconfig_entry_point_at_full_tile_size(tmp_path):
+    """BASELINE.json configs[0] at ITS size: one synthetic 3660 x 3660 HLS.L30 tile as seven DEFLATE
+    GeoTIFFs through `bin/dswx_hls.py <runconfig>` -- a child process, as a user runs it -- every product layer read back
+    and compared, whole, with the numpy oracle's layers of the same tile; coverage metadata from the counters; COG layout
+    of a 3660-wide layer."""
+    rcfile, files, _, s = synth_hls.make(str(tmp_path), sensor='L30', size=3660, tile=21)
+    t0 = time.perf_counter()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bin', 'dswx_hls.py'), rcfile,
+                          '--log', str(tmp_path / 'run.log')],
+                         capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    exp = o.classify_tile(s['bands'], s['fmask'], collapse=True)
+    out_dir = tmp_path / 'output'
+    for layer, stem in LAYER_FILES.items():
+        path = out_dir / f'dswx_hls_synth_v1.0_{stem}.tif'
+        assert path.exists(), (layer, sorted(os.listdir(out_dir)))
+        arr, info = geotiff.read_geotiff(str(path))
+        assert arr.shape == (3660, 3660) and np.array_equal(arr, exp[layer]), layer
+        assert geotiff.validate_cog(str(path)) == []
+        c = exp['counters']
+        assert info.metadata['SPATIAL_COVERAGE'] == str(c['SPATIAL_COVERAGE'])
+        assert info.metadata['CLOUD_COVERAGE'] == str(c['CLOUD_COVERAGE'])
+    assert [x['width'] for x in geotiff.cog_layout(str(out_dir / 'dswx_hls_synth_v1.0_B01_WTR.tif'))][:2] == [3660, 915]
+    log = (tmp_path / 'run.log').read_text()
+    assert 'per-pixel chain on GPU: dswx_classify_lut' in log
+    print(f'bin/dswx_hls.py on a 3660 x 3660 tile: {wall:.1f} s wall (child process, incl. interpreter start and GeoTIFF codec)')
 
 
 def test_api_with_masks_and_multiband(tmp_path):

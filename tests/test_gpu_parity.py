@@ -833,6 +833,51 @@ def test_sliding_placement_pools_its_memory_and_trim_returns_it(ctx):
     assert _capi.va_budget()['loose_bytes'] == acct0['loose_bytes']            # single-threaded: every range taken back
 
 
+def test_pool_trim_while_a_placed_batch_is_live(ctx):
+    """after a KEPT dswx_batch_place_slide the batch's chunks were moved out of the wide range, which is
+    retired; dswx_batch_pool_trim then frees that range's reservation while chunks that were once mapped in it back the
+    LIVE batch.  The header allows a trim whenever no other thread allocates, so this must be safe: four rounds of
+    place (until a placement is kept) -> trim while live -> new inputs through the same planes -> classify -> every layer
+    of every tile and the counters against the C oracle; the trim returns the pooled memory to the device while the batch
+    lives (hipMemGetInfo), and what the batch holds comes back when it is freed.  (Probe of 6 rounds on another box:
+    profiles/r05_trim_live_probe.json, 0 wrong.)"""
+    n, h, w = 6, 1024, 1024
+    p = _capi.default_params()
+    _capi.pool_trim()
+    f_start = _free_device_bytes()
+    for r in range(4):
+        b = _capi.DeviceBatch(ctx, n, h, w, sliding_outputs=True)
+        b.synth(SEED, tile0=100 * r)
+        kept = False
+        for _ in range(8):
+            before = b.info()['va_reserved_bytes']
+            rec = b.place_slide(p, slack_bytes=256 << 20, step_bytes=16 << 20, launches=2)
+            kept = b.info()['va_reserved_bytes'] != before or rec['kept_launch_ms'] < rec['first_come_launch_ms']
+            if kept:
+                break
+        assert kept, 'no placement was kept in 8 tries'
+        f0 = _free_device_bytes()
+        pooled = _capi.va_budget()['pooled_bytes']
+        assert pooled >= 200 << 20
+        released = _capi.pool_trim()                            # <-- the batch is live and placed
+        assert released == pooled and _capi.va_budget()['pooled_bytes'] == 0
+        assert _free_device_bytes() - f0 >= released - (8 << 20)
+        b.synth(SEED, tile0=100 * r + 50)
+        b.classify(p)
+        ctx.synchronize()
+        cnt = b.read_counters()
+        for t in range(n):
+            s_ = synth_tile(100 * r + 50 + t, h, w)
+            exp = c_oracle.classify(p, s_['bands'], s_['fmask'])
+            for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+                assert np.array_equal(b.read_tile(key, t), exp[key]), (r, key, t)
+            assert cnt[t].tolist() == exp['counters'].tolist()
+        b.free()
+        _capi.pool_trim()
+        assert f_start - _free_device_bytes() <= (8 << 20)
+    assert _capi.va_budget()['loose_bytes'] == 0
+
+
 def test_host_code_under_ubsan_on_the_gpu():
     """The HOST side of the library -- dispatch, launch geometry, the batch layer, both placements, the host-pointer entries --
     under the undefined-behaviour sanitizer while it drives real launches (proteus_amd.build.build_ubsan; GPU sanitizers
