@@ -62,6 +62,23 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         if (tile >= a.n_tiles_launch) return;           // the last group of tiles is partial (before any barrier)
     }
     const long long tile_base = tile * a.tile_stride;
+    {   // 2 KiB of tables (2.5 KiB with masks) per block: one element per thread and table.  (Filling them AFTER the first
+        // group's loads have been issued, so that the fill and its barrier overlap the HBM latency, was measured in round 5
+        // and LOSES: 1 - 2 % at 1 ... 256 tiles, 9 % on a single tile with masks -- profiles/r05_ab_hoisted_loads.txt.)
+        const int i = threadIdx.x;
+        if (i < 128) {
+            s_lut1[i] = tabs->lut1[i];
+            reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
+            s_chain[i] = MASKS ? tabs->chainm[i] : tabs->chain[i];
+        } else if (MASKS) {
+            const int k = i - 128;
+            if (k < 64) reinterpret_cast<uint32_t*>(s_land8)[k] = reinterpret_cast<const uint32_t*>(tabs->land8)[k];
+            else reinterpret_cast<uint32_t*>(s_pre16)[k - 64] = reinterpret_cast<const uint32_t*>(tabs->pre16)[k - 64];
+        }
+    }
+    if (EXTRAS) s_extra[threadIdx.x] = MASKS ? tabs->extram[threadIdx.x] : tabs->extra[threadIdx.x];
+    __syncthreads();
+
     // groups between the last 256-byte boundary of the u8 planes and this tile's first pixel (wave-uniform, SALU)
     const int lead = FLEX ? (int)((reinterpret_cast<uintptr_t>(a.in.fmask + tile_base) >> 3) & 31u) : 0;
     const bool has_l = MASKS && a.in.land, has_s = MASKS && a.in.shad, has_o = MASKS && a.in.ocean;
@@ -87,25 +104,6 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
                 const uint32_t so = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
                 t_ocean += in_range ? so : 0u;
             }
-        }
-        if (c == 0) {
-            // The tables (block-uniform: every thread of the block is here) AFTER the first group's loads have been issued:
-            // the table fill and its barrier then overlap the HBM latency of those loads instead of preceding it -- nothing
-            // in a batch launch, where other resident waves cover it, but 3 us of a single-tile launch's 50 (round 5 A/B)
-            {   // 2 KiB of tables (2.5 KiB with masks) per block: one element per thread and table
-                const int i = threadIdx.x;
-                if (i < 128) {
-                    s_lut1[i] = tabs->lut1[i];
-                    reinterpret_cast<uint32_t*>(s_fm16)[i] = reinterpret_cast<const uint32_t*>(tabs->fm16)[i];
-                    s_chain[i] = MASKS ? tabs->chainm[i] : tabs->chain[i];
-                } else if (MASKS) {
-                    const int k = i - 128;
-                    if (k < 64) reinterpret_cast<uint32_t*>(s_land8)[k] = reinterpret_cast<const uint32_t*>(tabs->land8)[k];
-                    else reinterpret_cast<uint32_t*>(s_pre16)[k - 64] = reinterpret_cast<const uint32_t*>(tabs->pre16)[k - 64];
-                }
-            }
-            if (EXTRAS) s_extra[threadIdx.x] = MASKS ? tabs->extram[threadIdx.x] : tabs->extra[threadIdx.x];
-            __syncthreads();
         }
         uint32_t w1w[8], chx[8], chy[8];      // per-pixel table words
         uint32_t idx2[EXTRAS ? 8 : 1];
@@ -142,7 +140,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         for (int sh = 32; sh > 0; sh >>= 1) { c0 += __shfl_xor(c0, sh); c2 += __shfl_xor(c2, sh); }
         if (a.fold_acc) {
             // Counters folded into this kernel (launches of a few tiles): two levels of last-block-done, ONE atomic per block,
-            // no fence.  The blocks of a tile form groups of a.fold_group blocks (<= 2^17 pixels); every group and every
+            // no fence.  The blocks of a tile form groups of 2^a.fold_group_log2 blocks (<= 2^17 pixels); every group and every
             // tile has an accumulator on a 128-byte line of its own, so that the groups' atomics spread over the memory
             // channels (one accumulator per tile serialised 6,541 same-address atomics and cost a 3660 x 3660 launch 35 us,
             // and a __threadfence per block -- an L2 write-back on this part -- cost six times the kernel: both measured
@@ -159,8 +157,10 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
                 unsigned long long v = 0, cl = 0, oc = 0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { v += s_red[w].x & 0xffffu; cl += s_red[w].x >> 16; oc += s_red[w].y; }
-                const long long gb = a.fold_group, G = (a.blocks_per_tile + gb - 1) / gb, g = blk / gb;
-                const long long in_group = min(gb, a.blocks_per_tile - g * gb);
+                // (fold_group is a power of two, passed as its log2: a 64-bit division here compiled to ~350 SALU instructions)
+                const int sh = a.fold_group_log2;
+                const long long gb = 1LL << sh, G = (a.blocks_per_tile + gb - 1) >> sh, g = blk >> sh;
+                const long long in_group = min(gb, a.blocks_per_tile - (g << sh));
                 unsigned long long* tacc = a.fold_acc + tile * (G + 1) * 16;        // [tile][1 + G] lines of 16 u64
                 unsigned long long* gacc = tacc + (1 + g) * 16;
                 const unsigned long long add = v | cl << 19 | oc << 38 | 1ull << 57;
@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
 }
 
 // `lead_max`: the largest per-tile lead-in of the launch (0 when every tile starts 256-byte aligned, else 31 groups)
-// blocks per group of the folded counters: at most 2^17 pixels per group (19-bit fields of the group accumulator)
-int dswx_lut_fold_group(bool extras) { return 64 / (extras ? LUT_EXTRAS_CHUNKS : 1); }
+// log2 of the blocks per group of the folded counters: at most 2^17 pixels per group (19-bit fields of the group accumulator)
+static_assert(LUT_EXTRAS_CHUNKS == 4, "dswx_lut_fold_group_log2 assumes 64 / 4 = 16 blocks of 8192 pixels");
+int dswx_lut_fold_group_log2(bool extras) { return extras ? 4 : 6; }
 
 void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int lead_max, int* threads, long long* gx) {
     (void)ctx;

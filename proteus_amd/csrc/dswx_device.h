@@ -45,8 +45,8 @@ struct KArgs {
     dswx_planes_out_t out;
     uint2* partials;                // fused kernel: per-wave counts, [tile][block][wave] (summed by dswx_counters_finish) ...
     unsigned long long* fold_acc;   // ... or, for launches of a few tiles, accumulators the blocks add to; the block that
-    int fold_group;                 //   draws a tile's last ticket writes counters[tile] itself (dswx_classify_lut.hip);
-                                    //   fold_group = blocks per first-level group
+    int fold_group_log2;            //   draws a tile's last ticket writes counters[tile] itself (dswx_classify_lut.hip);
+                                    //   2^fold_group_log2 = blocks per first-level group
     uint8_t* cover_state;           // 'cover' mode: stage 1 parks one state byte per pixel here
                                     //   (cover_state_of) ...
     uint32_t* cover_bits;           //   ... and the four dilation predicates of every 8-pixel group as one

@@ -607,7 +607,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         b.px_begin = 0;
         b.partials = nullptr;
         b.fold_acc = nullptr;
-        b.fold_group = 0;
+        b.fold_group_log2 = 0;
         const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
         // the finishing kernel of the vector path WRITES the counters; only the generic kernel
         // alone (atomic adds) needs them zeroed first
@@ -635,8 +635,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             if (fold) {
                 // [tile][1 + groups of 64 blocks] accumulators, one 128-byte line each: zeroed when (re)allocated or after a
                 // failed launch, left zero by every launch that completes
-                const int gb = dswx_lut_fold_group(!plain_outputs);
-                const size_t need = (size_t)nt * (size_t)(1 + (gx + gb - 1) / gb) * 128;
+                const int gl = dswx_lut_fold_group_log2(!plain_outputs);
+                const size_t need = (size_t)nt * (size_t)(1 + ((gx + (1LL << gl) - 1) >> gl)) * 128;
                 if (need > ctx->fold_bytes) {
                     HIP_TRY(hipStreamSynchronize(s));
                     if (ctx->fold_acc) HIP_TRY(hipFree(ctx->fold_acc));
@@ -650,7 +650,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
                     ctx->fold_clean = true;
                 }
                 b.fold_acc = ctx->fold_acc;
-                b.fold_group = gb;
+                b.fold_group_log2 = gl;
             } else if (b.counters) {
                 const size_t need = (size_t)nt * (size_t)gx * waves * sizeof(uint2);
                 if (need > ctx->partials_bytes) {

@@ -95,7 +95,7 @@ static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cas
 constexpr int DSWX_FOLD_MAX_TILES = 16;
 
 // ---- table-driven production kernel (dswx_classify_lut.hip)
-int dswx_lut_fold_group(bool extras);
+int dswx_lut_fold_group_log2(bool extras);
 void dswx_lut_geometry(const dswx_ctx* ctx, long long groups, bool extras, int lead_max, int* threads, long long* gx);
 int dswx_lut_launch(dswx_ctx* ctx, const KArgs& args, bool masks, dim3 grid, dim3 block, hipStream_t stream,
                     char* info, size_t info_len);
