@@ -1080,6 +1080,7 @@ def main():
     if world > 1 or args.preflight or cp.dist is not None:
         pre = preflight(args, env, cases)
         if args.preflight:
+            cp.barrier()
             if rank == 0:
                 print(json.dumps({'preflight': pre}), flush=True)
             if ctx is not None:

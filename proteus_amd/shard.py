@@ -34,6 +34,30 @@ def chunk_sizes(n_tiles, chunk):
     return [chunk] * full + ([rest] if rest else [])
 
 
+class _stdout_to_stderr:
+    """gloo and RCCL print banners ('[Gloo] Rank 0 is connected to ...', the RCCL version block) through C stdio on fd 1;
+    bench.py's contract is ONE JSON line on stdout.  While a process group comes up, fd 1 points at fd 2."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        import sys
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)          # C stdio is block-buffered when stdout is a pipe: empty it into fd 2
+        except Exception:                           # noqa: BLE001
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def env_rank():
     """(rank, local_rank, world) from the torch.distributed.run environment."""
     return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
@@ -80,12 +104,13 @@ class ControlPlane:
                 sock.bind(('127.0.0.1', 0))
                 port = sock.getsockname()[1]
             kw.update(init_method=f'tcp://127.0.0.1:{port}', rank=self.rank, world_size=self.world)
-        if not dist.is_initialized():
-            dist.init_process_group('gloo', **kw)
-        self.dist = dist
-        self.backend = 'gloo'
+        with _stdout_to_stderr():
+            if not dist.is_initialized():
+                dist.init_process_group('gloo', **kw)
+            self.dist = dist
+            self.backend = 'gloo'
+            err = self._bring_up_rccl() if backend == 'nccl' else None
         if backend == 'nccl':
-            err = self._bring_up_rccl()
             verdicts = self.gather_objects(err)
             bad = [(r, e) for r, e in enumerate(verdicts) if e]
             if not bad:
