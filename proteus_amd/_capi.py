@@ -686,7 +686,7 @@ class Context:
 
     # ---- libdswx_lab.so (experiments; tools/ and the variant tests only) -----------
     def lab_configure(self, **settings):
-        """A/B switches of this context, e.g. lab_configure(fused_variant=2) or (host_chunks=3);
+        """A/B switches of this context, e.g. lab_configure(fused_variant=3) or (host_chunks=3);
         loads libdswx_lab.so and attaches its kernel structures on first use."""
         lab = load_lab()
         if not getattr(self, '_lab_attached', False):
