@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument('--total-tiles', type=int, default=0,
                     help='strong scaling: tiles of the whole job, split over the ranks (BASELINE configs[3]: 4096)')
     ap.add_argument('--require-rccl', action='store_true',
-                    help='fail (every rank, no line) if the RCCL control plane cannot come up on every rank.  Default: fall '
+                    help='fail (every rank; the line carries no number, only the reason) if the RCCL control plane cannot come up on every rank.  Default: fall '
                          'back to gloo LOUDLY -- `config.control_plane` says why and `rccl_ranks` is 0; RCCL carries only the '
                          'barriers and the MAX / SUM of a few scalars here, tiles are independent')
     ap.add_argument('--allow-gloo', action='store_true', help=argparse.SUPPRESS)       # r04 spelling: now the default
@@ -1052,11 +1052,93 @@ def bring_up(args, rank, local_rank, world):
                               mem_info=lambda: torch.cuda.mem_get_info(local_rank))
 
 
+class LastWords:
+    """Rank 0 of an N > 1 run: what to print if the LAUNCHER ends this process.  An exception on a rank is a record
+    (RankGuard); a rank that dies hard -- a signal, a GPU fault that aborts the process -- is not: torchrun then sends
+    SIGTERM to the survivors, and rank 0 is usually inside a collective that will never complete (a C call: a Python
+    signal handler would not run).  So the C-level handler only writes to a wake-up pipe, and a helper thread that
+    blocks on the pipe prints the line as far as it got -- the cases that completed intact, the running one with
+    `value: null` and the reason -- and ends the process.  One JSON line on stdout in every ending bench.py can influence."""
+
+    instance = None
+
+    def __init__(self, args, world):
+        import signal
+        import threading
+        LastWords.instance = self
+        self.args, self.world = args, world
+        self.out = None                     # the line so far (the top-level record once the first case is complete)
+        self.running = 'bring-up'
+        self.done = False
+        self.lock = threading.Lock()
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        self.pipe = r
+        signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+        signal.signal(signal.SIGTERM, lambda *a: None)      # (a Python-level handler must exist for the C-level one to run)
+        threading.Thread(target=self.watch, daemon=True, name='bench-last-words').start()
+
+    def watch(self):
+        import signal
+        while True:
+            data = os.read(self.pipe, 16)
+            if not data:
+                return
+            if signal.SIGTERM in data:
+                self.speak('SIGTERM from the launcher (another rank died?)')
+
+    def speak(self, why):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            note = f'terminated while {self.running} was running: {why}'
+            out = self.out
+            if out is None:
+                out = {'metric': 'Mpixels/sec DSWx classify (3660^2 7-band HLS tiles)', 'value': None, 'unit': 'Mpixels/s',
+                       'n_gpus': self.world, 'n_ranks': self.world, 'steps': self.args.steps, 'warmup': self.args.warmup,
+                       'ms_per_step': None, 'higher_is_better': True, 'scaling': 'strong' if self.args.total_tiles else 'weak',
+                       'vs_baseline': None, 'dtype': 'int16+f64', 'data': 'synthetic', 'config': {}, 'roofline': None,
+                       'error': note}
+            else:
+                out = dict(out)
+                if self.running.startswith('case'):
+                    out['strong'] = {'value': None, 'error': note}
+                else:
+                    out['terminated'] = note
+            try:
+                sys.stdout.write(json.dumps(out) + '\n')
+                sys.stdout.flush()
+            finally:
+                os._exit(143)
+
+    def finished(self):
+        """The normal ending owns stdout from here on."""
+        with self.lock:
+            was = self.done
+            self.done = True
+        return not was
+
+
 SUB_RECORD_KEYS = ('value', 'unit', 'n_gpus', 'n_ranks', 'steps', 'warmup', 'ms_per_step', 'scaling', 'config', 'roofline',
                    'ranks', 'slowest_rank', 'parity_check', 'error', 'failed_ranks')
 
 
 def main():
+    try:
+        return _main()
+    except BaseException as e:              # noqa: BLE001
+        # what escapes RankGuard is a COLLECTIVE failing (a peer is gone: gloo reports the reset connection at once) or a bug:
+        # rank 0 still says what it knows, then the exception takes its course
+        lw = LastWords.instance
+        if lw is not None and not isinstance(e, SystemExit):
+            import traceback
+            traceback.print_exc()
+            lw.speak(f'{type(e).__name__}: {e}'[:300])
+        raise
+
+
+def _main():
     args = parse_args()
     if args.cpu_parallel_worker:
         cpu_parallel_main(args.cpu_parallel_worker)
@@ -1073,6 +1155,7 @@ def main():
     if args.plan_only:
         return plan_only(args, rank, world)
 
+    last_words = LastWords(args, world) if rank == 0 and world > 1 else None
     env = bring_up(args, rank, local_rank, world)
     ctx, cp = env.ctx, env.cp
     cases = cases_of(args, world)
@@ -1092,6 +1175,8 @@ def main():
     failed_any = []
     headline_tiles = args.tiles
     for index, case in enumerate(cases):
+        if last_words:
+            last_words.running = f'case {index}' + (f' ({case.key})' if case.key else '')
         rec, n_tiles, failed = measure_case(args, case, env, index)
         failed_any += failed
         if rank == 0:
@@ -1106,8 +1191,12 @@ def main():
             print('[bench partial] ' + json.dumps({k: out.get(k) for k in ('value', 'ms_per_step', 'n_gpus', 'error')}
                                                   | ({case.key: {'value': rec['value']}} if case.key else {})),
                   file=sys.stderr, flush=True)
+            if last_words:
+                last_words.out = out
         if case.key is None:
             headline_tiles = n_tiles
+    if last_words:
+        last_words.running = 'the legs after the timed regions'
 
     # ---- legs after the timed regions (none of them is `value`)
     host_path = None
@@ -1154,7 +1243,8 @@ def main():
                     out['cpu_baseline']['tile_parallel'] = par
             except Exception as e:      # a reported baseline must never cost the bench line
                 out['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
-        print(json.dumps(out), flush=True)
+        if last_words is None or last_words.finished():
+            print(json.dumps(out), flush=True)
     code = 1 if failed_any else 0           # non-zero AFTER the line
     try:
         if ctx is not None:

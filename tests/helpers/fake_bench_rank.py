@@ -57,7 +57,17 @@ class FakeBatch:
         FakeBatch.live -= 1
 
 
+PLACED = [0]
+
+
 def fake_place_batch(ctx, params, n_tiles, tile0, masks, how, trials, refine=1, slack_gib=48.0):
+    # FAKE_HARD_EXIT='<rank>:<n>': that rank dies HARD (no exception, no clean-up) in its n-th placement, i.e. case n - 1
+    spec = os.environ.get('FAKE_HARD_EXIT')
+    PLACED[0] += 1
+    if spec:
+        r, n = spec.split(':')
+        if int(r) == int(os.environ.get('RANK', '0')) and int(n) == PLACED[0]:
+            os._exit(7)
     return FakeBatch(), {'how': how, 'probes': 0, 'seconds': 0.0, 'slack_gib_used': slack_gib}
 
 

@@ -216,6 +216,22 @@ def test_a_rank_without_a_working_device_is_a_record_not_a_hang():
     assert 'error' in out['preflight']['ranks'][1] and 'error' not in out['preflight']['ranks'][0]
 
 
+@pytest.mark.parametrize('case_no', [2, 1])
+def test_a_rank_that_dies_hard_still_leaves_rank_zero_its_last_words(case_no):
+    """What RankGuard cannot catch: rank 1 ends with os._exit in the middle of a case (as a GPU fault or a signal would end
+    it).  torchrun then terminates rank 0, which is waiting in a collective that will never complete; its wake-up-pipe
+    thread prints the line as far as it got.  Dying in the SECOND case leaves the first (the weak record, the point of the
+    scaling curve) intact in the line; dying in the first leaves a line with `value: null` and the reason."""
+    res = _torchrun(FAKE_RANK, *TOY, env={'FAKE_HARD_EXIT': f'1:{case_no}'}, timeout=180)
+    assert res.returncode != 0
+    out = _line(res)
+    if case_no == 2:
+        assert out['value'] > 0 and 'error' not in out and out['parity_check']['result'] == 'bit-exact'
+        assert out['strong']['value'] is None and 'terminated while case 1 (strong) was running' in out['strong']['error']
+    else:
+        assert out['value'] is None and 'terminated while case 0 was running' in out['error']
+
+
 def test_preflight_alone_and_a_rank_short_of_hbm_shrinks_its_slack():
     res = _torchrun(FAKE_RANK, '--gpus', '2', '--preflight')
     assert res.returncode == 0, res.stderr[-3000:]
@@ -232,5 +248,9 @@ def test_preflight_alone_and_a_rank_short_of_hbm_shrinks_its_slack():
 
 
 def test_require_rccl_is_strict():
+    """--require-rccl: no measurement without RCCL.  Every rank raises; rank 0's last words are a line with no number and
+    the reason."""
     res = _torchrun(FAKE_RANK, *TOY, '--require-rccl')
-    assert res.returncode != 0 and '{"metric"' not in res.stdout and 'strict control plane' in res.stderr
+    assert res.returncode != 0 and 'strict control plane' in res.stderr
+    out = _line(res)
+    assert out['value'] is None and 'strict control plane' in out['error'] and 'strong' not in out

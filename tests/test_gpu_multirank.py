@@ -203,26 +203,11 @@ def test_address_space_budget_spent_falls_back_to_packed_planes():
     assert restored['info']['flags'] & SLIDING and restored['place']['positions'] > 0
 
 
-def test_plain_gpus_command_yields_the_weak_and_the_strong_record():
-    """VERDICT r03 next-1b on the GPU, at toy sizes (hidden --plain-tiles / --strong-total / --strong-chunk; two ranks on
-    one device): `bench.py --gpus 2` with no workload named measures the weak record AND BASELINE configs[3]'s strong
-    walk in the one line -- the strong sub-record with --distinct-chunks parity on every rank and its own per-rank
-    records."""
-    out = _bench('--gpus', '2', '--plain-tiles', '3', '--strong-total', '16', '--strong-chunk', '4', '--steps', '2',
-                 '--warmup', '1', '--no-cpu-baseline', '--no-host-path')
-    assert out['scaling'] == 'weak' and out['config']['tiles_per_step_all_ranks'] == 6
-    assert out['parity_check']['result'] == 'bit-exact'
-    st = out['strong']
-    assert st['scaling'] == 'strong' and st['config']['tiles_per_step_all_ranks'] == 16 and st['config']['launches_per_step'] == 2
-    assert 'configs[3]' in st['config']['workload'] and st['value'] > 0 and st['ms_per_step'] > 0
-    assert st['parity_check']['result'] == 'bit-exact'
-    assert [r['tiles'] for r in st['parity_check']['ranks']] == [[0, 2, 3, 4, 7], [8, 10, 11, 12, 15]]
-    assert [r['tiles_per_step'] for r in st['ranks']] == [8, 8] and st['slowest_rank']['rank'] in (0, 1)
-    assert st['roofline']['pixels_per_launch'] == 4 * 3660 * 3660 and 0 < st['roofline']['frac'] < 1
-
-
 def test_four_ranks_on_one_device_plain_command():
-    """More than two ranks (sharing this box's one device: gloo control plane, toy sizes), the plain two-record command.
+    """VERDICT r03 next-1b on the GPU, at toy sizes (hidden --plain-tiles / --strong-total / --strong-chunk): `bench.py
+    --gpus N` with no workload named measures the weak record AND BASELINE configs[3]'s strong walk in the one line.
+    More than two ranks (sharing this box's one device: gloo control plane), the plain two-record command; the two-rank
+    form of it runs in test_a_failing_rank_is_a_record_in_the_line_real_kernels.
     Every rank must hold and check ITS tiles -- weak: tiles 2r, 2r + 1; strong: 20 tiles split five per rank, walked as
     chunks of 2 + 2 + 1 with every chunk generated under its own indices -- and report its own record.  (The same with
     EIGHT ranks and the host-path leg was run by hand -- profiles/r04_bench_8ranks_one_device_toy.json -- and is not part
