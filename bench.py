@@ -575,17 +575,19 @@ class RankGuard:
     error record and the rest of the rank's local work in this case is skipped -- but the rank keeps walking the same
     sequence of collectives as the others (barriers, MAX, SUM, gathers: they sit OUTSIDE `run`), so nobody is stranded
     and rank 0 still prints the line, with `value: null` for the case a rank failed in and the failure named.
-    DSWX_BENCH_INJECT='<rank>:<case index>:<phase>' raises inside that phase (tests/: the injected failure)."""
+    DSWX_BENCH_INJECT='<rank>:<case index>:<phase>' raises inside that phase (tests/: the injected failure); with ':hard'
+    appended the rank's process ENDS there instead (what RankGuard cannot catch: LastWords below)."""
 
     def __init__(self, rank, case_index, boot_error=None):
         self.rank, self.case_index = rank, case_index
         self.error = dict(boot_error) if boot_error else None
-        self.inject = None
+        self.inject, self.inject_hard = None, False
         spec = os.environ.get('DSWX_BENCH_INJECT', '')
         if spec:
             r, c, phase = spec.split(':', 2)
             if int(r) == rank and int(c) == case_index:
-                self.inject = phase
+                self.inject_hard = phase.endswith(':hard')          # '<rank>:<case>:<phase>:hard' = the process ends there
+                self.inject = phase[:-5] if self.inject_hard else phase
 
     @property
     def ok(self):
@@ -595,6 +597,8 @@ class RankGuard:
         if self.error is not None:
             return default
         try:
+            if self.inject == phase and self.inject_hard:
+                os._exit(7)                 # as a GPU fault or a signal would end the rank: no exception, no clean-up
             if self.inject == phase:
                 raise RuntimeError(f'injected failure in phase {phase!r} (DSWX_BENCH_INJECT)')
             return fn()

@@ -245,6 +245,18 @@ def test_a_failing_rank_is_a_record_in_the_line_real_kernels():
     assert out['preflight']['distinct_devices'] == 1 and not out['preflight']['ok']      # both ranks on device 0: said
 
 
+def test_a_rank_that_dies_hard_in_the_second_case_leaves_the_first_in_the_line():
+    """What no try / except catches: rank 1's process ENDS (os._exit, as a GPU fault would end it) while it places the
+    batch of the second case.  torchrun terminates rank 0, which sits in a collective that will never complete; its
+    wake-up-pipe thread (or the exception gloo raises about the lost peer) prints the line as far as it got: the weak
+    record measured on real kernels by both ranks, bit-exact, and `strong.value: null` with the reason."""
+    out = _bench('--gpus', '2', '--plain-tiles', '2', '--strong-total', '8', '--strong-chunk', '2', '--steps', '2',
+                 '--warmup', '1', '--no-cpu-baseline', extra_env={'DSWX_BENCH_INJECT': '1:1:place:hard'}, expect_rc=1)
+    assert out['value'] > 0 and out['n_ranks'] == 2 and out['parity_check']['result'] == 'bit-exact'
+    assert [r['rank'] for r in out['ranks']] == [0, 1] and all(r['frac'] > 0 for r in out['ranks'])
+    assert out['strong']['value'] is None and 'terminated while case 1 (strong) was running' in out['strong']['error']
+
+
 def test_a_rank_whose_allocation_fails_is_a_record_and_the_memory_comes_back():
     """The failure VERDICT r04 names: the resident chunk does not fit (here: 40 000 tiles = 10 TB asked of the library).
     Both ranks fail in 'place' with the library's own error, the line says so, nothing is left allocated, exit non-zero."""
