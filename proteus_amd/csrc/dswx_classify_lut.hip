@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
     __shared__ uint2 s_chain[128];
     __shared__ uint2 s_extra[EXTRAS ? 256 : 1];
     const DevParams& P = a.P;
-    const long long n_groups = a.n_pixels >> 3;
+    long long n_groups = a.n_pixels >> 3;
     // which tile, which block of it (block-uniform): see KArgs::tile_interleave
     long long tile = blockIdx.y, blk = blockIdx.x;
     if (FLEX && a.tile_interleave > 1) {
@@ -61,7 +61,12 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         blk = blockIdx.x / G;
         if (tile >= a.n_tiles_launch) return;           // the last group of tiles is partial (before any barrier)
     }
-    const long long tile_base = tile * a.tile_stride;
+    long long tile_base = tile * a.tile_stride;
+    if (FLEX && a.ragged) {             // KArgs::ragged: start at the tile's first 8-pixel boundary (block-uniform, SALU)
+        const int head = ragged_head(a.in.fmask + tile_base);
+        tile_base += head;
+        n_groups = a.n_pixels > head ? (a.n_pixels - head) >> 3 : 0;
+    }
     {   // 2 KiB of tables (2.5 KiB with masks) per block: one element per thread and table.  (Filling them AFTER the first
         // group's loads have been issued, so that the fill and its barrier overlap the HBM latency, was measured in round 5
         // and LOSES: 1 - 2 % at 1 ... 256 tiles, 9 % on a single tile with masks -- profiles/r05_ab_hoisted_loads.txt.)

@@ -59,6 +59,11 @@ struct KArgs {
     long long n_pixels;             // per tile
     long long tile_stride;          // pixels between the starts of consecutive tiles in every plane
     long long px_begin;             // generic kernel: first pixel of the tile it covers
+    // Ragged contiguous batches (tile_stride % 8 != 0, plane bases 256-byte aligned): every tile starts somewhere inside
+    // an 8-pixel group of the planes.  The table-driven kernel then skips the tile's first `head` pixels, head = the
+    // distance to the next 8-byte boundary of the u8 planes (= 16-byte boundary of the int16 planes), a number every kernel
+    // derives from the tile's address; the generic kernel covers the < 8 head and < 8 tail pixels of every tile.
+    int ragged;
     // table-driven kernel: block order.  0 / 1 = a tile's blocks are consecutive in dispatch order (grid = blocks x tiles);
     // G > 1 = the blocks of G tiles interleaved (grid.x = blocks_per_tile * G, grid.y = ceil(tiles / G)), so that the
     // blocks in flight at any moment -- and the 14 streams they read and write -- spread over G tiles of every plane
@@ -298,6 +303,11 @@ __device__ __forceinline__ void classify_px_f32(const DevParams& P, uint32_t aer
     const bool lcpsw = ((land == 201) | ((uint32_t)land < 100u)) & bright;
     const bool lchigh = (uint32_t)(land - 100) < 100u;
     px_chain(P, w1, remap, pc, (fm & 16) != 0, shadrule, lcpsw, lchigh, o);
+}
+
+// ragged batches (KArgs::ragged): pixels of a tile in front of the first 8-pixel boundary of the planes
+__device__ __forceinline__ int ragged_head(const uint8_t* fmask_at_tile_start) {
+    return (8 - (int)(reinterpret_cast<uintptr_t>(fmask_at_tile_start) & 7u)) & 7;
 }
 
 template <typename T, bool NT> __device__ __forceinline__ T ldg(const void* p) {

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
 __global__ __launch_bounds__(1024) void dswx_counters_finish(const uint2* __restrict__ partials,
                                                              unsigned long long* __restrict__ counters,
                                                              long long per_tile, int has_ocean,
-                                                             long long vec_pixels) {
+                                                             long long vec_pixels, const uint8_t* ragged_fmask,
+                                                             long long tile_stride, long long n_pixels) {
     // one block of 1024 threads per tile, four independent loads in flight per thread: the
     // 26 k partials of a 3660 x 3660 tile are summed in ~7 dependent rounds (this kernel is pure
     // latency; with 256 threads and one load at a time it took 30 us, a third of a single-tile call)
@@ -196,7 +197,13 @@ __global__ __launch_bounds__(1024) void dswx_counters_finish(const uint2* __rest
         unsigned long long sum = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) sum += red[w][threadIdx.x];
-        if (threadIdx.x == 2 && !has_ocean) sum = (unsigned long long)vec_pixels;
+        if (threadIdx.x == 2 && !has_ocean) {
+            if (ragged_fmask) {         // KArgs::ragged: the pixels the vector kernel covered differ from tile to tile
+                const int head = ragged_head(ragged_fmask + (long long)blockIdx.x * tile_stride);
+                vec_pixels = n_pixels > head ? ((n_pixels - head) >> 3) * 8 : 0;
+            }
+            sum = (unsigned long long)vec_pixels;
+        }
         counters[(long long)blockIdx.x * 3 + threadIdx.x] = sum;
     }
 }
@@ -214,8 +221,18 @@ __global__ __launch_bounds__(256) void dswx_classify_v1(const KArgs a) {
     __syncthreads();
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
     uint32_t c0 = 0, c1 = 0, c2 = 0, cstate = 0, cflags = 0;
-    const long long px = a.px_begin + (long long)blockIdx.x * 256 + threadIdx.x;
-    if (px < a.n_pixels) {
+    long long px = a.px_begin + (long long)blockIdx.x * 256 + threadIdx.x;
+    bool active = px < a.n_pixels;
+    if (a.ragged) {
+        // the edges of a ragged tile behind the table-driven kernel (KArgs::ragged; grid.x = 1): threads 0-7 its head
+        // pixels, threads 8-15 its tail pixels
+        const int head = ragged_head(a.in.fmask + (long long)blockIdx.y * a.tile_stride);
+        const long long body = a.n_pixels > head ? ((a.n_pixels - head) >> 3) * 8 : 0;
+        const int t = threadIdx.x;
+        px = t < 8 ? t : head + body + (t - 8);
+        active = t < 16 && px < a.n_pixels && (t < 8 ? t < head : true);
+    }
+    if (active) {
         const long long off = (long long)blockIdx.y * a.tile_stride + px;
         int land = -1, shad = 1, ocean = 1;
         if (a.in.land) land = a.in.land[off];
@@ -496,7 +513,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     for (int k = 0; k < 6; ++k)
         if (!in->band[k]) return dswx_fail(DSWX_ERR_ARG, "band[%d] is NULL", k);
     if (!in->fmask) return dswx_fail(DSWX_ERR_ARG, "fmask is NULL");
-    KArgs a;
+    KArgs a = {};
     int rc = dswx_make_dev_params(params, &a.P);
     if (rc) return rc;
     const bool cover = params->mask_adjacent_to_cloud_mode == DSWX_ADJ_COVER;
@@ -555,8 +572,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         return dswx_fail(DSWX_ERR_UNSUPPORTED, "the float64 index planes describe the integer chain; not available with offset_and_scale_inputs");
     const bool masks = in->land || in->shad || in->ocean;
     // the fused kernels need every plane 16-byte aligned at every tile start (int16 planes: 8 pixels)
-    bool vec_ok = (tile_stride % 8 == 0) || n_tiles == 1;
-    const bool stride16 = (tile_stride % 16 == 0) || n_tiles == 1;     // the lab's LDS-DMA structures: 16 px per lane
+    const bool stride8 = (tile_stride % 8 == 0) || n_tiles == 1;
+    bool vec_ok = true;
     for (int k = 0; k < 6 && vec_ok; ++k) vec_ok = aligned_to(in->band[k], 16);
     vec_ok = vec_ok && aligned_to(in->fmask, 16) && (!in->land || aligned_to(in->land, 16)) &&
              (!in->shad || aligned_to(in->shad, 16)) && (!in->ocean || aligned_to(in->ocean, 16)) &&
@@ -575,7 +592,12 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
                (!out->diag || aligned_to(out->diag, 256));
     for (uint8_t* p : u8outs) bases256 = bases256 && (!p || aligned_to(p, 256));
     const bool stride256 = (tile_stride % 256 == 0) || n_tiles == 1;
-    const bool lut_ok = bases256 && (stride256 || tile_stride % 8 == 0);
+    // ragged contiguous batches (H * W not a multiple of 8, several tiles): the table-driven kernel starts every tile at
+    // its first 8-pixel boundary, the generic kernel does the < 8 + < 8 pixels at its edges (KArgs::ragged).  Not in
+    // 'cover' mode, whose bitmaps are indexed by tile-relative 8-pixel groups; not when the direct kernel is forced.
+    const bool ragged = !stride8 && bases256 && !cover && ctx->fused_variant != 0;
+    vec_ok = vec_ok && (stride8 || ragged);
+    const bool lut_ok = bases256 && (stride256 || tile_stride % 8 == 0 || ragged);
     // the lead-in is a property of the addresses (correct for any of them); 0 only when every tile start is aligned
     const int lead_max = (bases256 && stride256) ? 0 : 31;  // groups: dswx_lut_geometry
 
@@ -608,7 +630,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         b.partials = nullptr;
         b.fold_acc = nullptr;
         b.fold_group_log2 = 0;
-        const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;
+        const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;       // (ragged: the most a tile can have)
+        b.ragged = (ragged && groups > 0) ? 1 : 0;
         // the finishing kernel of the vector path WRITES the counters; only the generic kernel
         // alone (atomic adds) needs them zeroed first
         if (groups == 0 && b.counters)
@@ -689,12 +712,17 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             }
             if (b.counters && !fold) {
                 hipLaunchKernelGGL(dswx_counters_finish, dim3((unsigned)nt), dim3(1024), 0, s, b.partials,
-                                   b.counters, (long long)gx * waves, in->ocean ? 1 : 0, (long long)groups * 8);
+                                   b.counters, (long long)gx * waves, in->ocean ? 1 : 0, (long long)groups * 8,
+                                   b.ragged ? b.in.fmask : nullptr, (long long)tile_stride, (long long)n_pixels);
                 HIP_TRY(hipGetLastError());
             }
             b.px_begin = groups * 8;
         }
-        if (b.px_begin < n_pixels) {
+        if (b.ragged) {                     // head and tail pixels of every tile: 16 threads of one block per tile
+            hipLaunchKernelGGL(dswx_classify_v1, dim3(1, (unsigned)nt), dim3(256), 0, s, b);
+            const size_t len = strlen(info);
+            snprintf(info + len, sizeof info - len, " ragged tiles: edges by dswx_classify_v1");
+        } else if (b.px_begin < n_pixels) {
             const int64_t rest = n_pixels - b.px_begin;
             const int64_t gx = (rest + 255) / 256;
             dim3 grid((unsigned)gx, (unsigned)nt), block(256);

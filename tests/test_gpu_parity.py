@@ -1059,6 +1059,50 @@ def test_counters_folded_into_the_kernel_for_small_launches(ctx, masks):
     b.free()
 
 
+@pytest.mark.parametrize('masks', [False, True])
+def test_ragged_contiguous_batches_take_the_vector_kernel(ctx, masks):
+    """Round 5: contiguous multi-tile batches whose H * W is not a multiple of 8 -- every tile starts somewhere inside an
+    8-pixel group of the planes -- ran on the generic 1-pixel-per-thread kernel (0.17 of peak,
+    profiles/r05_generic_kernel_stats.csv).  Now the table-driven kernel starts every tile at its first 8-pixel boundary
+    and the generic kernel does the < 8 head and < 8 tail pixels of each tile.  Every residue of the tile start modulo 8
+    occurs below (strides 1517 = 5, 1519 = 7, 35 = 3 mod 8, tiles smaller than a head, a full-size 3660 x 3659 pair);
+    integer and float32 chain, masks, folded and separate counters (20 tiles), partial walks: every layer of every tile
+    and the counters against the C oracle."""
+    scale = [(1e-4, 0.0)] * 6
+    for (n, h, w) in [(5, 37, 41), (20, 31, 49), (9, 5, 7), (3, 1, 3), (2, 3660, 3659)]:
+        assert (h * w) % 8 != 0
+        b = _capi.DeviceBatch(ctx, n, h, w, masks=masks, tile_align=1)
+        assert b.tile_stride == h * w
+        b.synth(SEED, tile0=400)
+        tiles = [synth_tile(400 + t, h, w, with_masks=masks) for t in range(n)]
+        for p in (_capi.default_params(), _capi.make_params(offset_and_scale=scale)):
+            exp = []
+            for st in tiles:
+                kw = dict(land=st['land'], shad=st['shad'], ocean=st['ocean']) if masks else {}
+                exp.append(c_oracle.classify(p, st['bands'], st['fmask'], **kw))
+            for k in sorted({n, max(1, n // 2)}):
+                b.write_counters_sentinel(-3)
+                b.classify(p, n_tiles=k)
+                ctx.synchronize()
+                info = ctx.last_kernel_info()
+                if h * w >= 16 and k > 1:           # (a walk of ONE tile starts aligned: the ordinary path)
+                    assert 'dswx_classify_lut' in info and 'ragged tiles: edges by dswx_classify_v1' in info, info
+                cnt = b.read_counters()
+                for t in range(k):
+                    for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+                        assert np.array_equal(b.read_tile(key, t), exp[t][key]), (n, h, w, key, t, k)
+                    assert cnt[t].tolist() == exp[t]['counters'].tolist(), (n, h, w, t, k)
+                assert (cnt[k:] == -3).all()
+        b.free()
+    # 'cover' mode keeps the generic kernel on ragged batches (its bitmaps are indexed by tile-relative 8-pixel groups)
+    b = _capi.DeviceBatch(ctx, 3, 37, 41, masks=masks, tile_align=1)
+    b.synth(SEED, tile0=400)
+    b.classify(_capi.make_params(mask_adjacent_to_cloud_mode='cover'))
+    ctx.synchronize()
+    assert 'dswx_classify_v1' in ctx.last_kernel_info() and 'ragged' not in ctx.last_kernel_info()
+    b.free()
+
+
 def test_contexts_on_concurrent_host_threads():
     """'all functions thread-compatible, one context per device' -- the reference is single-threaded, a
     service is not.  Four host threads, each with its OWN context (own stream, own tables, own scratch), classify

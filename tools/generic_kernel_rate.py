@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Rate of the one-pixel-per-thread generic kernel `dswx_classify_v1` (VERDICT r04 "What's missing" 2: no rate for it
-existed anywhere).  It runs whole tiles only when the 8-pixel-per-thread kernels cannot: a contiguous multi-tile batch
-whose H*W is not a multiple of 8 (tiles 1.. then start off the 8-byte grid of the u8 planes) -- forced here with
-3660 x 3659 tiles -- and behind the vector kernels for a ragged tail of < 8 pixels per tile.  Also the float32 chain
-(flag_offset_and_scale_inputs) on the same ragged batch, and, for comparison in the same process, the vector kernels on
-3660 x 3660 tiles of the same count.  Prints one JSON object; run under `rocprofv3 --kernel-trace --stats` for the trace
-(profiles/r05_generic_kernel_stats.csv)."""
+existed anywhere) on a RAGGED contiguous batch -- 3660 x 3659 tiles: H*W = 4 (mod 8), so tiles 1.. start off the 8-byte
+grid of the u8 planes -- which until round 5 was the only kernel that could run such a batch, and of the table-driven
+kernel on the same batch since it learnt to start every tile at its first 8-pixel boundary (KArgs::ragged; the generic
+kernel then only does the < 8 + < 8 edge pixels of each tile).  The generic kernel is forced through the lab switch
+`fused_variant=0` (the direct kernel cannot take a ragged batch, so the dispatch falls through to it).  Integer and
+float32 chain; for comparison in the same process the vector kernels on 3660 x 3660 tiles of the same count.  Prints one
+JSON object; run under `rocprofv3 --kernel-trace --stats` for the trace (profiles/r05_generic_kernel_stats.csv)."""
 import json
 import os
 import sys
@@ -46,9 +47,17 @@ def main():
     out = {'tiles': n}
     ragged = _capi.DeviceBatch(ctx, n, 3660, 3659, tile_align=1)       # 13,391,940 px per tile: 4 (mod 8)
     ragged.synth(SEED)
-    out['generic_int16_f64'] = rate(ctx, ragged, p_int, reps)
-    out['generic_float32'] = rate(ctx, ragged, p_f32, reps)
+    out['ragged_vector_int16_f64'] = rate(ctx, ragged, p_int, reps)
+    out['ragged_vector_float32'] = rate(ctx, ragged, p_f32, reps)
     ragged.free()
+    forced = _capi.Context(0)                                          # its own context: the switch is per context
+    forced.lab_configure(fused_variant=0)
+    ragged = _capi.DeviceBatch(forced, n, 3660, 3659, tile_align=1)
+    ragged.synth(SEED)
+    out['generic_int16_f64'] = rate(forced, ragged, p_int, reps)
+    out['generic_float32'] = rate(forced, ragged, p_f32, reps)
+    ragged.free()
+    forced.close()
     for name, align in (('padded', 256), ('contiguous', 1)):
         b = _capi.DeviceBatch(ctx, n, 3660, 3660, tile_align=align)
         b.synth(SEED)
