@@ -24,7 +24,8 @@
  * store of tiles 1.. across partial lines (5.1 - 5.6 vs 5.7 - 6.3 TB/s, DESIGN.md
  * section 5); since ABI v5 the kernel shifts the mapping per tile instead, and a
  * stride padded to 256 pixels (dswx_batch_create's default) is no longer needed
- * for speed.  Planes at odd addresses and ragged strides remain legal (slower kernels).
+ * for speed.  Strides that are not multiples of 8 pixels run the same kernel too (it starts every tile at its first
+ * 8-pixel boundary; ABI unchanged, round 5), except in 'cover' mode; planes at odd addresses remain legal (slower kernels).
  */
 #ifndef DSWX_HIP_H
 #define DSWX_HIP_H
@@ -72,7 +73,8 @@ enum { DSWX_N_VALID = 0, DSWX_N_CLOUD_AND_VALID = 1, DSWX_N_NOT_OCEAN = 2,
  *    `add_offset` of the band's metadata (:2295-2298) -- and the whole chain (indices, five tests, `nir <=
  *    aerosol_max_nir`, `nir > lcmask_nir`) is evaluated in float32 as numpy does on float32 arrays (thresholds rounded
  *    to float32 first: a Python float is a weak scalar against a float32 array).  The fill test stays on the raw
- *    integers.  A generic one-pixel-per-thread kernel: the production configuration leaves this off.
+ *    integers.  Same kernels, the five tests in float32 (since round 5: 0.77 of the HBM peak; the production
+ *    configuration leaves this off).
  *  - browse_*: the keyword arguments of _compute_browse_array (:3057-3064); the browse
  *    layer is derived from the UNCOLLAPSED WTR (PSW-aggressive is dropped before the
  *    collapse, :3112-3119), which only exists inside the kernel.
