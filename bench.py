@@ -109,7 +109,11 @@ def parse_args():
     ap.add_argument('--plain-tiles', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--strong-total', type=int, default=STRONG_TOTAL_TILES, help=argparse.SUPPRESS)
     ap.add_argument('--strong-chunk', type=int, default=STRONG_CHUNK_TILES, help=argparse.SUPPRESS)
+    # tests of the control flow (tests/test_gpu_multirank.py) shrink the tile: the CPU-side checker dominates their time
+    ap.add_argument('--tile-size', type=int, default=TILE, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.tile_size != TILE:
+        globals()['TILE'] = args.tile_size
     # "plain": the command line names no workload -- what the driver runs (`bench.py --gpus N --steps K --warmup W`)
     args.plain_command = args.tiles <= 0 and args.total_tiles <= 0 and not args.chain and not args.masks and not args.scaled
     if args.chain:

@@ -36,7 +36,7 @@ def _bench(*argv, share_device=True, force_dist=False, extra_env=None, expect_rc
 
 def test_two_ranks_strong_scaling_every_rank_checks_every_chunk():
     out = _bench('--gpus', '2', '--total-tiles', '16', '--tiles', '4', '--steps', '2', '--warmup', '1',
-                 '--no-cpu-baseline', '--distinct-chunks')
+                 '--no-cpu-baseline', '--distinct-chunks', '--tile-size', '1024')
     # n_gpus counts DISTINCT devices (PCI address + UUID), not ranks: both ranks share device 0 here, and the line says so
     assert out['n_ranks'] == 2 and out['n_gpus'] == 1 and 'DSWX_BENCH_SHARE_DEVICE' in out['n_gpus_note']
     assert out['scaling'] == 'strong'
@@ -49,7 +49,7 @@ def test_two_ranks_strong_scaling_every_rank_checks_every_chunk():
     # resident chunk: first / middle / last; then the second chunk generated with ITS indices: first / last
     assert r0['tiles'] == [0, 2, 3, 4, 7] and r1['tiles'] == [8, 10, 11, 12, 15]
     assert r0['distinct_chunks'] == 2 and r1['distinct_chunks'] == 2
-    assert out['value'] > 0 and out['roofline']['pixels_per_launch'] == 4 * 3660 * 3660
+    assert out['value'] > 0 and out['roofline']['pixels_per_launch'] == 4 * 1024 * 1024
     # every rank's own numbers are in the line, the slowest one is named (value is bounded by it)
     ranks = out['ranks']
     assert [r['rank'] for r in ranks] == [0, 1] and ranks[0]['device'] == ranks[1]['device']
@@ -70,18 +70,19 @@ def test_chain_mode_shadow_and_land_layers_into_the_batch():
     aggregation written straight into the SHAD / LAND planes of the resident batch (dswx_shadow_layer_batch,
     dswx_landcover_mask_batch with the batch's tile stride), then the classifier with SHAD + LAND + OCEAN.  The line's
     parity record compares SHAD and LAND with the numpy oracle's layers and everything downstream with the C oracle."""
-    out = _bench('--chain', '--tiles', '3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', share_device=False)
+    out = _bench('--chain', '--tiles', '3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--tile-size', '1200',
+                 share_device=False)
     assert out['n_gpus'] == 1 and out['n_ranks'] == 1 and 'configs[4]' in out['config']['workload'] and out['config']['planes_in'] == 10
     assert out['parity_check']['result'] == 'bit-exact', out['parity_check']
     assert out['parity_check']['ranks'][0]['tiles'] == [0, 2]
     r = out['roofline']
-    assert abs(r['algorithmic_bytes_per_pixel'] - (24 + 11 + 4 * 3760 ** 2 / 3660 ** 2 + 1)) < 1e-3
+    assert abs(r['algorithmic_bytes_per_pixel'] - (24 + 11 + 4 * 1300 ** 2 / 1200 ** 2 + 1)) < 1e-3
     assert all(r['chain'][k] > 0 for k in ('terrain_shadow_ms', 'land_aggregation_ms', 'classify_ms'))
 
 
 def test_two_ranks_weak_scaling_rank_offsets():
     out = _bench('--gpus', '2', '--tiles', '3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--masks',
-                 '--no-host-path')
+                 '--no-host-path', '--tile-size', '1024')
     assert out['n_ranks'] == 2 and out['scaling'] == 'weak' and out['config']['tiles_per_step_all_ranks'] == 6
     assert 'host_path' not in out and 'strong' not in out
     par = out['parity_check']
@@ -213,7 +214,7 @@ def test_four_ranks_on_one_device_plain_command():
     EIGHT ranks and the host-path leg was run by hand -- profiles/r04_bench_8ranks_one_device_toy.json -- and is not part
     of the suite: nine HIP processes on one device took between 27 s and 6 min on the test boxes.)"""
     out = _bench('--gpus', '4', '--plain-tiles', '2', '--strong-total', '20', '--strong-chunk', '2', '--steps', '3',
-                 '--warmup', '1', '--no-cpu-baseline', '--no-host-path')
+                 '--warmup', '1', '--no-cpu-baseline', '--no-host-path', '--tile-size', '1024')
     assert out['n_ranks'] == 4 and out['n_gpus'] == 1 and out['config']['tiles_per_step_all_ranks'] == 8
     assert out['parity_check']['result'] == 'bit-exact'
     assert [r['tiles'] for r in out['parity_check']['ranks']] == [[2 * r, 2 * r + 1] for r in range(4)]
@@ -251,7 +252,8 @@ def test_a_rank_that_dies_hard_in_the_second_case_leaves_the_first_in_the_line()
     wake-up-pipe thread (or the exception gloo raises about the lost peer) prints the line as far as it got: the weak
     record measured on real kernels by both ranks, bit-exact, and `strong.value: null` with the reason."""
     out = _bench('--gpus', '2', '--plain-tiles', '2', '--strong-total', '8', '--strong-chunk', '2', '--steps', '2',
-                 '--warmup', '1', '--no-cpu-baseline', extra_env={'DSWX_BENCH_INJECT': '1:1:place:hard'}, expect_rc=1)
+                 '--warmup', '1', '--no-cpu-baseline', '--tile-size', '1024',
+                 extra_env={'DSWX_BENCH_INJECT': '1:1:place:hard'}, expect_rc=1)
     assert out['value'] > 0 and out['n_ranks'] == 2 and out['parity_check']['result'] == 'bit-exact'
     assert [r['rank'] for r in out['ranks']] == [0, 1] and all(r['frac'] > 0 for r in out['ranks'])
     assert out['strong']['value'] is None and 'terminated while case 1 (strong) was running' in out['strong']['error']
