@@ -84,9 +84,20 @@ def run_batch(runconfigs, n_gpus, python=sys.executable, workers_per_gpu=1, skip
             (['--skip-existing'] if skip_existing else []) + chunk
         procs.append(subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True))
+    # every worker's pipes are drained concurrently: a worker with more result lines than a pipe holds (64 KiB, a few
+    # hundred tiles) must not stall behind the worker the parent happens to be waiting for
+    import threading
+    outputs = [None] * len(procs)
+
+    def drain(i):
+        outputs[i] = procs[i].communicate()
+    threads = [threading.Thread(target=drain, args=(i,)) for i in range(len(procs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
     results, all_ok = {}, True
-    for p in procs:
-        out, err = p.communicate()
+    for p, (out, err) in zip(procs, outputs):
         for line in out.splitlines():
             if line.startswith('{'):
                 r = json.loads(line)

@@ -133,6 +133,9 @@ class ControlPlane:
 
         def body():
             try:
+                if self.device is not None:         # the current device is per THREAD: this one starts on device 0
+                    import torch
+                    torch.cuda.set_device(self.device)
                 box['result'] = fn()
             except BaseException as e:                      # noqa: BLE001
                 box['error'] = f'{type(e).__name__}: {e}'[:300]

@@ -246,11 +246,12 @@ def test_device_batch_and_synth(ctx, geom, tile_align):
     batch.classify(p)
     ctx.synchronize()
     info = ctx.last_kernel_info()
-    # contiguous ragged multi-tile batches go to the generic kernel; everything whose tiles start on 8-pixel
-    # boundaries to the table-driven kernel (the planes of a DeviceBatch start 256-byte aligned), never the direct one
+    # everything goes to the table-driven kernel (the planes of a DeviceBatch start 256-byte aligned), never the direct
+    # one: also contiguous ragged multi-tile batches since round 5 (the generic kernel then does their edge pixels only)
     vector = 'dswx_classify_lut' in info
     assert 'dswx_classify_v8' not in info
-    assert vector == (h * w >= 8 and (batch.tile_stride % 8 == 0 or n_tiles == 1)), info
+    assert vector == (h * w >= 8), info
+    assert ('ragged tiles' in info) == (h * w >= 8 and batch.tile_stride % 8 != 0 and n_tiles > 1), info
     cnt = batch.read_counters()
     for t in range(n_tiles):
         s = synth_tile(7 + t, h, w, with_masks=True)
@@ -272,18 +273,21 @@ def test_device_batch_and_synth(ctx, geom, tile_align):
 @pytest.mark.parametrize('tile_align,h,w', [(256, 7, 11), (1, 7, 11), (1, 8, 11), (1, 8, 13)])
 def test_more_tiles_than_one_grid_dimension(ctx, tile_align, h, w):
     """70,000 small tiles: the launch is split at 65,535 tiles (grid.y limit); tiles and counters
-    either side of the split match the oracle.  7 x 11 = 77 px: nine 8-pixel groups + a 5-pixel tail (contiguous: the
-    generic kernel); 8 x 11 = 88 and 8 x 13 = 104 px contiguous: the table-driven kernel's per-tile lead-in, whose second
-    launch starts at a tile whose residue modulo 256 is not the batch's (65,535 x 88 = 0xC8 mod 256)."""
+    either side of the split match the oracle.  7 x 11 = 77 px contiguous: a RAGGED batch (tile t starts at residue
+    5 t mod 8: the table-driven kernel from every tile's first 8-pixel boundary, the generic kernel on the edges -- round
+    5; also across the split, whose second launch starts at a tile of another residue); 8 x 11 = 88 and 8 x 13 = 104 px
+    contiguous: the per-tile lead-in, whose second launch starts at a tile whose residue modulo 256 is not the batch's
+    (65,535 x 88 = 0xC8 mod 256)."""
     n_tiles = 70000
     batch = _capi.DeviceBatch(ctx, n_tiles, h, w, masks=True, tile_align=tile_align)
     batch.synth(SEED, tile0=5)
     p = _capi.default_params()
     batch.classify(p)
     ctx.synchronize()
-    assert ('dswx_classify_lut' in ctx.last_kernel_info()) == (batch.tile_stride % 8 == 0)
+    assert 'dswx_classify_lut' in ctx.last_kernel_info()
+    assert ('ragged tiles' in ctx.last_kernel_info()) == (batch.tile_stride % 8 != 0)
     cnt = batch.read_counters()
-    for t in (0, 1, 65534, 65535, 65536, 69999):
+    for t in (0, 1, 2, 3, 4, 5, 6, 7, 65534, 65535, 65536, 65537, 69999):
         s = synth_tile(5 + t, h, w, with_masks=True)
         exp = c_oracle.classify(p, s['bands'], s['fmask'], land=s['land'], shad=s['shad'], ocean=s['ocean'])
         for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
