@@ -95,6 +95,10 @@ class ControlPlane:
             return
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if os.environ['MASTER_ADDR'] in ('127.0.0.1', 'localhost', '::1'):
+            # one node, rendezvous on loopback: gloo otherwise picks its interface by resolving the host name, which a
+            # container's may not do ("Unable to resolve hostname to a (local) address")
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
         kw = {}
         if self.world == 1 and 'MASTER_PORT' not in os.environ:
             # a forced world of one outside torchrun: a private rendezvous.  A world > 1 keeps env:// so that a launcher
