@@ -669,7 +669,10 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
                     ctx->fold_clean = false;
                 }
                 if (!ctx->fold_clean) {
+                    // (rare: first use, growth, or after a failed launch.  Synchronous, so that a later call on ANOTHER
+                    // stream of the caller's cannot overtake the zeroing)
                     HIP_TRY(hipMemsetAsync(ctx->fold_acc, 0, ctx->fold_bytes, s));
+                    HIP_TRY(hipStreamSynchronize(s));
                     ctx->fold_clean = true;
                 }
                 b.fold_acc = ctx->fold_acc;
