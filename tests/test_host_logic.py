@@ -531,3 +531,23 @@ def test_resident_batch_layout_rule():
     lay_c, geom = _capi.BatchLayout(), _capi.BatchGeom(1, 8, 8, 0)
     assert lib.dswx_batch_layout(ctypes.byref(geom), 1 << 20, ctypes.byref(lay_c)) == _capi.ERR_ARG   # unknown flag
     assert b'unknown batch flag' in lib.dswx_last_error()
+
+
+def test_scale_report_reads_bench_lines(tmp_path):
+    """tools/scale_report.py: the table north_star asks for, from bench.py lines of several GPU counts (here the two
+    round-5 lines that exist: N = 1, and the two-rank rehearsal that shares ONE device -- its efficiency is ~0.5 by
+    construction and the note says why)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, 'profiles', n) for n in ('r05_bench_driver_style_final.json',
+                                                         'r05_rehearsal_driver_command_2ranks_one_device.json')]
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'scale_report.py')] + files, capture_output=True,
+                         text=True, timeout=60)
+    assert res.returncode == 0, res.stderr
+    rep = json.loads(res.stdout)
+    r1, r2 = rep['rows']
+    assert r1['ranks'] == 1 and r1['efficiency_vs_n1'] == 1.0 and rep['baseline_n1_Mpx_s'] == r1['value_Mpx_s']
+    assert r2['ranks'] == 2 and r2['distinct_gpus'] == 1 and 0.4 < r2['efficiency_vs_n1'] < 0.6 and r2['error'] is None
+    assert r2['strong_4096_tiles']['parity'] == 'bit-exact' and 'distinct device' in r2['note']
