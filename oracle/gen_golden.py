@@ -315,6 +315,12 @@ TILE_CASES = [
     dict(name='t64_scaled_default_thr', tile=23, H=64, W=64, scale=[(0.0001, 0.0)] * 6),
     dict(name='t80x72_scaled_mixed', tile=24, H=80, W=72, land=1, thr='reflectance', mode='ignore',
          scale=[(0.0001, 0.0), (0.0001, 10.0), (0.0002, -50.0), (0.0001, 3.5), (0.00005, 0.0), (0.0001, -0.25)]),
+    # round 6: unusual fill values through the reference's own `image == fill_value` test (:2195-2209) --
+    # fills at 0 (which the clip turns into 1 AFTER the test), at both ends of int16, at 1 (a legal reflectance), a
+    # Fmask fill of 0 (the most common Fmask value); and NaN fills (no nodata value that any pixel can equal: the test is
+    # disabled for that plane), mixed with ordinary ones, with a Fmask fill of NaN
+    dict(name='t64_fills_zero_max', tile=25, H=64, W=64, land=1, ocean=1, fills='zero_max'),
+    dict(name='t72x40_fills_nan', tile=26, H=72, W=40, shad=1, fills='nan'),
 ]
 
 
@@ -391,6 +397,17 @@ def gen_tiles(ref):
                 if float(f).is_integer():
                     sel = rng.random(b.shape) < 0.02
                     b[sel] = int(f)
+        if case.get('fills') in ('zero_max', 'nan'):
+            frng = np.random.default_rng(2000 + case['tile'])       # (its own stream: the order of the cases above is frozen)
+            if case['fills'] == 'zero_max':
+                band_fills = [0.0, 32767.0, 1.0, -32768.0, 0.0, -1.0]
+                fmask_fill = 0.0
+            else:
+                band_fills = [float('nan'), -9999.0, float('nan'), float('nan'), 1000.0, float('nan')]
+                fmask_fill = float('nan')
+            for b, f in zip(bands, band_fills):
+                sel = frng.random(b.shape) < 0.03
+                b[sel] = -9999 if f != f else int(f)                # planes with a NaN fill still hold -9999s: now plain data
         if case.get('mode') == 'cover':
             # make spatially coherent snow / adjacent blobs so the dilation matters
             yy, xx = np.mgrid[0:H, 0:W]

@@ -55,6 +55,9 @@ struct dswx_ctx {
                                     // beyond G = 8; kept as a lab switch only
     int tune_wps = 6;        // launch bound of the direct kernel without masks (4, 6, 8)
     int tune_fold = 1;       // 0: always the separate dswx_counters_finish launch (lab A/B of the folded counters)
+    int place_force_candidate = -1;   // dswx_batch_place_slide: >= 0 keeps the candidate with that index (packed region at
+                                      // offset index * step of the wide range) WHATEVER it measures, without refinement --
+                                      // tests only (the kept-placement + trim-while-live case must not hang on a timing)
     int fused_variant = -1;  // -1 automatic (table-driven kernel when every plane starts on a 256-byte boundary, else the
                              // direct kernel); 0 / 3 force those two (lab A/B and the variant parity tests)
 };

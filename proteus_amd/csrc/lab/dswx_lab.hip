@@ -29,6 +29,7 @@ int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value) {
     else if (k == "tune_lut_wps") ctx->tune_lut_wps = value;
     else if (k == "tune_lut_interleave") ctx->tune_lut_interleave = value;
     else if (k == "tune_fold") ctx->tune_fold = value;
+    else if (k == "place_force_candidate") ctx->place_force_candidate = value;
     else if (k == "cover_kernel") ctx->cover_kernel = value;
     else if (k == "host_pipeline") ctx->host_pipeline = value;
     else if (k == "shadow_grid_pad") {
