@@ -130,6 +130,122 @@ def test_make_params_field_by_field_against_the_reference_defaults():
         _capi.make_params({k: (None if k == 'awgt' else 1.0) for k in _capi.THRESHOLD_NAMES})
 
 
+_PACKER_C = r"""
+/* test-only: fills dswx_params_t BY FIELD NAME from a line-oriented description on stdin and writes the raw
+ * struct bytes to stdout -- a packer that shares nothing with proteus_amd/_capi.py but include/dswx_hip.h */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "dswx_hip.h"
+static double num(void) { char t[64]; if (scanf("%63s", t) != 1) exit(3); return strtod(t, NULL); }
+int main(void) {
+    char key[64];
+    dswx_params_t p;
+    memset(&p, 0, sizeof p);
+    while (scanf("%63s", key) == 1) {
+        if (!strcmp(key, "begin")) memset(&p, 0, sizeof p);
+        else if (!strcmp(key, "thr")) {
+            p.wigt = num(); p.awgt = num(); p.pswt_1_mndwi = num(); p.pswt_1_nir = num(); p.pswt_1_swir1 = num();
+            p.pswt_1_ndvi = num(); p.pswt_2_mndwi = num(); p.pswt_2_blue = num(); p.pswt_2_nir = num();
+            p.pswt_2_swir1 = num(); p.pswt_2_swir2 = num(); p.lcmask_nir = num();
+        } else if (!strcmp(key, "band_fill")) { for (int i = 0; i < 6; ++i) p.band_fill[i] = num(); }
+        else if (!strcmp(key, "fmask_fill")) p.fmask_fill = num();
+        else if (!strcmp(key, "aerosol_max_nir")) p.aerosol_max_nir = num();
+        else if (!strcmp(key, "clip")) p.clip_negative_reflectance = (int)num();
+        else if (!strcmp(key, "mode")) {
+            char m[16]; if (scanf("%15s", m) != 1) return 3;
+            p.mask_adjacent_to_cloud_mode = !strcmp(m, "mask") ? DSWX_ADJ_MASK : !strcmp(m, "ignore") ? DSWX_ADJ_IGNORE : DSWX_ADJ_COVER;
+        } else if (!strcmp(key, "aerosol")) p.apply_aerosol_class_remapping = (int)num();
+        else if (!strcmp(key, "collapse")) p.collapse_wtr_classes = (int)num();
+        else if (!strcmp(key, "browse")) {
+            p.browse_exclude_psw_aggressive = (int)num(); p.browse_not_water_to_nodata = (int)num();
+            p.browse_cloud_to_nodata = (int)num(); p.browse_snow_to_nodata = (int)num();
+            p.browse_ocean_masked_to_nodata = (int)num();
+        } else if (!strcmp(key, "lut")) {             /* row (0..3 = WTR-1 class 0, 2, 3, 4), count, values */
+            int row = (int)num(), n = (int)num();
+            for (int i = 0; i < n; ++i) p.aerosol_fmask_lut[row][(int)num()] = 1;
+        } else if (!strcmp(key, "scale")) {
+            p.offset_and_scale_inputs = 1;
+            for (int i = 0; i < 6; ++i) { p.band_scale[i] = num(); p.band_offset[i] = num(); }
+        } else if (!strcmp(key, "noscale")) {
+            for (int i = 0; i < 6; ++i) { p.band_scale[i] = 1.0; p.band_offset[i] = 0.0; }
+        } else if (!strcmp(key, "end")) fwrite(&p, sizeof p, 1, stdout);
+        else return 2;
+    }
+    return 0;
+}
+"""
+
+
+def test_make_params_against_an_independent_c_packer(tmp_path):
+    """_capi.make_params is the one piece of PRODUCT code that both oracles and the GPU path share
+    (tests/test_c_oracle.py: params_of_case).  Twenty random runconfig-style parameter sets are packed twice -- by
+    make_params, and by a C program compiled here that assigns every field of dswx_params_t by NAME from
+    include/dswx_hip.h (the meaning of each runconfig knob restated in this test from dswx_hls.py:2195-2209 fills,
+    :1977-1981 modes, :1249-1302 + defaults yaml :77-89 aerosol lists, :5309-5316 browse options, :2295-2302 scale /
+    offset) -- and the struct BYTES are compared."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'packer.c'
+    src.write_text(_PACKER_C)
+    exe = tmp_path / 'packer'
+    subprocess.run(['gcc', '-O1', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    rng = np.random.default_rng(606)
+    classes = (0, 2, 3, 4)
+
+    def fmt(v):
+        return 'nan' if v != v else repr(float(v))
+    text, mine = [], []
+    for case in range(20):
+        thr = {k: float(rng.choice([rng.normal(0, 1), rng.integers(-3000, 3000), rng.integers(-8, 8) / 8.0]))
+               for k in _capi.THRESHOLD_NAMES}
+        fills = [None if rng.random() < 0.25 else float(rng.choice([-9999, 0, 32767, -32768, -1000, 1, -9999.5]))
+                 for _ in range(6)]
+        fmask_fill = None if rng.random() < 0.3 else float(rng.choice([255, 0, 64, 1]))
+        mode = str(rng.choice(['mask', 'ignore', 'cover']))
+        lists = {c: sorted(set(int(v) for v in rng.integers(0, 256, size=rng.integers(0, 7)))) for c in classes}
+        flags = {k: bool(rng.integers(0, 2)) for k in ('clip', 'aerosol', 'collapse', 'psw', 'ocean')}
+        browse = {k: str(rng.choice(['nodata', 'white', 'gray'])) for k in ('not_water', 'cloud', 'snow')}
+        scale = None if case % 3 else [(float(rng.choice([1e-4, 2e-4, 1.0])), float(rng.integers(-50, 50) / 4.0)) for _ in range(6)]
+        max_nir = None if case % 2 else float(rng.integers(1, 4000) / 2.0)
+        mine.append(_capi.make_params(
+            thr, band_fills=fills, fmask_fill=fmask_fill, clip_negative_reflectance=flags['clip'],
+            mask_adjacent_to_cloud_mode=mode, apply_aerosol_class_remapping=flags['aerosol'],
+            aerosol_fmask_values=lists, collapse_wtr_classes=flags['collapse'], aerosol_max_nir=max_nir,
+            exclude_psw_aggressive_in_browse=flags['psw'], not_water_in_browse=browse['not_water'],
+            cloud_in_browse=browse['cloud'], snow_in_browse=browse['snow'], set_ocean_masked_to_nodata=flags['ocean'],
+            offset_and_scale=scale))
+        # the same set as the packer's input; None (no nodata value: the `image == fill` test can never hold) = NaN
+        text += ['begin', 'thr ' + ' '.join(fmt(thr[k]) for k in _capi.THRESHOLD_NAMES),
+                 'band_fill ' + ' '.join(fmt(float('nan') if f is None else f) for f in fills),
+                 'fmask_fill ' + fmt(float('nan') if fmask_fill is None else fmask_fill),
+                 'aerosol_max_nir ' + fmt(0.1 / 0.0001 if max_nir is None else max_nir),      # dswx_hls.py:45-46
+                 f"clip {int(flags['clip'])}", f'mode {mode}', f"aerosol {int(flags['aerosol'])}",
+                 f"collapse {int(flags['collapse'])}",
+                 'browse ' + ' '.join(str(int(v)) for v in (
+                     flags['psw'], browse['not_water'] == 'nodata', browse['cloud'] == 'nodata',
+                     browse['snow'] == 'nodata', flags['ocean']))]
+        for row, c in enumerate(classes):
+            text.append(f'lut {row} {len(lists[c])} ' + ' '.join(map(str, lists[c])))
+        text.append('noscale' if scale is None else 'scale ' + ' '.join(f'{fmt(a)} {fmt(b)}' for a, b in scale))
+        text.append('end')
+    out = subprocess.run([str(exe)], input='\n'.join(text).encode(), capture_output=True, check=True).stdout
+    size = ctypes.sizeof(_capi.Params)
+    assert len(out) == 20 * size
+    for i, p in enumerate(mine):
+        theirs = out[i * size:(i + 1) * size]
+        if bytes(p) != theirs:
+            q = _capi.Params.from_buffer_copy(theirs)
+            for name, _ in _capi.Params._fields_:
+                a, b = getattr(p, name), getattr(q, name)
+                a = bytes(a) if hasattr(a, '_length_') else a
+                b = bytes(b) if hasattr(b, '_length_') else b
+                assert a == b or (a != a and b != b), (i, name, a, b)
+            raise AssertionError(f'set {i}: struct bytes differ outside the named fields (padding / NaN payload)')
+
+
 def test_struct_field_offsets_match_a_c_compiler(tmp_path):
     """The ctypes mirrors in _capi.py against `offsetof` as gcc sees include/dswx_hip.h (sizes alone would not
     notice two swapped fields)."""
