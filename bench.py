@@ -751,7 +751,7 @@ def measure_case(args, case, env, case_index=0):
     guard.run('sync before the timed region', lambda: (env.device_synchronize(), ctx.synchronize()))
     t0 = time.perf_counter()
     guard.run('timed region', timed)
-    cp.barrier()
+    closing_degraded = cp.barrier()          # True on EVERY rank if an RCCL barrier failed / hung on any (shard.ControlPlane.barrier)
     elapsed = time.perf_counter() - t0
     my_elapsed = elapsed
 
@@ -860,14 +860,23 @@ def measure_case(args, case, env, case_index=0):
                      + (', LAND+SHAD+OCEAN planes' if args.masks else ''))
         devices = sorted({r['device'] for r in per_rank})
         good = [r for r in per_rank if 'error' not in r]
+        # a number that is not a measurement is not printed as one: the barrier that closes the timed region
+        # waited for a failing RCCL call (up to its time limit), or several ranks timed one device without saying so
+        void = None
+        if closing_degraded:
+            void = ('the control plane degraded inside the timed region (the closing barrier waited for a failing RCCL call): '
+                    + str(cp.backend))[:400]
+        elif len(devices) != world and not env.share_device:
+            void = (f'{world} ranks ran on {len(devices)} distinct device(s) and DSWX_BENCH_SHARE_DEVICE is not set: '
+                    'not a whole-job rate')
         out = {
             'metric': 'Mpixels/sec DSWx classify (3660^2 7-band HLS tiles)',
             # a case in which ANY rank failed has no whole-job rate: null, with the failure named (`error`, `ranks`)
-            'value': None if failed else round(total_px_per_step * args.steps / elapsed / 1e6, 1),
+            'value': None if (failed or void) else round(total_px_per_step * args.steps / elapsed / 1e6, 1),
             'unit': 'Mpixels/s',
             # the number of DISTINCT devices the ranks report (PCI address + UUID), not the number of ranks started
             'n_gpus': len(devices), 'n_ranks': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': None if failed else round(elapsed / args.steps * 1e3, 4),
+            'ms_per_step': None if (failed or void) else round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'int16+f32' if args.scaled else 'int16+f64', 'data': 'synthetic',
             'rccl_ranks': cp.rccl_ranks,
@@ -885,6 +894,8 @@ def measure_case(args, case, env, case_index=0):
         if failed:
             out['error'] = '; '.join(f"rank {r['rank']} failed in {r['phase']}: {r['error']}" for r in failed)[:1200]
             out['failed_ranks'] = [r['rank'] for r in failed]
+        elif void:
+            out['error'] = void
         if good:
             slowest = max(good, key=lambda r: r['wall_ms_per_step'])
             out['slowest_rank'] = {'rank': slowest['rank'], 'device': slowest['device'],
@@ -1031,7 +1042,15 @@ def bring_up(args, rank, local_rank, world):
     else:
         # LOCAL_RANK is the device index when every rank sees all GPUs (torchrun's default); a launcher that narrows every
         # rank's view to its own GPU (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per rank) leaves one device, index 0
-        local_rank = local_rank % max(visible, 1)
+        # -- and ONLY then is the index folded (`local_rank % visible` put two ranks on one device without a
+        # word when --gpus N exceeded the devices of the box); more ranks than devices otherwise is this rank's failure
+        if visible == 1:
+            local_rank = 0              # (a 1-GPU box with N > 1 ranks ends here too: preflight names the duplicate
+                                        #  devices and the case's value is null unless DSWX_BENCH_SHARE_DEVICE=1)
+        elif visible > 1 and local_rank >= visible:
+            boot_error = boot_error or {'phase': 'device', 'error': f'LOCAL_RANK {local_rank} but only {visible} GPUs are visible '
+                                                                    'to this rank: more ranks than devices'}
+            local_rank = local_rank % visible
     device = torch.device('cuda', local_rank)
     if visible >= 1:
         try:
@@ -1079,6 +1098,7 @@ class LastWords:
         self.running = 'bring-up'
         self.done = False
         self.lock = threading.Lock()
+        self.stdout_fd = os.dup(1)          # the REAL stdout: during bring-up fd 1 points at stderr (shard._stdout_to_stderr)
         r, w = os.pipe()
         os.set_blocking(w, False)
         self.pipe = r
@@ -1103,11 +1123,13 @@ class LastWords:
             note = f'terminated while {self.running} was running: {why}'
             out = self.out
             if out is None:
+                shared = os.environ.get('DSWX_BENCH_SHARE_DEVICE') == '1'
                 out = {'metric': 'Mpixels/sec DSWx classify (3660^2 7-band HLS tiles)', 'value': None, 'unit': 'Mpixels/s',
-                       'n_gpus': self.world, 'n_ranks': self.world, 'steps': self.args.steps, 'warmup': self.args.warmup,
-                       'ms_per_step': None, 'higher_is_better': True, 'scaling': 'strong' if self.args.total_tiles else 'weak',
-                       'vs_baseline': None, 'dtype': 'int16+f64', 'data': 'synthetic', 'config': {}, 'roofline': None,
-                       'error': note}
+                       'n_gpus': 1 if shared else self.world, 'n_ranks': self.world, 'steps': self.args.steps,
+                       'warmup': self.args.warmup, 'ms_per_step': None, 'higher_is_better': True,
+                       'scaling': 'strong' if self.args.total_tiles else 'weak', 'vs_baseline': None,
+                       'dtype': 'int16+f32' if self.args.scaled else 'int16+f64', 'data': 'synthetic', 'config': {},
+                       'roofline': None, 'error': note}
             else:
                 out = dict(out)
                 if self.running.startswith('case'):
@@ -1115,8 +1137,11 @@ class LastWords:
                 else:
                     out['terminated'] = note
             try:
-                sys.stdout.write(json.dumps(out) + '\n')
-                sys.stdout.flush()
+                try:
+                    sys.stdout.flush()
+                except Exception:           # noqa: BLE001
+                    pass
+                os.write(self.stdout_fd, (json.dumps(out) + '\n').encode())
             finally:
                 os._exit(143)
 
@@ -1201,6 +1226,7 @@ def _main():
                   file=sys.stderr, flush=True)
             if last_words:
                 last_words.out = out
+                last_words.running = 'the step between two cases'     # a completed record is never overwritten with null
         if case.key is None:
             headline_tiles = n_tiles
     if last_words:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DSWX_ABI_VERSION 5
+#define DSWX_ABI_VERSION 6
 
 enum {
     DSWX_OK = 0,
@@ -459,6 +459,51 @@ int dswx_batch_place_slide(dswx_batch_t* batch, const dswx_params_t* params, uin
                            uint64_t step_bytes, int32_t spread_gaps, int32_t refine_passes,
                            int32_t launches, uint64_t keep_free_bytes);
 
+/* ---- the raster formats either side of the path (ABI v6) --------------------------------
+ * The reference reads and saves every raster through GDAL.  Reading a band file is inflate -> inverse predictor ->
+ * blocks into the raster (`ReadAsArray` in _load_hls_band_from_file, dswx_hls.py:2136-2302); saving a layer is
+ * `save_as_cog` (core.py:7-91): NEAREST overviews 4 / 16 / 64 / 128 for the integer layers (:37-46), 512 x 512 blocks,
+ * PREDICTOR=2 (integers) / 3 (floating point), DEFLATE (:60-75); the RGB composites are
+ * scale * (float32(band) - offset) with NaN on invalid pixels (_save_output_rgb_file, dswx_hls.py:3013-3036).
+ * Compression stays on the host (include/dswx_codec.h); the byte shuffling between an inflated block and the
+ * classifier's planes, and between its layers and the blocks to deflate, runs on the device with these entries.
+ * All pointers are DEVICE pointers; asynchronous on `stream` (NULL = the context's stream). */
+#define DSWX_COG_MAX_LEVELS 8
+typedef struct dswx_cog_layout {
+    int32_t n_levels;                                /* the full-resolution image + the overview levels */
+    int32_t tile;
+    int32_t factor[DSWX_COG_MAX_LEVELS];             /* 1, then the factors that produce a level */
+    int64_t height[DSWX_COG_MAX_LEVELS];             /* ceil(N / factor), what GDAL makes an overview */
+    int64_t width[DSWX_COG_MAX_LEVELS];
+    int32_t blocks_down[DSWX_COG_MAX_LEVELS];
+    int32_t blocks_across[DSWX_COG_MAX_LEVELS];
+    uint64_t offset_bytes[DSWX_COG_MAX_LEVELS];      /* of the level's first block in the blocked buffer */
+    uint64_t total_bytes;
+} dswx_cog_layout_t;
+/* Where dswx_cog_blocks_device puts what (pure function, no device needed).  A factor of 1, or any factor on a 1 x 1
+ * raster, produces no level (the host writer's rule). */
+int dswx_cog_layout(int64_t height, int64_t width, int32_t elem_bytes, int32_t tile, const int32_t* factors,
+                    int32_t n_factors, dswx_cog_layout_t* out);
+/* One plane [height][width] -> `blocks`: for every level of dswx_cog_layout, its tile x tile blocks in row-major block
+ * order, edge blocks zero-padded, each block row predictor-encoded and little endian -- exactly the bytes the TIFF writer
+ * hands to DEFLATE.  elem_bytes 1 / 2: integer samples, predictor 1 (none) or 2 (horizontal differencing in the sample's
+ * width), overview levels by GDAL's NEAREST rule (src = min(int(0.5 + dst * N / N_ovr), N - 1), restated from
+ * GDALResampleChunk_Near: GDAL is not in the reference tree, parity of the rule itself is unpinned).  elem_bytes 4:
+ * Float32 with predictor 3 (TIFF Technical Note 3), no overview factors (the reference's are CUBICSPLINE: host). */
+int dswx_cog_blocks_device(dswx_ctx_t* ctx, const void* plane, int32_t elem_bytes, int64_t height, int64_t width,
+                           int32_t tile, const int32_t* factors, int32_t n_factors, int32_t predictor, void* blocks,
+                           void* stream);
+/* The inverse for a file being read: `blocks` = every block of one plane of an image, inflated, in block order, each
+ * block_height x block_width samples (tiles; or strips: block_width = width, the short last strip's slot padded), native
+ * byte order; predictor 1 or 2.  -> plane [height][width]. */
+int dswx_untile_device(dswx_ctx_t* ctx, const void* blocks, int32_t elem_bytes, int64_t height, int64_t width,
+                       int32_t block_width, int32_t block_height, int32_t predictor, void* plane, void* stream);
+/* out[c][i] = scale[c] * (float32(band_c[i], clipped to >= 1 if clip_negative_reflectance) - offset[c]) in float32, NaN
+ * where diag[i] == 65535 (diag may be NULL: no masking); out = float [3][n_pixels]. */
+int dswx_rgb_planes_device(dswx_ctx_t* ctx, const int16_t* red, const int16_t* green, const int16_t* blue,
+                           const uint16_t* diag, int64_t n_pixels, const double scale[3], const double offset[3],
+                           int32_t clip_negative_reflectance, float* out, void* stream);
+
 /* ---- device plumbing for hosts without another HIP binding ------------------- */
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_device_free(dswx_ctx_t* ctx, void* ptr);
@@ -475,6 +520,10 @@ int dswx_host_free(dswx_ctx_t* ctx, void* ptr);
 int dswx_memcpy_h2d(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);
 int dswx_memcpy_d2h(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);
 int dswx_memset_d(dswx_ctx_t* ctx, void* dst, int value, size_t bytes);
+/* asynchronous on `stream` (NULL = the context's stream); the host side must be page-locked (dswx_host_alloc) for the
+ * copy to overlap with anything */
+int dswx_memcpy_h2d_async(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes, void* stream);
+int dswx_memcpy_d2h_async(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes, void* stream);
 int dswx_stream_synchronize(dswx_ctx_t* ctx, void* stream);
 /* HIP events on the stream the kernels run on (timing for bench.py) */
 int dswx_event_create(dswx_ctx_t* ctx, void** out);

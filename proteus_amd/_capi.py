@@ -12,7 +12,7 @@ import numpy as np
 
 from . import build as _build
 
-DSWX_ABI_VERSION = 5
+DSWX_ABI_VERSION = 6
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALIGN = 0, -1, -2, -3, -4, -5
 ADJ_MODES = {'mask': 0, 'ignore': 1, 'cover': 2}
 BAND_NAMES = ('blue', 'green', 'red', 'nir', 'swir1', 'swir2')
@@ -33,7 +33,9 @@ EXPORTED_SYMBOLS = (
     'dswx_batch_layout', 'dswx_batch_create', 'dswx_batch_destroy', 'dswx_batch_planes', 'dswx_batch_info',
     'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search', 'dswx_batch_place_slide',
     'dswx_batch_va_budget', 'dswx_batch_pool_trim',
-    'dswx_shadow_layer_batch', 'dswx_landcover_mask_batch')
+    'dswx_shadow_layer_batch', 'dswx_landcover_mask_batch',
+    'dswx_cog_layout', 'dswx_cog_blocks_device', 'dswx_untile_device', 'dswx_rgb_planes_device',
+    'dswx_memcpy_h2d_async', 'dswx_memcpy_d2h_async')
 
 
 class DswxError(RuntimeError):
@@ -101,6 +103,16 @@ class BatchInfo(ctypes.Structure):
                 ('kept_launch_ms', ctypes.c_float), ('va_reserved_bytes', ctypes.c_uint64),
                 ('va_retired_bytes', ctypes.c_uint64), ('va_budget_bytes', ctypes.c_uint64),
                 ('va_pooled_bytes', ctypes.c_uint64), ('note', ctypes.c_char * 256)]
+
+
+COG_MAX_LEVELS = 8
+
+
+class CogLayout(ctypes.Structure):
+    _fields_ = [('n_levels', ctypes.c_int32), ('tile', ctypes.c_int32), ('factor', ctypes.c_int32 * COG_MAX_LEVELS),
+                ('height', ctypes.c_int64 * COG_MAX_LEVELS), ('width', ctypes.c_int64 * COG_MAX_LEVELS),
+                ('blocks_down', ctypes.c_int32 * COG_MAX_LEVELS), ('blocks_across', ctypes.c_int32 * COG_MAX_LEVELS),
+                ('offset_bytes', ctypes.c_uint64 * COG_MAX_LEVELS), ('total_bytes', ctypes.c_uint64)]
 
 
 _lib = None
@@ -234,6 +246,16 @@ def load_library(path=None):
                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64]),
         'dswx_batch_va_budget': (ctypes.c_int, [ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_uint64)] * 5),
         'dswx_batch_pool_trim': (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64)]),
+        'dswx_cog_layout': (ctypes.c_int, [i64, i64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                           ctypes.c_int32, ctypes.POINTER(CogLayout)]),
+        'dswx_cog_blocks_device': (ctypes.c_int, [vp, vp, ctypes.c_int32, i64, i64, ctypes.c_int32,
+                                                  ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, vp, vp]),
+        'dswx_untile_device': (ctypes.c_int, [vp, vp, ctypes.c_int32, i64, i64, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_int32, vp, vp]),
+        'dswx_rgb_planes_device': (ctypes.c_int, [vp, vp, vp, vp, vp, i64, ctypes.POINTER(ctypes.c_double * 3),
+                                                  ctypes.POINTER(ctypes.c_double * 3), ctypes.c_int32, vp, vp]),
+        'dswx_memcpy_h2d_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
+        'dswx_memcpy_d2h_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
     }
     for name, (res, args) in sig.items():
         if alt and not hasattr(lib, name):
@@ -727,6 +749,37 @@ class Context:
     def malloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
+    # ---- the raster formats either side of the path (ABI v6; device pointers) ---------------
+    def cog_blocks_device(self, plane_ptr, elem_bytes, height, width, blocks_ptr, factors=(), tile=512, predictor=2,
+                          stream=None):
+        f = (ctypes.c_int32 * max(len(factors), 1))(*[int(x) for x in factors])
+        _check(self.lib.dswx_cog_blocks_device(self.handle, ctypes.c_void_p(plane_ptr), int(elem_bytes), int(height), int(width),
+                                               int(tile), f, len(factors), int(predictor), ctypes.c_void_p(blocks_ptr),
+                                               ctypes.c_void_p(stream) if stream else None))
+
+    def untile_device(self, blocks_ptr, elem_bytes, height, width, block_width, block_height, predictor, plane_ptr, stream=None):
+        _check(self.lib.dswx_untile_device(self.handle, ctypes.c_void_p(blocks_ptr), int(elem_bytes), int(height), int(width),
+                                           int(block_width), int(block_height), int(predictor), ctypes.c_void_p(plane_ptr),
+                                           ctypes.c_void_p(stream) if stream else None))
+
+    def rgb_planes_device(self, red_ptr, green_ptr, blue_ptr, diag_ptr, n_pixels, scale, offset, clip, out_ptr, stream=None):
+        sc = (ctypes.c_double * 3)(*[float(v) for v in scale])
+        of = (ctypes.c_double * 3)(*[float(v) for v in offset])
+        _check(self.lib.dswx_rgb_planes_device(self.handle, ctypes.c_void_p(red_ptr), ctypes.c_void_p(green_ptr),
+                                               ctypes.c_void_p(blue_ptr), ctypes.c_void_p(diag_ptr) if diag_ptr else None,
+                                               int(n_pixels), ctypes.byref(sc), ctypes.byref(of), int(bool(clip)),
+                                               ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream) if stream else None))
+
+    def h2d_async(self, dst_ptr, host_arr, nbytes=None, stream=None):
+        _check(self.lib.dswx_memcpy_h2d_async(self.handle, ctypes.c_void_p(dst_ptr), _host_ptr(host_arr),
+                                              int(host_arr.nbytes if nbytes is None else nbytes),
+                                              ctypes.c_void_p(stream) if stream else None))
+
+    def d2h_async(self, host_arr, src_ptr, nbytes=None, stream=None):
+        _check(self.lib.dswx_memcpy_d2h_async(self.handle, _host_ptr(host_arr), ctypes.c_void_p(src_ptr),
+                                              int(host_arr.nbytes if nbytes is None else nbytes),
+                                              ctypes.c_void_p(stream) if stream else None))
+
     def synchronize(self, stream=None):
         _check(self.lib.dswx_stream_synchronize(
             self.handle, ctypes.c_void_p(stream) if stream else None))
@@ -752,6 +805,18 @@ class Context:
         buf = ctypes.create_string_buffer(256)
         _check(self.lib.dswx_last_kernel_info(self.handle, buf, 256))
         return buf.value.decode()
+
+
+def cog_layout(height, width, elem_bytes, factors=(), tile=512):
+    """dswx_cog_layout (no device needed): {'n_levels', 'total_bytes', 'levels': [{'factor', 'height', 'width',
+    'blocks_down', 'blocks_across', 'offset_bytes'}]}."""
+    lay = CogLayout()
+    f = (ctypes.c_int32 * max(len(factors), 1))(*[int(x) for x in factors])
+    _check(load_library().dswx_cog_layout(int(height), int(width), int(elem_bytes), int(tile), f, len(factors), ctypes.byref(lay)))
+    return {'n_levels': lay.n_levels, 'total_bytes': int(lay.total_bytes), 'tile': lay.tile,
+            'levels': [{'factor': lay.factor[k], 'height': int(lay.height[k]), 'width': int(lay.width[k]),
+                        'blocks_down': lay.blocks_down[k], 'blocks_across': lay.blocks_across[k],
+                        'offset_bytes': int(lay.offset_bytes[k])} for k in range(lay.n_levels)]}
 
 
 def batch_layout(n_tiles, height, width, masks=False, extra_layers=(), tile_stride=0, separate_outputs=False,

@@ -32,56 +32,89 @@ def plan(runconfigs, n_gpus, workers_per_gpu=1):
     return out
 
 
-def _worker(device, runconfigs, skip_existing=False):
+def _one_tile(D, device, path, skip_existing):
+    t0 = time.perf_counter()
+    try:
+        args = D.get_dswx_hls_cli_parser().parse_args([path, '--device', str(device)])
+        consts = D.parse_runconfig_file(path, args)
+        kw = {k: getattr(args, k) for k in D.RunConfigConstants._FIELDS}
+        for k in ('output_interpreted_band', 'output_rgb_file', 'output_infrared_rgb_file',
+                  'output_binary_water', 'output_confidence_layer', 'output_diagnostic_layer',
+                  'output_non_masked_dswx', 'output_shadow_masked_dswx', 'output_landcover',
+                  'output_shadow_layer', 'output_cloud_layer', 'output_dem_layer',
+                  'output_browse_image', 'scratch_dir', 'product_id', 'product_version',
+                  'dem_file', 'dem_file_description', 'landcover_file',
+                  'landcover_file_description', 'worldcover_file', 'worldcover_file_description',
+                  'shoreline_shapefile', 'shoreline_shapefile_description',
+                  'flag_offset_and_scale_inputs', 'landcover_mask', 'shadow_layer', 'ocean_mask'):
+            kw[k] = getattr(args, k)
+        wanted = [kw[k] for k in kw if k.startswith('output_') and kw[k]] + \
+            ([args.output_file] if args.output_file else [])
+        if skip_existing and wanted and all(os.path.exists(f) for f in wanted):
+            return {'runconfig': path, 'device': device, 'ok': True, 'error': None, 'skipped': True, 'seconds': 0.0}
+        ok = D.generate_dswx_layers(args.input_list, args.output_file,
+                                    hls_thresholds=consts.hls_thresholds, device=device, **kw)
+        err = None
+    except Exception as e:                  # one bad tile must not stop the slice
+        ok, err = False, f'{type(e).__name__}: {e}'
+    return {'runconfig': path, 'device': device, 'ok': bool(ok), 'error': err,
+            'seconds': round(time.perf_counter() - t0, 3)}
+
+
+def _worker(device, runconfigs, skip_existing=False, in_flight=3, with_stages=False):
     """Runs inside the per-GPU process.  `skip_existing`: a tile whose requested output files all
-    exist is not recomputed (tiles are idempotent: this is the driver's resume)."""
+    exist is not recomputed (tiles are idempotent: this is the driver's resume).
+
+    `in_flight` tiles are processed side by side on threads of THIS process: the GPU part of a tile is milliseconds
+    (and serialised by the engine's lock), its host part -- inflating the band files, deflating the layers, on native
+    threads without the interpreter lock -- is what takes time, so tile k + 1 is being read and tile k - 1 written
+    while tile k is on the device, with ONE HIP context per GPU."""
     import logging
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    t_start = time.perf_counter()
     from . import dswx_hls as D
+    from . import stages
     logging.getLogger('dswx_hls').setLevel(logging.WARNING)
     D.get_context(device)                      # fail loudly before touching any tile
-    rc = 0
-    for path in runconfigs:
-        t0 = time.perf_counter()
-        try:
-            args = D.get_dswx_hls_cli_parser().parse_args([path, '--device', str(device)])
-            consts = D.parse_runconfig_file(path, args)
-            kw = {k: getattr(args, k) for k in D.RunConfigConstants._FIELDS}
-            for k in ('output_interpreted_band', 'output_rgb_file', 'output_infrared_rgb_file',
-                      'output_binary_water', 'output_confidence_layer', 'output_diagnostic_layer',
-                      'output_non_masked_dswx', 'output_shadow_masked_dswx', 'output_landcover',
-                      'output_shadow_layer', 'output_cloud_layer', 'output_dem_layer',
-                      'output_browse_image', 'scratch_dir', 'product_id', 'product_version',
-                      'dem_file', 'dem_file_description', 'landcover_file',
-                      'landcover_file_description', 'worldcover_file', 'worldcover_file_description',
-                      'shoreline_shapefile', 'shoreline_shapefile_description',
-                      'flag_offset_and_scale_inputs', 'landcover_mask', 'shadow_layer', 'ocean_mask'):
-                kw[k] = getattr(args, k)
-            wanted = [kw[k] for k in kw if k.startswith('output_') and kw[k]] + \
-                ([args.output_file] if args.output_file else [])
-            if skip_existing and wanted and all(os.path.exists(f) for f in wanted):
-                print(json.dumps({'runconfig': path, 'device': device, 'ok': True, 'error': None,
-                                  'skipped': True, 'seconds': 0.0}), flush=True)
-                continue
-            ok = D.generate_dswx_layers(args.input_list, args.output_file,
-                                        hls_thresholds=consts.hls_thresholds, device=device, **kw)
-            err = None
-        except Exception as e:                  # one bad tile must not stop the slice
-            ok, err = False, f'{type(e).__name__}: {e}'
-        if not ok:
-            rc = 1
-        print(json.dumps({'runconfig': path, 'device': device, 'ok': bool(ok), 'error': err,
-                          'seconds': round(time.perf_counter() - t0, 3)}), flush=True)
-    return rc
+    t_ready = time.perf_counter()
+    if with_stages:
+        stages.start()
+    out_lock = threading.Lock()
+    rc = [0]
+
+    def run(path):
+        r = _one_tile(D, device, path, skip_existing)
+        with out_lock:
+            if not r['ok']:
+                rc[0] = 1
+            print(json.dumps(r), flush=True)
+
+    n = max(1, min(int(in_flight), len(runconfigs)))
+    if n == 1:
+        for path in runconfigs:
+            run(path)
+    else:
+        with ThreadPoolExecutor(n, thread_name_prefix='dswx-tile') as ex:
+            list(ex.map(run, runconfigs))
+    if with_stages:
+        print(json.dumps({'worker_report': {'device': device, 'tiles': len(runconfigs), 'in_flight': n,
+                                            'bring_up_s': round(t_ready - t_start, 3),
+                                            'tiles_s': round(time.perf_counter() - t_ready, 3),
+                                            'stages': stages.stop()}}), flush=True)
+    return rc[0]
 
 
-def run_batch(runconfigs, n_gpus, python=sys.executable, workers_per_gpu=1, skip_existing=False):
-    """Launch the workers; returns (all_ok, [per-tile result dicts in input order])."""
+def run_batch(runconfigs, n_gpus, python=sys.executable, workers_per_gpu=1, skip_existing=False, in_flight=3,
+              reports=None):
+    """Launch the workers; returns (all_ok, [per-tile result dicts in input order]).  `reports`: a list that receives
+    every worker's stage report (proteus_amd.stages: where its wall time went)."""
     procs = []
     for gpu, chunk in plan(runconfigs, n_gpus, workers_per_gpu):
         if not chunk:
             continue
-        cmd = [python, '-m', 'proteus_amd.batch', '--worker', '--device', str(gpu)] + \
-            (['--skip-existing'] if skip_existing else []) + chunk
+        cmd = [python, '-m', 'proteus_amd.batch', '--worker', '--device', str(gpu), '--in-flight', str(in_flight)] + \
+            (['--skip-existing'] if skip_existing else []) + (['--stages'] if reports is not None else []) + chunk
         procs.append(subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True))
     # every worker's pipes are drained concurrently: a worker with more result lines than a pipe holds (64 KiB, a few
@@ -99,7 +132,10 @@ def run_batch(runconfigs, n_gpus, python=sys.executable, workers_per_gpu=1, skip
     results, all_ok = {}, True
     for p, (out, err) in zip(procs, outputs):
         for line in out.splitlines():
-            if line.startswith('{'):
+            if line.startswith('{"worker_report"'):
+                if reports is not None:
+                    reports.append(json.loads(line)['worker_report'])
+            elif line.startswith('{'):
                 r = json.loads(line)
                 results[r['runconfig']] = r
         if p.returncode != 0:
@@ -116,18 +152,24 @@ def main(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--workers-per-gpu', type=int, default=1,
                     help='worker processes per GPU (overlaps the host-side GeoTIFF codec of several tiles)')
+    ap.add_argument('--in-flight', type=int, default=3,
+                    help='tiles processed side by side inside one worker (read k+1 / device k / write k-1 overlap)')
+    ap.add_argument('--stages', action='store_true', help='workers report where their wall time went (proteus_amd.stages)')
     ap.add_argument('--skip-existing', action='store_true',
                     help='resume: do not recompute tiles whose requested output files all exist')
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--device', type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     if a.worker:
-        return _worker(a.device, a.runconfigs, a.skip_existing)
+        return _worker(a.device, a.runconfigs, a.skip_existing, a.in_flight, a.stages)
     t0 = time.perf_counter()
+    reports = [] if a.stages else None
     ok, results = run_batch(a.runconfigs, a.gpus, workers_per_gpu=max(1, a.workers_per_gpu),
-                            skip_existing=a.skip_existing)
+                            skip_existing=a.skip_existing, in_flight=max(1, a.in_flight), reports=reports)
     for r in results:
         print(json.dumps(r))
+    for r in reports or ():
+        print(json.dumps({'worker_report': r}))
     print(json.dumps({'tiles': len(results), 'gpus': a.gpus, 'ok': ok,
                       'seconds': round(time.perf_counter() - t0, 3)}))
     return 0 if ok else 1

@@ -1,6 +1,7 @@
 """Builds the HIP shared libraries in-tree (proteus_amd/_lib/).
 
   libdswx_hip.so   the product: production kernels + the C-ABI of include/dswx_hip.h
+  libdswx_codec.so host only (g++): DEFLATE of GeoTIFF blocks on a thread pool (include/dswx_codec.h)
   libdswx_lab.so   experiments only (csrc/lab/: roofline probes, A/B switches of the dispatch);
                    links against libdswx_hip.so; loaded by tools/ and the variant tests, never by the product
 
@@ -23,7 +24,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LAB = os.path.join(CSRC, 'lab')
 SOURCES = [os.path.join(CSRC, n) for n in ('dswx_hip.hip', 'dswx_classify_lut.hip', 'dswx_cover.hip',
-                                           'dswx_layers.hip', 'dswx_host_path.hip', 'dswx_batch.hip')]
+                                           'dswx_layers.hip', 'dswx_host_path.hip', 'dswx_batch.hip', 'dswx_writer.hip')]
 HEADERS = [os.path.join(CSRC, n) for n in ('dswx_device.h', 'dswx_host.h', 'dswx_tables.h', 'dswx_vmm.h')]
 LAB_SOURCES = [os.path.join(LAB, n) for n in ('dswx_lab.hip', 'dswx_probes.hip')]
 LAB_HEADERS = [os.path.join(LAB, 'dswx_lab.h')]
@@ -116,7 +117,7 @@ def _run(cmd, verbose):
         print(' '.join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
+        raise RuntimeError(f'{os.path.basename(cmd[0])} failed:\n' + res.stdout + res.stderr)
 
 
 @contextlib.contextmanager
@@ -194,6 +195,35 @@ def build_lab(force=False, verbose=False):
     return LAB_PATH
 
 
+CODEC_PATH = os.path.join(LIB_DIR, 'libdswx_codec.so')
+CODEC_SOURCES = [os.path.join(CSRC, 'dswx_codec.cpp')]
+CODEC_HEADER = os.path.join(INCLUDE, 'dswx_codec.h')
+CODEC_FLAGS = ['-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall']
+
+
+def build_codec(force=False, verbose=False):
+    """Compile libdswx_codec.so (host only: the DEFLATE side of the GeoTIFF reader / writer, include/dswx_codec.h)
+    with g++ -- or hipcc's clang when g++ is missing; links libz, loads libdeflate at run time if the system has it."""
+    deps, extra = CODEC_SOURCES + [CODEC_HEADER], ' '.join(CODEC_FLAGS).encode()
+    if not force and not _stale(CODEC_PATH, deps, extra):
+        return CODEC_PATH
+    with _build_lock():
+        if not force and not _stale(CODEC_PATH, deps, extra):
+            return CODEC_PATH
+        cxx = shutil.which('g++') or shutil.which('c++') or find_hipcc()
+        if cxx is None:
+            raise RuntimeError(f'no C++ compiler and {os.path.relpath(CODEC_PATH, ROOT)} is '
+                               + ('stale' if os.path.exists(CODEC_PATH) else 'missing'))
+        tmp = f'{CODEC_PATH}.{os.getpid()}.tmp'
+        digest = _digest(deps, extra)
+        _run([cxx] + CODEC_FLAGS + ['-I', INCLUDE] + CODEC_SOURCES + ['-o', tmp, '-lz', '-ldl'], verbose)
+        if os.path.exists(_stamp(CODEC_PATH)):
+            os.remove(_stamp(CODEC_PATH))
+        os.replace(tmp, CODEC_PATH)
+        _write_stamp(CODEC_PATH, digest)
+    return CODEC_PATH
+
+
 UBSAN_PATH = os.path.join(LIB_DIR, 'libdswx_hip_ubsan.so')
 
 
@@ -242,3 +272,4 @@ def build_ubsan(force=False, verbose=False):
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
     print(build_lab(force='--force' in sys.argv, verbose=True))
+    print(build_codec(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,284 @@
+// dswx_codec.cpp -- libdswx_codec.so: DEFLATE of GeoTIFF blocks on a pool of host threads (include/dswx_codec.h).
+// Host-only C++17; links libz, loads libdeflate at run time when the system has it (no header needed: six
+// prototypes of its stable public API are declared here).
+#include "dswx_codec.h"
+
+#include <dlfcn.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local char g_error[256] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---- libdeflate, if present ---------------------------------------------------------------------------------
+struct LibDeflate {
+    void* (*alloc_compressor)(int) = nullptr;
+    size_t (*zlib_compress)(void*, const void*, size_t, void*, size_t) = nullptr;
+    void (*free_compressor)(void*) = nullptr;
+    void* (*alloc_decompressor)() = nullptr;
+    int (*zlib_decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*free_decompressor)(void*) = nullptr;
+    bool ok = false;
+};
+
+std::once_flag g_engine_once;
+LibDeflate g_ld;
+std::atomic<int> g_force_zlib{0};
+
+void load_engine() {
+    void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    LibDeflate l;
+    l.alloc_compressor = reinterpret_cast<void* (*)(int)>(dlsym(h, "libdeflate_alloc_compressor"));
+    l.zlib_compress = reinterpret_cast<size_t (*)(void*, const void*, size_t, void*, size_t)>(dlsym(h, "libdeflate_zlib_compress"));
+    l.free_compressor = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_compressor"));
+    l.alloc_decompressor = reinterpret_cast<void* (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+    l.zlib_decompress = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(dlsym(h, "libdeflate_zlib_decompress"));
+    l.free_decompressor = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+    l.ok = l.alloc_compressor && l.zlib_compress && l.free_compressor && l.alloc_decompressor && l.zlib_decompress &&
+           l.free_decompressor;
+    if (l.ok) g_ld = l;
+}
+
+bool use_libdeflate() {
+    std::call_once(g_engine_once, load_engine);
+    return g_ld.ok && !g_force_zlib.load(std::memory_order_relaxed);
+}
+
+// per-thread codec objects (libdeflate's are not thread-safe; allocation is the expensive part)
+struct ThreadCodecs {
+    void* comp = nullptr;
+    int comp_level = -1;
+    void* decomp = nullptr;
+    ~ThreadCodecs() {
+        if (comp) g_ld.free_compressor(comp);
+        if (decomp) g_ld.free_decompressor(decomp);
+    }
+};
+thread_local ThreadCodecs t_codecs;
+
+int deflate_one(const void* src, size_t n, void* dst, size_t cap, size_t* out, int level) {
+    if (use_libdeflate()) {
+        ThreadCodecs& c = t_codecs;
+        if (!c.comp || c.comp_level != level) {
+            if (c.comp) g_ld.free_compressor(c.comp);
+            c.comp = g_ld.alloc_compressor(level);
+            c.comp_level = level;
+            if (!c.comp) return fail(DSWX_CODEC_ERR_ARG, "libdeflate_alloc_compressor(%d) failed", level);
+        }
+        const size_t got = g_ld.zlib_compress(c.comp, src, n, dst, cap);
+        if (got == 0) return fail(DSWX_CODEC_ERR_SPACE, "compressed block does not fit %zu bytes", cap);
+        *out = got;
+        return DSWX_CODEC_OK;
+    }
+    uLongf len = static_cast<uLongf>(cap);
+    const int rc = compress2(static_cast<Bytef*>(dst), &len, static_cast<const Bytef*>(src), static_cast<uLong>(n), level);
+    if (rc == Z_BUF_ERROR) return fail(DSWX_CODEC_ERR_SPACE, "compressed block does not fit %zu bytes", cap);
+    if (rc != Z_OK) return fail(DSWX_CODEC_ERR_DATA, "zlib compress2 failed (%d)", rc);
+    *out = len;
+    return DSWX_CODEC_OK;
+}
+
+int inflate_one(const void* src, size_t n, void* dst, size_t cap, size_t* out) {
+    if (use_libdeflate()) {
+        ThreadCodecs& c = t_codecs;
+        if (!c.decomp) {
+            c.decomp = g_ld.alloc_decompressor();
+            if (!c.decomp) return fail(DSWX_CODEC_ERR_ARG, "libdeflate_alloc_decompressor failed");
+        }
+        size_t got = 0;
+        const int rc = g_ld.zlib_decompress(c.decomp, src, n, dst, cap, &got);
+        if (rc == 0) { *out = got; return DSWX_CODEC_OK; }
+        if (rc == 3) return fail(DSWX_CODEC_ERR_SPACE, "block inflates to more than %zu bytes", cap);
+        return fail(DSWX_CODEC_ERR_DATA, "corrupt zlib stream (libdeflate result %d)", rc);
+    }
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit(&z) != Z_OK) return fail(DSWX_CODEC_ERR_DATA, "inflateInit failed");
+    z.next_in = const_cast<Bytef*>(static_cast<const Bytef*>(src));
+    z.avail_in = static_cast<uInt>(n);
+    z.next_out = static_cast<Bytef*>(dst);
+    z.avail_out = static_cast<uInt>(cap);
+    const int rc = inflate(&z, Z_FINISH);
+    const size_t got = z.total_out;
+    inflateEnd(&z);
+    if (rc == Z_STREAM_END) { *out = got; return DSWX_CODEC_OK; }
+    if (rc == Z_BUF_ERROR || rc == Z_OK) return fail(DSWX_CODEC_ERR_SPACE, "block inflates to more than %zu bytes", cap);
+    return fail(DSWX_CODEC_ERR_DATA, "corrupt zlib stream (zlib result %d)", rc);
+}
+
+// ---- the pool ------------------------------------------------------------------------------------------------
+// One process-wide set of workers; a call is a Batch of n independent blocks that the workers and the calling thread
+// take one at a time (atomic counter).  Several calls may be in flight at once (the product writes its layers side by
+// side): a worker serves the oldest batch that still has blocks to hand out and fewer helpers than it asked for.
+// A Batch is shared (shared_ptr): a worker may look at its counters after the owner has seen the last block done.
+struct Batch {
+    int n = 0;
+    int want = 0;                       // helpers this call asked for (besides the caller)
+    int inside = 0;                     // helpers working on it now (guarded by the pool mutex)
+    std::atomic<int> next{0};
+    std::atomic<int> done{0};
+    std::atomic<int> status{0};
+    char error[256] = "";
+    std::mutex err_mutex;
+    std::function<int(int)> work;       // only called for i < n, i.e. before done reaches n: may refer to the owner's stack
+    std::mutex m;
+    std::condition_variable cv;
+};
+
+void drain(Batch& b) {
+    for (;;) {
+        const int i = b.next.fetch_add(1);
+        if (i >= b.n) return;
+        const int rc = b.status.load() ? 0 : b.work(i);             // after a failure the rest is skipped
+        if (rc) {
+            std::lock_guard<std::mutex> lock(b.err_mutex);
+            if (!b.status.load()) {
+                snprintf(b.error, sizeof b.error, "%s", g_error);
+                b.status.store(rc);
+            }
+        }
+        if (b.done.fetch_add(1) + 1 >= b.n) {
+            { std::lock_guard<std::mutex> g(b.m); }
+            b.cv.notify_all();
+        }
+    }
+}
+
+class Pool {
+public:
+    static Pool& get() {
+        static Pool* p = new Pool;      // never destroyed: detached workers outlive static destructors at exit
+        return *p;
+    }
+    void run(const std::shared_ptr<Batch>& b, int threads) {
+        const int helpers = threads > 1 ? (threads - 1 < b->n - 1 ? threads - 1 : b->n - 1) : 0;
+        if (helpers > 0) {
+            b->want = helpers;
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                // as many workers as the calls in flight ask for together, up to the machine's hardware threads: several
+                // layers (and several tiles) are deflated side by side, each call bringing its own demand
+                int demand = helpers;
+                for (const auto& q : queue_) demand += q->want;
+                const int hw = (int)std::thread::hardware_concurrency();
+                const int cap = hw > 1 ? hw : 1;
+                while (n_workers_ < demand && n_workers_ < cap && n_workers_ < 1024) {
+                    std::thread([this] { loop(); }).detach();
+                    ++n_workers_;
+                }
+                queue_.push_back(b);
+            }
+            cv_.notify_all();
+        }
+        drain(*b);
+        if (helpers > 0) {
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                for (auto it = queue_.begin(); it != queue_.end(); ++it)
+                    if (it->get() == b.get()) { queue_.erase(it); break; }
+            }
+            std::unique_lock<std::mutex> lk(b->m);
+            b->cv.wait(lk, [&] { return b->done.load() >= b->n; });
+        }
+    }
+
+private:
+    void loop() {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            std::shared_ptr<Batch> b;
+            for (const auto& q : queue_)
+                if (q->next.load() < q->n && q->inside < q->want) { b = q; break; }
+            if (!b) { cv_.wait(lk); continue; }
+            ++b->inside;
+            lk.unlock();
+            drain(*b);
+            lk.lock();
+            --b->inside;
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Batch>> queue_;
+    int n_workers_ = 0;
+};
+
+int run_blocks(int n, int threads, std::function<int(int)> work) {
+    auto b = std::make_shared<Batch>();
+    b->n = n;
+    b->work = std::move(work);
+    Pool::get().run(b, threads);
+    if (b->status.load()) {
+        snprintf(g_error, sizeof g_error, "%s", b->error);
+        return b->status.load();
+    }
+    return DSWX_CODEC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dswx_codec_abi_version(void) { return DSWX_CODEC_ABI_VERSION; }
+
+const char* dswx_codec_engine(void) { return use_libdeflate() ? "libdeflate" : "zlib"; }
+
+const char* dswx_codec_last_error(void) { return g_error; }
+
+int dswx_codec_force_zlib(int on) {
+    g_force_zlib.store(on ? 1 : 0);
+    return DSWX_CODEC_OK;
+}
+
+size_t dswx_codec_deflate_bound(size_t bytes) {
+    // zlib's compressBound = n + n/4096 + n/16384 + n/33554432 + 13; libdeflate's bound is 5 bytes per 10 kB block + 1 + 9 + 6:
+    // the larger of the two with room to spare
+    return bytes + (bytes >> 9) + 64;
+}
+
+int dswx_codec_deflate_blocks(const void* const* src, const size_t* src_bytes, void* const* dst, const size_t* dst_cap,
+                              size_t* dst_bytes, int32_t n, int32_t level, int32_t threads) {
+    if (n < 0 || (n > 0 && (!src || !src_bytes || !dst || !dst_cap || !dst_bytes)))
+        return fail(DSWX_CODEC_ERR_ARG, "NULL argument");
+    if (level < 1 || level > 9) return fail(DSWX_CODEC_ERR_ARG, "level %d outside 1 .. 9", level);
+    if (n == 0) return DSWX_CODEC_OK;
+    return run_blocks(n, threads, [&](int i) {
+        if (!src[i] && src_bytes[i]) return fail(DSWX_CODEC_ERR_ARG, "block %d is NULL", i);
+        return deflate_one(src[i], src_bytes[i], dst[i], dst_cap[i], &dst_bytes[i], level);
+    });
+}
+
+int dswx_codec_inflate_blocks(const void* const* src, const size_t* src_bytes, void* const* dst, const size_t* dst_cap,
+                              size_t* dst_bytes, int32_t n, int32_t threads) {
+    if (n < 0 || (n > 0 && (!src || !src_bytes || !dst || !dst_cap || !dst_bytes)))
+        return fail(DSWX_CODEC_ERR_ARG, "NULL argument");
+    if (n == 0) return DSWX_CODEC_OK;
+    return run_blocks(n, threads, [&](int i) {
+        if (!src[i] || !dst[i]) return fail(DSWX_CODEC_ERR_ARG, "block %d is NULL", i);
+        return inflate_one(src[i], src_bytes[i], dst[i], dst_cap[i], &dst_bytes[i]);
+    });
+}
+
+}  // extern "C"

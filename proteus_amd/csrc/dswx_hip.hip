@@ -497,10 +497,33 @@ int dswx_ctx_destroy(dswx_ctx_t* ctx) {
         if (ctx->pipe_out[i]) (void)hipEventDestroy(ctx->pipe_out[i]);
     }
     if (ctx->pipe_counters) (void)hipHostFree(ctx->pipe_counters);
+    if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     delete ctx;
     return DSWX_OK;
 }
 
+
+// One launch of a context at a time on the GPU (dswx_host.h: the workspaces are shared): a call on another stream than
+// the previous call's waits for it.  The steady state -- every call on one stream -- costs nothing.
+static int dswx_ws_enter(dswx_ctx* ctx, hipStream_t s) {
+    if (ctx->ws_used && ctx->ws_last != s) {
+        if (!ctx->ws_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
+        // the context's own stream is alive as long as the context: mark its work now; a caller's stream may be gone by
+        // now, so its mark was set right behind its launch (dswx_ws_leave)
+        if (ctx->ws_last == ctx->stream) HIP_TRY(hipEventRecord(ctx->ws_event, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(s, ctx->ws_event, 0));
+    }
+    return DSWX_OK;
+}
+static int dswx_ws_leave(dswx_ctx* ctx, hipStream_t s) {
+    if (s != ctx->stream) {
+        if (!ctx->ws_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->ws_event, s));
+    }
+    ctx->ws_last = s;
+    ctx->ws_used = true;
+    return DSWX_OK;
+}
 
 // height/width are only needed (and only trusted) in 'cover' mode; 0 = unknown
 static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t n_pixels,
@@ -533,6 +556,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         ctx->last_kernel = "none (empty input)";
         return DSWX_OK;
     }
+    if (int wrc = dswx_ws_enter(ctx, s)) return wrc;
     a.in = *in;
     a.out = *out;
     a.counters = reinterpret_cast<unsigned long long*>(counters);
@@ -754,7 +778,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         }
     }
     ctx->last_kernel = info;
-    return DSWX_OK;
+    return dswx_ws_leave(ctx, s);
 }
 
 int dswx_classify_device(dswx_ctx_t* ctx, const dswx_params_t* params, int64_t n_tiles, int64_t n_pixels,

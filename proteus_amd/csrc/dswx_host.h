@@ -23,6 +23,14 @@ struct dswx_ctx {
     unsigned long long* fold_acc = nullptr;
     size_t fold_bytes = 0;
     bool fold_clean = false;
+    // The workspaces of a context (tables, counter partials, fold accumulators, 'cover' scratch) are shared by all its
+    // launches.  Launches on ONE stream are ordered by the stream; a launch on a different stream than the previous one
+    // waits for it (dswx_ws_enter / dswx_ws_leave in dswx_hip.hip: an event recorded behind every launch on a caller's
+    // stream, or on the context's own stream at the moment the stream changes) -- two launches of one context never
+    // overlap on the GPU (the fold accumulators would otherwise be left non-zero for good).
+    hipStream_t ws_last = nullptr;         // the stream of the last launch that used the workspaces
+    bool ws_used = false;
+    hipEvent_t ws_event = nullptr;
     // device copy of the lookup tables of the table-driven kernel (rebuilt per call)
     void* tables = nullptr;
     bool tables_valid = false;             // the device tables match tables_params, built on tables_stream

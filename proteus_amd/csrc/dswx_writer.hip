@@ -1,0 +1,362 @@
+// dswx_writer.hip -- the raster FORMATS either side of the per-pixel path, on the device (ABI v6).
+//
+// The reference leaves both to GDAL: reading a band file is inflate + inverse predictor + block -> raster
+// (`ReadAsArray`, src/proteus/dswx_hls.py:2136-2302), saving a layer is `save_as_cog` (src/proteus/core.py:7-91):
+// NEAREST overviews 4 / 16 / 64 / 128 for the integer layers (:37-46), 512 x 512 blocks, PREDICTOR=2 (integer) or 3
+// (floating point), DEFLATE (:60-75); the RGB composites are scale * (float32(band) - offset) with NaN on invalid
+// pixels (dswx_hls.py:3013-3036).  Compression stays on the host (libdswx_codec.so); everything between the inflated
+// block and the classifier's planes, and between its layers and the block to deflate, is byte shuffling over whole
+// rasters -- HBM-bound work with no arithmetic to speak of -- and runs here:
+//
+//   dswx_untile_v1        inflated blocks (tiles or strips, PREDICTOR 1 / 2) -> row-major plane: one wave per block row,
+//                         8 elements per lane, the horizontal accumulation as a wave scan
+//   dswx_cog_blocks_v1    plane -> the blocks of the full-resolution image AND of every NEAREST overview level (GDAL's
+//                         source-pixel rule), zero-padded edge blocks, horizontal differencing applied: one thread =
+//                         8 consecutive elements of a block row = one 8- or 16-byte store
+//   dswx_cog_blocks_f32   the same for one Float32 plane with the floating-point predictor (byte planes, MSB first,
+//                         byte-differenced over the row; no overviews: the reference's are CUBICSPLINE, host only)
+//   dswx_rgb_planes_v1    the three Float32 planes of an RGB / infrared-RGB composite
+//
+// The kernels work on device memory; the host moves the blocked buffers across PCIe with the copy engine (a kernel
+// that gathers single bytes straight from page-locked host memory would multiply the PCIe reads).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+
+#include "dswx_host.h"
+
+namespace {
+
+struct CogLevelDev {
+    int oh, ow, down, across;
+    double ry, rx;                      // source rows / columns per overview row / column (level 0: unused)
+    unsigned long long first_group;     // of this level, in units of 8 elements
+};
+
+struct CogArgs {
+    const void* src;
+    void* dst;
+    int height, width, tile, predictor, n_levels;
+    unsigned long long total_groups;
+    CogLevelDev lv[DSWX_COG_MAX_LEVELS];
+};
+
+// GDAL's NEAREST overview pick (GDALResampleChunk_Near, as proteus_amd/geotiff.py: overview_nearest restates it):
+// src = min(int(0.5 + dst * (N / N_ovr)), N - 1) in double precision, one multiplication and one addition (the build
+// has -ffp-contract=off: no fused multiply-add)
+__device__ __forceinline__ int near_src(int i, double ratio, int n) {
+    const double v = 0.5 + (double)i * ratio;
+    const long long k = (long long)v;
+    return k < (long long)n - 1 ? (int)k : n - 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dswx_cog_blocks_v1(const CogArgs a) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    if (g >= a.total_groups) return;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < DSWX_COG_MAX_LEVELS; ++j)
+        if (j < a.n_levels && g >= a.lv[j].first_group) k = j;
+    const CogLevelDev L = a.lv[k];
+    const unsigned long long idx = g - L.first_group;
+    const unsigned gpr = (unsigned)a.tile >> 3;                 // groups per block row
+    const unsigned long long per_block = (unsigned long long)gpr * (unsigned)a.tile;
+    const unsigned long long b = idx / per_block;
+    const unsigned w = (unsigned)(idx % per_block);
+    const int y = (int)(w / gpr), xg = (int)(w % gpr);
+    const int by = (int)(b / (unsigned)L.across), bx = (int)(b % (unsigned)L.across);
+    const int oy = by * a.tile + y, ox0 = bx * a.tile + xg * 8;
+    const T* __restrict__ src = static_cast<const T*>(a.src);
+    T v[9];                                                     // v[0] = the element left of the group
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v[j] = 0;
+    if (oy < L.oh) {
+        const long long row = (long long)(k == 0 ? oy : near_src(oy, L.ry, a.height)) * a.width;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int ox = ox0 + j - 1;
+            if ((j > 0 || xg > 0) && ox < L.ow) v[j] = src[row + (k == 0 ? ox : near_src(ox, L.rx, a.width))];
+        }
+    }
+    T out[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        out[j] = a.predictor == 2 ? (T)(v[j + 1] - v[j]) : v[j + 1];      // (v[0] = 0 at the start of a block row)
+    T* dst = static_cast<T*>(a.dst) + g * 8ull;
+    if constexpr (sizeof(T) == 1) {
+        uint2 pack;
+        memcpy(&pack, out, 8);
+        *reinterpret_cast<uint2*>(dst) = pack;
+    } else {
+        uint4 pack;
+        memcpy(&pack, out, 16);
+        *reinterpret_cast<uint4*>(dst) = pack;
+    }
+}
+
+struct F32BlockArgs {
+    const float* src;
+    unsigned char* dst;
+    int height, width, tile, down, across;
+    unsigned long long total_quads;       // output bytes / 4
+};
+
+// TIFF floating-point predictor (Adobe TIFF Technical Note 3, libtiff fpDiff), as geotiff._fp_predictor_encode: per block
+// row the bytes of the samples are regrouped into byte planes, most significant first, and the whole row of bytes is
+// differenced.  One thread = 4 consecutive output bytes.
+__device__ __forceinline__ unsigned f32_row_byte(const float* __restrict__ src, long long row, int x0, int width, bool row_ok,
+                                                 int q, int tile) {
+    const int plane = q / tile, j = q - plane * tile;           // plane 0 = most significant byte
+    const int x = x0 + j;
+    if (!row_ok || x >= width) return 0u;
+    return (__float_as_uint(src[row + x]) >> (8 * (3 - plane))) & 0xffu;
+}
+
+__global__ __launch_bounds__(256) void dswx_cog_blocks_f32(const F32BlockArgs a) {
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    if (t >= a.total_quads) return;
+    const unsigned qpr = (unsigned)a.tile;                      // quads per block row: 4 * tile bytes / 4
+    const unsigned long long per_block = (unsigned long long)qpr * (unsigned)a.tile;
+    const unsigned long long b = t / per_block;
+    const unsigned w = (unsigned)(t % per_block);
+    const int y = (int)(w / qpr), q0 = (int)(w % qpr) * 4;
+    const int by = (int)(b / (unsigned)a.across), bx = (int)(b % (unsigned)a.across);
+    const int oy = by * a.tile + y, x0 = bx * a.tile;
+    const bool row_ok = oy < a.height;
+    const long long row = (long long)oy * a.width;
+    unsigned prev = q0 > 0 ? f32_row_byte(a.src, row, x0, a.width, row_ok, q0 - 1, a.tile) : 0u;
+    unsigned pack = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned cur = f32_row_byte(a.src, row, x0, a.width, row_ok, q0 + j, a.tile);
+        pack |= ((cur - prev) & 0xffu) << (8 * j);
+        prev = cur;
+    }
+    reinterpret_cast<unsigned*>(a.dst)[t] = pack;
+}
+
+struct UntileArgs {
+    const void* blocks;
+    void* dst;
+    int height, width, bw, bh, across, down, predictor;
+    long long block_rows;                 // across * down * bh
+};
+
+// One wave per block row.  PREDICTOR=2 is a running sum over the row in the sample's own width (libtiff horAcc8 /
+// horAcc16: wrap-around), here a per-lane sum of 8 + a wave scan + the carry of the previous 512 elements.
+template <typename T>
+__global__ __launch_bounds__(256) void dswx_untile_v1(const UntileArgs a) {
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= a.block_rows) return;
+    const int lane = threadIdx.x & 63;
+    const long long blk = wave / a.bh;
+    const int y_in = (int)(wave - blk * a.bh);
+    const int by = (int)(blk / a.across), bx = (int)(blk - (long long)by * a.across);
+    const int y = by * a.bh + y_in;
+    if (y >= a.height) return;
+    const T* __restrict__ row = static_cast<const T*>(a.blocks) + (size_t)wave * (size_t)a.bw;
+    T* __restrict__ out = static_cast<T*>(a.dst) + (size_t)y * (size_t)a.width;
+    const int x_base = bx * a.bw;
+    unsigned carry = 0;
+    for (int c = 0; c < a.bw; c += 512) {
+        const int x_in = c + lane * 8;
+        unsigned v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (x_in + j < a.bw) ? (unsigned)row[x_in + j] : 0u;
+        if (a.predictor == 2) {
+#pragma unroll
+            for (int j = 1; j < 8; ++j) v[j] += v[j - 1];
+            const unsigned total = v[7];
+            unsigned incl = total;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned n = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += n;
+            }
+            const unsigned before = carry + incl - total;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += before;
+            carry += __shfl(incl, 63, 64);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int x = x_base + x_in + j;
+            if (x_in + j < a.bw && x < a.width) out[x] = (T)v[j];
+        }
+    }
+}
+
+struct RgbArgs {
+    const short* band[3];
+    const unsigned short* diag;
+    float* out;
+    long long n;
+    float scale[3], offset[3];
+    int clip;
+};
+
+// _save_output_rgb_file (dswx_hls.py:3013-3036): scale * (float32(band) - offset) in float32 (a Python float against a
+// float32 array is a weak scalar), NaN where the pixel is invalid (DIAG carries the fill code there, :5227).  The bands
+// are the CLIPPED reflectances (np.clip(img, 1, None), :2298-2299).
+__global__ __launch_bounds__(256) void dswx_rgb_planes_v1(const RgbArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const bool invalid = a.diag && a.diag[i] == 65535;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        short s = a.band[c][i];
+        if (a.clip && s < 1) s = 1;
+        const float d = (float)s - a.offset[c];
+        a.out[(long long)c * a.n + i] = invalid ? __uint_as_float(0x7fc00000u) : a.scale[c] * d;
+    }
+}
+
+int cog_layout_impl(int64_t height, int64_t width, int32_t elem_bytes, int32_t tile, const int32_t* factors, int32_t n_factors,
+                    dswx_cog_layout_t* out) {
+    if (!out || (n_factors > 0 && !factors)) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (height <= 0 || width <= 0 || height > 2147483647LL / 2 || width > 2147483647LL / 2)
+        return dswx_fail(DSWX_ERR_ARG, "raster size out of range");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4) return dswx_fail(DSWX_ERR_ARG, "elem_bytes must be 1, 2 or 4");
+    if (tile < 8 || tile > 4096 || (tile & 7)) return dswx_fail(DSWX_ERR_ARG, "tile must be a multiple of 8 (16 for TIFF) in 8 .. 4096");
+    if (n_factors < 0 || n_factors + 1 > DSWX_COG_MAX_LEVELS) return dswx_fail(DSWX_ERR_ARG, "too many overview levels");
+    memset(out, 0, sizeof *out);
+    out->tile = tile;
+    uint64_t off = 0;
+    int n = 0;
+    for (int k = -1; k < n_factors; ++k) {
+        const int32_t f = k < 0 ? 1 : factors[k];
+        if (k >= 0 && f < 1) return dswx_fail(DSWX_ERR_ARG, "overview factor %d", f);
+        // write_geotiff's rule: a factor of 1 or a 1 x 1 raster produces no level
+        if (k >= 0 && (f == 1 || (height == 1 && width == 1))) continue;
+        const int64_t oh = (height + f - 1) / f, ow = (width + f - 1) / f;
+        out->factor[n] = f;
+        out->height[n] = oh;
+        out->width[n] = ow;
+        out->blocks_down[n] = (int32_t)((oh + tile - 1) / tile);
+        out->blocks_across[n] = (int32_t)((ow + tile - 1) / tile);
+        out->offset_bytes[n] = off;
+        off += (uint64_t)out->blocks_down[n] * (uint64_t)out->blocks_across[n] * (uint64_t)tile * (uint64_t)tile * (uint64_t)elem_bytes;
+        ++n;
+    }
+    out->n_levels = n;
+    out->total_bytes = off;
+    return DSWX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dswx_cog_layout(int64_t height, int64_t width, int32_t elem_bytes, int32_t tile, const int32_t* factors, int32_t n_factors,
+                    dswx_cog_layout_t* out) {
+    return cog_layout_impl(height, width, elem_bytes, tile, factors, n_factors, out);
+}
+
+#pragma clang fp contract(off)
+int dswx_cog_blocks_device(dswx_ctx_t* ctx, const void* plane, int32_t elem_bytes, int64_t height, int64_t width, int32_t tile,
+                           const int32_t* factors, int32_t n_factors, int32_t predictor, void* blocks, void* stream) {
+    if (!ctx || !plane || !blocks) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    dswx_cog_layout_t lay;
+    if (int rc = cog_layout_impl(height, width, elem_bytes, tile, factors, n_factors, &lay)) return rc;
+    if (!aligned_to(blocks, 16) || !aligned_to(plane, (size_t)elem_bytes))
+        return dswx_fail(DSWX_ERR_ALIGN, "blocks must be 16-byte aligned, the plane aligned to its samples");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (elem_bytes == 4) {
+        if (predictor != 3) return dswx_fail(DSWX_ERR_UNSUPPORTED, "4-byte samples: Float32 with PREDICTOR=3 only");
+        if (lay.n_levels != 1)
+            return dswx_fail(DSWX_ERR_UNSUPPORTED, "Float32 layers carry CUBICSPLINE overviews in the reference (core.py:41-46): host only");
+        F32BlockArgs a = {};
+        a.src = static_cast<const float*>(plane);
+        a.dst = static_cast<unsigned char*>(blocks);
+        a.height = (int)height; a.width = (int)width; a.tile = tile;
+        a.down = lay.blocks_down[0]; a.across = lay.blocks_across[0];
+        a.total_quads = lay.total_bytes / 4;
+        hipLaunchKernelGGL(dswx_cog_blocks_f32, dim3((unsigned)((a.total_quads + 255) / 256)), dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
+    if (predictor != 1 && predictor != 2) return dswx_fail(DSWX_ERR_ARG, "integer samples: PREDICTOR 1 or 2");
+    CogArgs a = {};
+    a.src = plane; a.dst = blocks;
+    a.height = (int)height; a.width = (int)width; a.tile = tile; a.predictor = predictor; a.n_levels = lay.n_levels;
+    for (int k = 0; k < lay.n_levels; ++k) {
+        CogLevelDev& L = a.lv[k];
+        L.oh = (int)lay.height[k]; L.ow = (int)lay.width[k];
+        L.down = lay.blocks_down[k]; L.across = lay.blocks_across[k];
+        L.ry = (double)height / (double)lay.height[k];         // h / oh as Python divides two ints: one correctly rounded division
+        L.rx = (double)width / (double)lay.width[k];
+        L.first_group = lay.offset_bytes[k] / (uint64_t)elem_bytes / 8;
+    }
+    a.total_groups = lay.total_bytes / (uint64_t)elem_bytes / 8;
+    const dim3 grid((unsigned)((a.total_groups + 255) / 256)), block(256);
+    if (a.total_groups > 0xffffffffull * 256ull) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
+    if (elem_bytes == 1) hipLaunchKernelGGL(dswx_cog_blocks_v1<unsigned char>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(dswx_cog_blocks_v1<unsigned short>, grid, block, 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_untile_device(dswx_ctx_t* ctx, const void* blocks, int32_t elem_bytes, int64_t height, int64_t width,
+                       int32_t block_width, int32_t block_height, int32_t predictor, void* plane, void* stream) {
+    if (!ctx || !blocks || !plane) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (height <= 0 || width <= 0 || height > 2147483647LL / 2 || width > 2147483647LL / 2)
+        return dswx_fail(DSWX_ERR_ARG, "raster size out of range");
+    if (elem_bytes != 1 && elem_bytes != 2) return dswx_fail(DSWX_ERR_ARG, "elem_bytes must be 1 or 2");
+    if (block_width < 1 || block_height < 1) return dswx_fail(DSWX_ERR_ARG, "empty block");
+    if (predictor != 1 && predictor != 2) return dswx_fail(DSWX_ERR_UNSUPPORTED, "PREDICTOR 1 or 2 (the floating-point predictor is decoded on the host)");
+    if (!aligned_to(blocks, (size_t)elem_bytes) || !aligned_to(plane, (size_t)elem_bytes))
+        return dswx_fail(DSWX_ERR_ALIGN, "buffers must be aligned to their samples");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    UntileArgs a = {};
+    a.blocks = blocks; a.dst = plane;
+    a.height = (int)height; a.width = (int)width; a.bw = block_width; a.bh = block_height;
+    a.across = (int)((width + block_width - 1) / block_width);
+    a.down = (int)((height + block_height - 1) / block_height);
+    a.predictor = predictor;
+    a.block_rows = (long long)a.across * a.down * a.bh;
+    const unsigned long long groups = ((unsigned long long)a.block_rows + 3) / 4;
+    if (groups > 0x7fffffffull) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
+    const dim3 grid((unsigned)groups), block(256);
+    if (elem_bytes == 1) hipLaunchKernelGGL(dswx_untile_v1<unsigned char>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(dswx_untile_v1<unsigned short>, grid, block, 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_rgb_planes_device(dswx_ctx_t* ctx, const int16_t* red, const int16_t* green, const int16_t* blue, const uint16_t* diag,
+                           int64_t n_pixels, const double scale[3], const double offset[3], int32_t clip_negative_reflectance,
+                           float* out, void* stream) {
+    if (!ctx || !red || !green || !blue || !scale || !offset || !out) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_pixels < 0) return dswx_fail(DSWX_ERR_ARG, "negative size");
+    if (n_pixels == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    RgbArgs a = {};
+    a.band[0] = red; a.band[1] = green; a.band[2] = blue;
+    a.diag = diag; a.out = out; a.n = n_pixels; a.clip = clip_negative_reflectance != 0;
+    for (int c = 0; c < 3; ++c) { a.scale[c] = (float)scale[c]; a.offset[c] = (float)offset[c]; }
+    const unsigned long long groups = ((unsigned long long)n_pixels + 255) / 256;
+    if (groups > 0x7fffffffull) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
+    hipLaunchKernelGGL(dswx_rgb_planes_v1, dim3((unsigned)groups), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_memcpy_h2d_async(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream ? (hipStream_t)stream : ctx->stream));
+    return DSWX_OK;
+}
+
+int dswx_memcpy_d2h_async(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream ? (hipStream_t)stream : ctx->stream));
+    return DSWX_OK;
+}
+
+}  // extern "C"

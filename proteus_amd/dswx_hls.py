@@ -30,12 +30,13 @@ import glob
 import logging
 import os
 import sys
+import threading
 from collections import OrderedDict
 from datetime import datetime
 
 import numpy as np
 
-from . import _capi, geotiff, runconfig as _rc
+from . import _capi, geotiff, pipeline, stages, runconfig as _rc
 from .version import VERSION as SOFTWARE_VERSION
 
 FLAG_COLLAPSE_WTR_CLASSES = True          # :26
@@ -484,10 +485,11 @@ def _harvest_hls_metadata(meta, md):
     return True
 
 
-def _load_hls_product_v2(file_list, image, md, flag_debug=False, alloc=None):
+def _load_hls_product_v2(file_list, image, md, flag_debug=False, alloc=None, engine=None):
     """Reads the seven band files of an HLS v2 product.  Returns False on failure.
     Fill detection and clipping are NOT done here: the raw planes and the fill values go
-    to the kernel (A0 of the hot path)."""
+    to the kernel (A0 of the hot path).  With `engine` (pipeline.TileEngine) the planes come back RESIDENT in HBM
+    (pipeline.DevicePlane): the host only inflates the blocks, the device undoes the predictor and untiles them."""
     logger.info('loading HLS v.2.0 layers:')
     image['fills'] = {}
 
@@ -505,6 +507,8 @@ def _load_hls_product_v2(file_list, image, md, flag_debug=False, alloc=None):
         logger.info(f'ERROR band {key} not found within list of input file(s)')
         return False
     def read(path):
+        if engine is not None and not flag_debug:
+            return engine.read_plane(path)
         return geotiff.read_geotiff(path, window=(0, 0, 1000, 1000) if flag_debug else None, alloc=alloc)
 
     # the first band's metadata decide the sensor, hence the file names of the other six, which
@@ -554,7 +558,8 @@ def _load_bands(file_list, image, md, flag_debug, find, read, pending, pool):
         image.setdefault('length', arr.shape[0])
         image.setdefault('width', arr.shape[1])
         if key == 'fmask':
-            image[key] = np.ascontiguousarray(arr, dtype=np.uint8)
+            image[key] = arr if (isinstance(arr, pipeline.DevicePlane) and arr.dtype == np.uint8) else \
+                np.ascontiguousarray(arr.numpy() if isinstance(arr, pipeline.DevicePlane) else arr, dtype=np.uint8)
             continue
         if arr.dtype != np.int16:
             logger.info(f'ERROR band {key} of {path} is {arr.dtype}, expected int16')
@@ -725,6 +730,8 @@ def _save_output_rgb_file(red, green, blue, output_file, offset_dict, scale_dict
     NaN on invalid pixels."""
     keys = ('swir1', 'nir', 'red') if flag_infrared else ('red', 'green', 'blue')
     planes = []
+    import time as _time
+    t_rgb = _time.perf_counter()
     for arr, key in zip((red, green, blue), keys):
         # the reference scales here unless the loader already did (flag_offset_and_scale_inputs, :3013): the same
         # statement on the same clipped planes either way; this host keeps the integer planes and scales here in both cases
@@ -734,6 +741,7 @@ def _save_output_rgb_file(red, green, blue, output_file, offset_dict, scale_dict
         planes.append(np.asarray(arr, dtype=np.float32))
     _makedirs(output_file)
     stack = np.stack(planes)
+    stages.add('host: RGB scaling', t_rgb, _time.perf_counter())
 
     def job():
         geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict)
@@ -741,6 +749,36 @@ def _save_output_rgb_file(red, green, blue, output_file, offset_dict, scale_dict
     if output_files_list is not None:
         output_files_list.append(output_file)
     _run_or_defer(job)
+
+
+def _save_output_rgb_planes(engine, planes, diag, scales, offsets, output_file, dswx_metadata_dict, geo_tags,
+                            output_files_list=None):
+    """_save_output_rgb_file (:2961-3054) for planes RESIDENT on the device: the scaling, the clip and the NaN mask are
+    dswx_rgb_planes_device, the tiling and the floating-point predictor dswx_cog_blocks_device; DEFLATE on the host."""
+    _makedirs(output_file)
+
+    def job():
+        levels = engine.rgb_levels(planes[0], planes[1], planes[2], diag, scales, offsets, FLAG_CLIP_NEGATIVE_REFLECTANCE)
+        geotiff.write_geotiff(output_file, None, levels=levels, geo_tags=geo_tags, metadata=dswx_metadata_dict)
+        logger.info(f'file saved: {output_file}')
+    if output_files_list is not None:
+        output_files_list.append(output_file)
+    _run_or_defer(job)
+
+
+def _browse_png_job(browse, ctable, nodata, dest_png_filename, output_height, output_width):
+    """What geotiff2png makes of the browse GeoTIFF (nearest-neighbour resize, palette, transparent nodata), from the
+    plane itself."""
+    def job():
+        with stages.span('browse PNG (resample + encode)'):
+            arr = browse.numpy() if isinstance(browse, pipeline.DevicePlane) else np.asarray(browse)
+            h = arr.shape[0] if output_height is None else output_height
+            w = arr.shape[1] if output_width is None else output_width
+            _makedirs(dest_png_filename)
+            geotiff.write_png_palette(dest_png_filename, geotiff.resample_nearest(arr, h, w), ctable,
+                                      transparent_index=None if nodata is None else int(nodata))
+        logger.info(f'Browse Image PNG created: {dest_png_filename}')
+    return job
 
 
 def _get_binary_water_ctable():
@@ -793,18 +831,27 @@ class _DeferredWrites:
     """Collects the GeoTIFF writes of one product run and executes them side by side.  Every write
     already spreads its DEFLATE blocks over the codec's thread pool; running a few writes
     concurrently hides their serial parts (block assembly, overviews, file output).  File lists
-    keep the order of the calls; the files exist once flush() / the `with` block returns."""
-    active = None
+    keep the order of the calls; the files exist once flush() / the `with` block returns.  The active
+    collector is per THREAD: several product runs may be in flight in one process (proteus_amd.batch)."""
+    _local = threading.local()
 
     def __init__(self, workers=4):
         self.jobs, self.workers = [], workers
 
+    @classmethod
+    def current(cls):
+        return getattr(cls._local, 'active', None)
+
+    @classmethod
+    def reset(cls):
+        cls._local.active = None
+
     def __enter__(self):
-        _DeferredWrites.active = self
+        _DeferredWrites._local.active = self
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        _DeferredWrites.active = None
+        _DeferredWrites._local.active = None
         if exc_type is None:
             self.flush()
 
@@ -820,8 +867,9 @@ class _DeferredWrites:
 
 
 def _run_or_defer(job):
-    if _DeferredWrites.active is not None:
-        _DeferredWrites.active.jobs.append(job)
+    active = _DeferredWrites.current()
+    if active is not None:
+        active.jobs.append(job)
     else:
         job()
 
@@ -829,10 +877,20 @@ def _run_or_defer(job):
 def _save_array(input_array, output_file, dswx_metadata_dict, geo_tags, description=None,
                 output_files_list=None, ctable=None, no_data_value=None):
     _makedirs(output_file)
-    integer = np.asarray(input_array).dtype.kind in 'uib'
+    resident = isinstance(input_array, pipeline.DevicePlane)
+    integer = (input_array.dtype if resident else np.asarray(input_array).dtype).kind in 'uib'
 
     def job():
-        geotiff.write_geotiff(output_file, input_array, geo_tags=geo_tags,
+        if resident and (integer or input_array.dtype == np.float32):
+            # the blocks of the image and of its NEAREST overviews, predictor applied, made on the device: the host only
+            # deflates (pipeline.TileEngine.layer_levels; save_as_cog, core.py:7-91)
+            levels = input_array.engine.layer_levels(input_array, geotiff.COG_OVERVIEW_FACTORS if integer else ())
+            geotiff.write_geotiff(output_file, None, levels=levels, geo_tags=geo_tags, metadata=dswx_metadata_dict,
+                                  nodata=no_data_value, descriptions=[description] if description else None,
+                                  colormap=ctable)
+            logger.info(f'file saved: {output_file}')
+            return
+        geotiff.write_geotiff(output_file, input_array.numpy() if resident else input_array, geo_tags=geo_tags,
                               metadata=dswx_metadata_dict, nodata=no_data_value,
                               descriptions=[description] if description else None, colormap=ctable,
                               overviews=geotiff.COG_OVERVIEW_FACTORS if integer else None)
@@ -1061,7 +1119,7 @@ def generate_dswx_layers(input_list,
     reference (:4610-4657) plus four keyword-only extensions (pre-gridded LAND / SHAD /
     ocean planes, and the GPU to use).  Returns True, or False after logging 'ERROR ...'
     when the input cannot be read (:4988-4990)."""
-    _DeferredWrites.active = None          # a previous run that raised must not leave writes deferred
+    _DeferredWrites.reset()                # a previous run that raised must not leave writes deferred
     local = locals()
     needs_defaults = [hls_thresholds, check_ancillary_inputs_coverage, apply_ocean_masking,
                       apply_aerosol_class_remapping, shadow_masking_algorithm, min_slope_angle,
@@ -1146,13 +1204,19 @@ def generate_dswx_layers(input_list,
     image = {}
     # HLS v1 (a single HDF4 file, :4972-4980) needs GDAL's HDF4 driver; every input goes
     # through the v2 per-band GeoTIFF loader, which reports what is missing
-    # band planes are decoded straight into page-locked memory so that the library can
-    # work on them in place across PCIe (zero copy; dswx_host_alloc, include/dswx_hip.h)
-    ok = _load_hls_product_v2(list(input_list), image, md, flag_debug=flag_debug,
-                              alloc=lambda shape, dt: get_context(device).pinned_empty(shape, dt))
+    # the blocks of the band files are inflated on host threads into page-locked memory; the device undoes the
+    # predictor and untiles them: the planes are RESIDENT in HBM from here on (proteus_amd.pipeline)
+    ctx = get_context(device)
+    engine = pipeline.engine_of(ctx)
+    with stages.span('load HLS bands (7 files)'):
+        ok = _load_hls_product_v2(list(input_list), image, md, flag_debug=flag_debug,
+                                  alloc=lambda shape, dt: ctx.pinned_empty(shape, dt), engine=engine)
     if not ok:
         logger.info(f'ERROR could not read file(s): {input_list}')
         return False
+    for k in list(_capi.BAND_NAMES) + ['fmask']:          # (flag_debug reads a window on the host)
+        if not isinstance(image[k], pipeline.DevicePlane):
+            image[k] = engine.upload(image[k])
     version = '2.0'
     _populate_dswx_metadata_datasets(md, image['hls_dataset_name'], dem_file, dem_file_description,
                                      landcover_file, landcover_file_description,
@@ -1201,20 +1265,22 @@ def generate_dswx_layers(input_list,
             logger.warning(f'WARNING DEM margin is {margin} pixels, the reference uses '
                            f'{DEM_MARGIN_IN_PIXELS}: slopes along the tile border differ')
         dem_with_margin = np.ascontiguousarray(dem_with_margin, dtype=np.float32)
-        shadow_layer = _compute_opera_shadow_layer(
-            dem_with_margin, sun_azimuth_angle, sun_elevation_angle, min_slope_angle,
-            max_sun_local_inc_angle, margin=margin)
+        with stages.span('gpu: shadow layer'), engine.lock:
+            shadow_layer = _compute_opera_shadow_layer(
+                dem_with_margin, sun_azimuth_angle, sun_elevation_angle, min_slope_angle,
+                max_sun_local_inc_angle, margin=margin)
         dem = dem_with_margin[margin:dem_with_margin.shape[0] - margin,
                               margin:dem_with_margin.shape[1] - margin]
         if output_dem_layer:
             _save_array(dem, output_dem_layer, md, geo_tags, description=band_description_dict['DEM'],
                         output_files_list=early_list, no_data_value=float('nan'))
     if landcover_file is not None and worldcover_file is not None:
-        landcover_mask = create_landcover_mask(
-            landcover_file, worldcover_file, worldcover_file_description, output_landcover, scratch_dir,
-            landcover_mask_type, image['geotransform'], None, length, width,
-            forest_mask_landcover_classes, dswx_metadata_dict=md, output_files_list=early_list,
-            geo_tags=geo_tags, device=device)
+        with stages.span('landcover mask (read + gpu)'), engine.lock:
+            landcover_mask = create_landcover_mask(
+                landcover_file, worldcover_file, worldcover_file_description, output_landcover, scratch_dir,
+                landcover_mask_type, image['geotransform'], None, length, width,
+                forest_mask_landcover_classes, dswx_metadata_dict=md, output_files_list=early_list,
+                geo_tags=geo_tags, device=device)
         output_landcover = None          # saved by create_landcover_mask, as in the reference
     landcover_mask = _as_plane(landcover_mask, shape, 'landcover_mask')
     shadow_layer = _as_plane(shadow_layer, shape, 'shadow_layer')
@@ -1242,25 +1308,16 @@ def generate_dswx_layers(input_list,
         cloud_in_browse=pick(cloud_in_browse, 'cloud_in_browse'),
         snow_in_browse=pick(snow_in_browse, 'snow_in_browse'),
         set_ocean_masked_to_nodata=True)
-    ctx = get_context(device)
     wanted = ['diag', 'wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud']
     if output_browse_image:
         wanted.append('browse')
-    def like_bands(a):
-        # ancillary planes follow the bands into page-locked memory (one small copy)
-        if a is None or not ctx.is_pinned(bands[0]):
-            return a
-        p = ctx.pinned_empty(a.shape, np.uint8)
-        np.copyto(p, a, casting='unsafe')
-        return p
     import time as _time
     t_gpu = _time.perf_counter()
-    res = ctx.classify_host(bands, image['fmask'], params, land=like_bands(landcover_mask),
-                            shad=like_bands(shadow_layer), ocean=like_bands(ocean_mask),
-                            layers=tuple(wanted))
+    res = engine.classify(bands, image['fmask'], params, land=landcover_mask, shad=shadow_layer, ocean=ocean_mask,
+                          layers=tuple(wanted))
     t_gpu = _time.perf_counter() - t_gpu
-    logger.info(f'    per-pixel chain on GPU: {ctx.last_kernel_info()}')
-    logger.info(f'    per-pixel chain incl. host <-> device copies: {t_gpu * 1e3:.1f} ms'
+    logger.info(f'    per-pixel chain on GPU: {engine.kernel_info} on resident planes')
+    logger.info(f'    per-pixel chain incl. the upload of the ancillary planes: {t_gpu * 1e3:.1f} ms'
                 f' ({length * width / t_gpu / 1e6:.0f} Mpixels/s)')
     n_valid, n_cloud_and_valid, n_not_ocean = (int(v) for v in res['counters'][0])
 
@@ -1311,39 +1368,37 @@ def generate_dswx_layers(input_list,
                     description=band_description_dict['CONF'], output_files_list=build_list,
                     no_data_value=UINT8_FILL_VALUE, ctable=_get_confidence_layer_ctable())
     if output_rgb_file or output_infrared_rgb_file:
-        # writer-side packaging (:5204-5223): the composites use the clipped reflectances
-        invalid_mask = res['diag'] == DIAGNOSTIC_LAYER_NO_DATA_BINARY_REPR
-        clipped = {k: (np.clip(image[k], 1, None) if FLAG_CLIP_NEGATIVE_REFLECTANCE else image[k])
-                   for k in ('blue', 'green', 'red', 'nir', 'swir1')}
-        if output_rgb_file:
-            _save_output_rgb_file(clipped['red'], clipped['green'], clipped['blue'], output_rgb_file,
-                                  image['offset'], image['scale'], flag_offset_and_scale_inputs, md,
-                                  geo_tags, invalid_mask, output_files_list)
-        if output_infrared_rgb_file:
-            _save_output_rgb_file(clipped['swir1'], clipped['nir'], clipped['red'],
-                                  output_infrared_rgb_file, image['offset'], image['scale'],
-                                  flag_offset_and_scale_inputs, md, geo_tags, invalid_mask,
-                                  output_files_list, flag_infrared=True)
+        # writer-side packaging (:5204-5223): the composites use the CLIPPED reflectances, scaled to float32, NaN on
+        # invalid pixels -- all of it on the device from the resident planes (dswx_rgb_planes_device); the host deflates
+        for target, keys in ((output_rgb_file, ('red', 'green', 'blue')),
+                             (output_infrared_rgb_file, ('swir1', 'nir', 'red'))):
+            if target:
+                _save_output_rgb_planes(engine, [image[k] for k in keys], res['diag'],
+                                        [image['scale'][k] for k in keys], [image['offset'][k] for k in keys],
+                                        target, md, geo_tags, output_files_list)
     if output_browse_image:
         # browse = _compute_browse_array(WTR) from the kernel; full-res GeoTIFF + resized PNG
         # (:5301-5349)
         browse_tif = output_browse_image.replace('.png', '.tif')
+        browse_ctable = _get_browse_ctable(collapse, pick(not_water_in_browse, 'not_water_in_browse'),
+                                           pick(cloud_in_browse, 'cloud_in_browse'),
+                                           pick(snow_in_browse, 'snow_in_browse'))
         _save_array(res['browse'], browse_tif, md, geo_tags, output_files_list=output_files_list,
-                    no_data_value=UINT8_FILL_VALUE,
-                    ctable=_get_browse_ctable(collapse, pick(not_water_in_browse, 'not_water_in_browse'),
-                                              pick(cloud_in_browse, 'cloud_in_browse'),
-                                              pick(snow_in_browse, 'snow_in_browse')))
-        writes.flush()                                # the PNG is rendered from the browse GeoTIFF
-        geotiff2png(browse_tif, output_browse_image,
-                    output_height=pick(browse_image_height, 'browse_image_height'),
-                    output_width=pick(browse_image_width, 'browse_image_width'), logger=logger)
+                    no_data_value=UINT8_FILL_VALUE, ctable=browse_ctable)
+        # the PNG is what geotiff2png renders from that GeoTIFF (:5335-5349) -- from the plane itself, without the read back
+        browse_png_job = _browse_png_job(res['browse'], browse_ctable, UINT8_FILL_VALUE, output_browse_image,
+                                         pick(browse_image_height, 'browse_image_height'),
+                                         pick(browse_image_width, 'browse_image_width'))
+        _run_or_defer(browse_png_job)
         output_files_list.append(output_browse_image)
     if output_file and not output_file.endswith('.vrt'):
         # the multi-band file carries the post-aerosol WTR-1 (in-place remap, :5260 -> :5389)
         # CONF is NOT passed (:5383-5397): the loop skips it and the bands after BWTR move up one (see there)
-        save_dswx_product({'WTR': res['wtr'], 'BWTR': res['bwtr'], 'DIAG': res['diag'],
-                           'WTR-1': res['wtr1_aerosol'], 'WTR-2': res['wtr2'],
-                           'LAND': landcover_mask, 'SHAD': shadow_layer, 'CLOUD': res['cloud'], 'DEM': dem},
+        host = {n: res[k].numpy() for n, k in (('WTR', 'wtr'), ('BWTR', 'bwtr'), ('DIAG', 'diag'), ('WTR-1', 'wtr1_aerosol'),
+                                               ('WTR-2', 'wtr2'), ('CLOUD', 'cloud'))}
+        save_dswx_product({'WTR': host['WTR'], 'BWTR': host['BWTR'], 'DIAG': host['DIAG'],
+                           'WTR-1': host['WTR-1'], 'WTR-2': host['WTR-2'],
+                           'LAND': landcover_mask, 'SHAD': shadow_layer, 'CLOUD': host['CLOUD'], 'DEM': dem},
                           output_file, md, geo_tags, output_files_list=output_files_list)
     elif output_file:
         logger.warning(f'VRT output "{output_file}" skipped: needs GDAL')

@@ -23,10 +23,13 @@ way, :2256-2258 -> :2668).  BigTIFF and LZW are not supported.
 """
 import os
 import struct
+import time
 import zlib
 from xml.sax.saxutils import escape, unescape
 
 import numpy as np
+
+from . import stages
 
 TAG_NEW_SUBFILE_TYPE = 254
 TAG_WIDTH, TAG_LENGTH, TAG_BITS, TAG_COMPRESSION, TAG_PHOTOMETRIC = 256, 257, 258, 259, 262
@@ -113,140 +116,215 @@ def _parse_metadata_xml(text):
     return meta, desc
 
 
+class TiffDirectory:
+    """One image file directory of a TIFF file, parsed and ready to decode: the file's bytes, what `gdal.Open` would
+    report (`info`), and the block geometry.  Decoding is two steps so that the second can run on the GPU
+    (proteus_amd.pipeline): inflate() puts every block -- inflated, still predictor-encoded, still in block order -- into
+    one staging buffer [n_blocks][block_bytes] (native threads, proteus_amd.codec), untile() undoes the predictor and
+    moves the blocks into the row-major raster."""
+
+    def __init__(self, path, overview=None):
+        self.path = path
+        with stages.span('read: file'), open(path, 'rb') as fh:
+            buf = fh.read()
+        self.buf = buf
+        if len(buf) < 8:
+            raise GeoTiffError(f'{path}: not a TIFF file')
+        if buf[:2] == b'II':
+            e = '<'
+        elif buf[:2] == b'MM':
+            e = '>'
+        else:
+            raise GeoTiffError(f'{path}: not a TIFF file')
+        self.e = e
+        magic, ifd = struct.unpack(e + 'HI', buf[2:8])
+        if magic == 43:
+            raise GeoTiffError(f'{path}: BigTIFF is not supported')
+        if magic != 42:
+            raise GeoTiffError(f'{path}: not a TIFF file')
+        for _ in range(0 if overview is None else overview + 1):
+            (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
+            (ifd,) = struct.unpack(e + 'I', buf[ifd + 2 + 12 * n: ifd + 6 + 12 * n])
+            if not ifd:
+                raise GeoTiffError(f'{path}: no overview {overview}')
+        (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
+        tags = {}
+        for k in range(n):
+            ent = buf[ifd + 2 + 12 * k: ifd + 14 + 12 * k]
+            tag, typ, count = struct.unpack(e + 'HHI', ent[:8])
+            if typ not in _TYPE_SIZE:
+                continue
+            size = _TYPE_SIZE[typ] * count
+            if size <= 4:
+                raw = ent[8:8 + size]
+            else:
+                (off,) = struct.unpack(e + 'I', ent[8:12])
+                raw = buf[off:off + size]
+            if typ == 2:
+                vals = raw.rstrip(b'\x00').decode('latin-1')
+            elif typ in (5, 10):
+                flat = struct.unpack(e + _TYPE_FMT[typ][0] * (2 * count), raw)
+                vals = [flat[2 * i] / flat[2 * i + 1] if flat[2 * i + 1] else 0.0
+                        for i in range(count)]
+            else:
+                vals = list(struct.unpack(e + _TYPE_FMT[typ] * count, raw))
+            tags[tag] = (typ, vals)
+        self.tags = tags
+
+        def one(tag, default=None):
+            if tag not in tags:
+                return default
+            v = tags[tag][1]
+            return v if isinstance(v, str) else v[0]
+
+        info = self.info = GeoTiffInfo()
+        info.width, info.height = one(TAG_WIDTH), one(TAG_LENGTH)
+        self.spp = spp = one(TAG_SAMPLES, 1)
+        info.bands = spp
+        bits = one(TAG_BITS, 1)
+        fmt = one(TAG_SAMPLE_FORMAT, 1)
+        info.dtype = _dtype_of(bits, fmt)
+        self.comp = comp = one(TAG_COMPRESSION, 1)
+        if comp not in (1, 8, 32946):
+            raise GeoTiffError(f'{path}: compression {comp} is not supported')
+        self.predictor = predictor = one(TAG_PREDICTOR, 1)
+        self.planar = planar = one(TAG_PLANAR, 1)
+        if predictor not in (1, 2, 3) or (predictor == 3 and fmt != 3):
+            raise GeoTiffError(f'{path}: predictor {predictor} is not supported')
+        self.dt = info.dtype.newbyteorder(e)
+        H, W = info.height, info.width
+        self.tiled = tiled = TAG_TILE_OFFSETS in tags
+        if tiled:
+            self.bw, self.bh = one(TAG_TILE_W), one(TAG_TILE_L)
+            self.offs, self.cnts = tags[TAG_TILE_OFFSETS][1], tags[TAG_TILE_COUNTS][1]
+        else:
+            self.bw, self.bh = W, min(one(TAG_ROWS_PER_STRIP, H), H)
+            self.offs, self.cnts = tags[TAG_STRIP_OFFSETS][1], tags[TAG_STRIP_COUNTS][1]
+        if not self.bw or not self.bh:
+            raise GeoTiffError(f'{path}: empty block size')
+        self.across, self.down = (W + self.bw - 1) // self.bw, (H + self.bh - 1) // self.bh
+        self.planes = spp if planar == 2 else 1
+        self.chunk_spp = 1 if planar == 2 else spp
+        self.n_blocks = self.planes * self.across * self.down
+        self.block_bytes = self.bh * self.bw * self.chunk_spp * self.dt.itemsize
+        if len(self.offs) < self.n_blocks or len(self.cnts) < self.n_blocks:
+            raise GeoTiffError(f'{path}: truncated block table')
+
+        nod = one(TAG_GDAL_NODATA)
+        if nod is not None:
+            try:
+                info.nodata = float(nod.strip())
+            except ValueError:
+                info.nodata = None
+        if TAG_GDAL_METADATA in tags:
+            info.metadata, desc = _parse_metadata_xml(tags[TAG_GDAL_METADATA][1])
+            info.descriptions = [desc.get(i, '') for i in range(spp)]
+        else:
+            info.descriptions = [''] * spp
+        for t in GEO_TAGS:
+            if t in tags:
+                info.geo_tags[t] = tags[t]
+        if TAG_COLORMAP in tags:
+            cm = np.asarray(tags[TAG_COLORMAP][1], dtype=np.uint32).reshape(3, -1)
+            info.colormap = (cm >> 8).astype(np.uint8).T
+
+    # what a block of the last row of strips really holds (a tile is always whole)
+    def _rows_of(self, by):
+        return self.bh if self.tiled else min(self.bh, self.info.height - by * self.bh)
+
+    def inflate(self, staging=None, alloc=None):
+        """Every block, inflated (or copied, for an uncompressed file), at staging[i * block_bytes] in block order
+        (plane-major, then row-major).  `staging`: uint8-viewable, C-contiguous, >= n_blocks * block_bytes bytes, or
+        None (allocated, through alloc(shape, dtype) if given).  Bytes of a block beyond what the file holds for it
+        (the short last strip) are zero."""
+        need = self.n_blocks * self.block_bytes
+        if staging is None:
+            staging = np.empty(need, dtype=np.uint8) if alloc is None else alloc((need,), np.uint8)
+        raw = staging.reshape(-1).view(np.uint8)
+        if raw.size < need:
+            raise GeoTiffError('staging buffer too small')
+        offs = np.asarray(self.offs[:self.n_blocks], dtype=np.int64)
+        cnts = np.asarray(self.cnts[:self.n_blocks], dtype=np.int64)
+        if self.n_blocks and (int((offs + cnts).max()) > len(self.buf) or int(offs.min()) < 0):
+            raise GeoTiffError(f'{self.path}: block table points outside the file')
+        if self.comp == 1:
+            with stages.span('read: copy blocks'):
+                src = np.frombuffer(self.buf, dtype=np.uint8)
+                for i in range(self.n_blocks):
+                    n = min(int(cnts[i]), self.block_bytes)
+                    raw[i * self.block_bytes: i * self.block_bytes + n] = src[offs[i]: offs[i] + n]
+                    raw[i * self.block_bytes + n: (i + 1) * self.block_bytes] = 0
+            return staging
+        with stages.span('read: inflate'):
+            short = not self.tiled and self.info.height % self.bh
+            if short:           # the last strip of every plane inflates to fewer bytes: the rest of its slot is zero
+                per_plane = self.across * self.down
+                for p in range(self.planes):
+                    i = p * per_plane + per_plane - 1
+                    raw[i * self.block_bytes: (i + 1) * self.block_bytes] = 0
+            native = _codec()
+            if native is not None:
+                try:
+                    native.inflate_into(self.buf, offs, cnts, raw[:need], self.block_bytes)
+                except native.CodecError as e:
+                    raise GeoTiffError(f'{self.path}: {e}')
+            else:
+                def one_block(i):
+                    data = zlib.decompress(self.buf[offs[i]: offs[i] + cnts[i]])[:self.block_bytes]
+                    raw[i * self.block_bytes: i * self.block_bytes + len(data)] = np.frombuffer(data, dtype=np.uint8)
+                pool = _io_pool() if self.n_blocks > 1 else None
+                if pool:
+                    list(pool.map(one_block, range(self.n_blocks)))
+                else:
+                    for i in range(self.n_blocks):
+                        one_block(i)
+        return staging
+
+    def untile(self, staging, out=None, alloc=None):
+        """staging (inflate()) -> [spp, H, W] in the file's sample type, native byte order: inverse predictor over every
+        block row, blocks moved to their windows.  Whole-array numpy operations (the GPU pipeline does the same on the
+        device: dswx_untile_device)."""
+        info = self.info
+        H, W, spp = info.height, info.width, self.spp
+        if out is None:
+            out = np.zeros((spp, H, W), dtype=info.dtype) if alloc is None else alloc((spp, H, W), info.dtype)
+        with stages.span('read: predictor + untile'):
+            raw = staging.reshape(-1).view(np.uint8)[:self.n_blocks * self.block_bytes]
+            rows_all = self.n_blocks * self.bh
+            n = self.bw * self.chunk_spp
+            if self.predictor == 3:
+                blk = _fp_predictor_decode(raw, rows_all, n, self.chunk_spp, info.dtype)
+            else:
+                blk = raw.view(self.dt).reshape(rows_all, self.bw, self.chunk_spp)
+                if self.dt.byteorder not in ('=', '|') and self.dt != info.dtype:
+                    blk = blk.astype(info.dtype)
+                if self.predictor == 2:
+                    blk = np.cumsum(blk, axis=1, dtype=info.dtype)
+            blk = blk.reshape(self.planes, self.down, self.across, self.bh, self.bw, self.chunk_spp)
+            # [planes, down, bh, across, bw, spp'] -> rows x columns of the padded raster
+            full = blk.transpose(0, 1, 3, 2, 4, 5).reshape(self.planes, self.down * self.bh, self.across * self.bw,
+                                                            self.chunk_spp)[:, :H, :W, :]
+            if self.planar == 2 or spp == 1:
+                out[...] = full[..., 0]
+            else:
+                out[...] = np.moveaxis(full[0], 2, 0)
+        return out
+
+
+def open_geotiff(path, overview=None):
+    return TiffDirectory(path, overview)
+
+
 def read_geotiff(path, window=None, overview=None, alloc=None):
     """Returns (array, GeoTiffInfo).  array is [H,W] for one band, [B,H,W] otherwise.
     window = (xoff, yoff, xsize, ysize) crops after decoding (the reference's
     flag_debug read, :2187-2190).  overview = k reads the k-th internal overview
     (IFD k + 1) instead of the full-resolution image.  alloc(shape, dtype) -> ndarray lets the
     caller own the destination memory (e.g. page-locked host memory for the GPU path)."""
-    with open(path, 'rb') as fh:
-        buf = fh.read()
-    if len(buf) < 8:
-        raise GeoTiffError(f'{path}: not a TIFF file')
-    if buf[:2] == b'II':
-        e = '<'
-    elif buf[:2] == b'MM':
-        e = '>'
-    else:
-        raise GeoTiffError(f'{path}: not a TIFF file')
-    magic, ifd = struct.unpack(e + 'HI', buf[2:8])
-    if magic == 43:
-        raise GeoTiffError(f'{path}: BigTIFF is not supported')
-    if magic != 42:
-        raise GeoTiffError(f'{path}: not a TIFF file')
-    for _ in range(0 if overview is None else overview + 1):
-        (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
-        (ifd,) = struct.unpack(e + 'I', buf[ifd + 2 + 12 * n: ifd + 6 + 12 * n])
-        if not ifd:
-            raise GeoTiffError(f'{path}: no overview {overview}')
-    (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
-    tags = {}
-    for k in range(n):
-        ent = buf[ifd + 2 + 12 * k: ifd + 14 + 12 * k]
-        tag, typ, count = struct.unpack(e + 'HHI', ent[:8])
-        if typ not in _TYPE_SIZE:
-            continue
-        size = _TYPE_SIZE[typ] * count
-        if size <= 4:
-            raw = ent[8:8 + size]
-        else:
-            (off,) = struct.unpack(e + 'I', ent[8:12])
-            raw = buf[off:off + size]
-        if typ == 2:
-            vals = raw.rstrip(b'\x00').decode('latin-1')
-        elif typ in (5, 10):
-            flat = struct.unpack(e + _TYPE_FMT[typ][0] * (2 * count), raw)
-            vals = [flat[2 * i] / flat[2 * i + 1] if flat[2 * i + 1] else 0.0
-                    for i in range(count)]
-        else:
-            vals = list(struct.unpack(e + _TYPE_FMT[typ] * count, raw))
-        tags[tag] = (typ, vals)
-
-    def one(tag, default=None):
-        if tag not in tags:
-            return default
-        v = tags[tag][1]
-        return v if isinstance(v, str) else v[0]
-
-    info = GeoTiffInfo()
-    info.width, info.height = one(TAG_WIDTH), one(TAG_LENGTH)
-    spp = one(TAG_SAMPLES, 1)
-    info.bands = spp
-    bits = one(TAG_BITS, 1)
-    fmt = one(TAG_SAMPLE_FORMAT, 1)
-    info.dtype = _dtype_of(bits, fmt)
-    comp = one(TAG_COMPRESSION, 1)
-    if comp not in (1, 8, 32946):
-        raise GeoTiffError(f'{path}: compression {comp} is not supported')
-    predictor = one(TAG_PREDICTOR, 1)
-    planar = one(TAG_PLANAR, 1)
-    if predictor not in (1, 2, 3) or (predictor == 3 and fmt != 3):
-        raise GeoTiffError(f'{path}: predictor {predictor} is not supported')
-    dt = info.dtype.newbyteorder(e)
-    H, W = info.height, info.width
-
-    tiled = TAG_TILE_OFFSETS in tags
-    if tiled:
-        bw, bh = one(TAG_TILE_W), one(TAG_TILE_L)
-        offs, cnts = tags[TAG_TILE_OFFSETS][1], tags[TAG_TILE_COUNTS][1]
-    else:
-        bw, bh = W, min(one(TAG_ROWS_PER_STRIP, H), H)
-        offs, cnts = tags[TAG_STRIP_OFFSETS][1], tags[TAG_STRIP_COUNTS][1]
-    across, down = (W + bw - 1) // bw, (H + bh - 1) // bh
-    planes = spp if planar == 2 else 1
-    chunk_spp = 1 if planar == 2 else spp
-    out = np.zeros((spp, H, W), dtype=info.dtype) if alloc is None else alloc((spp, H, W), info.dtype)
-    if len(offs) < planes * across * down:
-        raise GeoTiffError(f'{path}: truncated block table')
-    def decode(idx):
-        # blocks write disjoint windows of `out`: safe to run concurrently
-        p, rem = divmod(idx, across * down)
-        by, bx = divmod(rem, across)
-        raw = buf[offs[idx]: offs[idx] + cnts[idx]]
-        if comp != 1:
-            raw = zlib.decompress(raw)
-        rows = bh if tiled else min(bh, H - by * bh)
-        need = rows * bw * chunk_spp * dt.itemsize
-        if predictor == 3:
-            blk = _fp_predictor_decode(np.frombuffer(raw[:need], dtype=np.uint8), rows, bw * chunk_spp,
-                                       chunk_spp, info.dtype).reshape(rows, bw, chunk_spp)
-        else:
-            blk = np.frombuffer(raw[:need], dtype=dt).reshape(rows, bw, chunk_spp)
-        if predictor == 2:
-            blk = np.cumsum(blk.astype(info.dtype), axis=1, dtype=info.dtype)
-        y0, x0 = by * bh, bx * bw
-        hh, ww = min(rows, H - y0), min(bw, W - x0)
-        if planar == 2:
-            out[p, y0:y0 + hh, x0:x0 + ww] = blk[:hh, :ww, 0]
-        else:
-            out[:, y0:y0 + hh, x0:x0 + ww] = np.moveaxis(blk[:hh, :ww, :], 2, 0)
-
-    n_blocks = planes * across * down
-    pool = _io_pool() if (comp != 1 and n_blocks > 1) else None
-    if pool:
-        list(pool.map(decode, range(n_blocks)))
-    else:
-        for i in range(n_blocks):
-            decode(i)
-
-    nod = one(TAG_GDAL_NODATA)
-    if nod is not None:
-        try:
-            info.nodata = float(nod.strip())
-        except ValueError:
-            info.nodata = None
-    if TAG_GDAL_METADATA in tags:
-        info.metadata, desc = _parse_metadata_xml(tags[TAG_GDAL_METADATA][1])
-        info.descriptions = [desc.get(i, '') for i in range(spp)]
-    else:
-        info.descriptions = [''] * spp
-    for t in GEO_TAGS:
-        if t in tags:
-            info.geo_tags[t] = tags[t]
-    if TAG_COLORMAP in tags:
-        cm = np.asarray(tags[TAG_COLORMAP][1], dtype=np.uint32).reshape(3, -1)
-        info.colormap = (cm >> 8).astype(np.uint8).T
-    arr = out[0] if spp == 1 else out
+    d = TiffDirectory(path, overview)
+    out = d.untile(d.inflate(), alloc=alloc)
+    info = d.info
+    arr = out[0] if d.spp == 1 else out
     if window is not None:
         xo, yo, xs, ys = window
         arr = arr[..., yo:yo + ys, xo:xo + xs]
@@ -386,33 +464,76 @@ def _io_pool():
     return _pool
 
 
-def _encode_blocks(arr, tile, compress, predictor):
-    """[B,H,W] -> list of encoded tile blocks (band-major, row-major)."""
+_codec_state = {'mod': None, 'tried': False}
+
+
+def _codec():
+    """proteus_amd.codec (native DEFLATE on a thread pool) or None -- said once on stderr -- when its library can be
+    neither loaded nor built (no C++ compiler): Python's zlib on Python threads then writes the same files, slower."""
+    if not _codec_state['tried']:
+        _codec_state['tried'] = True
+        try:
+            from . import codec
+            codec.load()
+            _codec_state['mod'] = codec
+        except Exception as e:                  # noqa: BLE001
+            import sys
+            print(f'[dswx geotiff] native codec unavailable ({type(e).__name__}: {str(e)[:200]}); using the zlib module',
+                  file=sys.stderr, flush=True)
+    return _codec_state['mod']
+
+
+class BlockedLevel:
+    """One resolution level of a raster as the TIFF writer stores it: `data` = uint8 [n_blocks * block_bytes], the
+    tile x tile blocks (band-major, then row-major; edge blocks zero-padded) with the predictor already applied, little
+    endian.  blocked_level() makes one on the host; the GPU pipeline makes them on the device (dswx_cog_blocks_device)."""
+
+    def __init__(self, height, width, bands, dtype, tile, predictor, data):
+        self.height, self.width, self.bands = int(height), int(width), int(bands)
+        self.dtype, self.tile, self.predictor, self.data = np.dtype(dtype), int(tile), int(predictor), data
+        self.across, self.down = (self.width + tile - 1) // tile, (self.height + tile - 1) // tile
+        self.block_bytes = tile * tile * self.dtype.itemsize
+        self.n_blocks = self.bands * self.across * self.down
+
+
+def blocked_level(arr, tile, predictor):
+    """[B,H,W] -> BlockedLevel (whole-array numpy operations)."""
     B, H, W = arr.shape
     dt = arr.dtype.newbyteorder('<')
     across, down = (W + tile - 1) // tile, (H + tile - 1) // tile
-
-    def encode(idx):
-        b, rem = divmod(idx, across * down)
-        by, bx = divmod(rem, across)
-        blk = np.zeros((tile, tile), dtype=dt)
-        y0, x0 = by * tile, bx * tile
-        hh, ww = min(tile, H - y0), min(tile, W - x0)
-        blk[:hh, :ww] = arr[b, y0:y0 + hh, x0:x0 + ww]
+    with stages.span('write: tile + predictor'):
+        pad = np.zeros((B, down * tile, across * tile), dtype=dt)
+        pad[:, :H, :W] = arr
+        blk = np.ascontiguousarray(pad.reshape(B, down, tile, across, tile).transpose(0, 1, 3, 2, 4))
         if predictor == 2:
             d = blk.copy()
-            d[:, 1:] = blk[:, 1:] - blk[:, :-1]
+            d[..., 1:] -= blk[..., :-1]              # integer arithmetic wraps, as libtiff's horizontal differencing does
             blk = d
-        raw = _fp_predictor_encode(blk) if predictor == 3 else blk.tobytes()
-        return zlib.compress(raw, 6) if compress else raw
+        if predictor == 3:
+            data = np.frombuffer(_fp_predictor_encode(blk.reshape(-1, tile)), dtype=np.uint8)
+        else:
+            data = blk.reshape(-1).view(np.uint8)
+    return BlockedLevel(H, W, B, arr.dtype, tile, predictor, data)
 
-    n = B * across * down
-    pool = _io_pool() if (compress and n > 1) else None
-    return list(pool.map(encode, range(n))) if pool else [encode(i) for i in range(n)]
+
+def _encode_level(level, compress):
+    """BlockedLevel -> list of the encoded blocks (buffer objects), in block order."""
+    bb, n = level.block_bytes, level.n_blocks
+    raw = level.data.reshape(-1).view(np.uint8)
+    if not compress:
+        return [raw[i * bb:(i + 1) * bb] for i in range(n)]
+    with stages.span('write: deflate'):
+        native = _codec()
+        if native is not None:
+            out, offs, sizes = native.deflate_uniform(raw[:n * bb], bb, 6)
+            return [out[o:o + k] for o, k in zip(offs.tolist(), sizes.tolist())]
+        pool = _io_pool() if n > 1 else None
+        enc = lambda i: zlib.compress(raw[i * bb:(i + 1) * bb], 6)      # noqa: E731
+        return list(pool.map(enc, range(n))) if pool else [enc(i) for i in range(n)]
 
 
 def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
-                  descriptions=None, colormap=None, tile=512, compress=True, overviews=None):
+                  descriptions=None, colormap=None, tile=512, compress=True, overviews=None, levels=None):
     """array: [H,W] or [B,H,W] (planar multi-band).  colormap: {value: (r,g,b[,a])} or
     [256][3] (single-band u8 only).  NaN nodata is written as 'nan' like GDAL does.
 
@@ -422,21 +543,38 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
     smallest overview ... the largest overview, the full-resolution image last; 512 x 512 tiles,
     DEFLATE; integer types: NEAREST overviews + PREDICTOR=2, floating point: CUBICSPLINE
     overviews (cascaded, as GDAL builds them) + PREDICTOR=3 (core.py:37-46, :66-69).
+    `levels`: instead of `array` (pass None), the full-resolution image and its overviews ALREADY tiled and
+    predictor-encoded (list of BlockedLevel, level 0 first: what dswx_cog_blocks_device leaves in page-locked
+    memory) -- the host then only deflates.
     The file is written under a temporary name and renamed when complete, so a reader (or the
     batch driver's --skip-existing) never sees a truncated product."""
-    arr = np.asarray(array)
-    if arr.ndim == 2:
-        arr = arr[None]
-    if arr.ndim != 3:
-        raise GeoTiffError('array must be [H,W] or [B,H,W]')
-    if arr.dtype == np.bool_:
-        arr = arr.astype(np.uint8)
-    B = arr.shape[0]
-    kind = {'u': 1, 'i': 2, 'f': 3}.get(arr.dtype.kind)
-    if kind is None or arr.dtype.itemsize not in (1, 2, 4, 8):
-        raise GeoTiffError(f'unsupported dtype {arr.dtype}')
-    predictor = (3 if (kind == 3 and arr.dtype.itemsize in (4, 8)) else 2) if compress else 1
-    palette = colormap is not None and B == 1 and arr.dtype == np.uint8
+    if levels is not None:
+        if array is not None or not levels:
+            raise GeoTiffError('pass either `array` or a non-empty `levels`')
+        lv0 = levels[0]
+        B, dtype = lv0.bands, lv0.dtype
+        tile = lv0.tile
+        predictor = lv0.predictor if compress else 1
+        if any(lv.tile != tile or lv.bands != B or lv.dtype != dtype or lv.predictor != lv0.predictor for lv in levels):
+            raise GeoTiffError('levels disagree about tile / bands / dtype / predictor')
+        if not compress and lv0.predictor != 1:
+            raise GeoTiffError('predictor-encoded levels need compress=True')
+        kind = {'u': 1, 'i': 2, 'f': 3}.get(dtype.kind)
+    else:
+        arr = np.asarray(array)
+        if arr.ndim == 2:
+            arr = arr[None]
+        if arr.ndim != 3:
+            raise GeoTiffError('array must be [H,W] or [B,H,W]')
+        if arr.dtype == np.bool_:
+            arr = arr.astype(np.uint8)
+        B, dtype = arr.shape[0], arr.dtype
+        kind = {'u': 1, 'i': 2, 'f': 3}.get(dtype.kind)
+    if kind is None or dtype.itemsize not in (1, 2, 4, 8):
+        raise GeoTiffError(f'unsupported dtype {dtype}')
+    if levels is None:
+        predictor = (3 if (kind == 3 and dtype.itemsize in (4, 8)) else 2) if compress else 1
+    palette = colormap is not None and B == 1 and dtype == np.uint8
     cm_values = None
     if palette:
         cm = np.zeros((256, 3), dtype=np.uint32)
@@ -451,24 +589,35 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
         nodata_text = 'nan' if (isinstance(nodata, float) and np.isnan(nodata)) else \
             (str(int(nodata)) if float(nodata).is_integer() else repr(float(nodata)))
 
-    # level 0 = full resolution, then the overviews by descending size
-    levels = [arr]
-    prev_f = 1
-    for f in (overviews or ()):
-        if f > 1 and (arr.shape[1] > 1 or arr.shape[2] > 1):
-            if kind == 3:
-                # cascade: level f from the previous level when it divides evenly (GDAL's
-                # GDALRegenerateCascadingOverviews), else from the full-resolution image
-                lv = overview_cubicspline(levels[-1], int(f) // prev_f) if (prev_f > 1 and int(f) % prev_f == 0) \
-                    else overview_cubicspline(arr, int(f))
-                want = ((arr.shape[1] + int(f) - 1) // int(f), (arr.shape[2] + int(f) - 1) // int(f))
-                if lv.shape[1:] != want:          # ceil of a ceil can differ by one: take it from the full image
-                    lv = overview_cubicspline(arr, int(f))
-                levels.append(lv)
-                prev_f = int(f)
-            else:
-                levels.append(overview_nearest(arr, int(f)))
-    level_blocks = [_encode_blocks(lv, tile, compress, predictor) for lv in levels]
+    if levels is None:
+        # level 0 = full resolution, then the overviews by descending size
+        rasters = [arr]
+        prev_f = 1
+        t_ovr = time.perf_counter()
+        for f in (overviews or ()):
+            if f > 1 and (arr.shape[1] > 1 or arr.shape[2] > 1):
+                if kind == 3:
+                    # cascade: level f from the previous level when it divides evenly (GDAL's
+                    # GDALRegenerateCascadingOverviews), else from the full-resolution image
+                    lv = overview_cubicspline(rasters[-1], int(f) // prev_f) if (prev_f > 1 and int(f) % prev_f == 0) \
+                        else overview_cubicspline(arr, int(f))
+                    want = ((arr.shape[1] + int(f) - 1) // int(f), (arr.shape[2] + int(f) - 1) // int(f))
+                    if lv.shape[1:] != want:          # ceil of a ceil can differ by one: take it from the full image
+                        lv = overview_cubicspline(arr, int(f))
+                    rasters.append(lv)
+                    prev_f = int(f)
+                else:
+                    rasters.append(overview_nearest(arr, int(f)))
+        if overviews:
+            stages.add('write: overviews (CUBICSPLINE)' if kind == 3 else 'write: overviews (NEAREST)', t_ovr, time.perf_counter())
+        levels = [blocked_level(r, tile, predictor) for r in rasters]
+    level_blocks = [_encode_level(lv, compress) for lv in levels]
+
+    class _Shape:           # what entries_of reads of a level: [bands, height, width]
+        def __init__(self, lv):
+            self.shape = (lv.bands, lv.height, lv.width)
+    levels = [_Shape(lv) for lv in levels]
+    itemsize = dtype.itemsize
 
     def entries_of(k):
         lv = levels[k]
@@ -476,7 +625,7 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
         if k > 0:
             ent.append((TAG_NEW_SUBFILE_TYPE, 4, [1]))       # reduced-resolution image
         ent += [(TAG_WIDTH, 4, [lv.shape[2]]), (TAG_LENGTH, 4, [lv.shape[1]]),
-                (TAG_BITS, 3, [arr.dtype.itemsize * 8] * B),
+                (TAG_BITS, 3, [itemsize * 8] * B),
                 (TAG_COMPRESSION, 3, [8 if compress else 1]),
                 (TAG_PHOTOMETRIC, 3, [3 if palette else 1]),
                 (TAG_SAMPLES, 3, [B]), (TAG_PLANAR, 3, [2 if B > 1 else 1])]
@@ -528,8 +677,8 @@ def write_geotiff(path, array, *, geo_tags=None, metadata=None, nodata=None,
         block_offs[k] = offs
     if cursor >= 2 ** 32:
         raise GeoTiffError('file would exceed 4 GiB (BigTIFF not supported)')
-    tmp_path = f'{path}.{os.getpid()}.{id(arr):x}.tmp'
-    with open(tmp_path, 'wb') as fh:
+    tmp_path = f'{path}.{os.getpid()}.{id(level_blocks):x}.tmp'
+    with stages.span('write: file'), open(tmp_path, 'wb') as fh:
         fh.write(struct.pack('<2sHI', b'II', 42, ifd_offs[0]))
         for k, ent in enumerate(all_entries):
             fh.write(struct.pack('<H', len(ent)))

@@ -1,0 +1,267 @@
+"""The product run on the device between the two codecs.
+
+    band files --inflate (host threads, proteus_amd.codec)--> blocks in page-locked memory
+        --copy engine--> HBM --dswx_untile_device--> planes
+        --dswx_classify_device_2d--> layers (HBM)
+        --dswx_cog_blocks_device (blocks + NEAREST overviews + predictor) / dswx_rgb_planes_device--> HBM
+        --copy engine--> page-locked memory --deflate (host threads)--> GeoTIFF / COG
+
+The host touches pixels only inside the DEFLATE codec; everything else the reference's GDAL calls do to a raster
+(`ReadAsArray`, `save_as_cog`: core.py:7-91) is byte shuffling that runs in HBM.  One TileEngine per context; its
+lock serialises the GPU part (milliseconds per tile), so that several tiles can be IN FLIGHT in one process -- tile
+k + 1 inflating and tile k - 1 deflating on host threads while tile k is on the device (proteus_amd.batch) -- with one
+HIP context per GPU.
+
+No fallback hides here: a file layout the device kernels do not take (floating-point predictor, several samples per
+pixel, big endian) is untiled by the host reader (geotiff.TiffDirectory.untile, the same bytes) and uploaded; the
+classification itself has no host form anywhere.
+"""
+import ctypes
+import threading
+import time
+
+import numpy as np
+
+from . import _capi, geotiff, stages
+
+
+class DevicePlane:
+    """A raster in HBM: device pointer + shape + dtype.  The memory goes back to the engine's pool when the object dies."""
+
+    def __init__(self, engine, buf, shape, dtype):
+        self.engine, self.buf = engine, buf
+        self.shape, self.dtype = tuple(int(v) for v in shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self._host = None
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    def numpy(self):
+        """The raster on the host (copied once, then kept)."""
+        if self._host is None:
+            self._host = self.engine.download(self)
+        return self._host
+
+    def release(self):
+        if self.buf is not None:
+            self.engine._give(self.buf)
+            self.buf = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:           # noqa: BLE001
+            pass
+
+
+class TileEngine:
+    POOL_CAP = 6 << 30          # bytes of released device buffers kept for the next tile
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lock = threading.RLock()
+        self._free = {}                     # nbytes -> [DeviceBuffer]
+        self._free_bytes = 0
+        self._pool_lock = threading.Lock()
+
+    # ---- device memory ------------------------------------------------------------------------------------
+    @staticmethod
+    def _round(nbytes):
+        return max((int(nbytes) + 0xffff) & ~0xffff, 1 << 16)
+
+    def _take(self, nbytes):
+        n = self._round(nbytes)
+        with self._pool_lock:
+            spare = self._free.get(n)
+            if spare:
+                self._free_bytes -= n
+                return spare.pop()
+        with self.lock:
+            return self.ctx.malloc(n)
+
+    def _give(self, buf):
+        with self._pool_lock:
+            if self.ctx.handle and self._free_bytes + buf.nbytes <= self.POOL_CAP:
+                self._free.setdefault(buf.nbytes, []).append(buf)
+                self._free_bytes += buf.nbytes
+                return
+        buf.free()
+
+    def close(self):
+        with self._pool_lock:
+            spare, self._free, self._free_bytes = self._free, {}, 0
+        for bufs in spare.values():
+            for b in bufs:
+                b.free()
+
+    def plane(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        return DevicePlane(self, self._take(int(np.prod(shape, dtype=np.int64)) * dtype.itemsize), shape, dtype)
+
+    def upload(self, arr):
+        """numpy raster -> DevicePlane (through page-locked memory)."""
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype == np.bool_:
+            arr = arr.view(np.uint8)
+        p = self.plane(arr.shape, arr.dtype)
+        pinned = arr if self.ctx.is_pinned(arr) else None
+        if pinned is None:
+            pinned = self.ctx.pinned_empty(arr.shape, arr.dtype)
+            np.copyto(pinned, arr)
+        with self.lock, stages.span('gpu: upload'):
+            self.ctx.h2d_async(p.ptr, pinned)
+            self.ctx.synchronize()
+        return p
+
+    def download(self, plane):
+        out = self.ctx.pinned_empty(plane.shape, plane.dtype)
+        with self.lock, stages.span('gpu: download'):
+            self.ctx.d2h_async(out, plane.ptr, plane.nbytes)
+            self.ctx.synchronize()
+        return out
+
+    # ---- reader side ----------------------------------------------------------------------------------------
+    def device_untile_ok(self, d):
+        return (d.spp == 1 and d.predictor in (1, 2) and d.dt.itemsize in (1, 2) and d.dt.kind in 'iu'
+                and d.dt.byteorder in ('=', '|', '<') and d.n_blocks * d.block_bytes < (1 << 32))
+
+    def read_plane(self, path):
+        """One single-band GeoTIFF -> (DevicePlane [H, W], GeoTiffInfo).  Inflate on host threads into page-locked memory;
+        predictor + untile on the device when its kernel takes the layout, else by the host reader (same bytes)."""
+        d = geotiff.open_geotiff(path)
+        info = d.info
+        if d.spp != 1:
+            raise geotiff.GeoTiffError(f'{path}: {d.spp} samples per pixel, expected a single band')
+        if not self.device_untile_ok(d):
+            return self.upload(d.untile(d.inflate())[0]), info
+        need = d.n_blocks * d.block_bytes
+        staging = self.ctx.pinned_empty((need,), np.uint8)
+        d.inflate(staging)
+        dev_blocks = self._take(need)
+        plane = self.plane((info.height, info.width), info.dtype)
+        try:
+            with self.lock, stages.span('gpu: blocks -> plane (h2d + untile)'):
+                self.ctx.h2d_async(dev_blocks.ptr, staging, need)
+                self.ctx.untile_device(dev_blocks.ptr, d.dt.itemsize, info.height, info.width, d.bw, d.bh, d.predictor, plane.ptr)
+                self.ctx.synchronize()
+        finally:
+            self._give(dev_blocks)
+        return plane, info
+
+    # ---- the classifier on resident planes --------------------------------------------------------------------
+    def classify(self, bands, fmask, params, land=None, shad=None, ocean=None, layers=()):
+        """bands: six DevicePlanes (int16 [H, W]); fmask / land / shad / ocean: DevicePlane or ndarray or None.
+        Returns {layer: DevicePlane} + 'counters' (ndarray int64 [1, 3])."""
+        H, W = bands[0].shape
+        keep = []
+
+        def dev(a, name):
+            if a is None:
+                return None
+            if not isinstance(a, DevicePlane):
+                a = np.ascontiguousarray(a, dtype=np.uint8)
+                if a.shape != (H, W):
+                    raise ValueError(f'{name} shape {a.shape} != bands shape {(H, W)}')
+                a = self.upload(a)
+            elif a.shape != (H, W):
+                raise ValueError(f'{name} shape {a.shape} != bands shape {(H, W)}')
+            keep.append(a)
+            return a
+
+        pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
+        for i, b in enumerate(bands):
+            if b.shape != (H, W) or b.dtype != np.int16:
+                raise ValueError('bands must be int16 planes of one shape')
+            pin.band[i] = b.ptr
+        pin.fmask = dev(fmask, 'fmask').ptr
+        for name, a in (('land', land), ('shad', shad), ('ocean', ocean)):
+            p = dev(a, name)
+            setattr(pin, name, p.ptr if p is not None else None)
+        res = {}
+        for name in layers:
+            if name != 'diag' and name not in _capi.U8_LAYERS:
+                raise KeyError(name)
+            res[name] = self.plane((H, W), np.uint16 if name == 'diag' else np.uint8)
+            setattr(pout, name, res[name].ptr)
+        d_cnt = self._take(256)
+        cnt = self.ctx.pinned_empty((1, 3), np.int64)
+        try:
+            with self.lock:
+                t0 = time.perf_counter()
+                self.ctx.classify_device_2d(params, 1, H, W, pin, pout, d_cnt.ptr)
+                self.ctx.d2h_async(cnt, d_cnt.ptr, 24)
+                self.ctx.synchronize()
+                stages.add('gpu: classify (resident planes)', t0, time.perf_counter())
+                self.kernel_info = self.ctx.last_kernel_info()
+        finally:
+            self._give(d_cnt)
+        res['counters'] = np.array(cnt, dtype=np.int64)
+        del keep
+        return res
+
+    # ---- writer side ----------------------------------------------------------------------------------------
+    def layer_levels(self, plane, factors=(), tile=512):
+        """DevicePlane (u8 / u16 / i16 [H, W], or float32: no factors) -> [geotiff.BlockedLevel]: the blocks of the
+        full-resolution image and of every NEAREST overview, predictor-encoded, in page-locked memory."""
+        H, W = plane.shape
+        dt = plane.dtype
+        if dt.kind == 'f':
+            if dt.itemsize != 4:
+                raise ValueError('float planes: float32 only')
+            factors, predictor = (), 3
+        else:
+            predictor = 2
+        lay = _capi.cog_layout(H, W, dt.itemsize, factors, tile)
+        total = lay['total_bytes']
+        dev_blocks = self._take(total)
+        host = self.ctx.pinned_empty((total,), np.uint8)
+        try:
+            with self.lock, stages.span('gpu: plane -> COG blocks (+ d2h)'):
+                self.ctx.cog_blocks_device(plane.ptr, dt.itemsize, H, W, dev_blocks.ptr, factors, tile, predictor)
+                self.ctx.d2h_async(host, dev_blocks.ptr, total)
+                self.ctx.synchronize()
+        finally:
+            self._give(dev_blocks)
+        out = []
+        for k, lv in enumerate(lay['levels']):
+            n = lv['blocks_down'] * lv['blocks_across'] * tile * tile * dt.itemsize
+            out.append(geotiff.BlockedLevel(lv['height'], lv['width'], 1, dt, tile, predictor,
+                                            host[lv['offset_bytes']: lv['offset_bytes'] + n]))
+        return out
+
+    def rgb_levels(self, red, green, blue, diag, scale, offset, clip, tile=512):
+        """The three-band Float32 composite of _save_output_rgb_file (dswx_hls.py:3013-3036) as ONE planar BlockedLevel
+        (bands 3, floating-point predictor): scaling on the device, NaN where `diag` carries the fill code."""
+        H, W = red.shape
+        n = H * W
+        lay = _capi.cog_layout(H, W, 4, (), tile)
+        per_band = lay['total_bytes']
+        rgb = self._take(3 * n * 4)
+        dev_blocks = self._take(3 * per_band)
+        host = self.ctx.pinned_empty((3 * per_band,), np.uint8)
+        try:
+            with self.lock, stages.span('gpu: RGB planes -> blocks (+ d2h)'):
+                self.ctx.rgb_planes_device(red.ptr, green.ptr, blue.ptr, diag.ptr if diag is not None else None, n,
+                                           scale, offset, clip, rgb.ptr)
+                for c in range(3):
+                    self.ctx.cog_blocks_device(rgb.ptr + c * n * 4, 4, H, W, dev_blocks.ptr + c * per_band, (), tile, 3)
+                self.ctx.d2h_async(host, dev_blocks.ptr, 3 * per_band)
+                self.ctx.synchronize()
+        finally:
+            self._give(rgb)
+            self._give(dev_blocks)
+        return [geotiff.BlockedLevel(H, W, 3, np.float32, tile, 3, host)]
+
+
+_engines = {}
+_engines_lock = threading.Lock()
+
+
+def engine_of(ctx):
+    with _engines_lock:
+        e = _engines.get(id(ctx))
+        if e is None or e.ctx is not ctx:
+            e = _engines[id(ctx)] = TileEngine(ctx)
+        return e

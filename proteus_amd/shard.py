@@ -77,8 +77,8 @@ class ControlPlane:
     `backend` becomes 'gloo (fallback: nccl ... failed on rank(s) [..]: <first error>)' and `rccl_ranks` is 0 -- unless
     `require=True` (bench.py --require-rccl), which raises on every rank.  RCCL is not on the data path (tiles are
     independent), so the fallback loses nothing of the measurement.  A reduction that fails over RCCL later in the run
-    is caught the same way: every reduction is followed by a one-integer agreement over gloo, and one bad rank moves all
-    ranks to gloo, where the reduction is repeated.  Barriers carry no agreement (they bracket the timed region)."""
+    is caught the same way: every reduction AND every barrier over RCCL is followed by a one-integer agreement over gloo,
+    and one bad rank moves all ranks to gloo, where a reduction is repeated (the agreement is itself a barrier)."""
 
     PROBE_TIMEOUT_S = 120.0
 
@@ -90,7 +90,6 @@ class ControlPlane:
         self.rccl_ranks = 0
         self.fast = None                # the RCCL group, when every rank's probe passed
         self.hung = False               # an RCCL call never returned: leave with os._exit, never through destroy
-        self._pending = None            # an RCCL failure seen by a barrier, folded into the next agreement
         if not (self.world > 1 or os.environ.get('DSWX_FORCE_DIST') == '1'):
             return
         import torch.distributed as dist
@@ -189,8 +188,7 @@ class ControlPlane:
         """After a reduction over RCCL: did it work on EVERY rank?  One int64 MIN over gloo; if not, all ranks move to
         gloo (the caller repeats its reduction there)."""
         import torch
-        err = my_error or self._pending
-        self._pending = None
+        err = my_error
         ok = torch.tensor([0 if err else 1], dtype=torch.int64)
         self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
@@ -203,16 +201,14 @@ class ControlPlane:
     def _reduce(self, value, dtype, op_name):
         import torch
         op = getattr(self.dist.ReduceOp, op_name)
-        if self.fast is not None or self._pending:
-            out, err = None, self._pending
-            if self.fast is not None:
-                group = self.fast
+        if self.fast is not None:           # (the same on every rank: only an agreement clears it)
+            group = self.fast
 
-                def over_rccl():
-                    t = torch.tensor([value], dtype=dtype, device=self.device)
-                    self.dist.all_reduce(t, op=op, group=group)
-                    return t.item()
-                out, err = self._timed_call(over_rccl, f'all_reduce {op_name}')
+            def over_rccl():
+                t = torch.tensor([value], dtype=dtype, device=self.device)
+                self.dist.all_reduce(t, op=op, group=group)
+                return t.item()
+            out, err = self._timed_call(over_rccl, f'all_reduce {op_name}')
             if self._agree(err):
                 return out
         t = torch.tensor([value], dtype=dtype)
@@ -221,16 +217,23 @@ class ControlPlane:
 
     # ---- what bench.py calls
     def barrier(self):
+        """All ranks meet.  Returns True when the control plane DEGRADED during this barrier (an RCCL barrier failed or
+        did not return on some rank: every rank is on gloo afterwards) -- a timed region that such a barrier closes has
+        waited for the time limit of the failing call and is not a measurement (bench.py: value null, with the reason).
+
+        ADVICE r05: while RCCL is in use, the RCCL barrier is followed on EVERY rank by the one-integer agreement over
+        gloo that the reductions use (itself a barrier), so the ranks leave with the same view of the control plane and
+        the same number of gloo collectives behind them -- a rank whose RCCL barrier raised no longer runs one gloo
+        barrier more than a rank whose barrier completed.  Cost: one gloo all_reduce of 8 bytes per barrier."""
         if self.dist is None:
-            return
-        if self.fast is not None:
-            group = self.fast
-            idx = self.device.index if self.device is not None and self.device.index is not None else 0
-            _, err = self._timed_call(lambda: self.dist.barrier(group=group, device_ids=[idx]), 'barrier')
-            if err is None:
-                return
-            self._pending = err             # reported by the next agreement; this rank meets the others on gloo
-        self.dist.barrier()
+            return False
+        if self.fast is None:
+            self.dist.barrier()
+            return False
+        group = self.fast
+        idx = self.device.index if self.device is not None and self.device.index is not None else 0
+        _, err = self._timed_call(lambda: self.dist.barrier(group=group, device_ids=[idx]), 'barrier')
+        return not self._agree(err)
 
     def max_over_ranks(self, value):
         if self.dist is None:

@@ -72,23 +72,37 @@ CP_WORKER = textwrap.dedent('''
                     raise RuntimeError('injected: ncclAllReduce failed')
             return real_all_reduce(t, op=op, group=group, **kw)
         dist.all_reduce = flaky
+    if mode.startswith('barrier_failure'):
+        real_barrier = dist.barrier
+        bstate = {'calls': 0}
+        def flaky_barrier(group=None, **kw):
+            if group is not None and rank == 1:
+                bstate['calls'] += 1
+                if bstate['calls'] == 2:                    # the barrier that CLOSES the timed region
+                    if mode == 'barrier_failure_after':
+                        real_barrier(group=group, **kw)
+                    raise RuntimeError('injected: ncclBarrier failed')
+            return real_barrier(group=group, **kw)
+        dist.barrier = flaky_barrier
     try:
         cp = shard.ControlPlane(backend='nccl', device=None, require=(mode == 'real_strict'))
     except Exception as e:
         sys.stdout.write(f'RAISED {type(e).__name__} {str(e)[:200]}\\n'); sys.stdout.flush()
         raise SystemExit(3)
     seen = [cp.backend]
-    cp.barrier()
+    degraded = [cp.barrier()]
     a = cp.max_over_ranks(1.0 + rank)
     seen.append(cp.backend)
     b = cp.sum_over_ranks(2 ** 40 + rank)
     seen.append(cp.backend)
     c = cp.max_over_ranks(10.0 - rank)
     objs = cp.gather_objects({'rank': rank})
-    cp.barrier()
+    degraded.append(cp.barrier())
+    d = cp.max_over_ranks(3.0 + rank)           # the ranks are still in step after the barrier: values right on every rank
+    degraded_all = cp.gather_objects(degraded)
     if rank == 0:
-        print(json.dumps({'seen': seen, 'a': a, 'b': b, 'c': c, 'objs': objs, 'final': cp.backend, 'rccl_ranks': cp.rccl_ranks,
-                          'hung': cp.hung}), flush=True)
+        print(json.dumps({'seen': seen, 'a': a, 'b': b, 'c': c, 'd': d, 'objs': objs, 'final': cp.backend, 'rccl_ranks': cp.rccl_ranks,
+                          'hung': cp.hung, 'degraded': degraded_all}), flush=True)
     hung = cp.hung
     cp.close()
     if hung:                # a helper thread is still inside the abandoned collective (bench.py leaves the same way)
@@ -148,6 +162,28 @@ def test_all_ranks_good_use_the_fast_group_and_a_late_failure_still_agrees(cp_wo
     out = _line(res, '{"seen"')
     assert out['seen'][2].startswith('gloo (fallback: nccl collective failed on rank(s) [0, 1]: RCCL all_reduce SUM did not return within 4 s')
     assert (out['a'], out['b'], out['c']) == (2.0, 2 ** 41 + 1, 10.0) and out['rccl_ranks'] == 0 and out['hung']
+
+
+def test_a_barrier_that_fails_on_one_rank_leaves_the_ranks_in_step(cp_worker):
+    """the RCCL barrier raises on rank 1 and completes on rank 0 (or rank 0 waits in it alone until
+    the time limit).  Every barrier over RCCL is followed by the one-integer agreement over gloo on EVERY rank, so both
+    ranks report the barrier as degraded, both move to gloo, and the reductions after it carry the right values -- the
+    ranks are not one gloo collective apart."""
+    res = _torchrun(cp_worker, 'all_good')
+    out = _line(res, '{"seen"')
+    assert out['degraded'] == [[False, False], [False, False]] and out['d'] == 4.0
+    res = _torchrun(cp_worker, 'barrier_failure_after')
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = _line(res, '{"seen"')
+    assert out['degraded'] == [[False, True], [False, True]], out
+    assert out['seen'] == ['nccl'] * 3 and out['final'].startswith('gloo (fallback: nccl collective failed on rank(s) [1]: RuntimeError: injected: ncclBarrier')
+    assert (out['a'], out['b'], out['c'], out['d']) == (2.0, 2 ** 41 + 1, 10.0, 4.0) and not out['hung']
+    res = _torchrun(cp_worker, 'barrier_failure_before', env={'DSWX_RCCL_PROBE_TIMEOUT_S': '4'})
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = _line(res, '{"seen"')
+    assert out['degraded'] == [[False, True], [False, True]], out
+    assert 'RCCL barrier did not return within 4 s' in out['final'] and out['hung']
+    assert (out['a'], out['b'], out['c'], out['d']) == (2.0, 2 ** 41 + 1, 10.0, 4.0)
 
 
 def test_world_above_one_without_master_port_fails_at_once(tmp_path):

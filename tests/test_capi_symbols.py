@@ -28,6 +28,25 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert sorted(_capi.EXPORTED_SYMBOLS) == names
 
 
+def test_codec_library_exports_its_header():
+    """include/dswx_codec.h (round 6: the DEFLATE side of the GeoTIFF reader / writer, host only): every declared symbol
+    is exported by libdswx_codec.so, and nothing else."""
+    import subprocess
+    text = open(os.path.join(ROOT, 'include', 'dswx_codec.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    names = sorted(set(re.findall(r'\b(dswx_codec_[a-z0-9_]+)\s*\(', text)))
+    assert len(names) == 7
+    path = build.build_codec()
+    lib = ctypes.CDLL(path)
+    for name in names:
+        assert hasattr(lib, name), name
+    out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True, check=True).stdout
+    c_syms = sorted(l.split()[-1] for l in out.splitlines() if ' T ' in l and not l.split()[-1].startswith('_'))
+    assert c_syms == names
+    lib.dswx_codec_abi_version.restype = ctypes.c_int
+    assert lib.dswx_codec_abi_version() == 1
+
+
 def test_product_library_carries_no_experiments():
     """the drop-in library exports exactly the C-ABI of include/dswx_hip.h -- no
     probe / lab entry points -- reads no environment switch, and the experiments live in libdswx_lab.so,

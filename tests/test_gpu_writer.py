@@ -1,0 +1,158 @@
+"""SURVEY section 8 f4, the GPU half: the raster formats either side of the per-pixel path on the
+device -- COG blocks + NEAREST overviews + predictor (dswx_cog_blocks_device), inflated blocks -> plane
+(dswx_untile_device), the Float32 RGB composites (dswx_rgb_planes_device) -- against the host writer / reader's own
+whole-array restatements in proteus_amd/geotiff.py (blocked_level, overview_nearest, TiffDirectory.untile), which the
+CPU suite pins against files written by another TIFF library.  Bit-exact: integer and byte work."""
+import numpy as np
+import pytest
+
+from proteus_amd import _capi, geotiff
+
+pytestmark = pytest.mark.gpu
+
+FACTORS = geotiff.COG_OVERVIEW_FACTORS
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = _capi.Context(0)
+    yield c
+    c.close()
+
+
+def _device_blocks(ctx, arr, factors, tile, predictor):
+    """arr [H,W] -> the device's blocked buffer (uint8) + the layout."""
+    lay = _capi.cog_layout(arr.shape[0], arr.shape[1], arr.dtype.itemsize, factors, tile)
+    d_in = ctx.malloc(max(arr.nbytes, 16))
+    d_out = ctx.malloc(max(lay['total_bytes'], 16))
+    try:
+        d_in.upload(arr)
+        ctx.lib.dswx_memset_d(ctx.handle, d_out.ptr, 0xAB, d_out.nbytes)           # every byte must be written
+        ctx.cog_blocks_device(d_in.ptr, arr.dtype.itemsize, arr.shape[0], arr.shape[1], d_out.ptr, factors, tile, predictor)
+        ctx.synchronize()
+        return d_out.download(np.uint8, lay['total_bytes']), lay
+    finally:
+        d_in.free()
+        d_out.free()
+
+
+def _host_levels(arr, factors, tile, predictor):
+    levels = [arr] + [geotiff.overview_nearest(arr, f) for f in factors if f > 1 and arr.shape != (1, 1)]
+    return [geotiff.blocked_level(lv[None], tile, predictor) for lv in levels]
+
+
+@pytest.mark.parametrize('shape', [(3660, 3660), (1, 1), (7, 3), (513, 1025), (1000, 333), (129, 4097), (2048, 512)])
+@pytest.mark.parametrize('dtype', [np.uint8, np.uint16])
+def test_cog_blocks_and_nearest_overviews(ctx, shape, dtype):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    arr = rng.integers(0, np.iinfo(dtype).max + 1, size=shape).astype(dtype)
+    arr[::5] = 3                                                        # runs, as class maps have
+    for predictor in (2, 1):
+        for tile in ((512, 16) if shape[0] < 2000 else (512,)):
+            got, lay = _device_blocks(ctx, arr, FACTORS, tile, predictor)
+            want = _host_levels(arr, FACTORS, tile, predictor)
+            assert lay['n_levels'] == len(want)
+            for k, (lv, host) in enumerate(zip(lay['levels'], want)):
+                assert (lv['height'], lv['width']) == (host.height, host.width)
+                assert (lv['blocks_down'], lv['blocks_across']) == (host.down, host.across)
+                n = host.n_blocks * host.block_bytes
+                dev = got[lv['offset_bytes']: lv['offset_bytes'] + n]
+                assert np.array_equal(dev, host.data.reshape(-1).view(np.uint8)), (shape, dtype, predictor, tile, k)
+            assert lay['total_bytes'] == sum(h.n_blocks * h.block_bytes for h in want)
+
+
+def test_cog_blocks_without_overviews_and_signed_samples(ctx):
+    rng = np.random.default_rng(4)
+    arr = rng.integers(-32768, 32768, size=(700, 900)).astype(np.int16)
+    got, lay = _device_blocks(ctx, arr.view(np.uint16), (), 512, 2)
+    host = geotiff.blocked_level(arr[None], 512, 2)
+    assert lay['n_levels'] == 1 and np.array_equal(got, host.data.reshape(-1).view(np.uint8))
+
+
+@pytest.mark.parametrize('shape', [(3660, 3660), (300, 257), (1, 1), (513, 100)])
+def test_float32_blocks_with_the_floating_point_predictor(ctx, shape):
+    rng = np.random.default_rng(shape[1])
+    arr = rng.normal(0.1, 0.05, size=shape).astype(np.float32)
+    arr[rng.random(shape) < 0.05] = np.nan
+    arr.reshape(-1)[:3] = [np.inf, -0.0, 1e-40][:arr.size]
+    got, lay = _device_blocks(ctx, arr, (), 512, 3)
+    host = geotiff.blocked_level(arr[None], 512, 3)
+    assert np.array_equal(got, np.asarray(host.data).reshape(-1).view(np.uint8))
+    if shape != (1, 1):                 # (a 1 x 1 raster has no overview level whatever the factors)
+        with pytest.raises(_capi.DswxError, match='CUBICSPLINE'):
+            _device_blocks(ctx, arr, (4,), 512, 3)
+
+
+def _untile(ctx, staging, dtype, H, W, bw, bh, predictor):
+    d_in = ctx.malloc(max(staging.nbytes, 16))
+    d_out = ctx.malloc(max(H * W * np.dtype(dtype).itemsize, 16))
+    try:
+        d_in.upload(staging)
+        ctx.lib.dswx_memset_d(ctx.handle, d_out.ptr, 0xCD, d_out.nbytes)
+        ctx.untile_device(d_in.ptr, np.dtype(dtype).itemsize, H, W, bw, bh, predictor, d_out.ptr)
+        ctx.synchronize()
+        return d_out.download(dtype, H * W).reshape(H, W)
+    finally:
+        d_in.free()
+        d_out.free()
+
+
+@pytest.mark.parametrize('shape', [(3660, 3660), (1, 1), (7, 3), (513, 1025), (1000, 333)])
+@pytest.mark.parametrize('dtype', [np.uint8, np.int16])
+def test_untile_tiles_and_strips(ctx, tmp_path, shape, dtype):
+    """Round trip through REAL files: our writer's tiles (512 and 16... 256) and Pillow / libtiff's DEFLATE strips (short
+    last strip), inflated on the host (native codec), untiled + un-predicted on the device == the host reader."""
+    rng = np.random.default_rng(shape[0] + 3 * shape[1])
+    info = np.iinfo(dtype)
+    arr = rng.integers(info.min, info.max + 1, size=shape).astype(dtype)
+    H, W = shape
+    for tile in (512, 256):
+        p = str(tmp_path / f't{tile}.tif')
+        geotiff.write_geotiff(p, arr, tile=tile)
+        d = geotiff.open_geotiff(p)
+        staging = d.inflate()
+        got = _untile(ctx, staging, dtype, H, W, d.bw, d.bh, d.predictor)
+        assert d.predictor == 2 and np.array_equal(got, arr), (shape, dtype, tile)
+        assert np.array_equal(d.untile(staging)[0], arr)
+    from PIL import Image, features
+    if not features.check('libtiff') or dtype != np.uint8:
+        return
+    q = str(tmp_path / 'strips.tif')
+    Image.fromarray(arr, mode='L').save(q, compression='tiff_adobe_deflate', tiffinfo={317: 2})
+    d = geotiff.open_geotiff(q)
+    assert not d.tiled and d.bw == W
+    got = _untile(ctx, d.inflate(), dtype, H, W, d.bw, d.bh, d.predictor)
+    assert np.array_equal(got, arr)
+
+
+def test_rgb_planes(ctx):
+    """_save_output_rgb_file's arithmetic (dswx_hls.py:3013-3036) in float32, NaN on invalid pixels, clipped bands."""
+    rng = np.random.default_rng(12)
+    n = 3660 * 37 + 5
+    bands = [rng.integers(-200, 12000, size=n).astype(np.int16) for _ in range(3)]
+    diag = rng.integers(0, 11112, size=n).astype(np.uint16)
+    diag[rng.random(n) < 0.1] = 65535
+    for scale, offset, clip in (([1e-4] * 3, [0.0] * 3, True), ([1e-4, 2e-4, 0.5], [0.0, -12.5, 3.0], True),
+                                ([1e-4] * 3, [0.0] * 3, False)):
+        d = [ctx.malloc(b.nbytes) for b in bands]
+        d_diag = ctx.malloc(diag.nbytes)
+        d_out = ctx.malloc(3 * n * 4)
+        try:
+            for buf, b in zip(d, bands):
+                buf.upload(b)
+            d_diag.upload(diag)
+            for use_diag in (True, False):
+                ctx.rgb_planes_device(d[0].ptr, d[1].ptr, d[2].ptr, d_diag.ptr if use_diag else None, n, scale, offset, clip,
+                                      d_out.ptr)
+                ctx.synchronize()
+                got = d_out.download(np.float32, 3 * n).reshape(3, n)
+                for c in range(3):
+                    b = np.clip(bands[c], 1, None) if clip else bands[c]
+                    want = scale[c] * (np.asarray(b, dtype=np.float32) - offset[c])       # the reference's statement
+                    assert want.dtype == np.float32
+                    if use_diag:
+                        want[diag == 65535] = np.nan
+                    assert np.array_equal(got[c], want, equal_nan=True), (scale, offset, clip, use_diag, c)
+        finally:
+            for buf in d + [d_diag, d_out]:
+                buf.free()

@@ -157,6 +157,67 @@ def test_float_predictor_and_foreign_layouts(tmp_path):
     assert b.dtype == np.float32 and np.array_equal(b, a)
 
 
+def test_foreign_deflate_strips_chunky_and_short_last_strip(tmp_path):
+    """Round 6: the reader inflates every block into one staging buffer (native codec, proteus_amd.codec) and undoes the
+    predictor / moves the blocks with whole-array operations.  Files written by ANOTHER library (Pillow / libtiff) pin
+    the layouts our own writer never produces: DEFLATE strips whose last strip is short, horizontal predictor on int16
+    and on chunky RGB (three samples per pixel, differenced per sample), with both DEFLATE engines; and the codec's
+    own contract (bound, thread count independence, corrupt / oversized streams)."""
+    from PIL import Image, features
+    from proteus_amd import codec
+    if not features.check('libtiff'):
+        pytest.skip('Pillow without libtiff')
+    rng = np.random.default_rng(66)
+    a16 = rng.integers(-3000, 12000, size=(203, 331)).astype(np.int16)
+    rgb = rng.integers(0, 256, size=(157, 211, 3)).astype(np.uint8)
+    u8 = (rng.integers(0, 5, size=(1000, 77)) * 50).astype(np.uint8)
+    p16, prgb, pu8 = (str(tmp_path / n) for n in ('i16.tif', 'rgb.tif', 'u8.tif'))
+    Image.fromarray(a16, mode='I;16').save(p16, compression='tiff_adobe_deflate', tiffinfo={317: 2})
+    Image.fromarray(rgb, mode='RGB').save(prgb, compression='tiff_adobe_deflate', tiffinfo={317: 2})
+    Image.fromarray(u8, mode='L').save(pu8, compression='tiff_adobe_deflate')
+    for force in (False, True):
+        codec.force_zlib(force)
+        try:
+            d = geotiff.open_geotiff(pu8)
+            assert not d.tiled and d.down > 1 and d.info.height % d.bh           # several strips, the last one short
+            assert np.array_equal(geotiff.read_geotiff(pu8)[0], u8)
+            b16 = geotiff.read_geotiff(p16)[0]
+            assert np.array_equal(b16.astype(np.uint16), a16.astype(np.uint16))  # ('I;16' is unsigned in the file)
+            back, info = geotiff.read_geotiff(prgb)
+            assert info.bands == 3 and np.array_equal(back, np.moveaxis(rgb, 2, 0))
+            # our own files, every dtype, through this engine and back through Python's zlib
+            for dt in (np.uint8, np.int16, np.uint16, np.float32):
+                a = rng.integers(0, 200, size=(2, 700, 600)).astype(dt)
+                p = str(tmp_path / f'own_{np.dtype(dt).name}_{int(force)}.tif')
+                geotiff.write_geotiff(p, a, overviews=geotiff.COG_OVERVIEW_FACTORS if dt != np.float32 else None)
+                assert np.array_equal(geotiff.read_geotiff(p)[0], a) and not geotiff.validate_cog(p)
+                dd = geotiff.open_geotiff(p)
+                import zlib
+                raw = zlib.decompress(dd.buf[dd.offs[0]: dd.offs[0] + dd.cnts[0]])    # a standard zlib stream
+                assert len(raw) == dd.block_bytes
+        finally:
+            codec.force_zlib(False)
+    assert codec.engine() in ('libdeflate', 'zlib')
+    # the codec alone: the bytes do not depend on the thread count; errors are errors
+    blocks = rng.integers(0, 4, size=(37, 4096)).astype(np.uint8)
+    one = codec.deflate_uniform(blocks, 4096, 6, threads=1)
+    many = codec.deflate_uniform(blocks, 4096, 6, threads=8)
+    assert np.array_equal(one[2], many[2]) and all(
+        one[0][o:o + k].tobytes() == many[0][o2:o2 + k].tobytes() for o, o2, k in zip(one[1], many[1], one[2]))
+    blob = b''.join(one[0][o:o + k].tobytes() for o, k in zip(one[1], one[2]))
+    offs = np.concatenate([[0], np.cumsum(one[2])[:-1]])
+    dst = np.zeros_like(blocks)
+    assert (codec.inflate_into(blob, offs, one[2], dst, 4096) == 4096).all() and np.array_equal(dst, blocks)
+    with pytest.raises(codec.CodecError, match='more than'):
+        codec.inflate_into(blob, offs, one[2], np.zeros((37, 100), np.uint8), 100)
+    bad = bytearray(blob)
+    bad[int(offs[5]) + 4] ^= 0xff
+    with pytest.raises(codec.CodecError):
+        codec.inflate_into(bytes(bad), offs, one[2], dst, 4096)
+    with pytest.raises(codec.CodecError, match='outside'):
+        codec.inflate_into(blob[:100], offs, one[2], dst, 4096)
+
+
 def test_cubicspline_overviews_of_float_layers():
     """CUBICSPLINE overviews for non-integer layers (reference core.py:41-46).  GDAL is absent, so the
     kernel is pinned by its defining properties: weights sum to one (a constant stays constant), the cubic
