@@ -142,6 +142,30 @@ def bench_params(args):
     return _capi.make_params(SCALED_THRESHOLDS, offset_and_scale=[(SCALED_UNITS, 0.0)] * 6, aerosol_max_nir=1000 * SCALED_UNITS)
 
 
+def cpu_quota_cores():
+    """Processors this process may really use: the logical cores, cut down to the container's CPU bandwidth quota (cgroup
+    v2 cpu.max / v1 cfs quota).  The GPU boxes of this project show 256 logical cores under a quota of 16: worker pools
+    sized by os.cpu_count() are throttled, and a `cores` figure that ignores the quota overstates the baseline's hardware."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota, period = None, 100000
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        quota, period = (None if q == 'max' else int(q)), int(p)
+    except (OSError, ValueError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        except (OSError, ValueError):
+            quota = None
+    if quota and quota > 0 and period > 0:
+        n = max(1, min(n, -(-quota // period)))
+    return n
+
+
 def cpu_baseline_sample(n_tiles=4):
     """The numpy restatement of the reference path (oracle, kind 'port') on a bounded sample of
     the workload: `n_tiles` synthetic 3660x3660 tiles (~10 s), single thread as the reference runs.
@@ -162,7 +186,7 @@ def cpu_baseline_sample(n_tiles=4):
             'sample': f'{n_tiles} synthetic {TILE}x{TILE} L30 tiles, numpy {np.__version__} '
                       f'oracle/dswx_oracle.py classify_tile (same array passes as the reference functions: '
                       f'0.975x their time stage by stage, profiles/r02_cpu_port_vs_reference.json), '
-                      f'{dt:.2f} s, host has {os.cpu_count()} logical cores'}
+                      f'{dt:.2f} s, host has {os.cpu_count()} logical cores, CPU quota of this container {cpu_quota_cores()} cores'}
 
 
 def cpu_baseline_next_rows(dem, worldcover_up3, copernicus, forest_classes, sample=1500):
@@ -222,9 +246,10 @@ def cpu_parallel_main(workers):
 
 def cpu_baseline_parallel():
     """tile-parallel numpy oracle on min(cores, 32) worker processes (bounded by
-    free memory, ~4 GB per worker), run in a child process that never initialises the GPU."""
+    free memory, ~4 GB per worker; cores = what the container's CPU quota allows, cpu_quota_cores), run in a child
+    process that never initialises the GPU."""
     import subprocess
-    workers = min(os.cpu_count() or 1, 32)
+    workers = min(cpu_quota_cores(), 32)
     try:
         import psutil
         workers = max(1, min(workers, int(psutil.virtual_memory().available // (4 << 30))))

@@ -34,6 +34,10 @@ const char* dswx_codec_last_error(void);
 /* Tests: on != 0 makes every later call use zlib even when libdeflate is present (both engines are parity-tested). */
 int dswx_codec_force_zlib(int on);
 
+/* Processors this process may use: hardware threads, cut down to the container's CPU bandwidth quota (cgroup cpu.max).
+ * The pool never runs more workers than this, whatever the calls ask for. */
+int dswx_codec_cpu_budget(void);
+
 /* Upper bound of the compressed size of `bytes` input bytes (any level, either engine). */
 size_t dswx_codec_deflate_bound(size_t bytes);
 

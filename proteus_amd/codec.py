@@ -36,6 +36,7 @@ def load():
         lib.dswx_codec_engine.restype = ctypes.c_char_p
         lib.dswx_codec_last_error.restype = ctypes.c_char_p
         lib.dswx_codec_force_zlib.argtypes = [ctypes.c_int]
+        lib.dswx_codec_cpu_budget.restype = ctypes.c_int
         lib.dswx_codec_deflate_bound.restype = ctypes.c_size_t
         lib.dswx_codec_deflate_bound.argtypes = [ctypes.c_size_t]
         lib.dswx_codec_deflate_blocks.restype = ctypes.c_int
@@ -56,11 +57,17 @@ def force_zlib(on):
     load().dswx_codec_force_zlib(int(bool(on)))
 
 
+def cpu_budget():
+    """Processors this process may really use: hardware threads cut down to the container's CPU quota (cgroup)."""
+    return int(load().dswx_codec_cpu_budget())
+
+
 def default_threads():
-    """Workers of one call.  DSWX_IO_THREADS overrides (1 = serial); default: the host's cores up to 64 (several
-    files are read / written side by side, each with its own call)."""
+    """Workers of one call.  DSWX_IO_THREADS overrides (1 = serial); default: the processors this process may use
+    (cpu_budget) up to 64 -- several files are read / written side by side, each with its own call, and the pool as a
+    whole never exceeds the budget."""
     n = int(os.environ.get('DSWX_IO_THREADS', '0'))
-    return n if n > 0 else min(64, os.cpu_count() or 1)
+    return n if n > 0 else min(64, cpu_budget())
 
 
 def _check(rc):

@@ -35,7 +35,7 @@ def test_codec_library_exports_its_header():
     text = open(os.path.join(ROOT, 'include', 'dswx_codec.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     names = sorted(set(re.findall(r'\b(dswx_codec_[a-z0-9_]+)\s*\(', text)))
-    assert len(names) == 7
+    assert len(names) == 8
     path = build.build_codec()
     lib = ctypes.CDLL(path)
     for name in names:
@@ -45,6 +45,7 @@ def test_codec_library_exports_its_header():
     assert c_syms == names
     lib.dswx_codec_abi_version.restype = ctypes.c_int
     assert lib.dswx_codec_abi_version() == 1
+    assert 1 <= lib.dswx_codec_cpu_budget() <= (os.cpu_count() or 1)
 
 
 def test_product_library_carries_no_experiments():
