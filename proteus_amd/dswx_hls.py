@@ -508,7 +508,8 @@ def _load_hls_product_v2(file_list, image, md, flag_debug=False, alloc=None, eng
         return False
     def read(path):
         if engine is not None and not flag_debug:
-            return engine.read_plane(path)
+            d = geotiff.open_geotiff(path)          # (an unreadable input is reported before the GPU is asked for)
+            return (engine() if callable(engine) else engine).read_directory(d)
         return geotiff.read_geotiff(path, window=(0, 0, 1000, 1000) if flag_debug else None, alloc=alloc)
 
     # the first band's metadata decide the sensor, hence the file names of the other six, which
@@ -1206,14 +1207,15 @@ def generate_dswx_layers(input_list,
     # through the v2 per-band GeoTIFF loader, which reports what is missing
     # the blocks of the band files are inflated on host threads into page-locked memory; the device undoes the
     # predictor and untiles them: the planes are RESIDENT in HBM from here on (proteus_amd.pipeline)
-    ctx = get_context(device)
-    engine = pipeline.engine_of(ctx)
     with stages.span('load HLS bands (7 files)'):
         ok = _load_hls_product_v2(list(input_list), image, md, flag_debug=flag_debug,
-                                  alloc=lambda shape, dt: ctx.pinned_empty(shape, dt), engine=engine)
+                                  alloc=lambda shape, dt: get_context(device).pinned_empty(shape, dt),
+                                  engine=lambda: pipeline.engine_of(get_context(device)))
     if not ok:
         logger.info(f'ERROR could not read file(s): {input_list}')
         return False
+    ctx = get_context(device)
+    engine = pipeline.engine_of(ctx)
     for k in list(_capi.BAND_NAMES) + ['fmask']:          # (flag_debug reads a window on the host)
         if not isinstance(image[k], pipeline.DevicePlane):
             image[k] = engine.upload(image[k])

@@ -128,12 +128,15 @@ class TileEngine:
                 and d.dt.byteorder in ('=', '|', '<') and d.n_blocks * d.block_bytes < (1 << 32))
 
     def read_plane(self, path):
-        """One single-band GeoTIFF -> (DevicePlane [H, W], GeoTiffInfo).  Inflate on host threads into page-locked memory;
-        predictor + untile on the device when its kernel takes the layout, else by the host reader (same bytes)."""
-        d = geotiff.open_geotiff(path)
+        return self.read_directory(geotiff.open_geotiff(path))
+
+    def read_directory(self, d):
+        """One single-band GeoTIFF (geotiff.TiffDirectory) -> (DevicePlane [H, W], GeoTiffInfo).  Inflate on host threads
+        into page-locked memory; predictor + untile on the device when its kernel takes the layout, else by the host
+        reader (same bytes)."""
         info = d.info
         if d.spp != 1:
-            raise geotiff.GeoTiffError(f'{path}: {d.spp} samples per pixel, expected a single band')
+            raise geotiff.GeoTiffError(f'{d.path}: {d.spp} samples per pixel, expected a single band')
         if not self.device_untile_ok(d):
             return self.upload(d.untile(d.inflate())[0]), info
         need = d.n_blocks * d.block_bytes
