@@ -220,12 +220,12 @@ __global__ __launch_bounds__(256) void dswx_cover_dilate(const KArgs a) {
 
 // ------------------------------------------------------------------------------
 // Stage 3: A11-A15 of every pixel from its state byte and its final snow bit.  Flat, 8 pixels per thread:
-// one 8-byte state load + one byte of the snow plane in, four (five) 8-byte stores out.  VEC = the planes
-// allow 8-byte accesses (tile starts and pointers 8-byte aligned); otherwise the same with byte accesses.
+// one 8-byte state load + one byte of the snow plane in, four (five) 8-byte stores out -- unaligned global accesses since
+// round 6 (any plane address, any tile stride: ragged contiguous batches used to take byte accesses throughout); the
+// incomplete last group of a tile goes byte by byte.
 // ------------------------------------------------------------------------------
 constexpr int FIN_GROUPS = 4;     // 8-pixel groups per thread, 256 groups apart: four loads in flight per thread
 
-template <bool VEC>
 __global__ __launch_bounds__(256) void dswx_cover_finish(const KArgs a) {
     __shared__ uint32_t s_fin[128];             // WTR | BWTR << 8 | CONF << 16 | CLOUD << 24
     __shared__ uint32_t s_fbr[128];             // browse
@@ -262,15 +262,15 @@ __global__ __launch_bounds__(256) void dswx_cover_finish(const KArgs a) {
     // stores on a 256-byte boundary of the layers whatever the tile stride (contiguous tiles: 3660 x 3660 = 144 mod 256)
     const uint8_t* const anchor = a.out.wtr ? a.out.wtr : a.out.bwtr ? a.out.bwtr : a.out.conf ? a.out.conf :
                                   a.out.cloud ? a.out.cloud : a.out.browse ? a.out.browse : a.cover_state;
-    const int lead = VEC ? (int)((reinterpret_cast<uintptr_t>(anchor + tile_base) >> 3) & 31u) : 0;
+    const int lead = (int)((reinterpret_cast<uintptr_t>(anchor + tile_base) >> 3) & 31u);
     const long long grp0 = (long long)blockIdx.x * FIN_GROUPS * 256 + t - lead;
-    if (VEC && grp0 >= 0 && (grp0 + (FIN_GROUPS - 1) * 256) * 8 + 8 <= a.n_pixels) {
+    if (grp0 >= 0 && (grp0 + (FIN_GROUPS - 1) * 256) * 8 + 8 <= a.n_pixels) {
         // every group of this thread is complete: straight-line code, all loads before the first use
         u32x2 st[FIN_GROUPS];
         uint32_t snow8[FIN_GROUPS];
 #pragma unroll
         for (int u = 0; u < FIN_GROUPS; ++u) {
-            st[u] = ldg<u32x2, true>(a.cover_state + tile_base + (grp0 + u * 256) * 8);
+            st[u] = ldg_u<u32x2_u, u32x2, true>(a.cover_state + tile_base + (grp0 + u * 256) * 8);
             snow8[u] = snow_plane[grp0 + u * 256];
         }
 #pragma unroll
@@ -281,11 +281,11 @@ __global__ __launch_bounds__(256) void dswx_cover_finish(const KArgs a) {
             const long long off = tile_base + (grp0 + u * 256) * 8;
 #pragma unroll
             for (int k = 0; k < 5; ++k)
-                if (planes[k]) stg<u32x2, true>(planes[k] + off, u32x2{lo[k], hi[k]});
+                if (planes[k]) stg_u<u32x2_u, u32x2, true>(planes[k] + off, u32x2{lo[k], hi[k]});
         }
         return;
     }
-    // the tile's last groups, or planes without 8-byte alignment: byte accesses
+    // the tile's last groups (and the lead-in threads of its first block): byte accesses
     for (int u = 0; u < FIN_GROUPS; ++u) {
         const long long px0 = (grp0 + u * 256) * 8;
         const long long left = a.n_pixels - px0;
@@ -321,14 +321,10 @@ int dswx_cover_stage2_launch(dswx_ctx* ctx, const KArgs& c2, long long n_tiles, 
         else if (staged) hipLaunchKernelGGL((dswx_cover_dilate<8, true>), grid, dim3(256), 0, s, c2);
         else hipLaunchKernelGGL((dswx_cover_dilate<8, false>), grid, dim3(256), 0, s, c2);
         HIP_TRY(hipGetLastError());
-        bool vec = c2.tile_stride % 8 == 0 && aligned_to(c2.cover_state, 8);
-        uint8_t* const outs[5] = {c2.out.wtr, c2.out.bwtr, c2.out.conf, c2.out.cloud, c2.out.browse};
-        for (uint8_t* o : outs) vec = vec && (!o || aligned_to(o, 8));
         const long long groups = (c2.n_pixels + 7) / 8;
-        const long long lead_max = vec ? 31 : 0;
+        const long long lead_max = 31;
         dim3 fgrid((unsigned)((groups + lead_max + 256 * FIN_GROUPS - 1) / (256 * FIN_GROUPS)), (unsigned)n_tiles);
-        if (vec) hipLaunchKernelGGL(dswx_cover_finish<true>, fgrid, dim3(256), 0, s, c2);
-        else hipLaunchKernelGGL(dswx_cover_finish<false>, fgrid, dim3(256), 0, s, c2);
+        hipLaunchKernelGGL(dswx_cover_finish, fgrid, dim3(256), 0, s, c2);
         HIP_TRY(hipGetLastError());
     }
     snprintf(info, info_len, " + dswx_cover_dilate<%d%s> grid=(%u,%u,%u) + dswx_cover_finish", nw, staged ? "" : ",direct",

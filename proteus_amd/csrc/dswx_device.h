@@ -320,6 +320,19 @@ template <typename T, bool NT> __device__ __forceinline__ void stg(void* p, T v)
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// the same vectors at ANY address (int16 planes: 2-byte aligned, byte planes: 1): gfx950 performs unaligned 16- / 8-byte
+// global accesses in hardware and the compiler emits the same global_load_dwordx4 / dwordx2 for these types (a wave
+// access that straddles cache lines costs a line more, nothing else) -- the direct kernel takes any plane this way
+typedef u32x4 __attribute__((aligned(2))) u32x4_u;
+typedef u32x2 __attribute__((aligned(1))) u32x2_u;
+template <typename TU, typename T, bool NT> __device__ __forceinline__ T ldg_u(const void* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const TU*>(p));
+    return *reinterpret_cast<const TU*>(p);
+}
+template <typename TU, typename T, bool NT> __device__ __forceinline__ void stg_u(void* p, T v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<TU*>(p));
+    else *reinterpret_cast<TU*>(p) = v;
+}
 typedef const __attribute__((address_space(1))) void* gptr_t;     // LDS-DMA source
 typedef __attribute__((address_space(3))) void* lptr_t;           // LDS-DMA destination
 

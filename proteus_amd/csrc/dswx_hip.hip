@@ -79,16 +79,16 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
         const long long off = (long long)blockIdx.y * a.tile_stride + (in_range ? grp : n_groups - 1) * 8;
         u32x4 v[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
-        const u32x2 vf = ldg<u32x2, true>(a.in.fmask + off);
+        for (int k = 0; k < 6; ++k) v[k] = ldg_u<u32x4_u, u32x4, true>(a.in.band[k] + off);
+        const u32x2 vf = ldg_u<u32x2_u, u32x2, true>(a.in.fmask + off);
         u32x2 vl = {0u, 0u}, vs = {0u, 0u}, vo = {0u, 0u};
         bool has_l = false, has_s = false, has_o = false;
         if (MASKS) {
             has_l = a.in.land != nullptr; has_s = a.in.shad != nullptr; has_o = a.in.ocean != nullptr;
-            if (has_l) vl = ldg<u32x2, true>(a.in.land + off);
-            if (has_s) vs = ldg<u32x2, true>(a.in.shad + off);
+            if (has_l) vl = ldg_u<u32x2_u, u32x2, true>(a.in.land + off);
+            if (has_s) vs = ldg_u<u32x2_u, u32x2, true>(a.in.shad + off);
             if (has_o) {
-                vo = ldg<u32x2, true>(a.in.ocean + off);
+                vo = ldg_u<u32x2_u, u32x2, true>(a.in.ocean + off);
                 t_ocean = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
                 t_ocean = in_range ? t_ocean : 0u;
             }
@@ -133,17 +133,17 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_v8(const KArgs a) {
             }
         }
         if (in_range) {
-        if (a.out.diag) stg<u32x4, true>(a.out.diag + off, u32x4{q_diag[0], q_diag[1], q_diag[2], q_diag[3]});
-        if (a.out.wtr1) stg<u32x2, true>(a.out.wtr1 + off, u32x2{q_w1[0], q_w1[1]});
-        if (a.out.wtr1_aerosol) stg<u32x2, true>(a.out.wtr1_aerosol + off, u32x2{q_w1a[0], q_w1a[1]});
-        if (a.out.wtr2) stg<u32x2, true>(a.out.wtr2 + off, u32x2{q_w2[0], q_w2[1]});
-        if (a.out.wtr) stg<u32x2, true>(a.out.wtr + off, u32x2{q_w[0], q_w[1]});
-        if (a.out.bwtr) stg<u32x2, true>(a.out.bwtr + off, u32x2{q_bw[0], q_bw[1]});
-        if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{q_cf[0], q_cf[1]});
-        if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{q_cl[0], q_cl[1]});
-        if (EXTRAS && a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{q_br[0], q_br[1]});
+        if (a.out.diag) stg_u<u32x4_u, u32x4, true>(a.out.diag + off, u32x4{q_diag[0], q_diag[1], q_diag[2], q_diag[3]});
+        if (a.out.wtr1) stg_u<u32x2_u, u32x2, true>(a.out.wtr1 + off, u32x2{q_w1[0], q_w1[1]});
+        if (a.out.wtr1_aerosol) stg_u<u32x2_u, u32x2, true>(a.out.wtr1_aerosol + off, u32x2{q_w1a[0], q_w1a[1]});
+        if (a.out.wtr2) stg_u<u32x2_u, u32x2, true>(a.out.wtr2 + off, u32x2{q_w2[0], q_w2[1]});
+        if (a.out.wtr) stg_u<u32x2_u, u32x2, true>(a.out.wtr + off, u32x2{q_w[0], q_w[1]});
+        if (a.out.bwtr) stg_u<u32x2_u, u32x2, true>(a.out.bwtr + off, u32x2{q_bw[0], q_bw[1]});
+        if (a.out.conf) stg_u<u32x2_u, u32x2, true>(a.out.conf + off, u32x2{q_cf[0], q_cf[1]});
+        if (a.out.cloud) stg_u<u32x2_u, u32x2, true>(a.out.cloud + off, u32x2{q_cl[0], q_cl[1]});
+        if (EXTRAS && a.out.browse) stg_u<u32x2_u, u32x2, true>(a.out.browse + off, u32x2{q_br[0], q_br[1]});
         if (EXTRAS && a.cover_state) {   // 'cover' stage 1 (wave-uniform)
-            *reinterpret_cast<u32x2*>(a.cover_state + off) = u32x2{q_st[0], q_st[1]};
+            *reinterpret_cast<u32x2_u*>(a.cover_state + off) = u32x2{q_st[0], q_st[1]};
             uint32_t fl[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) fl[j] = cflags[EXTRAS ? j : 0];
@@ -595,16 +595,14 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     if (any_index && a.P.f32_mode)
         return dswx_fail(DSWX_ERR_UNSUPPORTED, "the float64 index planes describe the integer chain; not available with offset_and_scale_inputs");
     const bool masks = in->land || in->shad || in->ocean;
-    // the fused kernels need every plane 16-byte aligned at every tile start (int16 planes: 8 pixels)
+    // The direct kernel (dswx_classify_v8) takes ANY plane address and ANY tile stride since round 6: its 16- / 8-byte
+    // accesses are unaligned global accesses, which gfx950 performs in hardware (int16 planes 2-byte aligned: checked
+    // above).  It works on tile-relative 8-pixel groups from pixel 0 of every tile, the generic kernel does the
+    // n_pixels % 8 tail.  Up to round 5 such planes -- and ragged batches in 'cover' mode -- ran whole tiles on the
+    // 1-pixel-per-thread kernel at 0.17 of the HBM peak (profiles/r05_generic_kernel_stats.csv).
     const bool stride8 = (tile_stride % 8 == 0) || n_tiles == 1;
-    bool vec_ok = true;
-    for (int k = 0; k < 6 && vec_ok; ++k) vec_ok = aligned_to(in->band[k], 16);
-    vec_ok = vec_ok && aligned_to(in->fmask, 16) && (!in->land || aligned_to(in->land, 16)) &&
-             (!in->shad || aligned_to(in->shad, 16)) && (!in->ocean || aligned_to(in->ocean, 16)) &&
-             (!out->diag || aligned_to(out->diag, 16));
     uint8_t* const u8outs[] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud,
                                out->browse};
-    for (uint8_t* p : u8outs) vec_ok = vec_ok && (!p || aligned_to(p, 16));
     // Do all planes START on 256-byte boundaries?  Then every tile of every plane has the same residue modulo 256
     // pixels and the table-driven kernel can put every wave access on a line boundary: directly when the tile stride
     // is a multiple of 256 pixels (the padded batch layout), through its per-tile lead-in otherwise (contiguous
@@ -620,7 +618,6 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     // its first 8-pixel boundary, the generic kernel does the < 8 + < 8 pixels at its edges (KArgs::ragged).  Not in
     // 'cover' mode, whose bitmaps are indexed by tile-relative 8-pixel groups; not when the direct kernel is forced.
     const bool ragged = !stride8 && bases256 && !cover && ctx->fused_variant != 0;
-    vec_ok = vec_ok && (stride8 || ragged);
     const bool lut_ok = bases256 && (stride256 || tile_stride % 8 == 0 || ragged);
     // the lead-in is a property of the addresses (correct for any of them); 0 only when every tile start is aligned
     const int lead_max = (bases256 && stride256) ? 0 : 31;  // groups: dswx_lut_geometry
@@ -654,7 +651,7 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
         b.partials = nullptr;
         b.fold_acc = nullptr;
         b.fold_group_log2 = 0;
-        const int64_t groups = vec_ok ? (n_pixels >> 3) : 0;       // (ragged: the most a tile can have)
+        const int64_t groups = n_pixels >> 3;                      // (ragged: the most a tile can have)
         b.ragged = (ragged && groups > 0) ? 1 : 0;
         // the finishing kernel of the vector path WRITES the counters; only the generic kernel
         // alone (atomic adds) needs them zeroed first

@@ -108,9 +108,14 @@ __global__ __launch_bounds__(256) void dswx_shadow_v2(const ShadowArgs a) {
 }
 
 // ------------------------------------------------------------------------------
-// Production form (margin >= 2 and even, even DEM width, output width % 4 == 0 -- the reference's
-// 3760 x 3760 DEM with its 50-pixel margin): FOUR output pixels per thread, 8-byte DEM loads, one
-// dword store, and a floating-point FILTER in front of the exact arithmetic.
+// Production form (margin >= 2, output at least 4 pixels wide: every output pixel and the two columns beside a quad
+// are interior): FOUR output pixels per thread, 8-byte DEM loads, one dword store, and a floating-point FILTER in
+// front of the exact arithmetic.  Up to round 5 it also asked for an even margin, an even DEM width and an output
+// width that is a multiple of 4 (8-byte aligned loads, dword-aligned stores); since round 6 the loads and the store
+// are UNALIGNED global accesses (gfx950 does them in hardware; same instructions, the reference's 3760 x 3760 / margin 50
+// geometry is aligned anyway) and the last quad of a row starts at ow - 4, overlapping its neighbour with identical
+// values -- so any margin >= 2, any width, any alignment of the buffers takes this kernel (the
+// general kernel below, 0.24 of the HBM peak and 2.0 x the algorithmic traffic, keeps margins 0 / 1 and tiny rasters).
 //
 // The exact chain costs ~106 VALU per pixel (two correctly rounded float32 divisions, a correctly
 // rounded sqrtf, a float64 division) and made the one-pixel kernel issue-bound at 0.2 of the HBM
@@ -136,6 +141,8 @@ struct ShadowFilter {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 __attribute__((aligned(4))) f32x2_u;          // 8 bytes at any float boundary
+typedef uint32_t __attribute__((aligned(1))) u32_u;          // 4 bytes anywhere
 
 // One quad (four horizontally adjacent output pixels) from the three DEM rows around it: c0..c3 = centre
 // row d[x-2 .. x+5], u0 u1 / b0 b1 = rows above / below d[x .. x+3].  Returns the four 0 / 1 bytes.
@@ -232,15 +239,16 @@ __global__ __launch_bounds__(64 * SHADOW_WAVES) void dswx_shadow_v3(const Shadow
     const int oq = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy0 = (blockIdx.y * SHADOW_WAVES + (threadIdx.x >> 6)) * SHADOW_ROWS;
     if (4 * oq >= ow || oy0 >= oh) return;
-    const float* __restrict__ col = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W + (size_t)(4 * oq + margin);
-    uint8_t* __restrict__ dst = a.shadow + (size_t)blockIdx.z * (size_t)a.out_stride + (size_t)(4 * oq);
-    struct Row { f32x2 v[4]; };         // d[x-2 .. x+5]; x is even, rows are 8-byte aligned
+    const int ox = 4 * oq + 4 <= ow ? 4 * oq : ow - 4;          // the last quad of a ragged row overlaps the one before it
+    const float* __restrict__ col = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W + (size_t)(ox + margin);
+    uint8_t* __restrict__ dst = a.shadow + (size_t)blockIdx.z * (size_t)a.out_stride + (size_t)ox;
+    struct Row { f32x2 v[4]; };         // d[x-2 .. x+5] (inside the row: margin >= 2)
     auto load_row = [&](int y) {
         const float* r = col + (size_t)(y < H ? y : H - 1) * (size_t)W;        // rows past the last output row: clamped, unused
         // plain (cacheable) loads: neighbouring lanes' 32-byte pieces overlap by half, the second touch must hit
         // the cache (non-temporal loads measured 8 % slower)
-        return Row{{*reinterpret_cast<const f32x2*>(r - 2), *reinterpret_cast<const f32x2*>(r),
-                    *reinterpret_cast<const f32x2*>(r + 2), *reinterpret_cast<const f32x2*>(r + 4)}};
+        return Row{{*reinterpret_cast<const f32x2_u*>(r - 2), *reinterpret_cast<const f32x2_u*>(r),
+                    *reinterpret_cast<const f32x2_u*>(r + 2), *reinterpret_cast<const f32x2_u*>(r + 4)}};
     };
     const int y0 = oy0 + margin;
     // software pipeline: the rows of output row i + 2 are requested before output row i is computed, so a
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(64 * SHADOW_WAVES) void dswx_shadow_v3(const Shadow
         const Row nn = i + 3 <= SHADOW_ROWS ? load_row(y0 + i + 3) : nx;       // only rows an output row of this wave needs
         if (oy0 + i < oh) {
             const uint32_t out = shadow_quad<F32, TINY>(a, f, ce.v[0], ce.v[1], ce.v[2], ce.v[3], up.v[1], up.v[2], dn.v[1], dn.v[2]);
-            __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(dst + (size_t)(oy0 + i) * (size_t)ow));
+            __builtin_nontemporal_store(out, reinterpret_cast<u32_u*>(dst + (size_t)(oy0 + i) * (size_t)ow));
         }
         up = ce;
         ce = dn;
@@ -607,9 +615,9 @@ static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles
         return dswx_fail(DSWX_ERR_ARG, "shadow_tile_stride smaller than the shadow raster");
     a.out_stride = shadow_tile_stride ? shadow_tile_stride : oh * ow;
     if ((oh + 3) / 4 > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
-    // four pixels per thread behind the filter where the geometry allows 8-byte loads and dword stores
-    const bool quads = margin >= 2 && margin % 2 == 0 && width % 2 == 0 && ow % 4 == 0 && aligned_to(dem, 8) &&
-                       aligned_to(shadow, 4) && a.out_stride % 4 == 0;
+    // four pixels per thread behind the filter wherever a quad and the columns beside it are interior pixels (unaligned
+    // 8-byte loads / dword stores: any margin >= 2, any width, any buffer alignment -- see dswx_shadow_v3)
+    const bool quads = margin >= 2 && ow >= 4 && aligned_to(dem, 4) && ctx->shadow_kernel != 2;
     if (quads) {
         ShadowFilter f;
         shadow_filter(a, f32, &f);
@@ -620,7 +628,7 @@ static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles
         // 1.27 x over-fetch the L2 counters show is absorbed behind the L2 (Infinity Cache), it is not what the
         // kernel waits for.  Default 1 = as it comes.
         const long long pad = ctx->shadow_grid_pad > 0 ? ctx->shadow_grid_pad : 1;
-        const long long gx = ((ow / 4 + 63) / 64 + pad - 1) / pad * pad;
+        const long long gx = (((ow + 3) / 4 + 63) / 64 + pad - 1) / pad * pad;
         dim3 grid((unsigned)gx, (unsigned)((oh + SHADOW_WAVES * SHADOW_ROWS - 1) / (SHADOW_WAVES * SHADOW_ROWS)), (unsigned)n_tiles), block(64 * SHADOW_WAVES);
         if (f32 && f.t_tiny) hipLaunchKernelGGL((dswx_shadow_v3<true, true>), grid, block, 0, s, a, f);
         else if (f32) hipLaunchKernelGGL((dswx_shadow_v3<true, false>), grid, block, 0, s, a, f);

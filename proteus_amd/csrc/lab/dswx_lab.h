@@ -20,7 +20,7 @@ extern "C" {
 int dswx_lab_attach(dswx_ctx_t* ctx);
 
 /* A/B switches (what round 1 read from DSWX_* environment variables): "fused_variant" (-1 automatic,
- * 0 direct kernel, 3 table-driven kernel), "tune_wps", "tune_lut_wps", "tune_lut_interleave", "cover_kernel", "host_pipeline", "host_chunks", "shadow_grid_pad",
+ * 0 direct kernel, 3 table-driven kernel), "tune_wps", "tune_lut_wps", "tune_lut_interleave", "cover_kernel", "host_pipeline", "host_chunks", "shadow_grid_pad", "shadow_kernel" (2: dswx_shadow_v2 always),
  * "place_force_candidate" (>= 0: dswx_batch_place_slide keeps that candidate position whatever it measures; tests). */
 int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value);
 

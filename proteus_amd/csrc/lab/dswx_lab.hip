@@ -32,6 +32,10 @@ int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value) {
     else if (k == "place_force_candidate") ctx->place_force_candidate = value;
     else if (k == "cover_kernel") ctx->cover_kernel = value;
     else if (k == "host_pipeline") ctx->host_pipeline = value;
+    else if (k == "shadow_kernel") {
+        if (value != 0 && value != 2) return dswx_fail(DSWX_ERR_ARG, "shadow_kernel: 0 automatic, 2 the general kernel");
+        ctx->shadow_kernel = value;
+    }
     else if (k == "shadow_grid_pad") {
         if (value < 1 || value > 64) return dswx_fail(DSWX_ERR_ARG, "shadow_grid_pad out of range");
         ctx->shadow_grid_pad = value;

@@ -430,6 +430,11 @@ def _compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
     mode = (numpy_promotion or os.environ.get('DSWX_NUMPY_PROMOTION', 'legacy')).lower()
     if mode not in ('nep50', 'legacy'):
         raise ValueError(f"numpy_promotion must be 'nep50' or 'legacy', not {mode!r}")
+    if margin < 2 and dem.size >= 1 << 20:
+        # the only geometry left on the general one-pixel kernel (border pixels take one-sided differences there):
+        # ~0.2 of the HBM rate instead of ~0.65 -- the reference's own call has a margin of 50 (:58, :5161-5167)
+        logger.warning(f'WARNING terrain shadow layer with a margin of {margin} pixel(s): the general kernel '
+                       '(dswx_shadow_v2) computes the whole raster, about three times slower than the filter kernel')
     return get_context().shadow_layer(
         dem, target_to_sun_unit_vector, np.sin(sun_azimuth), np.cos(sun_azimuth),
         min_slope_angle, max_sun_local_inc_angle, pixel_spacing_x, pixel_spacing_y,

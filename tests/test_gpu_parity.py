@@ -296,35 +296,47 @@ def test_more_tiles_than_one_grid_dimension(ctx, tile_align, h, w):
     batch.free()
 
 
-def test_unaligned_device_pointers_take_generic_kernel(ctx):
-    """Planes at odd byte offsets: still correct (dswx_classify_v1)."""
-    h, w = 40, 40
+@pytest.mark.parametrize('shape', [(40, 40), (41, 43), (1, 5)])
+def test_unaligned_device_pointers_take_the_direct_kernel(ctx, shape):
+    """Planes at ODD addresses (int16 planes 2-byte aligned, byte planes anywhere) with masks and every layer: the direct
+    kernel takes them since round 6 (unaligned 16- / 8-byte global accesses) -- up to round 5 the
+    1-pixel-per-thread kernel did (0.17 of peak).  The generic kernel still does the n % 8 tail pixels."""
+    h, w = shape
     n = h * w
-    s = synth_tile(3, h, w)
-    arena = ctx.malloc(n * 32)
+    s = synth_tile(3, h, w, with_masks=True)
+    arena = ctx.malloc(n * 40 + 256)
     pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
     off = 2
     for i, b in enumerate(s['bands']):
         arena.upload(b.ravel(), off)
         pin.band[i] = arena.ptr + off
-        off += n * 2 + 2
+        off += n * 2 + 2 + 4 * i
     off += 1
-    arena.upload(s['fmask'].ravel(), off)
-    pin.fmask = arena.ptr + off
-    off += n + 1
+    where = {}
+    for name in ('fmask', 'land', 'shad', 'ocean'):
+        arena.upload(s[name].ravel(), off)
+        setattr(pin, name, arena.ptr + off)
+        off += n + 1 + (n % 2)
     off += off % 2
     pout.diag = arena.ptr + off
-    diag_off = off
+    where['diag'] = off
     off += 2 * n + 3
-    pout.wtr = arena.ptr + off
-    wtr_off = off
+    for name in ('wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+        setattr(pout, name, arena.ptr + off)
+        where[name] = off
+        off += n + 3
+    off += (-off) % 8
+    cnt_off = off
     p = _capi.default_params()
-    ctx.classify_device(p, 1, n, pin, pout)
+    ctx.classify_device(p, 1, n, pin, pout, counters_ptr=arena.ptr + cnt_off)
     ctx.synchronize()
-    assert 'v1' in ctx.last_kernel_info()
-    exp = c_oracle.classify(p, s['bands'], s['fmask'])
-    assert np.array_equal(arena.download(np.uint16, n, diag_off), exp['diag'].ravel())
-    assert np.array_equal(arena.download(np.uint8, n, wtr_off), exp['wtr'].ravel())
+    info = ctx.last_kernel_info()
+    assert ('dswx_classify_v8' in info) == (n >= 8) and 'dswx_classify_lut' not in info, info
+    exp = c_oracle.classify(p, s['bands'], s['fmask'], land=s['land'], shad=s['shad'], ocean=s['ocean'])
+    assert np.array_equal(arena.download(np.uint16, n, where['diag']), exp['diag'].ravel())
+    for name in ('wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
+        assert np.array_equal(arena.download(np.uint8, n, where[name]), exp[name].ravel()), name
+    assert arena.download(np.int64, 3, cnt_off).tolist() == exp['counters'].tolist()
     arena.free()
 
 
@@ -415,8 +427,8 @@ def test_zero_copy_writes_stay_inside_the_planes(ctx, align):
                     assert np.array_equal(buf[ptr['wtr']:ptr['wtr'] + P].reshape(h, w), exp['wtr'])
                     assert np.array_equal(buf[ptr['diag']:ptr['diag'] + 2 * P].view(np.uint16).reshape(h, w), exp['diag'])
                 del buf
-    # 256 -> table-driven (+ generic for the ragged tails), 16 -> direct, 1 -> generic only
-    want = {256: 'dswx_classify_lut', 16: 'dswx_classify_v8', 1: 'dswx_classify_v1'}[align]
+    # 256 -> table-driven (+ generic for the ragged tails), 16 and 1 -> direct (any address since round 6)
+    want = {256: 'dswx_classify_lut', 16: 'dswx_classify_v8', 1: 'dswx_classify_v8'}[align]
     assert any(want in k for k in kinds), kinds
 
 
@@ -1120,13 +1132,29 @@ def test_ragged_contiguous_batches_take_the_vector_kernel(ctx, masks):
                     assert cnt[t].tolist() == exp[t]['counters'].tolist(), (n, h, w, t, k)
                 assert (cnt[k:] == -3).all()
         b.free()
-    # 'cover' mode keeps the generic kernel on ragged batches (its bitmaps are indexed by tile-relative 8-pixel groups)
-    b = _capi.DeviceBatch(ctx, 3, 37, 41, masks=masks, tile_align=1)
-    b.synth(SEED, tile0=400)
-    b.classify(_capi.make_params(mask_adjacent_to_cloud_mode='cover'))
-    ctx.synchronize()
-    assert 'dswx_classify_v1' in ctx.last_kernel_info() and 'ragged' not in ctx.last_kernel_info()
-    b.free()
+    # 'cover' mode on ragged batches: its bitmaps are indexed by tile-relative 8-pixel groups, which is how the DIRECT kernel
+    # walks a tile -- since round 6 it takes every tile start as it is (unaligned accesses) instead of leaving whole tiles
+    # to the generic kernel; all layers against the numpy oracle's 'cover' chain
+    from oracle import dswx_oracle as o
+    for (n, h, w) in [(3, 37, 41), (2, 301, 263)]:
+        b = _capi.DeviceBatch(ctx, n, h, w, masks=masks, tile_align=1)
+        b.synth(SEED, tile0=400)
+        b.classify(_capi.make_params(mask_adjacent_to_cloud_mode='cover'))
+        ctx.synchronize()
+        info = ctx.last_kernel_info()
+        assert 'dswx_classify_v8' in info and 'dswx_classify_lut' not in info and 'ragged' not in info, info
+        cnt = b.read_counters()
+        for t in range(n):
+            st = synth_tile(400 + t, h, w, with_masks=masks)
+            kw = dict(landcover=st['land'], shadow=st['shad'], ocean_mask=st['ocean']) if masks else {}
+            exp = o.classify_tile(st['bands'], st['fmask'], mask_adjacent_to_cloud_mode='cover', **kw)
+            for key, layer in (('diag', 'DIAG'), ('wtr1', 'WTR-1'), ('wtr2', 'WTR-2'), ('wtr', 'WTR'), ('bwtr', 'BWTR'),
+                               ('conf', 'CONF'), ('cloud', 'CLOUD')):
+                want = exp[layer + '.collapsed'] if layer + '.collapsed' in exp else exp[layer]
+                assert np.array_equal(b.read_tile(key, t), want), (n, h, w, key, t)
+            c = exp['counters']
+            assert cnt[t].tolist() == [c['n_valid'], c['n_cloud_and_valid'], c['n_not_ocean']]
+        b.free()
 
 
 def test_contexts_on_concurrent_host_threads():
@@ -1408,10 +1436,18 @@ def test_shadow_layer_filter_adversarial(ctx, legacy):
             exp = o.compute_opera_shadow_layer(dem, az, el, mn, mx, legacy_promotion=legacy)[50:-50, 50:-50]
         assert got.shape == (160, 228)
         assert np.array_equal(got, exp), (k, az, el, mn, mx, int(np.count_nonzero(got != exp)))
-        # the general one-pixel kernel (odd margin) agrees on the same interior
+        # an ODD margin (the quad kernel too since round 6: unaligned accesses) agrees on the same interior, and so does
+        # the general one-pixel kernel (lab switch: the exact arithmetic alone)
         got1 = D._compute_opera_shadow_layer(dem, az, el, mn, mx, margin=49,
                                              numpy_promotion='legacy' if legacy else 'nep50')
         assert np.array_equal(got1[1:-1, 1:-1], exp), k
+        D.get_context().lab_configure(shadow_kernel=2)
+        try:
+            got2 = D._compute_opera_shadow_layer(dem, az, el, mn, mx, margin=49,
+                                                 numpy_promotion='legacy' if legacy else 'nep50')
+        finally:
+            D.get_context().lab_configure(shadow_kernel=0)
+        assert np.array_equal(got2, got1), k
 
 
 @pytest.mark.parametrize('legacy', [False, True])
@@ -1448,15 +1484,17 @@ def test_shadow_layer_thresholds_inside_the_data(ctx, legacy):
 
 @pytest.mark.parametrize('legacy', [False, True])
 def test_shadow_filter_vs_exact_kernel_soak(ctx, legacy):
-    """The filter kernel (even margin) against the general kernel (odd margin: exact arithmetic only, itself
+    """The filter kernel against the general kernel (lab switch shadow_kernel=2: exact arithmetic only, itself
     pinned to numpy above) on the same pixels: 120 random DEMs x sun geometries x pixel spacings, thresholds
     at random quantiles of each case's own arccos / arctan arguments, degenerate thresholds, rough / gentle /
-    terraced terrain.  No numpy in the loop, so the soak is wide."""
+    terraced terrain.  No numpy in the loop, so the soak is wide.  Round 6: ANY margin >= 2 and
+    ANY width take the filter kernel now (unaligned loads and stores, the last quad of a ragged row overlapping its
+    neighbour) -- margins even and odd, widths of every residue modulo 4 below."""
     rng = np.random.default_rng(777)
     c = ctx
     n_diff_cases = 0
     for k in range(120):
-        h, w = int(rng.integers(60, 400)), 4 * int(rng.integers(20, 110))     # even margin + width % 4 == 0: the filter kernel
+        h, w = int(rng.integers(60, 400)), int(rng.integers(80, 440))
         kind = k % 4
         yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
         z = rng.uniform(5, 400) * np.sin(xx / rng.uniform(5, 60) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(5, 60)) \
@@ -1473,13 +1511,55 @@ def test_shadow_filter_vs_exact_kernel_soak(ctx, legacy):
         t = n0 * np.sin(az) + n1 * np.cos(az)
         max_inc = (float(np.degrees(np.arccos(np.clip(np.quantile(q, rng.uniform(0.05, 0.95)), -1, 1)))), 0.0, 180.0)[(k // 4) % 3 if k % 11 == 0 else 0]
         min_slope = (float(np.degrees(np.arctan(np.quantile(t, rng.uniform(0.05, 0.95))))), 0.0, -90.0, 90.0)[(k // 5) % 4 if k % 7 == 0 else 0]
-        m = 2 * int(rng.integers(1, 10))
+        m = int(rng.integers(2, 20))
         a = c.shadow_layer(dem, sun, np.sin(az), np.cos(az), min_slope, max_inc, sx, sy, margin=m, float32=legacy)
-        b = c.shadow_layer(dem, sun, np.sin(az), np.cos(az), min_slope, max_inc, sx, sy, margin=m - 1, float32=legacy)
+        c.lab_configure(shadow_kernel=2)
+        try:
+            b = c.shadow_layer(dem, sun, np.sin(az), np.cos(az), min_slope, max_inc, sx, sy, margin=m - 1, float32=legacy)
+        finally:
+            c.lab_configure(shadow_kernel=0)
         assert a.shape == (h - 2 * m, w - 2 * m)
         assert np.array_equal(a, b[1:-1, 1:-1]), (k, h, w, m, max_inc, min_slope, sx, sy, int(np.count_nonzero(a != b[1:-1, 1:-1])))
         n_diff_cases += int(0.02 < a.mean() < 0.98)
     assert n_diff_cases > 60          # most cases have the thresholds cutting through the data
+
+
+def test_shadow_quad_kernel_at_any_address_and_stride(ctx):
+    """Round 6: the DEM at a 4-byte (not 8-byte) boundary, the shadow rasters at odd addresses an odd stride apart, three
+    tiles, odd margin, output width 4 k + {1, 2, 3}: the filter kernel (unaligned 8-byte loads, unaligned dword stores,
+    overlapping last quad) against the general kernel on aligned buffers -- and nothing written outside the rasters."""
+    from proteus_amd.synth import synth_dem
+    n, h, w = 3, 121, 150
+    dems = np.stack([synth_dem(60 + t, h, w) for t in range(n)])
+    sun, sa, ca = _sun(143.2, 35.0)
+    for margin in (3, 2, 8):
+        oh, ow = h - 2 * margin, w - 2 * margin
+        stride = oh * ow + 5
+        d_dem = ctx.malloc(dems.nbytes + 64)
+        d_out = ctx.malloc(n * stride + 64)
+        d_ref = ctx.malloc(n * oh * ow + 64)
+        try:
+            d_dem.upload(dems.ravel(), 4)
+            ctx.lib.dswx_memset_d(ctx.handle, d_out.ptr, 0x77, d_out.nbytes)
+            ctx.shadow_layer_device(d_dem.ptr + 4, n, h, w, margin, sun, sa, ca, -5.0, 40.0, d_out.ptr + 3, out_tile_stride=stride)
+            ctx.synchronize()
+            d_dem.upload(dems.ravel(), 0)
+            ctx.lab_configure(shadow_kernel=2)
+            try:
+                ctx.shadow_layer_device(d_dem.ptr, n, h, w, margin, sun, sa, ca, -5.0, 40.0, d_ref.ptr)
+                ctx.synchronize()
+            finally:
+                ctx.lab_configure(shadow_kernel=0)
+            got = d_out.download(np.uint8, n * stride + 64)
+            ref = d_ref.download(np.uint8, n * oh * ow).reshape(n, oh * ow)
+            assert (got[:3] == 0x77).all() and (got[3 + n * stride - 5:] == 0x77).all()
+            for t in range(n):
+                assert np.array_equal(got[3 + t * stride: 3 + t * stride + oh * ow], ref[t]), (margin, t)
+                if t + 1 < n:
+                    assert (got[3 + t * stride + oh * ow: 3 + (t + 1) * stride] == 0x77).all()
+            assert 0.02 < ref.mean() < 0.98
+        finally:
+            d_dem.free(); d_out.free(); d_ref.free()
 
 
 def _sun(az_deg, el_deg):
