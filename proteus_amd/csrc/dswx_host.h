@@ -51,7 +51,8 @@ struct dswx_ctx {
     int host_pipeline = 2;                 // page-locked host planes: 2 zero copy, 1 staged three-stream pipeline (lab A/B),
                                            // 0 forces the synchronous path
     int host_chunks = 8;                   // pieces per tile of the pipelined host path
-    int shadow_kernel = 0;                 // 2 forces the general one-pixel kernel dswx_shadow_v2 (tests: the exact arithmetic alone)
+    int shadow_kernel = 0;                 // 2 forces the general one-pixel kernel dswx_shadow_v2 (tests: the exact arithmetic alone);
+                                           // 3: the filter kernel in two launches, even block rows then odd (Infinity Cache probe)
     int shadow_grid_pad = 1;               // dswx_shadow_v3: grid.x rounded up to a multiple of this (lab A/B, see the launch)
     std::string last_kernel;
     int tune_lut_wps = 0;    // table-driven kernel: launch bound (4, 5, 6; 0 = automatic)

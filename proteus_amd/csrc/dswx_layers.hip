@@ -58,6 +58,10 @@ struct ShadowArgs {
     //   degrees(arccos(q)) <= max_sun_local_inc_angle  <=>  inc_q_min <= q <= 1
     //   degrees(arctan(t)) <= min_slope_angle          <=>  t <= slope_arg_max
     double inc_q_min, slope_arg_max;
+    // dswx_shadow_v3: block row = by_first + blockIdx.y * by_step (0 / 1 in production; the lab's two-pass launch -- even
+    // block rows of every tile, then the odd ones -- puts > 256 MiB of traffic between the two reads of every halo row,
+    // which separates what the Infinity Cache absorbs from what reaches HBM: profiles/r06_next_rows_pmc.json)
+    int by_first, by_step;
 };
 
 // The arithmetic of one pixel exactly as the reference orders it, given the two finite differences
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(64 * SHADOW_WAVES) void dswx_shadow_v3(const Shadow
     const int W = (int)a.width, H = (int)a.height, margin = (int)a.margin;
     const int ow = W - 2 * margin, oh = H - 2 * margin;
     const int oq = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int oy0 = (blockIdx.y * SHADOW_WAVES + (threadIdx.x >> 6)) * SHADOW_ROWS;
+    const int oy0 = ((a.by_first + (int)blockIdx.y * a.by_step) * SHADOW_WAVES + (threadIdx.x >> 6)) * SHADOW_ROWS;
     if (4 * oq >= ow || oy0 >= oh) return;
     const int ox = 4 * oq + 4 <= ow ? 4 * oq : ow - 4;          // the last quad of a ragged row overlaps the one before it
     const float* __restrict__ col = a.dem + (size_t)blockIdx.z * (size_t)H * (size_t)W + (size_t)(ox + margin);
@@ -545,6 +549,7 @@ static int shadow_args(ShadowArgs* a, int64_t height, int64_t width, int64_t mar
     for (int i = 0; i < 3; ++i) a->sun[i] = sun_vector[i];
     a->sin_az = sin_azimuth; a->cos_az = cos_azimuth;
     a->slope_arg_max = slope_arg_max; a->inc_q_min = inc_q_min;
+    a->by_first = 0; a->by_step = 1;
     return DSWX_OK;
 }
 
@@ -629,11 +634,19 @@ static int shadow_device_impl(dswx_ctx_t* ctx, const float* dem, int64_t n_tiles
         // kernel waits for.  Default 1 = as it comes.
         const long long pad = ctx->shadow_grid_pad > 0 ? ctx->shadow_grid_pad : 1;
         const long long gx = (((ow + 3) / 4 + 63) / 64 + pad - 1) / pad * pad;
-        dim3 grid((unsigned)gx, (unsigned)((oh + SHADOW_WAVES * SHADOW_ROWS - 1) / (SHADOW_WAVES * SHADOW_ROWS)), (unsigned)n_tiles), block(64 * SHADOW_WAVES);
-        if (f32 && f.t_tiny) hipLaunchKernelGGL((dswx_shadow_v3<true, true>), grid, block, 0, s, a, f);
-        else if (f32) hipLaunchKernelGGL((dswx_shadow_v3<true, false>), grid, block, 0, s, a, f);
-        else if (f.t_tiny) hipLaunchKernelGGL((dswx_shadow_v3<false, true>), grid, block, 0, s, a, f);
-        else hipLaunchKernelGGL((dswx_shadow_v3<false, false>), grid, block, 0, s, a, f);
+        const unsigned block_rows = (unsigned)((oh + SHADOW_WAVES * SHADOW_ROWS - 1) / (SHADOW_WAVES * SHADOW_ROWS));
+        const dim3 block(64 * SHADOW_WAVES);
+        const int passes = ctx->shadow_kernel == 3 ? 2 : 1;      // lab: even block rows of all tiles, then the odd ones
+        for (int pass = 0; pass < passes; ++pass) {
+            a.by_first = pass; a.by_step = passes;
+            const unsigned gy = (block_rows - (unsigned)pass + (unsigned)passes - 1) / (unsigned)passes;
+            if (gy == 0) continue;
+            const dim3 grid((unsigned)gx, gy, (unsigned)n_tiles);
+            if (f32 && f.t_tiny) hipLaunchKernelGGL((dswx_shadow_v3<true, true>), grid, block, 0, s, a, f);
+            else if (f32) hipLaunchKernelGGL((dswx_shadow_v3<true, false>), grid, block, 0, s, a, f);
+            else if (f.t_tiny) hipLaunchKernelGGL((dswx_shadow_v3<false, true>), grid, block, 0, s, a, f);
+            else hipLaunchKernelGGL((dswx_shadow_v3<false, false>), grid, block, 0, s, a, f);
+        }
     } else {
         dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)n_tiles), block(256);
         if (f32) hipLaunchKernelGGL(dswx_shadow_v2<true>, grid, block, 0, s, a);

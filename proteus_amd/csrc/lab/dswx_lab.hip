@@ -33,7 +33,8 @@ int dswx_lab_configure(dswx_ctx_t* ctx, const char* key, int value) {
     else if (k == "cover_kernel") ctx->cover_kernel = value;
     else if (k == "host_pipeline") ctx->host_pipeline = value;
     else if (k == "shadow_kernel") {
-        if (value != 0 && value != 2) return dswx_fail(DSWX_ERR_ARG, "shadow_kernel: 0 automatic, 2 the general kernel");
+        if (value != 0 && value != 2 && value != 3)
+            return dswx_fail(DSWX_ERR_ARG, "shadow_kernel: 0 automatic, 2 the general kernel, 3 the filter kernel in two passes (even / odd block rows)");
         ctx->shadow_kernel = value;
     }
     else if (k == "shadow_grid_pad") {
