@@ -170,3 +170,51 @@ def test_c_example_runs_and_matches_the_oracle(tmp_path):
         return h
     for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
         assert f'checksum {key} {fnv([e[key] for e in exp]):016x}' in lines, key
+
+
+def cog_stub_source():
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r"```python\n(# src/proteus/_dswx_hip_cog\.py.*?\n.*?)```", text, re.S)
+    assert m, 'cog stub block not found in INTEGRATION.md'
+    return m.group(1)
+
+
+def test_cog_stub_structure_matches_the_header():
+    ns = {'ctypes': ctypes}
+    src = cog_stub_source()
+    exec(compile(src[:src.index('def cog_blocks(')], 'INTEGRATION.md (cog)', 'exec'), ns)
+    mine, ref = ns['CogLayout'], _capi.CogLayout
+    assert ctypes.sizeof(mine) == ctypes.sizeof(ref)
+    assert [(f[0], getattr(mine, f[0]).offset) for f in mine._fields_] == [(f[0], getattr(ref, f[0]).offset) for f in ref._fields_]
+
+
+@pytest.mark.gpu
+def test_cog_stub_runs_and_matches_the_host_writer():
+    """ABI v6 from the stub of INTEGRATION.md alone: a layer in HBM -> the blocks of the image and of its NEAREST overviews,
+    predictor applied == what the host writer (geotiff.blocked_level / overview_nearest) hands to DEFLATE."""
+    from proteus_amd import geotiff
+    ns = {}
+    exec(compile(stub_source(), 'INTEGRATION.md', 'exec'), ns)
+    bsrc = batch_stub_source()
+    exec(compile(bsrc[bsrc.index('def _ok(rc):'):bsrc.index('def resident_batch(')], 'INTEGRATION.md (batch)', 'exec'), ns)
+    exec(compile(cog_stub_source(), 'INTEGRATION.md (cog)', 'exec'), ns)
+    lib, ctx = ns['_lib'], ns['_ctx']
+    rng = np.random.default_rng(5)
+    layer = rng.integers(0, 5, size=(1300, 777)).astype(np.uint8)
+    d_layer, d_blocks = ctypes.c_void_p(), ctypes.c_void_p()
+    want = [geotiff.blocked_level(lv[None], 512, 2) for lv in [layer] + [geotiff.overview_nearest(layer, f) for f in (4, 16, 64, 128)]]
+    total = sum(lv.n_blocks * lv.block_bytes for lv in want)
+    assert lib.dswx_device_malloc(ctx, ctypes.c_size_t(layer.nbytes), ctypes.byref(d_layer)) == 0
+    assert lib.dswx_device_malloc(ctx, ctypes.c_size_t(total), ctypes.byref(d_blocks)) == 0
+    assert lib.dswx_memcpy_h2d(ctx, d_layer, ctypes.c_void_p(layer.ctypes.data), ctypes.c_size_t(layer.nbytes)) == 0
+    lay = ns['cog_blocks'](d_layer, 1, 1300, 777, d_blocks)
+    assert lib.dswx_stream_synchronize(ctx, None) == 0
+    assert lay.n_levels == 5 and lay.total_bytes == total
+    got = np.empty(total, np.uint8)
+    assert lib.dswx_memcpy_d2h(ctx, ctypes.c_void_p(got.ctypes.data), d_blocks, ctypes.c_size_t(total)) == 0
+    for k, lv in enumerate(want):
+        n = lv.n_blocks * lv.block_bytes
+        assert np.array_equal(got[lay.offset_bytes[k]: lay.offset_bytes[k] + n], lv.data.reshape(-1).view(np.uint8)), k
+    lib.dswx_device_free(ctx, d_layer)
+    lib.dswx_device_free(ctx, d_blocks)
+    lib.dswx_ctx_destroy(ctx)
