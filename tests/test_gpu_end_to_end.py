@@ -342,6 +342,42 @@ def test_batch_driver_single_gpu(tmp_path):
     assert not ok and results[0]['ok'] and not results[1]['ok']
 
 
+def test_tiles_in_flight_inside_one_worker(tmp_path):
+    """Round 6: ONE worker process keeps several tiles going at once on its threads -- tile k + 1
+    inflating and tile k - 1 deflating while tile k is on the device, the engine's lock serialising the GPU part, one HIP
+    context.  Eight tiles of different sizes, sensors and ancillary sets, six in flight: every layer of every product is
+    what the same tile gives alone (oracle), every file is a valid COG, and the worker's stage report says the stages
+    overlapped."""
+    from proteus_amd import batch
+    rcs, want = [], []
+    for t in range(8):
+        size = (96, 160, 131, 64)[t % 4]
+        d = tmp_path / f'f{t}'
+        anc = t % 3 == 0
+        rcfile, _, _, _ = synth_hls.make(str(d), sensor=('L30', 'S30')[t % 2], size=size, tile=50 + t, product_id=f'F{t}',
+                                         ancillary=anc, ocean=anc)
+        rcs.append(rcfile)
+        want.append((size, anc))
+    reports = []
+    ok, results = batch.run_batch(rcs, 1, in_flight=6, reports=reports)
+    assert ok, results
+    assert len(reports) == 1 and reports[0]['in_flight'] == 6 and reports[0]['tiles'] == 8
+    st = reports[0]['stages']['stages']
+    assert st['gpu: classify (resident planes)']['spans'] == 8 and st['write: deflate']['spans'] >= 8 * 7
+    for t, (size, anc) in enumerate(want):
+        out = tmp_path / f'f{t}' / 'output'
+        s = synth_hls.synth_tile(50 + t, size, size)
+        if anc:
+            continue                    # (ancillary products: test_mixed_stream_... checks their layers; here: they ran side by side)
+        exp = o.classify_tile(s['bands'], s['fmask'])
+        for stem, layer in (('B01_WTR', 'WTR'), ('B02_BWTR', 'BWTR'), ('B03_CONF', 'CONF'), ('B04_DIAG', 'DIAG'),
+                            ('B05_WTR-1', 'WTR-1'), ('B06_WTR-2', 'WTR-2'), ('B09_CLOUD', 'CLOUD')):
+            path = str(out / f'F{t}_v1.0_{stem}.tif')
+            arr, _ = geotiff.read_geotiff(path)
+            assert np.array_equal(arr, exp[layer]), (t, layer)
+            assert geotiff.validate_cog(path) == []
+
+
 def test_mixed_stream_with_terrain_shadow_and_landcover(tmp_path):
     """BASELINE.json configs[4] on one GPU: a mixed HLS.L30 / HLS.S30 stream through the node-level
     driver, from runconfigs alone, with terrain shadow + ocean masking + land cover enabled: SHAD computed

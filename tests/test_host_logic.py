@@ -612,3 +612,61 @@ def test_scale_report_reads_bench_lines(tmp_path):
     assert r1['ranks'] == 1 and r1['efficiency_vs_n1'] == 1.0 and rep['baseline_n1_Mpx_s'] == r1['value_Mpx_s']
     assert r2['ranks'] == 2 and r2['distinct_gpus'] == 1 and 0.4 < r2['efficiency_vs_n1'] < 0.6 and r2['error'] is None
     assert r2['strong_4096_tiles']['parity'] == 'bit-exact' and 'distinct device' in r2['note']
+
+
+def test_stage_clock_reports_work_and_wall_per_stage():
+    """proteus_amd.stages (round 6: where the wall time of a product run goes): spans from several threads, per stage
+    the sum of the spans (work) and the length of their UNION (wall); off unless started."""
+    import threading
+    import time
+    from proteus_amd import stages
+    assert not stages.recording()
+    with stages.span('ignored'):
+        pass
+    stages.start()
+    t0 = time.perf_counter()
+    stages.add('a', t0, t0 + 1.0)
+    stages.add('a', t0 + 0.5, t0 + 2.0)           # overlaps the first: union 2.0, work 2.5
+    stages.add('a', t0 + 3.0, t0 + 3.5)           # disjoint
+    stages.add('b', t0 + 1.0, t0 + 1.25)
+
+    def worker():
+        with stages.span('c'):
+            time.sleep(0.01)
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    rep = stages.stop()
+    assert not stages.recording()
+    a = rep['stages']['a']
+    assert a['spans'] == 3 and abs(a['thread_s'] - 3.0) < 1e-3 and abs(a['wall_s'] - 2.5) < 1e-3
+    assert rep['stages']['b'] == {'spans': 1, 'thread_s': 0.25, 'wall_s': 0.25}
+    assert rep['stages']['c']['spans'] == 4 and rep['stages']['c']['thread_s'] >= 0.04
+    assert list(rep['stages']) == ['a', 'c', 'b'] and rep['wall_s'] >= 3.5          # stages in the order of their first start
+    assert stages.report([]) == {'wall_s': 0.0, 'stages': {}}
+
+
+@pytest.mark.parametrize('shape', [(3660, 3660), (1, 1), (1, 7), (513, 1025), (4096, 512), (29, 58)])
+def test_cog_layout_is_the_host_writers_layout(shape):
+    """dswx_cog_layout (ABI v6, no device needed) against the levels the host writer makes: sizes ceil(N / f), blocks,
+    offsets in file-independent level order, for u8 / u16 / f32 and the reference's factors (core.py:37)."""
+    from proteus_amd import _capi
+    h, w = shape
+    for itemsize, factors in ((1, geotiff.COG_OVERVIEW_FACTORS), (2, geotiff.COG_OVERVIEW_FACTORS), (4, ()), (1, (1, 4))):
+        lay = _capi.cog_layout(h, w, itemsize, factors, 512)
+        arr = np.zeros(shape, {1: np.uint8, 2: np.uint16, 4: np.float32}[itemsize])
+        levels = [arr] + [geotiff.overview_nearest(arr, f) for f in factors if f > 1 and shape != (1, 1)]
+        assert lay['n_levels'] == len(levels)
+        off = 0
+        for lv, want in zip(lay['levels'], levels):
+            b = geotiff.blocked_level(want[None], 512, 2 if itemsize < 4 else 3)
+            assert (lv['height'], lv['width'], lv['blocks_down'], lv['blocks_across']) == (b.height, b.width, b.down, b.across)
+            assert lv['offset_bytes'] == off
+            off += b.n_blocks * b.block_bytes
+        assert lay['total_bytes'] == off
+    with pytest.raises(_capi.DswxError):
+        _capi.cog_layout(h, w, 3, (), 512)
+    with pytest.raises(_capi.DswxError):
+        _capi.cog_layout(h, w, 1, (), 100)
