@@ -275,7 +275,7 @@ def load_library(path=None):
 
 
 _lab = None
-# every symbol csrc/lab/dswx_lab.h declares
+# every symbol tools/lab/csrc/dswx_lab.h declares
 LAB_SYMBOLS = ('dswx_lab_attach', 'dswx_lab_configure', 'dswx_stream_probe')
 
 

@@ -2,7 +2,7 @@
 
   libdswx_hip.so   the product: production kernels + the C-ABI of include/dswx_hip.h
   libdswx_codec.so host only (g++): DEFLATE of GeoTIFF blocks on a thread pool (include/dswx_codec.h)
-  libdswx_lab.so   experiments only (csrc/lab/: roofline probes, A/B switches of the dispatch);
+  libdswx_lab.so   experiments only (tools/lab/csrc/, outside the package: roofline probes, A/B switches of the dispatch);
                    links against libdswx_hip.so; loaded by tools/ and the variant tests, never by the product
 
 hipcc cross-compiles gfx950 without a GPU; the built .so files are git-ignored but travel with the
@@ -22,7 +22,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
-LAB = os.path.join(CSRC, 'lab')
+LAB = os.path.join(ROOT, 'tools', 'lab', 'csrc')         # experiments live outside the package (VERDICT r05 'weak' 9)
 SOURCES = [os.path.join(CSRC, n) for n in ('dswx_hip.hip', 'dswx_classify_lut.hip', 'dswx_cover.hip',
                                            'dswx_layers.hip', 'dswx_host_path.hip', 'dswx_batch.hip', 'dswx_writer.hip')]
 HEADERS = [os.path.join(CSRC, n) for n in ('dswx_device.h', 'dswx_host.h', 'dswx_tables.h', 'dswx_vmm.h')]

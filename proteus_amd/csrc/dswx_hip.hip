@@ -5,7 +5,7 @@
 //   dswx_classify_lut.hip table-driven production kernel (+ dswx_tables.h)
 //   dswx_host_path.hip    dswx_classify_host (synchronous and pipelined), page-locked memory
 //   dswx_layers.hip       shadow layer, LAND aggregation, interpret-alone, synthetic tiles
-//   (roofline probes and A/B switches: libdswx_lab.so, csrc/lab/)
+//   (roofline probes and A/B switches: libdswx_lab.so, tools/lab/csrc/)
 //
 // One fused streaming kernel computes, per pixel, everything the reference does
 // in ~100 whole-array numpy passes between src/proteus/dswx_hls.py:5088 and :5369:

@@ -51,7 +51,7 @@ def test_codec_library_exports_its_header():
 def test_product_library_carries_no_experiments():
     """the drop-in library exports exactly the C-ABI of include/dswx_hip.h -- no
     probe / lab entry points -- reads no environment switch, and the experiments live in libdswx_lab.so,
-    whose own header (csrc/lab/dswx_lab.h) it exports in full."""
+    whose own header (tools/lab/csrc/dswx_lab.h) it exports in full."""
     import subprocess
     out = subprocess.run(['nm', '-D', '--defined-only', build.build()], capture_output=True, text=True, check=True).stdout
     c_syms = sorted(l.split()[-1] for l in out.splitlines() if ' T ' in l and not l.split()[-1].startswith('_'))
@@ -62,7 +62,7 @@ def test_product_library_carries_no_experiments():
     blob = open(build.build(), 'rb').read()
     assert b'DSWX_FUSED_VARIANT' not in blob and b'DSWX_COVER_KERNEL' not in blob and b'getenv' not in blob
     lab = ctypes.CDLL(build.build_lab())
-    text = open(os.path.join(ROOT, 'proteus_amd', 'csrc', 'lab', 'dswx_lab.h')).read()
+    text = open(os.path.join(ROOT, 'tools', 'lab', 'csrc', 'dswx_lab.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     lab_names = sorted(set(re.findall(r'\b(dswx_[a-z0-9_]+)\s*\(', text)))
     assert lab_names == sorted(_capi.LAB_SYMBOLS)

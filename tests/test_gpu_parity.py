@@ -860,7 +860,7 @@ def test_pool_trim_while_a_placed_batch_is_live():
     retired range (deterministic: that is how the pool works), (b) after a KEPT dswx_batch_place_slide the batch's chunks
     were moved out of the retired wide range into a range of their own (VmRange::rehome, csrc/dswx_vmm.h) -- the family of
     tools/vmm_reuse_repro.hip's stale translations.  A placement is normally kept only if it measures faster, which no
-    test can require; the lab switch `place_force_candidate` (csrc/lab/dswx_lab.h: not an environment variable, not in the
+    test can require; the lab switch `place_force_candidate` (tools/lab/csrc/dswx_lab.h: not an environment variable, not in the
     product ABI) makes dswx_batch_place_slide keep a NAMED, non-first candidate whatever the clock says.  Four rounds of
     predecessor -> successor from the pool -> forced kept placement (the planes must have MOVED) -> trim while live -> new
     inputs through the same planes -> classify -> every layer of every tile and the counters against the C oracle; the

@@ -156,3 +156,52 @@ def test_rgb_planes(ctx):
         finally:
             for buf in d + [d_diag, d_out]:
                 buf.free()
+
+
+def test_files_from_device_blocks_are_the_host_writers_files(ctx, tmp_path):
+    """The whole writer side: a layer resident on the device -> COG through pipeline.TileEngine.layer_levels (device
+    blocks + overviews + predictor, host DEFLATE) is BYTE FOR BYTE the file the host writer makes from the same array
+    (same blocks -> same DEFLATE streams -> same directory), palette / nodata / metadata included; the same for the
+    three-band Float32 composite of _save_output_rgb_file; and the reader side: the engine's resident plane of a band
+    file == read_geotiff's array."""
+    from proteus_amd import dswx_hls as D
+    from proteus_amd import pipeline
+    eng = pipeline.TileEngine(ctx)
+    rng = np.random.default_rng(31)
+    geo = geotiff.geo_tags_from_geotransform((600000.0, 30.0, 0.0, 4000020.0, 0.0, -30.0), epsg=32615)
+    md = {'PRODUCT_ID': 'x', 'N': 5}
+    try:
+        for shape, dtype in (((3660, 3660), np.uint8), ((1000, 333), np.uint8), ((517, 1031), np.uint16), ((1, 1), np.uint8)):
+            arr = rng.integers(0, 5, size=shape).astype(dtype) * (1 if dtype == np.uint8 else 1111)
+            ct = {0: (255, 255, 255), 1: (0, 0, 255), 255: (0, 0, 0)} if dtype == np.uint8 else None
+            p_host, p_dev = str(tmp_path / 'host.tif'), str(tmp_path / 'dev.tif')
+            geotiff.write_geotiff(p_host, arr, geo_tags=geo, metadata=md, nodata=255, descriptions=['layer'], colormap=ct,
+                                  overviews=FACTORS)
+            plane = eng.upload(arr)
+            geotiff.write_geotiff(p_dev, None, levels=eng.layer_levels(plane, FACTORS), geo_tags=geo, metadata=md, nodata=255,
+                                  descriptions=['layer'], colormap=ct)
+            assert open(p_host, 'rb').read() == open(p_dev, 'rb').read(), (shape, dtype)
+            assert geotiff.validate_cog(p_dev) == []
+            # reader side: the file back into a resident plane
+            back, info = eng.read_plane(p_dev)
+            assert back.shape == shape and back.dtype == dtype and np.array_equal(back.numpy(), arr)
+            assert info.nodata == 255.0 and info.metadata['PRODUCT_ID'] == 'x'
+        # RGB composite: host statement vs device planes, files identical
+        h, w = 700, 900
+        bands = {k: rng.integers(-50, 9000, size=(h, w)).astype(np.int16) for k in ('red', 'green', 'blue')}
+        diag = rng.integers(0, 11112, size=(h, w)).astype(np.uint16)
+        diag[rng.random((h, w)) < 0.05] = 65535
+        scale = {'red': 1e-4, 'green': 2e-4, 'blue': 1e-4}
+        offset = {'red': 0.0, 'green': -3.0, 'blue': 12.5}
+        p_host, p_dev = str(tmp_path / 'rgb_host.tif'), str(tmp_path / 'rgb_dev.tif')
+        clipped = {k: np.clip(v, 1, None) for k, v in bands.items()}
+        D._save_output_rgb_file(clipped['red'], clipped['green'], clipped['blue'], p_host, offset, scale, False, md, geo,
+                                invalid_mask=diag == 65535)
+        planes = [eng.upload(bands[k]) for k in ('red', 'green', 'blue')]
+        D._save_output_rgb_planes(eng, planes, eng.upload(diag), [scale[k] for k in ('red', 'green', 'blue')],
+                                  [offset[k] for k in ('red', 'green', 'blue')], p_dev, md, geo)
+        assert open(p_host, 'rb').read() == open(p_dev, 'rb').read()
+        rgb, _ = geotiff.read_geotiff(p_dev)
+        assert rgb.shape == (3, h, w) and np.isnan(rgb[:, diag == 65535]).all()
+    finally:
+        eng.close()

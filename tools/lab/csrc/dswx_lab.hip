@@ -8,7 +8,7 @@
 #include "dswx_host.h"
 
 // ==============================================================================
-// lab C-ABI (csrc/lab/dswx_lab.h)
+// lab C-ABI (tools/lab/csrc/dswx_lab.h)
 // ==============================================================================
 #include "dswx_lab.h"
 
