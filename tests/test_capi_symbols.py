@@ -371,6 +371,15 @@ def test_host_entry_points_under_ubsan():
         "    t, q = ctypes.c_double(), ctypes.c_double()\n"
         "    lib.dswx_shadow_thresholds(float(ms), float(mi), ctypes.byref(t), ctypes.byref(q))\n"
         "_capi.va_budget(1 << 40); _capi.va_budget((1 << 64) - 1); _capi.va_budget(64 << 40)\n"
+        "m = 0\n"      # ABI v6: the COG layout rule at the edges of its range
+        "for h, w, eb, tile, fac in itertools.product((0, 1, 29, 3660, (1 << 30) - 1, 1 << 30, 1 << 31), (1, 3660, (1 << 30) - 1, 1 << 40),\n"
+        "                                             (0, 1, 2, 3, 4), (0, 8, 16, 100, 512, 4096, 4104), ((), (4, 16, 64, 128), (1, 1, 1), (0,), (1 << 30,), tuple(range(2, 10)))):\n"
+        "    lay = _capi.CogLayout()\n"
+        "    f = (ctypes.c_int32 * max(len(fac), 1))(*fac)\n"
+        "    rc = lib.dswx_cog_layout(h, w, eb, tile, f, len(fac), ctypes.byref(lay))\n"
+        "    assert rc in (0, -1), rc\n"
+        "    m += rc == 0\n"
+        "assert m > 50\n"
         "if _capi.device_count() == 0:\n"
         "    try:\n"
         "        _capi.Context(0)\n"

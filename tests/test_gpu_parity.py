@@ -1677,3 +1677,49 @@ def test_randomized_parameter_sweep(variant):
             assert got['counters'][0].tolist() == exp['counters'].tolist(), (variant, it, cs)
     finally:
         c2.close()
+
+
+def test_launches_on_two_streams_of_one_context_do_not_share_the_fold_accumulators():
+    """dswx_classify_device* takes a caller's stream, and the folded counters (launches of <= 16 tiles) use ONE
+    set of accumulators per context: two launches on different streams could overlap on the GPU, mix their tickets and
+    leave the accumulators non-zero for good.  Since round 6 a launch on another stream than the previous one waits for it
+    (an event behind every launch on a caller's stream).  Two batches, two torch streams, 40 alternating launches without
+    any host synchronisation in between: counters and layers of both batches right every time, and right again afterwards
+    on the context's own stream."""
+    torch = pytest.importorskip('torch')
+    c = _capi.Context(0)
+    p = _capi.default_params()
+    try:
+        s1, s2 = torch.cuda.Stream(device=0), torch.cuda.Stream(device=0)
+        a = _capi.DeviceBatch(c, 8, 512, 512)
+        b = _capi.DeviceBatch(c, 5, 640, 384, masks=True)
+        a.synth(SEED, tile0=300)
+        b.synth(SEED, tile0=700)
+        c.synchronize()
+        exp_a = [c_oracle.classify(p, *(lambda s_: (s_['bands'], s_['fmask']))(synth_tile(300 + t, 512, 512))) for t in range(8)]
+        exp_b = []
+        for t in range(5):
+            s_ = synth_tile(700 + t, 640, 384, with_masks=True)
+            exp_b.append(c_oracle.classify(p, s_['bands'], s_['fmask'], land=s_['land'], shad=s_['shad'], ocean=s_['ocean']))
+        for rep in range(40):
+            a.classify(p, stream=s1.cuda_stream)
+            b.classify(p, stream=s2.cuda_stream)
+            if rep % 10 == 9:
+                s1.synchronize()
+                s2.synchronize()
+                assert 'counters folded' in c.last_kernel_info()
+                ca, cb = a.read_counters(), b.read_counters()
+                assert [r.tolist() for r in ca] == [e['counters'].tolist() for e in exp_a], rep
+                assert [r.tolist() for r in cb] == [e['counters'].tolist() for e in exp_b], rep
+                a.write_counters_sentinel(-7)
+                b.write_counters_sentinel(-7)
+        a.classify(p)                       # the context's own stream after a caller's: ordered as well
+        c.synchronize()
+        assert [r.tolist() for r in a.read_counters()] == [e['counters'].tolist() for e in exp_a]
+        for t in (0, 7):
+            assert np.array_equal(a.read_tile('wtr', t), exp_a[t]['wtr'])
+        assert np.array_equal(b.read_tile('conf', 4), exp_b[4]['conf'])
+        a.free()
+        b.free()
+    finally:
+        c.close()

@@ -205,3 +205,40 @@ def test_files_from_device_blocks_are_the_host_writers_files(ctx, tmp_path):
         assert rgb.shape == (3, h, w) and np.isnan(rgb[:, diag == 65535]).all()
     finally:
         eng.close()
+
+
+def test_writer_kernels_fuzz(ctx):
+    """300 random geometries: raster sizes 1 ... 1400, tiles 8 ... 512, factor sets with odd and repeated factors and the
+    reference's, both predictors, u8 / u16 -- dswx_cog_blocks_device against blocked_level(overview_nearest(...)); and the
+    inverse on random BLOCK shapes (tiles whose width is not a multiple of 8, strips, blocks larger than the raster):
+    dswx_untile_device of blocked_level's own output gives the raster back."""
+    rng = np.random.default_rng(20260606)
+    for case in range(300):
+        h, w = (int(rng.integers(1, 1400)), int(rng.integers(1, 1400))) if case % 5 else (int(rng.integers(1, 40)), int(rng.integers(1, 40)))
+        dtype = (np.uint8, np.uint16)[case % 2]
+        tile = int(rng.choice([8, 16, 24, 64, 256, 512]))
+        factors = [tuple(FACTORS), (2,), (3, 5, 7), (4, 4), (128, 2), ()][int(rng.integers(0, 6))]
+        predictor = 1 + case % 2 if case % 7 else 2
+        arr = rng.integers(0, np.iinfo(dtype).max + 1, size=(h, w)).astype(dtype)
+        if case % 3 == 0:
+            arr = (arr % 5).astype(dtype)
+        got, lay = _device_blocks(ctx, arr, factors, tile, predictor)
+        want = _host_levels(arr, factors, tile, predictor)
+        assert lay['n_levels'] == len(want), (case, h, w, factors)
+        for k, (lv, host) in enumerate(zip(lay['levels'], want)):
+            n = host.n_blocks * host.block_bytes
+            assert np.array_equal(got[lv['offset_bytes']: lv['offset_bytes'] + n], host.data.reshape(-1).view(np.uint8)), \
+                (case, h, w, dtype, tile, factors, predictor, k)
+        # the inverse, on a block shape of its own (bw x bh: any width, strips when bw >= w)
+        bw = int(rng.choice([w, int(rng.integers(1, 700)), 8 * int(rng.integers(1, 80))]))
+        bh = int(rng.integers(1, 300))
+        across, down = -(-w // bw), -(-h // bh)
+        pad = np.zeros((down * bh, across * bw), dtype)
+        pad[:h, :w] = arr
+        blk = np.ascontiguousarray(pad.reshape(down, bh, across, bw).transpose(0, 2, 1, 3))
+        if predictor == 2:
+            d = blk.copy()
+            d[..., 1:] -= blk[..., :-1]
+            blk = d
+        back = _untile(ctx, blk.reshape(-1), dtype, h, w, bw, bh, predictor)
+        assert np.array_equal(back, arr), (case, h, w, dtype, bw, bh, predictor)
