@@ -187,10 +187,13 @@ class TiffDirectory:
         self.comp = comp = one(TAG_COMPRESSION, 1)
         if comp not in (1, 8, 32946):
             raise GeoTiffError(f'{path}: compression {comp} is not supported')
-        self.predictor = predictor = one(TAG_PREDICTOR, 1)
+        predictor = one(TAG_PREDICTOR, 1)
         self.planar = planar = one(TAG_PLANAR, 1)
         if predictor not in (1, 2, 3) or (predictor == 3 and fmt != 3):
             raise GeoTiffError(f'{path}: predictor {predictor} is not supported')
+        if comp == 1:
+            predictor = 1       # libtiff: the predictor belongs to the LZW / DEFLATE codecs; an uncompressed file's tag is ignored
+        self.predictor = predictor
         self.dt = info.dtype.newbyteorder(e)
         H, W = info.height, info.width
         self.tiled = tiled = TAG_TILE_OFFSETS in tags

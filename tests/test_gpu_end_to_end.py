@@ -342,6 +342,49 @@ def test_batch_driver_single_gpu(tmp_path):
     assert not ok and results[0]['ok'] and not results[1]['ok']
 
 
+def test_product_from_band_files_written_by_another_library(tmp_path):
+    """The reader side of the pipeline on FOREIGN layouts: the seven band files rewritten by Pillow / libtiff -- DEFLATE
+    STRIPS with the horizontal predictor (the short last strip; the device's untile kernel with block width = raster
+    width, not a multiple of 8), one of them uncompressed with a stray PREDICTOR tag (libtiff ignores it there) -- carrying
+    the GDAL metadata and nodata tags of the originals.  The product's layers are what the oracle computes from the
+    arrays."""
+    from PIL import Image, TiffImagePlugin, features
+    if not features.check('libtiff'):
+        pytest.skip('Pillow without libtiff')
+    from proteus_amd import dswx_hls as D
+    size = 333
+    rcfile, files, _, s = synth_hls.make(str(tmp_path / 'own'), size=size, tile=61)
+    foreign = tmp_path / 'foreign'
+    foreign.mkdir()
+    new_files = []
+    for k, path in enumerate(files):
+        arr, info = geotiff.read_geotiff(path)
+        ifd = TiffImagePlugin.ImageFileDirectory_v2()
+        ifd[42112] = geotiff._metadata_xml(info.metadata, None)
+        ifd.tagtype[42112] = 2
+        if info.nodata is not None:
+            ifd[42113] = str(int(info.nodata))
+            ifd.tagtype[42113] = 2
+        ifd[317] = 2
+        if arr.dtype == np.int16:
+            ifd[339] = 2                                        # SampleFormat: two's complement
+        dst = str(foreign / os.path.basename(path))
+        img = Image.fromarray(arr.view(np.uint16) if arr.dtype == np.int16 else arr)
+        img.save(dst, compression=None if k == 2 else 'tiff_adobe_deflate', tiffinfo=ifd)
+        d = geotiff.open_geotiff(dst)
+        assert not d.tiled and d.bw == size and d.info.dtype == arr.dtype and d.predictor == (1 if k == 2 else 2)
+        assert k == 2 or (d.down > 1 and size % d.bh)           # DEFLATE: several strips, the last one short
+        new_files.append(dst)
+    out = {n: str(tmp_path / f'{n}.tif') for n in ('wtr', 'conf', 'diag', 'cloud')}
+    assert D.generate_dswx_layers(new_files, output_interpreted_band=out['wtr'], output_confidence_layer=out['conf'],
+                                  output_diagnostic_layer=out['diag'], output_cloud_layer=out['cloud'],
+                                  scratch_dir=str(tmp_path / 'scratch'))
+    exp = o.classify_tile(s['bands'], s['fmask'])
+    for n, layer in (('wtr', 'WTR'), ('conf', 'CONF'), ('diag', 'DIAG'), ('cloud', 'CLOUD')):
+        arr, _ = geotiff.read_geotiff(out[n])
+        assert np.array_equal(arr, exp[layer]), layer
+
+
 def test_tiles_in_flight_inside_one_worker(tmp_path):
     """Round 6: ONE worker process keeps several tiles going at once on its threads -- tile k + 1
     inflating and tile k - 1 deflating while tile k is on the device, the engine's lock serialising the GPU part, one HIP

@@ -198,6 +198,17 @@ def test_foreign_deflate_strips_chunky_and_short_last_strip(tmp_path):
         finally:
             codec.force_zlib(False)
     assert codec.engine() in ('libdeflate', 'zlib')
+    # an UNCOMPRESSED file with a stray PREDICTOR tag: libtiff ignores the tag there (the predictor belongs to the codec)
+    from PIL import TiffImagePlugin
+    ifd = TiffImagePlugin.ImageFileDirectory_v2()
+    ifd[317] = 2
+    ifd[339] = 2
+    s16 = rng.integers(-3000, 12000, size=(57, 91)).astype(np.int16)
+    praw = str(tmp_path / 'raw_with_predictor_tag.tif')
+    Image.fromarray(s16.view(np.uint16)).save(praw, tiffinfo=ifd)
+    d = geotiff.open_geotiff(praw)
+    assert d.comp == 1 and d.predictor == 1 and d.info.dtype == np.int16
+    assert np.array_equal(geotiff.read_geotiff(praw)[0], s16)
     # the codec alone: the bytes do not depend on the thread count; errors are errors
     blocks = rng.integers(0, 4, size=(37, 4096)).astype(np.uint8)
     one = codec.deflate_uniform(blocks, 4096, 6, threads=1)
