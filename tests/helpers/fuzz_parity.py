@@ -3,7 +3,7 @@
 hugging the thresholds) through dswx_classify_host, every layer and the counters compared with
 the scalar C oracle.  Exit code 1 and a JSON description of the first mismatch on failure.
 
-    python tests/helpers/fuzz_parity.py [--iters 300] [--seed 1] [--variant N] [--device-batch] [--pinned]
+    python tests/helpers/fuzz_parity.py [--iters 300] [--seed 1] [--variant N] [--device-batch] [--pinned] [--odd-planes]
 
 (Lives under tests/ because it uses the oracle, which only tests/, smoke() and bench.py's CPU baseline may do;
 its name keeps pytest from collecting it.)
@@ -90,6 +90,112 @@ def device_batch_soak(ctx, rng, a, kernels):
     return 0
 
 
+def odd_planes_soak(ctx, rng, a, kernels):
+    """Round 6: planes carved out of one arena at RANDOM addresses (int16 planes at any even address, byte planes anywhere),
+    random tile stride >= H W, several tiles, every mode incl. 'cover', masks, optional layers, both chains: the direct
+    kernel's unaligned accesses (and 'cover' stage 3's), the generic kernel's tails -- every tile against the oracles,
+    and no byte outside the planes touched."""
+    from oracle import dswx_oracle as o
+    from tests.test_c_oracle import NAME
+    for it in range(a.iters):
+        cs = _random_case(rng)
+        n = int(rng.integers(1, 5))
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 130))
+        P = h * w
+        stride = P + int(rng.choice([0, 0, 1, 3, 5, 8, 13]))
+        masks = bool(rng.integers(2))
+        mode = str(rng.choice(['mask', 'ignore', 'cover']))
+        scaled = None
+        if mode != 'cover' and rng.integers(5) == 0:
+            scaled = [(float(rng.choice([1.0, 0.5, 1e-4])), float(rng.choice([0.0, 0.5, -100.0]))) for _ in range(6)]
+        p = _capi.make_params(cs['thr'], clip_negative_reflectance=cs['clip'], mask_adjacent_to_cloud_mode=mode,
+                              apply_aerosol_class_remapping=cs['aerosol'], aerosol_fmask_values=cs['lists'],
+                              collapse_wtr_classes=cs['collapse'], aerosol_max_nir=None if mode == 'cover' else cs['aer_nir'],
+                              offset_and_scale=scaled)
+        tiles = [synth_tile(9000 + 7 * it + t, h, w, with_masks=True) for t in range(n)]
+        in_names = list(_capi.BAND_NAMES) + ['fmask'] + (['land', 'shad', 'ocean'] if masks else [])
+        out_names = ['diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'] + (['wtr1_aerosol'] if rng.integers(2) else [])
+        sizes = {k: n * stride * (2 if (k in _capi.BAND_NAMES or k == 'diag') else 1) for k in in_names + out_names}
+        off, where = int(rng.integers(0, 16)), {}
+        for k in in_names + out_names:
+            two = k in _capi.BAND_NAMES or k == 'diag'
+            off += int(rng.integers(0, 9))
+            if two:
+                off += off % 2
+            where[k] = off
+            off += sizes[k]
+        off += (-off) % 8
+        cnt_off = off
+        total = off + n * 24 + 64
+        host = np.full(total, 0x5A, np.uint8)
+        for k in in_names:
+            for t in range(n):
+                src = tiles[t]['bands'][_capi.BAND_NAMES.index(k)] if k in _capi.BAND_NAMES else tiles[t][k]
+                raw = np.ascontiguousarray(src).reshape(-1).view(np.uint8)
+                esz = 2 if k in _capi.BAND_NAMES else 1
+                host[where[k] + t * stride * esz: where[k] + t * stride * esz + raw.size] = raw
+        arena = ctx.malloc(total)
+        arena.upload(host)
+        pin, pout = _capi.PlanesIn(), _capi.PlanesOut()
+        for i, k in enumerate(_capi.BAND_NAMES):
+            pin.band[i] = arena.ptr + where[k]
+        for k in in_names[6:]:
+            setattr(pin, k, arena.ptr + where[k])
+        for k in out_names:
+            setattr(pout, k, arena.ptr + where[k])
+        geom = _capi.BatchGeom(n, h, w, stride)
+        ctx.classify_batch(p, geom, pin, pout, arena.ptr + cnt_off)
+        ctx.synchronize()
+        key = ctx.last_kernel_info().split(' grid')[0]
+        kernels[key] = kernels.get(key, 0) + 1
+        got = arena.download(np.uint8, total)
+        arena.free()
+        bad = []
+        touched = np.ones(total, bool)
+        for k in in_names:
+            touched[where[k]: where[k] + sizes[k]] = False
+        for k in out_names:
+            esz = 2 if k == 'diag' else 1
+            for t in range(n):
+                touched[where[k] + t * stride * esz: where[k] + (t * stride + P) * esz] = False
+        touched[cnt_off: cnt_off + n * 24] = False
+        if (got[touched] != host[touched]).any() or not np.array_equal(got[~touched][:0], host[~touched][:0]):
+            bad.append('bytes outside the planes')
+        for k in in_names:
+            if not np.array_equal(got[where[k]: where[k] + sizes[k]], host[where[k]: where[k] + sizes[k]]):
+                bad.append('input plane ' + k + ' modified')
+        cnt = got[cnt_off: cnt_off + n * 24].view(np.int64).reshape(n, 3)
+        for t in range(n):
+            st = tiles[t]
+            kw = {m: st[m] for m in ('land', 'shad', 'ocean')} if masks else {}
+            if mode == 'cover':
+                with np.errstate(all='ignore'):
+                    e = o.classify_tile(st['bands'], st['fmask'], o.Thresholds(**cs['thr']), landcover=kw.get('land'),
+                                        shadow=kw.get('shad'), ocean_mask=kw.get('ocean'), mask_adjacent_to_cloud_mode='cover',
+                                        apply_aerosol=cs['aerosol'], aerosol_fmask_values=cs['lists'],
+                                        clip_negative_reflectance=cs['clip'], collapse=cs['collapse'])
+                exp = {kk: e[layer] for layer, kk in NAME.items()}
+                ec = e['counters']
+                exp_cnt = [ec['n_valid'], ec['n_cloud_and_valid'], ec['n_not_ocean']]
+            else:
+                exp = c_oracle.classify(p, st['bands'], st['fmask'], **kw)
+                exp_cnt = exp['counters'].tolist()
+            for k in out_names:
+                esz = 2 if k == 'diag' else 1
+                g = got[where[k] + t * stride * esz: where[k] + (t * stride + P) * esz]
+                g = g.view(np.uint16) if k == 'diag' else g
+                if not np.array_equal(g.reshape(h, w), exp[k]):
+                    bad.append(f'{k}[{t}]')
+            if cnt[t].tolist() != exp_cnt:
+                bad.append(f'counters[{t}]')
+        if bad:
+            print(json.dumps({'ok': False, 'iteration': it, 'geom': [n, h, w, stride], 'masks': masks, 'mode': mode,
+                              'scaled': scaled, 'what': bad[:8], 'kernel': ctx.last_kernel_info()}, default=str))
+            return 1
+    print(json.dumps({'ok': True, 'iterations': a.iters, 'seed': a.seed, 'kernels': kernels}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=300)
@@ -97,6 +203,7 @@ def main():
     ap.add_argument('--variant', default=None, help='force a product kernel for this run (libdswx_lab.so switch: 0 direct, 3 table-driven)')
     ap.add_argument('--device-batch', action='store_true', help='soak the device-resident batch entry instead')
     ap.add_argument('--pinned', action='store_true', help='inputs in page-locked arrays: the zero-copy host path')
+    ap.add_argument('--odd-planes', action='store_true', help='planes at random (odd) addresses and strides through dswx_classify_batch')
     a = ap.parse_args()
     ctx = _capi.Context(0)
     if a.variant is not None:
@@ -105,6 +212,8 @@ def main():
     kernels = {}
     if a.device_batch:
         return device_batch_soak(ctx, rng, a, kernels)
+    if a.odd_planes:
+        return odd_planes_soak(ctx, rng, a, kernels)
     for it in range(a.iters):
         cs = _random_case(rng)
         kind = it % 4

@@ -927,7 +927,7 @@ def test_pool_trim_while_a_placed_batch_is_live():
 def test_host_code_under_ubsan_on_the_gpu():
     """The HOST side of the library -- dispatch, launch geometry, the batch layer, both placements, the host-pointer entries --
     under the undefined-behaviour sanitizer while it drives real launches (proteus_amd.build.build_ubsan; GPU sanitizers
-    are not available on this pool, clang ignores the flag for device code).  Three soaks of tests/helpers/fuzz_parity.py in child
+    are not available on this pool, clang ignores the flag for device code).  Four soaks of tests/helpers/fuzz_parity.py in child
     processes with DSWX_HIP_LIB pointing at the sanitised build: any finding aborts the child (-fno-sanitize-recover)."""
     import subprocess
     import sys
@@ -939,7 +939,7 @@ def test_host_code_under_ubsan_on_the_gpu():
         pytest.skip(f'no sanitised build on this box: {e}')
     env = dict(os.environ, DSWX_HIP_LIB=ubsan_lib, UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1')
     for argv in (['--iters', '120', '--seed', '7'], ['--device-batch', '--iters', '200', '--seed', '8'],
-                 ['--pinned', '--iters', '80', '--seed', '9']):
+                 ['--pinned', '--iters', '80', '--seed', '9'], ['--odd-planes', '--iters', '150', '--seed', '10']):
         res = subprocess.run([sys.executable, os.path.join(root, 'tests', 'helpers', 'fuzz_parity.py')] + argv, capture_output=True,
                              text=True, timeout=900, env=env, cwd=root)
         assert res.returncode == 0, (argv, res.stdout[-500:], res.stderr[-3000:])

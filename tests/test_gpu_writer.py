@@ -118,7 +118,7 @@ def test_untile_tiles_and_strips(ctx, tmp_path, shape, dtype):
     if not features.check('libtiff') or dtype != np.uint8:
         return
     q = str(tmp_path / 'strips.tif')
-    Image.fromarray(arr, mode='L').save(q, compression='tiff_adobe_deflate', tiffinfo={317: 2})
+    Image.fromarray(arr).save(q, compression='tiff_adobe_deflate', tiffinfo={317: 2})
     d = geotiff.open_geotiff(q)
     assert not d.tiled and d.bw == W
     got = _untile(ctx, d.inflate(), dtype, H, W, d.bw, d.bh, d.predictor)

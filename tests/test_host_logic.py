@@ -150,7 +150,7 @@ def test_float_predictor_and_foreign_layouts(tmp_path):
         pytest.skip('Pillow without libtiff')
     a = rng.normal(100.0, 30.0, size=(200, 333)).astype(np.float32)
     q = str(tmp_path / 'foreign.tif')
-    Image.fromarray(a, mode='F').save(q, compression='tiff_adobe_deflate', tiffinfo={317: 3})
+    Image.fromarray(a).save(q, compression='tiff_adobe_deflate', tiffinfo={317: 3})
     with Image.open(q) as im:
         assert im.tag_v2[317] == 3                                      # libtiff really applied the predictor
     b, info = geotiff.read_geotiff(q)                                   # strips, written by another library
@@ -172,9 +172,9 @@ def test_foreign_deflate_strips_chunky_and_short_last_strip(tmp_path):
     rgb = rng.integers(0, 256, size=(157, 211, 3)).astype(np.uint8)
     u8 = (rng.integers(0, 5, size=(1000, 77)) * 50).astype(np.uint8)
     p16, prgb, pu8 = (str(tmp_path / n) for n in ('i16.tif', 'rgb.tif', 'u8.tif'))
-    Image.fromarray(a16, mode='I;16').save(p16, compression='tiff_adobe_deflate', tiffinfo={317: 2})
-    Image.fromarray(rgb, mode='RGB').save(prgb, compression='tiff_adobe_deflate', tiffinfo={317: 2})
-    Image.fromarray(u8, mode='L').save(pu8, compression='tiff_adobe_deflate')
+    Image.fromarray(a16.view(np.uint16)).save(p16, compression='tiff_adobe_deflate', tiffinfo={317: 2})
+    Image.fromarray(rgb).save(prgb, compression='tiff_adobe_deflate', tiffinfo={317: 2})
+    Image.fromarray(u8).save(pu8, compression='tiff_adobe_deflate')
     for force in (False, True):
         codec.force_zlib(force)
         try:
