@@ -519,7 +519,7 @@ int dswx_host_alloc(dswx_ctx_t* ctx, size_t bytes, void** out);
 int dswx_host_free(dswx_ctx_t* ctx, void* ptr);
 int dswx_memcpy_h2d(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);
 int dswx_memcpy_d2h(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes);
-int dswx_memset_d(dswx_ctx_t* ctx, void* dst, int value, size_t bytes);
+int dswx_memset_d(dswx_ctx_t* ctx, void* dst, int value, size_t bytes);      /* complete on return, like the two copies above */
 /* asynchronous on `stream` (NULL = the context's stream); the host side must be page-locked (dswx_host_alloc) for the
  * copy to overlap with anything */
 int dswx_memcpy_h2d_async(dswx_ctx_t* ctx, void* dst, const void* src, size_t bytes, void* stream);

@@ -834,6 +834,10 @@ int dswx_memset_d(dswx_ctx_t* ctx, void* dst, int value, size_t bytes) {
     if (!ctx) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemset(dst, value, bytes));
+    // hipMemset on device memory returns before the fill has run, and the fill is queued on the NULL stream, which the
+    // context's (non-blocking) stream does not wait for: a launch issued right after could be overtaken by it (found by the
+    // writer kernels' fuzz test, round 6).  Like the two memcpy entries beside it, this one is complete when it returns.
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return DSWX_OK;
 }
 
