@@ -17,40 +17,34 @@ from proteus_amd import stages                  # noqa: E402
 
 
 def main():
-    size = int(sys.argv[1]) if len(sys.argv) > 1 else 3660
-    out = {'size': size}
+    size = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3660
+    ancillary = '--ancillary' in sys.argv      # BASELINE configs[4]'s product: DEM -> SHAD, CGLS + WorldCover -> LAND, ocean mask; 10 layers
+    out = {'size': size, 'ancillary': ancillary}
     with tempfile.TemporaryDirectory() as d:
         t0 = time.perf_counter()
-        rcfile, files, _, _ = synth_hls.make(d, size=size)
+        rcfile, files, _, _ = synth_hls.make(d, size=size, ancillary=ancillary, ocean=ancillary)
         out['make_inputs_s'] = round(time.perf_counter() - t0, 2)
-        parser = D.get_dswx_hls_cli_parser()
+        from proteus_amd import batch
+        import logging
+        logging.getLogger('dswx_hls').setLevel(logging.WARNING)
         for threads in ('1', '0'):
             os.environ['DSWX_IO_THREADS'] = threads
-            args = parser.parse_args([rcfile])
-            rc = D.parse_runconfig_file(user_runconfig_file=rcfile, args=args)
             best = None
             for rep in range(3):
                 stages.start()
                 t0 = time.perf_counter()
-                ok = D.generate_dswx_layers(args.input_list, args.output_file, hls_thresholds=rc.hls_thresholds,
-                                            product_id=args.product_id, product_version=args.product_version,
-                                            scratch_dir=args.scratch_dir,
-                                            output_interpreted_band=args.output_interpreted_band,
-                                            output_binary_water=args.output_binary_water,
-                                            output_confidence_layer=args.output_confidence_layer,
-                                            output_diagnostic_layer=args.output_diagnostic_layer,
-                                            output_non_masked_dswx=args.output_non_masked_dswx,
-                                            output_shadow_masked_dswx=args.output_shadow_masked_dswx,
-                                            output_cloud_layer=args.output_cloud_layer)
+                res = batch._one_tile(D, 0, rcfile, False)         # the runconfig with every field, as the batch worker runs it
                 dt = time.perf_counter() - t0
                 rep_stages = stages.stop()
-                assert ok
+                assert res['ok'], res
                 if best is None or dt < best:
                     best, best_stages = dt, rep_stages
             tag = 'default' if threads == '0' else threads
             out[f'generate_dswx_layers_s_io_threads_{tag}'] = round(best, 3)
             out[f'stages_io_threads_{tag}'] = best_stages
-        out['io_threads_default'] = min(32, os.cpu_count() or 1)
+        from proteus_amd import codec
+        out['io_threads_default'] = codec.default_threads()
+        out['outputs'] = sorted(os.listdir(os.path.join(d, 'output')))
         out['kernel'] = D.get_context().last_kernel_info()
     print(json.dumps(out, indent=1))
 
