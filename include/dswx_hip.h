@@ -495,9 +495,14 @@ int dswx_cog_blocks_device(dswx_ctx_t* ctx, const void* plane, int32_t elem_byte
                            void* stream);
 /* The inverse for a file being read: `blocks` = every block of one plane of an image, inflated, in block order, each
  * block_height x block_width samples (tiles; or strips: block_width = width, the short last strip's slot padded), native
- * byte order; predictor 1 or 2.  -> plane [height][width]. */
+ * byte order; elem_bytes 1 / 2 / 4 with predictor 1 (none) or 2 (running sum in the sample's width), or elem_bytes 4 with
+ * predictor 3 (Float32, TIFF Technical Note 3: what GDAL writes for a Float32 DEM with PREDICTOR=3).  -> plane [height][width]. */
 int dswx_untile_device(dswx_ctx_t* ctx, const void* blocks, int32_t elem_bytes, int64_t height, int64_t width,
                        int32_t block_width, int32_t block_height, int32_t predictor, void* plane, void* stream);
+/* Rows of `width_bytes` bytes from one device raster to another (hipMemcpy2DAsync, device to device): the crop of a DEM
+ * with its margin to the product grid (_crop_2d_array_all_sides, dswx_hls.py:4320) without a trip to the host. */
+int dswx_copy_2d_device(dswx_ctx_t* ctx, void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes,
+                        size_t width_bytes, size_t height, void* stream);
 /* out[c][i] = scale[c] * (float32(band_c[i], clipped to >= 1 if clip_negative_reflectance) - offset[c]) in float32, NaN
  * where diag[i] == 65535 (diag may be NULL: no masking); out = float [3][n_pixels]. */
 int dswx_rgb_planes_device(dswx_ctx_t* ctx, const int16_t* red, const int16_t* green, const int16_t* blue,

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search', 'dswx_batch_place_slide',
     'dswx_batch_va_budget', 'dswx_batch_pool_trim',
     'dswx_shadow_layer_batch', 'dswx_landcover_mask_batch',
-    'dswx_cog_layout', 'dswx_cog_blocks_device', 'dswx_untile_device', 'dswx_rgb_planes_device',
+    'dswx_cog_layout', 'dswx_cog_blocks_device', 'dswx_untile_device', 'dswx_rgb_planes_device', 'dswx_copy_2d_device',
     'dswx_memcpy_h2d_async', 'dswx_memcpy_d2h_async')
 
 
@@ -254,6 +254,7 @@ def load_library(path=None):
                                               ctypes.c_int32, vp, vp]),
         'dswx_rgb_planes_device': (ctypes.c_int, [vp, vp, vp, vp, vp, i64, ctypes.POINTER(ctypes.c_double * 3),
                                                   ctypes.POINTER(ctypes.c_double * 3), ctypes.c_int32, vp, vp]),
+        'dswx_copy_2d_device': (ctypes.c_int, [vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]),
         'dswx_memcpy_h2d_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
         'dswx_memcpy_d2h_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
     }
@@ -769,6 +770,11 @@ class Context:
                                                ctypes.c_void_p(blue_ptr), ctypes.c_void_p(diag_ptr) if diag_ptr else None,
                                                int(n_pixels), ctypes.byref(sc), ctypes.byref(of), int(bool(clip)),
                                                ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream) if stream else None))
+
+    def copy_2d_device(self, dst_ptr, dst_pitch, src_ptr, src_pitch, width_bytes, height, stream=None):
+        _check(self.lib.dswx_copy_2d_device(self.handle, ctypes.c_void_p(dst_ptr), int(dst_pitch), ctypes.c_void_p(src_ptr),
+                                            int(src_pitch), int(width_bytes), int(height),
+                                            ctypes.c_void_p(stream) if stream else None))
 
     def h2d_async(self, dst_ptr, host_arr, nbytes=None, stream=None):
         _check(self.lib.dswx_memcpy_h2d_async(self.handle, ctypes.c_void_p(dst_ptr), _host_ptr(host_arr),

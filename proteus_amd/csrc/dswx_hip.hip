@@ -487,6 +487,7 @@ int dswx_ctx_destroy(dswx_ctx_t* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->fold_acc) (void)hipFree(ctx->fold_acc);
     if (ctx->cover) (void)hipFree(ctx->cover);
+    if (ctx->untile_tmp) (void)hipFree(ctx->untile_tmp);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);

@@ -39,6 +39,9 @@ struct dswx_ctx {
     // grow-only scratch of 'cover' mode: state byte per pixel + bitmap dword per 8-pixel group + final snow bits
     void* cover = nullptr;
     size_t cover_bytes = 0;
+    // grow-only scratch of dswx_untile_device for Float32 + floating-point predictor (the byte-wise running sums)
+    void* untile_tmp = nullptr;
+    size_t untile_bytes = 0;
     // pipelined host path (pinned host buffers): copy streams, per-slot events, pinned counter scratch
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     hipEvent_t pipe_in[3] = {nullptr, nullptr, nullptr}, pipe_k[3] = {nullptr, nullptr, nullptr},

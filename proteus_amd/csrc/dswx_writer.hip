@@ -187,6 +187,23 @@ __global__ __launch_bounds__(256) void dswx_untile_v1(const UntileArgs a) {
     }
 }
 
+// Float32 with the floating-point predictor, second step: `acc` = the block rows after the byte-wise running sum (each row
+// 4 bw bytes: the four byte planes of its bw samples, most significant first -- libtiff fpAcc) -> the samples of the raster.
+struct Fp3Args {
+    const unsigned char* acc;
+    unsigned* dst;
+    int height, width, bw, bh, across;
+};
+
+__global__ __launch_bounds__(256) void dswx_untile_fp3_gather(const Fp3Args a) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= a.width) return;
+    const int by = y / a.bh, y_in = y - by * a.bh, bx = x / a.bw, j = x - bx * a.bw;
+    const unsigned char* __restrict__ row = a.acc + ((size_t)(by * a.across + bx) * (size_t)a.bh + (size_t)y_in) * (size_t)(4 * a.bw);
+    const unsigned bits = (unsigned)row[j] << 24 | (unsigned)row[a.bw + j] << 16 | (unsigned)row[2 * a.bw + j] << 8 | (unsigned)row[3 * a.bw + j];
+    a.dst[(size_t)y * (size_t)a.width + (size_t)x] = bits;
+}
+
 struct RgbArgs {
     const short* band[3];
     const unsigned short* diag;
@@ -303,9 +320,10 @@ int dswx_untile_device(dswx_ctx_t* ctx, const void* blocks, int32_t elem_bytes, 
     if (!ctx || !blocks || !plane) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
     if (height <= 0 || width <= 0 || height > 2147483647LL / 2 || width > 2147483647LL / 2)
         return dswx_fail(DSWX_ERR_ARG, "raster size out of range");
-    if (elem_bytes != 1 && elem_bytes != 2) return dswx_fail(DSWX_ERR_ARG, "elem_bytes must be 1 or 2");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4) return dswx_fail(DSWX_ERR_ARG, "elem_bytes must be 1, 2 or 4");
     if (block_width < 1 || block_height < 1) return dswx_fail(DSWX_ERR_ARG, "empty block");
-    if (predictor != 1 && predictor != 2) return dswx_fail(DSWX_ERR_UNSUPPORTED, "PREDICTOR 1 or 2 (the floating-point predictor is decoded on the host)");
+    if (predictor != 1 && predictor != 2 && !(predictor == 3 && elem_bytes == 4))
+        return dswx_fail(DSWX_ERR_UNSUPPORTED, "PREDICTOR 1 or 2 (any sample size), or 3 with 4-byte samples (Float32)");
     if (!aligned_to(blocks, (size_t)elem_bytes) || !aligned_to(plane, (size_t)elem_bytes))
         return dswx_fail(DSWX_ERR_ALIGN, "buffers must be aligned to their samples");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -317,12 +335,53 @@ int dswx_untile_device(dswx_ctx_t* ctx, const void* blocks, int32_t elem_bytes, 
     a.down = (int)((height + block_height - 1) / block_height);
     a.predictor = predictor;
     a.block_rows = (long long)a.across * a.down * a.bh;
+    if ((long long)block_width * elem_bytes > 2147483647LL / 4) return dswx_fail(DSWX_ERR_ARG, "block too wide");
+    if (predictor == 3) {
+        // (1) the byte-wise running sum over every block row (4 bw bytes) -- the integer kernel on a "raster" of
+        // block_rows x 4 bw bytes that is one block -- into a scratch of the context, (2) the byte planes back into samples
+        const size_t need = (size_t)a.block_rows * (size_t)block_width * 4;
+        if (need > ctx->untile_bytes) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (ctx->untile_tmp) HIP_TRY(hipFree(ctx->untile_tmp));
+            ctx->untile_tmp = nullptr; ctx->untile_bytes = 0;
+            HIP_TRY(dswx_locked_malloc(&ctx->untile_tmp, need));
+            ctx->untile_bytes = need;
+        }
+        if (a.block_rows > 2147483647LL) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
+        UntileArgs b = {};
+        b.blocks = blocks; b.dst = ctx->untile_tmp;
+        b.height = (int)a.block_rows; b.width = 4 * block_width; b.bw = 4 * block_width; b.bh = (int)a.block_rows;
+        b.across = 1; b.down = 1; b.predictor = 2; b.block_rows = a.block_rows;
+        const unsigned long long groups = ((unsigned long long)b.block_rows + 3) / 4;
+        if (groups > 0x7fffffffull) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
+        hipLaunchKernelGGL(dswx_untile_v1<unsigned char>, dim3((unsigned)groups), dim3(256), 0, s, b);
+        HIP_TRY(hipGetLastError());
+        if (height > 65535) return dswx_fail(DSWX_ERR_ARG, "raster too tall for one launch");
+        Fp3Args g = {};
+        g.acc = static_cast<const unsigned char*>(ctx->untile_tmp); g.dst = static_cast<unsigned*>(plane);
+        g.height = (int)height; g.width = (int)width; g.bw = block_width; g.bh = block_height; g.across = a.across;
+        hipLaunchKernelGGL(dswx_untile_fp3_gather, dim3((unsigned)((width + 255) / 256), (unsigned)height), dim3(256), 0, s, g);
+        HIP_TRY(hipGetLastError());
+        return DSWX_OK;
+    }
     const unsigned long long groups = ((unsigned long long)a.block_rows + 3) / 4;
     if (groups > 0x7fffffffull) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
     const dim3 grid((unsigned)groups), block(256);
     if (elem_bytes == 1) hipLaunchKernelGGL(dswx_untile_v1<unsigned char>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(dswx_untile_v1<unsigned short>, grid, block, 0, s, a);
+    else if (elem_bytes == 2) hipLaunchKernelGGL(dswx_untile_v1<unsigned short>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(dswx_untile_v1<unsigned int>, grid, block, 0, s, a);
     HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_copy_2d_device(dswx_ctx_t* ctx, void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes,
+                        size_t width_bytes, size_t height, void* stream) {
+    if (!ctx || !dst || !src) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (width_bytes > dst_pitch_bytes || width_bytes > src_pitch_bytes) return dswx_fail(DSWX_ERR_ARG, "row wider than its pitch");
+    if (width_bytes == 0 || height == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch_bytes, src, src_pitch_bytes, width_bytes, height, hipMemcpyDeviceToDevice,
+                             stream ? (hipStream_t)stream : ctx->stream));
     return DSWX_OK;
 }
 

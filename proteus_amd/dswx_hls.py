@@ -413,32 +413,37 @@ def _compute_opera_shadow_layer(dem, sun_azimuth_angle, sun_elevation_angle,
     `margin` on all sides, fusing _crop_2d_array_all_sides :4320).  The five float64 sun
     scalars are formed here with numpy exactly as the reference forms them (:4246-4253,
     :4276-4277) and handed to the kernel."""
-    sun_azimuth = np.radians(sun_azimuth_angle)
-    sun_zenith = np.radians(90 - sun_elevation_angle)
-    target_to_sun_unit_vector = [np.sin(sun_azimuth) * np.sin(sun_zenith),
-                                 np.cos(sun_azimuth) * np.sin(sun_zenith),
-                                 np.cos(sun_zenith)]
     dem = np.asarray(dem)
     if dem.ndim != 2 or min(dem.shape) < 2:
         raise ValueError('Shape of array too small to calculate a numerical gradient, '
                          'at least 2 elements are required.')
-    # which numpy does the caller want to agree with?  'legacy' (DEFAULT: numpy < 2 value-based casting,
-    # what the reference computes in its supported environment -- it pins numpy==1.23.5, setup.py:78 --
-    # where the float64 sun scalars do not upcast the float32 DEM arrays) or 'nep50' (numpy >= 2: what
-    # the same source computes under a current numpy; the committed shadow_s_*.npz goldens were generated
-    # by importing the reference under numpy 2.2 and pin this mode).  env DSWX_NUMPY_PROMOTION overrides.
-    mode = (numpy_promotion or os.environ.get('DSWX_NUMPY_PROMOTION', 'legacy')).lower()
-    if mode not in ('nep50', 'legacy'):
-        raise ValueError(f"numpy_promotion must be 'nep50' or 'legacy', not {mode!r}")
+    sun, sin_az, cos_az, legacy = _shadow_geometry(sun_azimuth_angle, sun_elevation_angle, numpy_promotion)
     if margin < 2 and dem.size >= 1 << 20:
         # the only geometry left on the general one-pixel kernel (border pixels take one-sided differences there):
         # ~0.2 of the HBM rate instead of ~0.65 -- the reference's own call has a margin of 50 (:58, :5161-5167)
         logger.warning(f'WARNING terrain shadow layer with a margin of {margin} pixel(s): the general kernel '
                        '(dswx_shadow_v2) computes the whole raster, about three times slower than the filter kernel')
     return get_context().shadow_layer(
-        dem, target_to_sun_unit_vector, np.sin(sun_azimuth), np.cos(sun_azimuth),
-        min_slope_angle, max_sun_local_inc_angle, pixel_spacing_x, pixel_spacing_y,
-        margin=margin, float32=(mode == 'legacy'))
+        dem, sun, sin_az, cos_az, min_slope_angle, max_sun_local_inc_angle, pixel_spacing_x, pixel_spacing_y,
+        margin=margin, float32=legacy)
+
+
+def _shadow_geometry(sun_azimuth_angle, sun_elevation_angle, numpy_promotion=None):
+    """The five float64 sun scalars, formed with numpy exactly as the reference forms them (:4246-4253, :4276-4277), and
+    which numpy the caller wants to agree with: 'legacy' (DEFAULT: numpy < 2 value-based casting, what the reference
+    computes in its supported environment -- it pins numpy==1.23.5, setup.py:78 -- where the float64 sun scalars do not
+    upcast the float32 DEM arrays) or 'nep50' (numpy >= 2: what the same source computes under a current numpy; the
+    committed shadow_s_*.npz goldens were generated by importing the reference under numpy 2.2 and pin this mode).
+    env DSWX_NUMPY_PROMOTION overrides.  -> (sun vector, sin az, cos az, legacy?)"""
+    sun_azimuth = np.radians(sun_azimuth_angle)
+    sun_zenith = np.radians(90 - sun_elevation_angle)
+    target_to_sun_unit_vector = [np.sin(sun_azimuth) * np.sin(sun_zenith),
+                                 np.cos(sun_azimuth) * np.sin(sun_zenith),
+                                 np.cos(sun_zenith)]
+    mode = (numpy_promotion or os.environ.get('DSWX_NUMPY_PROMOTION', 'legacy')).lower()
+    if mode not in ('nep50', 'legacy'):
+        raise ValueError(f"numpy_promotion must be 'nep50' or 'legacy', not {mode!r}")
+    return target_to_sun_unit_vector, np.sin(sun_azimuth), np.cos(sun_azimuth), mode == 'legacy'
 
 
 def _crop_2d_array_all_sides(input_2d_array, margin):
@@ -960,10 +965,18 @@ def save_dswx_product(layers, output_file, dswx_metadata_dict, geo_tags,
     _run_or_defer(job)
 
 
-def _as_plane(value, shape, name, dtype=np.uint8):
-    """Keyword-extension ancillary layer: ndarray or GeoTIFF path on the HLS grid."""
+def _as_plane(value, shape, name, dtype=np.uint8, engine=None):
+    """Keyword-extension ancillary layer: ndarray, resident plane or GeoTIFF path on the HLS grid."""
     if value is None:
         return None
+    if isinstance(value, (str, os.PathLike)) and engine is not None:
+        value, _ = engine.read_plane(os.fspath(value))
+    if isinstance(value, pipeline.DevicePlane):
+        if value.shape != tuple(shape):
+            raise ValueError(f'{name} has shape {value.shape}, the HLS grid is {tuple(shape)}')
+        if value.dtype == np.dtype(dtype):
+            return value
+        value = value.numpy()
     if isinstance(value, (str, os.PathLike)):
         value, _ = geotiff.read_geotiff(os.fspath(value))
     arr = np.asarray(value)
@@ -1034,7 +1047,7 @@ def _worldcover_year(metadata, worldcover_file_description):
 def create_landcover_mask(copernicus_landcover_file, worldcover_file, worldcover_file_description,
                           output_file, scratch_dir, mask_type, geotransform, projection, length, width,
                           forest_mask_landcover_classes, dswx_metadata_dict=None,
-                          output_files_list=None, temp_files_list=None, *, geo_tags=None, device=None):
+                          output_files_list=None, temp_files_list=None, *, geo_tags=None, device=None, engine=None):
     """LAND layer from the Copernicus CGLS 100 m and ESA WorldCover 10 m maps (:906-1115) with the
     3 x 3 aggregation and class hierarchy on the GPU (dswx_landcover_mask_host).  The two
     reprojections of the reference (`_warp`, nearest, :970-992) are GDAL's: here both rasters must
@@ -1045,8 +1058,14 @@ def create_landcover_mask(copernicus_landcover_file, worldcover_file, worldcover
         if not os.path.isfile(f):
             logger.error(f'ERROR file not found: {f}')
             return None
-    cg, cg_info = geotiff.read_geotiff(copernicus_landcover_file)
-    wc, wc_info = geotiff.read_geotiff(worldcover_file)
+    if engine is not None:
+        # resident: both maps inflated on host threads, untiled on the device, aggregated there; the LAND layer stays in HBM
+        # for the classifier and leaves as COG blocks (pipeline.TileEngine)
+        cg_dir, wc_dir = geotiff.open_geotiff(copernicus_landcover_file), geotiff.open_geotiff(worldcover_file)
+        cg_info, wc_info = cg_dir.info, wc_dir.info
+    else:
+        cg, cg_info = geotiff.read_geotiff(copernicus_landcover_file)
+        wc, wc_info = geotiff.read_geotiff(worldcover_file)
     if _grid_margin(cg_info, geotransform, length, width) != 0 or \
             _grid_margin(wc_info, geotransform, length, width, scale=3) != 0:
         raise NotImplementedError(
@@ -1055,9 +1074,19 @@ def create_landcover_mask(copernicus_landcover_file, worldcover_file, worldcover
             'drop-in (SURVEY.md section 2)')
     logger.info(f'    CGLS Land Cover 100m forest classes: {forest_mask_landcover_classes}')
     year = _worldcover_year(wc_info.metadata, worldcover_file_description)
-    land = get_context(device).landcover_mask(
-        wc, cg, forest_mask_landcover_classes, thresholds=landcover_threshold_dict[mask_type.lower()],
-        year_offset=year - 2000)
+    if engine is not None:
+        planes = []
+        for d in (wc_dir, cg_dir):
+            plane, _ = engine.read_directory(d)
+            if plane.dtype != np.uint8:
+                plane = engine.upload(np.ascontiguousarray(plane.numpy(), dtype=np.uint8))
+            planes.append(plane)
+        land = engine.landcover_mask(planes[0], planes[1], forest_mask_landcover_classes,
+                                     landcover_threshold_dict[mask_type.lower()], year - 2000)
+    else:
+        land = get_context(device).landcover_mask(
+            wc, cg, forest_mask_landcover_classes, thresholds=landcover_threshold_dict[mask_type.lower()],
+            year_offset=year - 2000)
     if output_file:
         _save_array(land, output_file, dswx_metadata_dict, geo_tags,
                     description=band_description_dict['LAND'], output_files_list=output_files_list,
@@ -1255,43 +1284,49 @@ def generate_dswx_layers(input_list,
     early_list = []
     if dem_file is not None:
         # :5161-5186 with the warp taken out: the DEM must already be on the HLS grid with a
-        # margin of DEM_MARGIN_IN_PIXELS (what `_warp(..., margin_in_pixels=50)` hands over)
+        # margin of DEM_MARGIN_IN_PIXELS (what `_warp(..., margin_in_pixels=50)` hands over).  Resident like the bands:
+        # inflated on host threads, un-predicted (Float32 + PREDICTOR=3 as GDAL writes a DEM) and untiled on the device,
+        # the SHAD layer and the cropped DEM layer made there (dswx_shadow_layer_device, dswx_copy_2d_device)
         logger.info(f'Preparing DEM file: {dem_file}')
-        dem_with_margin, dem_info = geotiff.read_geotiff(dem_file)
-        margin = _grid_margin(dem_info, image['geotransform'], length, width)
-        if margin is None or dem_with_margin.ndim != 2:
-            raise NotImplementedError(
-                'dem_file is not on the HLS grid (same pixel size, same margin on all sides): '
-                'reprojecting it needs GDAL, which stays on the host and is outside this drop-in '
-                '(SURVEY.md section 2); warp it first or pass shadow_layer=')
+        with stages.span('load DEM'):
+            dem_dir = geotiff.open_geotiff(dem_file)
+            dem_info = dem_dir.info
+            margin = _grid_margin(dem_info, image['geotransform'], length, width) if dem_dir.spp == 1 else None
+            if margin is None:
+                raise NotImplementedError(
+                    'dem_file is not on the HLS grid (same pixel size, same margin on all sides): '
+                    'reprojecting it needs GDAL, which stays on the host and is outside this drop-in '
+                    '(SURVEY.md section 2); warp it first or pass shadow_layer=')
+            dem_with_margin, _ = engine.read_directory(dem_dir)
+            if dem_with_margin.dtype != np.float32:                 # (the reference: np.asarray(..., dtype=np.float32))
+                dem_with_margin = engine.upload(np.ascontiguousarray(dem_with_margin.numpy(), dtype=np.float32))
         if margin > DEM_MARGIN_IN_PIXELS:
-            k = margin - DEM_MARGIN_IN_PIXELS
-            dem_with_margin = dem_with_margin[k:-k, k:-k]
+            dem_with_margin = engine.crop(dem_with_margin, margin - DEM_MARGIN_IN_PIXELS)
             margin = DEM_MARGIN_IN_PIXELS
         elif margin < DEM_MARGIN_IN_PIXELS:
             logger.warning(f'WARNING DEM margin is {margin} pixels, the reference uses '
                            f'{DEM_MARGIN_IN_PIXELS}: slopes along the tile border differ')
-        dem_with_margin = np.ascontiguousarray(dem_with_margin, dtype=np.float32)
-        with stages.span('gpu: shadow layer'), engine.lock:
-            shadow_layer = _compute_opera_shadow_layer(
-                dem_with_margin, sun_azimuth_angle, sun_elevation_angle, min_slope_angle,
-                max_sun_local_inc_angle, margin=margin)
-        dem = dem_with_margin[margin:dem_with_margin.shape[0] - margin,
-                              margin:dem_with_margin.shape[1] - margin]
+            if margin < 2:
+                logger.warning(f'WARNING terrain shadow layer with a margin of {margin} pixel(s): the general kernel '
+                               '(dswx_shadow_v2) computes the whole raster, about three times slower than the filter kernel')
+        sun, sin_az, cos_az, legacy = _shadow_geometry(sun_azimuth_angle, sun_elevation_angle)
+        shadow_layer = engine.shadow_layer(dem_with_margin, sun, sin_az, cos_az, min_slope_angle, max_sun_local_inc_angle,
+                                           margin, legacy)
+        dem = engine.crop(dem_with_margin, margin)
         if output_dem_layer:
             _save_array(dem, output_dem_layer, md, geo_tags, description=band_description_dict['DEM'],
                         output_files_list=early_list, no_data_value=float('nan'))
     if landcover_file is not None and worldcover_file is not None:
-        with stages.span('landcover mask (read + gpu)'), engine.lock:
+        with stages.span('landcover mask (read + gpu)'):
             landcover_mask = create_landcover_mask(
                 landcover_file, worldcover_file, worldcover_file_description, output_landcover, scratch_dir,
                 landcover_mask_type, image['geotransform'], None, length, width,
                 forest_mask_landcover_classes, dswx_metadata_dict=md, output_files_list=early_list,
-                geo_tags=geo_tags, device=device)
+                geo_tags=geo_tags, device=device, engine=engine)
         output_landcover = None          # saved by create_landcover_mask, as in the reference
-    landcover_mask = _as_plane(landcover_mask, shape, 'landcover_mask')
-    shadow_layer = _as_plane(shadow_layer, shape, 'shadow_layer')
-    ocean_mask = _as_plane(ocean_mask, shape, 'ocean_mask')
+    landcover_mask = _as_plane(landcover_mask, shape, 'landcover_mask', engine=engine)
+    shadow_layer = _as_plane(shadow_layer, shape, 'shadow_layer', engine=engine)
+    ocean_mask = _as_plane(ocean_mask, shape, 'ocean_mask', engine=engine)
 
     # ---- the hot path: one call into the HIP library ------------------------------
     bands = [image[k] for k in _capi.BAND_NAMES]
@@ -1403,9 +1438,12 @@ def generate_dswx_layers(input_list,
         # CONF is NOT passed (:5383-5397): the loop skips it and the bands after BWTR move up one (see there)
         host = {n: res[k].numpy() for n, k in (('WTR', 'wtr'), ('BWTR', 'bwtr'), ('DIAG', 'diag'), ('WTR-1', 'wtr1_aerosol'),
                                                ('WTR-2', 'wtr2'), ('CLOUD', 'cloud'))}
+        def on_host(a):
+            return a.numpy() if isinstance(a, pipeline.DevicePlane) else a
         save_dswx_product({'WTR': host['WTR'], 'BWTR': host['BWTR'], 'DIAG': host['DIAG'],
                            'WTR-1': host['WTR-1'], 'WTR-2': host['WTR-2'],
-                           'LAND': landcover_mask, 'SHAD': shadow_layer, 'CLOUD': host['CLOUD'], 'DEM': dem},
+                           'LAND': on_host(landcover_mask), 'SHAD': on_host(shadow_layer), 'CLOUD': host['CLOUD'],
+                           'DEM': on_host(dem)},
                           output_file, md, geo_tags, output_files_list=output_files_list)
     elif output_file:
         logger.warning(f'VRT output "{output_file}" skipped: needs GDAL')

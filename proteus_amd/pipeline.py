@@ -124,8 +124,13 @@ class TileEngine:
 
     # ---- reader side ----------------------------------------------------------------------------------------
     def device_untile_ok(self, d):
-        return (d.spp == 1 and d.predictor in (1, 2) and d.dt.itemsize in (1, 2) and d.dt.kind in 'iu'
-                and d.dt.byteorder in ('=', '|', '<') and d.n_blocks * d.block_bytes < (1 << 32))
+        """Layouts dswx_untile_device takes: one sample per pixel, little endian; 1- / 2- / 4-byte integers with PREDICTOR
+        1 / 2, Float32 with PREDICTOR 1 / 3 (a GDAL-written DEM)."""
+        if d.spp != 1 or d.dt.byteorder not in ('=', '|', '<') or d.n_blocks * d.block_bytes >= (1 << 32):
+            return False
+        if d.dt.kind in 'iu':
+            return d.dt.itemsize in (1, 2, 4) and d.predictor in (1, 2)
+        return d.dt.kind == 'f' and d.dt.itemsize == 4 and d.predictor in (1, 3)
 
     def read_plane(self, path):
         return self.read_directory(geotiff.open_geotiff(path))
@@ -203,6 +208,44 @@ class TileEngine:
         res['counters'] = np.array(cnt, dtype=np.int64)
         del keep
         return res
+
+    # ---- the layers next to the path, resident --------------------------------------------------------------------
+    def crop(self, plane, margin):
+        """_crop_2d_array_all_sides (dswx_hls.py:4320) on the device: plane[margin:-margin, margin:-margin]."""
+        if margin == 0:
+            return plane
+        H, W = plane.shape
+        out = self.plane((H - 2 * margin, W - 2 * margin), plane.dtype)
+        es = plane.dtype.itemsize
+        with self.lock, stages.span('gpu: crop'):
+            self.ctx.copy_2d_device(out.ptr, out.shape[1] * es, plane.ptr + (margin * W + margin) * es, W * es,
+                                    out.shape[1] * es, out.shape[0])
+            self.ctx.synchronize()
+        return out
+
+    def shadow_layer(self, dem, sun_vector, sin_azimuth, cos_azimuth, min_slope_angle, max_sun_local_inc_angle, margin,
+                     float32, pixel_spacing_x=30, pixel_spacing_y=30):
+        """dem: DevicePlane float32 [H, W] (with its margin) -> SHAD DevicePlane u8 [H - 2 m, W - 2 m] (1 = not shadow)."""
+        H, W = dem.shape
+        out = self.plane((H - 2 * margin, W - 2 * margin), np.uint8)
+        with self.lock, stages.span('gpu: shadow layer'):
+            self.ctx.shadow_layer_device(dem.ptr, 1, H, W, margin, sun_vector, sin_azimuth, cos_azimuth, min_slope_angle,
+                                         max_sun_local_inc_angle, out.ptr, pixel_spacing_x, pixel_spacing_y, float32=float32)
+            self.ctx.synchronize()
+        return out
+
+    def landcover_mask(self, worldcover_up3, copernicus, forest_classes, thresholds, year_offset):
+        """WorldCover [3H, 3W] + CGLS [H, W] (DevicePlanes, u8) -> LAND DevicePlane [H, W] (create_landcover_mask's
+        per-pixel part, :994-1115)."""
+        H, W = copernicus.shape
+        if worldcover_up3.shape != (3 * H, 3 * W):
+            raise ValueError(f'WorldCover raster {worldcover_up3.shape} is not three times the CGLS grid {(H, W)}')
+        out = self.plane((H, W), np.uint8)
+        with self.lock, stages.span('gpu: LAND aggregation'):
+            self.ctx.landcover_mask_device(worldcover_up3.ptr, copernicus.ptr, 1, H, W, forest_classes, out.ptr,
+                                           thresholds=thresholds, year_offset=year_offset)
+            self.ctx.synchronize()
+        return out
 
     # ---- writer side ----------------------------------------------------------------------------------------
     def layer_levels(self, plane, factors=(), tile=512):

@@ -242,3 +242,44 @@ def test_writer_kernels_fuzz(ctx):
             blk = d
         back = _untile(ctx, blk.reshape(-1), dtype, h, w, bw, bh, predictor)
         assert np.array_equal(back, arr), (case, h, w, dtype, bw, bh, predictor)
+
+
+@pytest.mark.parametrize('shape', [(3760, 3760), (300, 257), (1, 1), (513, 100)])
+def test_untile_float32_with_the_floating_point_predictor_and_four_byte_integers(ctx, tmp_path, shape):
+    """A Float32 DEM as GDAL writes it (PREDICTOR=3: byte planes, MSB first, byte-wise running sum; TIFF Technical Note 3)
+    read back on the device: our writer's tiles and Pillow / libtiff's strips; bit for bit incl. NaN / inf / denormals.
+    And 4-byte integer samples with PREDICTOR=2 (wrap-around in 32 bits).  Then the crop of a margin on the device."""
+    from proteus_amd import pipeline
+    rng = np.random.default_rng(shape[0] + shape[1])
+    arr = rng.normal(300.0, 120.0, size=shape).astype(np.float32)
+    arr[rng.random(shape) < 0.02] = np.nan
+    arr.reshape(-1)[:3] = [np.inf, -0.0, 1e-40][:arr.size]
+    eng = pipeline.TileEngine(ctx)
+    try:
+        for tile in (512, 256):
+            p = str(tmp_path / f'f{tile}.tif')
+            geotiff.write_geotiff(p, arr, tile=tile, nodata=float('nan'))
+            d = geotiff.open_geotiff(p)
+            assert d.predictor == 3 and eng.device_untile_ok(d)
+            plane, info = eng.read_directory(d)
+            assert plane.dtype == np.float32 and plane.numpy().tobytes() == arr.tobytes(), (shape, tile)
+        from PIL import Image, features
+        if features.check('libtiff'):
+            q = str(tmp_path / 'strips.tif')
+            Image.fromarray(arr).save(q, compression='tiff_adobe_deflate', tiffinfo={317: 3})
+            d = geotiff.open_geotiff(q)
+            assert d.predictor == 3 and not d.tiled and eng.device_untile_ok(d)
+            assert eng.read_directory(d)[0].numpy().tobytes() == arr.tobytes()
+        ints = rng.integers(-2 ** 31, 2 ** 31, size=shape).astype(np.int32)
+        p = str(tmp_path / 'i32.tif')
+        geotiff.write_geotiff(p, ints)
+        d = geotiff.open_geotiff(p)
+        assert d.predictor == 2 and d.dt.itemsize == 4 and eng.device_untile_ok(d)
+        assert np.array_equal(eng.read_directory(d)[0].numpy(), ints)
+        if min(shape) > 8:
+            m = 3
+            plane = eng.upload(arr)
+            assert eng.crop(plane, m).numpy().tobytes() == np.ascontiguousarray(arr[m:-m, m:-m]).tobytes()
+            assert eng.crop(plane, 0) is plane
+    finally:
+        eng.close()
