@@ -1237,6 +1237,17 @@ def _main():
             last_words.running = f'case {index}' + (f' ({case.key})' if case.key else '')
         rec, n_tiles, failed = measure_case(args, case, env, index)
         failed_any += failed
+        if index + 1 < len(cases) and env.ctx is not None:
+            # the next case allocates its own resident chunk (512 tiles = 144 GB for configs[3]): hand the library's pool --
+            # the chunks of this case's placed batch and of its dropped ranges, ~100 GiB at 256 tiles -- back to the device
+            # first (this process has no other thread that allocates; outside every timed region)
+            try:
+                from proteus_amd import _capi as _c
+                freed = _c.pool_trim()
+                if rank == 0:
+                    print(f'[bench] pool trimmed between cases: {freed / 2 ** 30:.1f} GiB', file=sys.stderr, flush=True)
+            except Exception as e:          # noqa: BLE001
+                print(f'[bench rank {rank}] pool trim between cases: {e}', file=sys.stderr, flush=True)
         if rank == 0:
             if case.key is None:
                 out = rec
