@@ -283,3 +283,63 @@ def test_untile_float32_with_the_floating_point_predictor_and_four_byte_integers
             assert eng.crop(plane, 0) is plane
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (7, 3), (65, 130), (150, 201), (259, 77)])
+def test_device_kernels_against_the_row_by_row_oracle(ctx, shape):
+    """The device kernels against oracle/cog_oracle.py -- the block-by-block, row-by-row restatement that shares no code
+    with the product's writer and is pinned both ways against libtiff (tests/test_cog_oracle.py): block bytes of every
+    level (u8 / u16 with PREDICTOR 2 and 1, Float32 with PREDICTOR 3), the way back (tiles and strips, incl. Float32), and
+    the RGB planes."""
+    from oracle import cog_oracle as co
+    rng = np.random.default_rng(shape[0] * 13 + shape[1])
+    for dtype in (np.uint8, np.uint16):
+        arr = rng.integers(0, np.iinfo(dtype).max + 1, size=shape).astype(dtype)
+        for tile, predictor in ((16, 2), (64, 2), (16, 1)):
+            got, lay = _device_blocks(ctx, arr, FACTORS, tile, predictor)
+            want = co.cog_levels(arr, FACTORS, tile, predictor)
+            assert lay['n_levels'] == len(want)
+            for lv, (h, w, data) in zip(lay['levels'], want):
+                assert (lv['height'], lv['width']) == (h, w)
+                assert np.array_equal(got[lv['offset_bytes']: lv['offset_bytes'] + data.size], data), (dtype, tile, predictor)
+            back = _untile(ctx, want[0][2], dtype, shape[0], shape[1], tile, tile, predictor)
+            assert np.array_equal(back, arr)
+        # strips: one block row of the raster's own width, several rows per strip, the last strip short
+        bh = 7
+        down = -(-shape[0] // bh)
+        pad = np.zeros((down * bh, shape[1]), dtype)
+        pad[:shape[0]] = arr
+        d = pad.copy()
+        d[:, 1:] -= pad[:, :-1]
+        assert np.array_equal(co.unblocks(d.reshape(-1).view(np.uint8), dtype, shape[0], shape[1], shape[1], bh, 2), arr)
+        assert np.array_equal(_untile(ctx, d.reshape(-1), dtype, shape[0], shape[1], shape[1], bh, 2), arr)
+    f = rng.normal(10.0, 4.0, size=shape).astype(np.float32)
+    f[rng.random(shape) < 0.1] = np.nan
+    got, lay = _device_blocks(ctx, f, (), 16, 3)
+    (h, w, data), = co.cog_levels(f, (), 16, 3)
+    assert np.array_equal(got, data)
+    d_in, d_out = ctx.malloc(max(data.size, 16)), ctx.malloc(max(f.nbytes, 16))
+    try:
+        d_in.upload(data)
+        ctx.untile_device(d_in.ptr, 4, shape[0], shape[1], 16, 16, 3, d_out.ptr)
+        ctx.synchronize()
+        assert d_out.download(np.float32, f.size).tobytes() == f.tobytes()
+    finally:
+        d_in.free()
+        d_out.free()
+    # RGB planes
+    n = shape[0] * shape[1]
+    bands = [rng.integers(-100, 9000, size=n).astype(np.int16) for _ in range(3)]
+    diag = rng.integers(0, 11112, size=n).astype(np.uint16)
+    diag[::5] = 65535
+    bufs = [ctx.malloc(max(b.nbytes, 16)) for b in bands] + [ctx.malloc(max(diag.nbytes, 16)), ctx.malloc(max(12 * n, 16))]
+    try:
+        for buf, b in zip(bufs, bands + [diag]):
+            buf.upload(b)
+        ctx.rgb_planes_device(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, n, [1e-4, 2e-4, 1.0], [0.0, -3.0, 12.5], True, bufs[4].ptr)
+        ctx.synchronize()
+        want = co.rgb_planes(bands, diag, [1e-4, 2e-4, 1.0], [0.0, -3.0, 12.5])
+        assert np.array_equal(bufs[4].download(np.float32, 3 * n).reshape(3, n), want, equal_nan=True)
+    finally:
+        for buf in bufs:
+            buf.free()
