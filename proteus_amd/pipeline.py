@@ -16,7 +16,6 @@ No fallback hides here: a file layout the device kernels do not take (floating-p
 pixel, big endian) is untiled by the host reader (geotiff.TiffDirectory.untile, the same bytes) and uploaded; the
 classification itself has no host form anywhere.
 """
-import ctypes
 import threading
 import time
 
