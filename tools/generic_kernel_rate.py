@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Rate of the one-pixel-per-thread generic kernel `dswx_classify_v1` (VERDICT r04 "What's missing" 2: no rate for it
+"""ROUND 6 NOTE: the direct kernel takes ragged batches itself now (unaligned accesses), so `fused_variant=0` below no longer
+falls through to the generic kernel: the entries named generic_* of a run of THIS version measure dswx_classify_v8 on the
+ragged batch (see the `kernel` field; tools/fallback_rates.py is the round-6 harness; profiles/r05_generic_kernel_rate.json
+keeps the generic kernel's 0.15 - 0.17).  Original description:
+
+Rate of the one-pixel-per-thread generic kernel `dswx_classify_v1` (VERDICT r04 "What's missing" 2: no rate for it
 existed anywhere) on a RAGGED contiguous batch -- 3660 x 3659 tiles: H*W = 4 (mod 8), so tiles 1.. start off the 8-byte
 grid of the u8 planes -- which until round 5 was the only kernel that could run such a batch, and of the table-driven
 kernel on the same batch since it learnt to start every tile at its first 8-pixel boundary (KArgs::ragged; the generic
