@@ -383,6 +383,7 @@ def parse_runconfig_file(user_runconfig_file=None, args=None):
 # GPU context (one per process and device)
 # -----------------------------------------------------------------------------------
 _contexts = {}
+_contexts_lock = threading.Lock()
 
 
 def get_context(device=None):
@@ -390,9 +391,13 @@ def get_context(device=None):
     Raises if the library is not built or no MI355X is visible: no CPU fallback."""
     if device is None:
         device = int(os.environ.get('DSWX_DEVICE', '0'))
-    if device not in _contexts:
-        _contexts[device] = _capi.Context(device)
-    return _contexts[device]
+    ctx = _contexts.get(device)
+    if ctx is None:
+        with _contexts_lock:            # (several tiles may be in flight on threads of one process: proteus_amd.batch)
+            ctx = _contexts.get(device)
+            if ctx is None:
+                ctx = _contexts[device] = _capi.Context(device)
+    return ctx
 
 
 def generate_interpreted_layer(diagnostic_layer):
