@@ -5,7 +5,7 @@ tiles in flight on its threads -- one HIP context, the engine's lock, the pooled
 shared thread pool -- every layer of every product against the numpy oracle computed from the arrays that were written.
 Prints one JSON object; exit code 1 on the first mismatch.
 
-    python tests/helpers/inflight_soak.py [--tiles 96] [--in-flight 8] [--workers 1]
+    python tests/helpers/inflight_soak.py [--tiles 96] [--in-flight 8] [--workers 1] [--size 3660]
 
 (Lives under tests/ because it uses the oracle; its name keeps pytest from collecting it.)"""
 import argparse
@@ -33,12 +33,13 @@ def main():
     ap.add_argument('--tiles', type=int, default=96)
     ap.add_argument('--in-flight', type=int, default=8)
     ap.add_argument('--workers', type=int, default=1)
+    ap.add_argument('--size', type=int, default=0, help='every tile this size (default: random 192 ... 487)')
     a = ap.parse_args()
     rng = np.random.default_rng(606)
     with tempfile.TemporaryDirectory() as d:
         rcs, tiles = [], []
         for t in range(a.tiles):
-            size = int(rng.integers(24, 60)) * 8 + int(rng.integers(0, 8))
+            size = a.size or int(rng.integers(24, 60)) * 8 + int(rng.integers(0, 8))
             anc = t % 5 == 0
             rc, _, _, s = synth_hls.make(os.path.join(d, f't{t}'), sensor=('L30', 'S30')[t % 2], size=size, tile=1000 + t,
                                          product_id=f'S{t}', ancillary=anc, ocean=anc)
