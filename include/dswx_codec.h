@@ -37,6 +37,9 @@ int dswx_codec_force_zlib(int on);
 /* Processors this process may use: hardware threads, cut down to the container's CPU bandwidth quota (cgroup cpu.max).
  * The pool never runs more workers than this, whatever the calls ask for. */
 int dswx_codec_cpu_budget(void);
+/* A process that shares the machine with sibling workers (the node-level driver: one worker per GPU) takes only its share:
+ * the budget becomes min(processors, what was detected); 0 = back to the detected value. */
+int dswx_codec_set_cpu_budget(int processors);
 
 /* Upper bound of the compressed size of `bytes` input bytes (any level, either engine). */
 size_t dswx_codec_deflate_bound(size_t bytes);

@@ -43,8 +43,12 @@ def load():
         lib.dswx_codec_deflate_blocks.argtypes = [vpp, szp, vpp, szp, szp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
         lib.dswx_codec_inflate_blocks.restype = ctypes.c_int
         lib.dswx_codec_inflate_blocks.argtypes = [vpp, szp, vpp, szp, szp, ctypes.c_int32, ctypes.c_int32]
+        lib.dswx_codec_set_cpu_budget.argtypes = [ctypes.c_int]
         if lib.dswx_codec_abi_version() != 1:
             raise CodecError(f'{path}: ABI version {lib.dswx_codec_abi_version()}, expected 1')
+        share = int(os.environ.get('DSWX_CPU_SHARE', '0'))           # set by proteus_amd.batch for its worker processes
+        if share > 0:
+            lib.dswx_codec_set_cpu_budget(share)
         _lib = lib
     return _lib
 
@@ -60,6 +64,11 @@ def force_zlib(on):
 def cpu_budget():
     """Processors this process may really use: hardware threads cut down to the container's CPU quota (cgroup)."""
     return int(load().dswx_codec_cpu_budget())
+
+
+def set_cpu_budget(processors):
+    """This process's share of the machine (0 = what was detected)."""
+    load().dswx_codec_set_cpu_budget(int(processors))
 
 
 def default_threads():

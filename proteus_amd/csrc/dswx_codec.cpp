@@ -133,7 +133,9 @@ int inflate_one(const void* src, size_t n, void* dst, size_t cap, size_t* out) {
 // (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  More runnable threads than that do not run faster: the quota is spent
 // earlier in every period and the whole group is throttled until the next (measured on the MI355X box of this
 // project: 256 hardware threads, quota 16 -> 1,740 blocks/s with 32 threads, 830 with 256).
-int cpu_budget() {
+std::atomic<int> g_budget_override{0};
+
+int detected_cpu_budget() {
     static const int budget = [] {
         int n = (int)std::thread::hardware_concurrency();
         if (n < 1) n = 1;
@@ -153,6 +155,14 @@ int cpu_budget() {
         return n;
     }();
     return budget;
+}
+
+// the detected budget, or the share of it the caller was given (dswx_codec_set_cpu_budget: the node-level driver divides
+// the container's processors among its worker processes)
+int cpu_budget() {
+    const int o = g_budget_override.load(std::memory_order_relaxed);
+    const int d = detected_cpu_budget();
+    return (o >= 1 && o < d) ? o : d;
 }
 
 // ---- the pool ------------------------------------------------------------------------------------------------
@@ -274,6 +284,11 @@ const char* dswx_codec_engine(void) { return use_libdeflate() ? "libdeflate" : "
 const char* dswx_codec_last_error(void) { return g_error; }
 
 int dswx_codec_cpu_budget(void) { return cpu_budget(); }
+
+int dswx_codec_set_cpu_budget(int processors) {
+    g_budget_override.store(processors > 0 ? processors : 0);
+    return DSWX_CODEC_OK;
+}
 
 int dswx_codec_force_zlib(int on) {
     g_force_zlib.store(on ? 1 : 0);

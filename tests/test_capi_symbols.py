@@ -35,7 +35,7 @@ def test_codec_library_exports_its_header():
     text = open(os.path.join(ROOT, 'include', 'dswx_codec.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     names = sorted(set(re.findall(r'\b(dswx_codec_[a-z0-9_]+)\s*\(', text)))
-    assert len(names) == 8
+    assert len(names) == 9
     path = build.build_codec()
     lib = ctypes.CDLL(path)
     for name in names:
@@ -45,7 +45,14 @@ def test_codec_library_exports_its_header():
     assert c_syms == names
     lib.dswx_codec_abi_version.restype = ctypes.c_int
     assert lib.dswx_codec_abi_version() == 1
-    assert 1 <= lib.dswx_codec_cpu_budget() <= (os.cpu_count() or 1)
+    full = lib.dswx_codec_cpu_budget()
+    assert 1 <= full <= (os.cpu_count() or 1)
+    lib.dswx_codec_set_cpu_budget(1)
+    assert lib.dswx_codec_cpu_budget() == 1
+    lib.dswx_codec_set_cpu_budget(10 ** 6)
+    assert lib.dswx_codec_cpu_budget() == full          # never more than what was detected
+    lib.dswx_codec_set_cpu_budget(0)
+    assert lib.dswx_codec_cpu_budget() == full
 
 
 def test_product_library_carries_no_experiments():

@@ -22,7 +22,7 @@ def main():
         rcs = [synth_hls.make(os.path.join(d, f't{i}'), sensor=('L30', 'S30')[i % 2], size=size, tile=i,
                               product_id=f'P{i}')[0] for i in range(n)]
         import shutil
-        for wpg, in_flight in ((1, 1), (1, 2), (1, 3), (1, 4), (2, 2), (4, 1), (8, 1)):
+        for wpg, in_flight in ((1, 1), (1, 3), (2, 2), (4, 1), (8, 1)):
             for i in range(n):
                 shutil.rmtree(os.path.join(d, f't{i}', 'output'), ignore_errors=True)
             reports = []
