@@ -143,11 +143,19 @@ class TiffDirectory:
         if magic != 42:
             raise GeoTiffError(f'{path}: not a TIFF file')
         for _ in range(0 if overview is None else overview + 1):
+            if ifd + 2 > len(buf):
+                raise GeoTiffError(f'{path}: directory outside the file')
             (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
+            if ifd + 6 + 12 * n > len(buf):
+                raise GeoTiffError(f'{path}: truncated directory')
             (ifd,) = struct.unpack(e + 'I', buf[ifd + 2 + 12 * n: ifd + 6 + 12 * n])
             if not ifd:
                 raise GeoTiffError(f'{path}: no overview {overview}')
+        if ifd + 2 > len(buf):
+            raise GeoTiffError(f'{path}: directory outside the file')
         (n,) = struct.unpack(e + 'H', buf[ifd:ifd + 2])
+        if ifd + 2 + 12 * n + 4 > len(buf):
+            raise GeoTiffError(f'{path}: truncated directory')
         tags = {}
         for k in range(n):
             ent = buf[ifd + 2 + 12 * k: ifd + 14 + 12 * k]
@@ -159,6 +167,8 @@ class TiffDirectory:
                 raw = ent[8:8 + size]
             else:
                 (off,) = struct.unpack(e + 'I', ent[8:12])
+                if off + size > len(buf):           # a damaged count / offset: not a reason to build a gigabyte format string
+                    raise GeoTiffError(f'{path}: directory entry {tag} points outside the file')
                 raw = buf[off:off + size]
             if typ == 2:
                 vals = raw.rstrip(b'\x00').decode('latin-1')
@@ -212,6 +222,12 @@ class TiffDirectory:
         self.block_bytes = self.bh * self.bw * self.chunk_spp * self.dt.itemsize
         if len(self.offs) < self.n_blocks or len(self.cnts) < self.n_blocks:
             raise GeoTiffError(f'{path}: truncated block table')
+        # a damaged header must not make the reader allocate the moon: DEFLATE expands at most ~1032 : 1, so a raster
+        # that claims more decoded bytes than that (or, uncompressed, more than the file holds) is not what the file contains
+        claimed = self.n_blocks * self.block_bytes
+        if info.width < 1 or info.height < 1 or spp < 1 or \
+                claimed > (1100 * len(buf) + (1 << 20) if comp != 1 else len(buf) + self.block_bytes * self.planes * self.across):
+            raise GeoTiffError(f'{path}: the directory claims {claimed} bytes of raster, the file has {len(buf)}')
 
         nod = one(TAG_GDAL_NODATA)
         if nod is not None:

@@ -3,6 +3,7 @@ product comparison and the error conventions of the reference interface."""
 import ctypes
 import os
 import struct
+import zlib
 import sys
 
 import numpy as np
@@ -681,3 +682,53 @@ def test_cog_layout_is_the_host_writers_layout(shape):
         _capi.cog_layout(h, w, 3, (), 512)
     with pytest.raises(_capi.DswxError):
         _capi.cog_layout(h, w, 1, (), 100)
+
+
+def test_reader_survives_damaged_files(tmp_path):
+    """A damaged band file is an ERROR the product reports (generate_dswx_layers returns False after 'ERROR could not open',
+    as the reference does when gdal.Open fails, dswx_hls.py:4988-4990) -- never a crash of the native codec, a read outside
+    the file or an absurd allocation: 400 mutations (byte flips in the header and directory, in the block table, in the
+    compressed data; truncations; a few bytes of garbage) of tiled, stripped, multi-level and Float32 files either decode
+    or raise GeoTiffError / a plain Python lookup error."""
+    rng = np.random.default_rng(99)
+    a = rng.integers(0, 3000, size=(300, 260)).astype(np.int16)
+    files = []
+    p = str(tmp_path / 'tiled.tif')
+    geotiff.write_geotiff(p, a, tile=64, overviews=(2, 4), nodata=-9999, metadata={'K': 'v'})
+    files.append(p)
+    p = str(tmp_path / 'float.tif')
+    geotiff.write_geotiff(p, a.astype(np.float32) / 7, tile=128)
+    files.append(p)
+    p = str(tmp_path / 'raw.tif')
+    geotiff.write_geotiff(p, a.astype(np.uint8), compress=False, tile=256)
+    files.append(p)
+    ok = bad = 0
+    for case in range(400):
+        src = open(files[case % len(files)], 'rb').read()
+        buf = bytearray(src)
+        kind = case % 5
+        if kind == 0:                                   # header + first directory
+            for _ in range(int(rng.integers(1, 4))):
+                buf[int(rng.integers(0, min(400, len(buf))))] = int(rng.integers(0, 256))
+        elif kind == 1:                                 # anywhere
+            for _ in range(int(rng.integers(1, 20))):
+                buf[int(rng.integers(0, len(buf)))] ^= int(rng.integers(1, 256))
+        elif kind == 2:                                 # truncated
+            buf = buf[:int(rng.integers(0, len(buf)))]
+        elif kind == 3:                                 # the tail (block data) overwritten with noise
+            k = int(rng.integers(1, max(2, len(buf) // 3)))
+            buf[-k:] = rng.integers(0, 256, size=k, dtype=np.uint8).tobytes()
+        else:                                           # a 32-bit field set to a huge value somewhere in the directory
+            q = int(rng.integers(8, min(600, len(buf) - 4)))
+            buf[q:q + 4] = (0xfffffff0).to_bytes(4, 'little')
+        q = str(tmp_path / 'damaged.tif')
+        open(q, 'wb').write(bytes(buf))
+        try:
+            for ov in (None, 0):
+                arr, info = geotiff.read_geotiff(q, overview=ov)
+                assert arr.size < 50_000_000
+            ok += 1
+        except (geotiff.GeoTiffError, KeyError, IndexError, ValueError, struct.error, TypeError, UnicodeDecodeError,
+                ZeroDivisionError, OverflowError, zlib.error):
+            bad += 1
+    assert ok + bad == 400 and bad > 100
