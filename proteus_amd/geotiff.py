@@ -128,6 +128,15 @@ class TiffDirectory:
         with stages.span('read: file'), open(path, 'rb') as fh:
             buf = fh.read()
         self.buf = buf
+        try:
+            self._parse(path, buf, overview)
+        except (KeyError, IndexError, ValueError, struct.error, TypeError, UnicodeDecodeError, ZeroDivisionError,
+                OverflowError) as e:
+            # a damaged directory is an unreadable FILE to the caller (the reference: gdal.Open returns None -> 'ERROR could
+            # not open', dswx_hls.py:4988-4990), not a lookup error from inside the parser
+            raise GeoTiffError(f'{path}: damaged TIFF directory ({type(e).__name__}: {e})')
+
+    def _parse(self, path, buf, overview):
         if len(buf) < 8:
             raise GeoTiffError(f'{path}: not a TIFF file')
         if buf[:2] == b'II':
@@ -341,7 +350,10 @@ def read_geotiff(path, window=None, overview=None, alloc=None):
     (IFD k + 1) instead of the full-resolution image.  alloc(shape, dtype) -> ndarray lets the
     caller own the destination memory (e.g. page-locked host memory for the GPU path)."""
     d = TiffDirectory(path, overview)
-    out = d.untile(d.inflate(), alloc=alloc)
+    try:
+        out = d.untile(d.inflate(), alloc=alloc)
+    except (ValueError, IndexError, MemoryError) as e:              # geometry that does not hold together
+        raise GeoTiffError(f'{path}: damaged TIFF ({type(e).__name__}: {e})')
     info = d.info
     arr = out[0] if d.spp == 1 else out
     if window is not None:

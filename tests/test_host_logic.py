@@ -689,7 +689,7 @@ def test_reader_survives_damaged_files(tmp_path):
     as the reference does when gdal.Open fails, dswx_hls.py:4988-4990) -- never a crash of the native codec, a read outside
     the file or an absurd allocation: 400 mutations (byte flips in the header and directory, in the block table, in the
     compressed data; truncations; a few bytes of garbage) of tiled, stripped, multi-level and Float32 files either decode
-    or raise GeoTiffError / a plain Python lookup error."""
+    or raise GeoTiffError -- the one error type the loader turns into 'ERROR could not open'."""
     rng = np.random.default_rng(99)
     a = rng.integers(0, 3000, size=(300, 260)).astype(np.int16)
     files = []
@@ -728,7 +728,6 @@ def test_reader_survives_damaged_files(tmp_path):
                 arr, info = geotiff.read_geotiff(q, overview=ov)
                 assert arr.size < 50_000_000
             ok += 1
-        except (geotiff.GeoTiffError, KeyError, IndexError, ValueError, struct.error, TypeError, UnicodeDecodeError,
-                ZeroDivisionError, OverflowError, zlib.error):
+        except geotiff.GeoTiffError:                    # the ONE error type a damaged file may raise
             bad += 1
     assert ok + bad == 400 and bad > 100
