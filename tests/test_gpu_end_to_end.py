@@ -385,6 +385,31 @@ def test_product_from_band_files_written_by_another_library(tmp_path):
         assert np.array_equal(arr, exp[layer]), layer
 
 
+def test_a_damaged_band_file_is_an_error_return_not_a_crash(tmp_path):
+    """The reference: gdal.Open fails -> 'ERROR could not open' -> generate_dswx_layers returns False (:4988-4990).  Here a
+    band file with corrupt block data (the native codec reports it), one with a damaged directory, and a truncated one
+    each make the run return False; the next run on the intact files succeeds (nothing is left in a bad state)."""
+    from proteus_amd import dswx_hls as D
+    _, files, _, s = synth_hls.make(str(tmp_path / 'ok'), size=200, tile=77)
+    good = open(files[3], 'rb').read()
+    out = str(tmp_path / 'wtr.tif')
+    for kind in ('data', 'directory', 'truncated'):
+        buf = bytearray(good)
+        if kind == 'data':
+            buf[-2000:-1000] = bytes(1000)
+        elif kind == 'directory':
+            buf[20:24] = (0xfffffff0).to_bytes(4, 'little')
+        else:
+            buf = buf[:len(buf) // 2]
+        open(files[3], 'wb').write(bytes(buf))
+        assert D.generate_dswx_layers(files, output_interpreted_band=out, scratch_dir=str(tmp_path / 'scratch')) is False, kind
+        assert not os.path.exists(out)
+    open(files[3], 'wb').write(good)
+    assert D.generate_dswx_layers(files, output_interpreted_band=out, scratch_dir=str(tmp_path / 'scratch')) is True
+    arr, _ = geotiff.read_geotiff(out)
+    assert np.array_equal(arr, o.classify_tile(s['bands'], s['fmask'])['WTR'])
+
+
 def test_tiles_in_flight_inside_one_worker(tmp_path):
     """Round 6: ONE worker process keeps several tiles going at once on its threads -- tile k + 1
     inflating and tile k - 1 deflating while tile k is on the device, the engine's lock serialising the GPU part, one HIP
