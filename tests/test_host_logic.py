@@ -731,3 +731,17 @@ def test_reader_survives_damaged_files(tmp_path):
         except geotiff.GeoTiffError:                    # the ONE error type a damaged file may raise
             bad += 1
     assert ok + bad == 400 and bad > 100
+
+
+def test_every_tool_and_helper_script_parses():
+    """tools/, tools/lab/, tests/helpers/, bin/ hold the measurement and soak scripts the profiles were made with: they only
+    run on a GPU box, so at least their syntax is checked here."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sorted(glob.glob(os.path.join(root, 'tools', '*.py')) + glob.glob(os.path.join(root, 'tools', 'lab', '*.py')) +
+                   glob.glob(os.path.join(root, 'tests', 'helpers', '*.py')) + glob.glob(os.path.join(root, 'bin', '*.py')) +
+                   [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')])
+    assert len(paths) > 20
+    for p in paths:
+        ast.parse(open(p).read(), filename=p)
