@@ -63,7 +63,7 @@ class TileEngine:
         self.lock = threading.RLock()
         self._free = {}                     # nbytes -> [DeviceBuffer]
         self._free_bytes = 0
-        self._pool_lock = threading.Lock()
+        self._pool_lock = threading.RLock()   # re-entrant: a plane's finalizer (_give) may run -- cyclic GC -- on a thread that is inside _take
 
     # ---- device memory ------------------------------------------------------------------------------------
     @staticmethod
