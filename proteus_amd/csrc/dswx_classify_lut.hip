@@ -98,14 +98,14 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
         const long long off = tile_base + (in_range ? grp : (FLEX && grp < 0 ? 0 : max(n_groups - 1, 0LL))) * 8;
         u32x4 v[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = ldg<u32x4, true>(a.in.band[k] + off);
-        const u32x2 vf = ldg<u32x2, true>(a.in.fmask + off);
+        for (int k = 0; k < 6; ++k) v[k] = ldg_u<u32x4_u, u32x4, true>(a.in.band[k] + off);
+        const u32x2 vf = ldg_u<u32x2_u, u32x2, true>(a.in.fmask + off);
         u32x2 vl = {0u, 0u}, vs = {0x01010101u, 0x01010101u}, vo = {0x01010101u, 0x01010101u};
         if (MASKS) {
-            if (has_l) vl = ldg<u32x2, true>(a.in.land + off);
-            if (has_s) vs = ldg<u32x2, true>(a.in.shad + off);
+            if (has_l) vl = ldg_u<u32x2_u, u32x2, true>(a.in.land + off);
+            if (has_s) vs = ldg_u<u32x2_u, u32x2, true>(a.in.shad + off);
             if (has_o) {
-                vo = ldg<u32x2, true>(a.in.ocean + off);
+                vo = ldg_u<u32x2_u, u32x2, true>(a.in.ocean + off);
                 const uint32_t so = __builtin_amdgcn_sad_u8(vo.x, 0u, __builtin_amdgcn_sad_u8(vo.y, 0u, 0u));
                 t_ocean += in_range ? so : 0u;
             }
@@ -121,22 +121,22 @@ __global__ __launch_bounds__(256, WPS) void dswx_classify_lut(const KArgs a, con
             for (int j = 0; j < 8; ++j) { const uint2 e = s_extra[idx2[j]]; ex[j] = e.x; bitmaps |= e.y << j; }
             transpose4(ex, pa); transpose4(ex + 4, pb);
             if (a.cover_state) {              // read back by stages 2 / 3 only after the whole batch: stream them out
-                stg<u32x2, true>(a.cover_state + off, u32x2{pa[0], pb[0]});
+                stg_u<u32x2_u, u32x2, true>(a.cover_state + off, u32x2{pa[0], pb[0]});
                 __builtin_nontemporal_store(bitmaps, a.cover_bits + tile * a.cover_bits_stride + grp);
             }
-            if (a.out.browse) stg<u32x2, true>(a.out.browse + off, u32x2{pa[2], pb[2]});
+            if (a.out.browse) stg_u<u32x2_u, u32x2, true>(a.out.browse + off, u32x2{pa[2], pb[2]});
         }
         if (in_range) {
             GroupPlanes gp;
             lut_pack(w1w, chx, chy, gp);
-            if (a.out.diag) stg<u32x4, true>(a.out.diag + off, u32x4{gp.diag[0], gp.diag[1], gp.diag[2], gp.diag[3]});
-            if (a.out.wtr1) stg<u32x2, true>(a.out.wtr1 + off, u32x2{gp.w1[0], gp.w1[1]});
-            if (a.out.wtr1_aerosol) stg<u32x2, true>(a.out.wtr1_aerosol + off, u32x2{gp.w1a[0], gp.w1a[1]});
-            if (a.out.wtr2) stg<u32x2, true>(a.out.wtr2 + off, u32x2{gp.w2[0], gp.w2[1]});
-            if (a.out.wtr) stg<u32x2, true>(a.out.wtr + off, u32x2{gp.w[0], gp.w[1]});
-            if (a.out.bwtr) stg<u32x2, true>(a.out.bwtr + off, u32x2{gp.bw[0], gp.bw[1]});
-            if (a.out.conf) stg<u32x2, true>(a.out.conf + off, u32x2{gp.cf[0], gp.cf[1]});
-            if (a.out.cloud) stg<u32x2, true>(a.out.cloud + off, u32x2{gp.cl[0], gp.cl[1]});
+            if (a.out.diag) stg_u<u32x4_u, u32x4, true>(a.out.diag + off, u32x4{gp.diag[0], gp.diag[1], gp.diag[2], gp.diag[3]});
+            if (a.out.wtr1) stg_u<u32x2_u, u32x2, true>(a.out.wtr1 + off, u32x2{gp.w1[0], gp.w1[1]});
+            if (a.out.wtr1_aerosol) stg_u<u32x2_u, u32x2, true>(a.out.wtr1_aerosol + off, u32x2{gp.w1a[0], gp.w1a[1]});
+            if (a.out.wtr2) stg_u<u32x2_u, u32x2, true>(a.out.wtr2 + off, u32x2{gp.w2[0], gp.w2[1]});
+            if (a.out.wtr) stg_u<u32x2_u, u32x2, true>(a.out.wtr + off, u32x2{gp.w[0], gp.w[1]});
+            if (a.out.bwtr) stg_u<u32x2_u, u32x2, true>(a.out.bwtr + off, u32x2{gp.bw[0], gp.bw[1]});
+            if (a.out.conf) stg_u<u32x2_u, u32x2, true>(a.out.conf + off, u32x2{gp.cf[0], gp.cf[1]});
+            if (a.out.cloud) stg_u<u32x2_u, u32x2, true>(a.out.cloud + off, u32x2{gp.cl[0], gp.cl[1]});
         }
     }
     if (a.partials || a.fold_acc) {

@@ -596,11 +596,16 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     if (any_index && a.P.f32_mode)
         return dswx_fail(DSWX_ERR_UNSUPPORTED, "the float64 index planes describe the integer chain; not available with offset_and_scale_inputs");
     const bool masks = in->land || in->shad || in->ocean;
-    // The direct kernel (dswx_classify_v8) takes ANY plane address and ANY tile stride since round 6: its 16- / 8-byte
-    // accesses are unaligned global accesses, which gfx950 performs in hardware (int16 planes 2-byte aligned: checked
-    // above).  It works on tile-relative 8-pixel groups from pixel 0 of every tile, the generic kernel does the
-    // n_pixels % 8 tail.  Up to round 5 such planes -- and ragged batches in 'cover' mode -- ran whole tiles on the
-    // 1-pixel-per-thread kernel at 0.17 of the HBM peak (profiles/r05_generic_kernel_stats.csv).
+    // Since round 6 BOTH vector kernels take ANY plane address and ANY tile stride: their 16- / 8-byte accesses go through
+    // under-aligned vector types (dswx_device.h: u32x4_u, u32x2_u), for which the compiler emits the very same
+    // global_load_dwordx4 / dwordx2 -- gfx950 performs unaligned global accesses in hardware, at a cost of 0 - 6 %
+    // (profiles/r06_fallback_rates.json) -- and the generated code of the table-driven kernel is identical instruction for
+    // instruction to the round-5 build.  So the table-driven kernel is THE kernel for every layout (int16 planes 2-byte
+    // aligned: checked above): tile-relative 8-pixel groups from pixel 0 of every tile, its per-tile lead-in from the
+    // Fmask plane's address, the generic kernel for the n_pixels % 8 tail.  Up to round 5 planes without 16-byte
+    // alignment -- and ragged batches in 'cover' mode -- ran whole tiles on the 1-pixel-per-thread kernel at 0.17 of the
+    // HBM peak (profiles/r05_generic_kernel_stats.csv); the direct kernel (dswx_classify_v8) stays behind the lab switch
+    // fused_variant = 0 (A/B partner and variant parity tests).
     const bool stride8 = (tile_stride % 8 == 0) || n_tiles == 1;
     uint8_t* const u8outs[] = {out->wtr1, out->wtr1_aerosol, out->wtr2, out->wtr, out->bwtr, out->conf, out->cloud,
                                out->browse};
@@ -616,10 +621,12 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
     for (uint8_t* p : u8outs) bases256 = bases256 && (!p || aligned_to(p, 256));
     const bool stride256 = (tile_stride % 256 == 0) || n_tiles == 1;
     // ragged contiguous batches (H * W not a multiple of 8, several tiles): the table-driven kernel starts every tile at
-    // its first 8-pixel boundary, the generic kernel does the < 8 + < 8 pixels at its edges (KArgs::ragged).  Not in
-    // 'cover' mode, whose bitmaps are indexed by tile-relative 8-pixel groups; not when the direct kernel is forced.
+    // its first 8-pixel boundary, the generic kernel does the < 8 + < 8 pixels at its edges (KArgs::ragged) -- with
+    // 256-byte aligned bases that keeps every access of every tile aligned.  Not in 'cover' mode, whose bitmaps are indexed
+    // by tile-relative 8-pixel groups (there, and for bases that are not aligned anyway, every tile starts at its pixel 0
+    // and the accesses are unaligned); not when the direct kernel is forced.
     const bool ragged = !stride8 && bases256 && !cover && ctx->fused_variant != 0;
-    const bool lut_ok = bases256 && (stride256 || tile_stride % 8 == 0 || ragged);
+    const bool lut_ok = true;
     // the lead-in is a property of the addresses (correct for any of them); 0 only when every tile start is aligned
     const int lead_max = (bases256 && stride256) ? 0 : 31;  // groups: dswx_lut_geometry
 
@@ -662,9 +669,8 @@ static int classify_device_impl(dswx_ctx_t* ctx, const dswx_params_t* params, in
             // 'cover' stage 1 and the browse plane: the direct kernel or the table-driven one (3), not
             // the experimental structures
             const bool plain_outputs = !cover && !b.out.browse;
-            // automatic choice: the table-driven kernel when every plane starts on a 256-byte boundary (its per-tile
-            // lead-in takes care of strides that are not multiples of 256 pixels), the direct kernel for planes at
-            // odd addresses (>= 16-byte aligned)
+            // automatic choice: the table-driven kernel, whatever the addresses (its per-tile lead-in takes care of
+            // strides that are not multiples of 256 pixels and of plane bases that are not 256-byte aligned)
             int vsel = ctx->fused_variant;
             if (vsel != 0 && vsel != 3) vsel = lut_ok ? 3 : 0;
             const bool variant = vsel == 3;

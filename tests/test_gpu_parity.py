@@ -297,10 +297,11 @@ def test_more_tiles_than_one_grid_dimension(ctx, tile_align, h, w):
 
 
 @pytest.mark.parametrize('shape', [(40, 40), (41, 43), (1, 5)])
-def test_unaligned_device_pointers_take_the_direct_kernel(ctx, shape):
-    """Planes at ODD addresses (int16 planes 2-byte aligned, byte planes anywhere) with masks and every layer: the direct
-    kernel takes them since round 6 (unaligned 16- / 8-byte global accesses) -- up to round 5 the
-    1-pixel-per-thread kernel did (0.17 of peak).  The generic kernel still does the n % 8 tail pixels."""
+def test_unaligned_device_pointers_take_the_vector_kernel(ctx, shape):
+    """Planes at ODD addresses (int16 planes 2-byte aligned, byte planes anywhere) with masks and every layer: the
+    table-driven kernel takes them since round 6 (unaligned 16- / 8-byte global accesses) -- up to
+    round 5 the 1-pixel-per-thread kernel did (0.17 of peak).  The generic kernel still does the n % 8 tail pixels; the
+    direct kernel (lab switch) takes the same planes."""
     h, w = shape
     n = h * w
     s = synth_tile(3, h, w, with_masks=True)
@@ -331,12 +332,24 @@ def test_unaligned_device_pointers_take_the_direct_kernel(ctx, shape):
     ctx.classify_device(p, 1, n, pin, pout, counters_ptr=arena.ptr + cnt_off)
     ctx.synchronize()
     info = ctx.last_kernel_info()
-    assert ('dswx_classify_v8' in info) == (n >= 8) and 'dswx_classify_lut' not in info, info
+    assert ('dswx_classify_lut' in info) == (n >= 8) and 'dswx_classify_v8' not in info, info
     exp = c_oracle.classify(p, s['bands'], s['fmask'], land=s['land'], shad=s['shad'], ocean=s['ocean'])
     assert np.array_equal(arena.download(np.uint16, n, where['diag']), exp['diag'].ravel())
     for name in ('wtr1', 'wtr1_aerosol', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
         assert np.array_equal(arena.download(np.uint8, n, where[name]), exp[name].ravel()), name
     assert arena.download(np.int64, 3, cnt_off).tolist() == exp['counters'].tolist()
+    # the direct kernel on the same planes (lab switch)
+    c2 = _capi.Context(0)
+    try:
+        c2.lab_configure(fused_variant=0)
+        ctx.lib.dswx_memset_d(ctx.handle, arena.ptr + where['wtr'], 0xEE, n)
+        c2.classify_device(p, 1, n, pin, pout, counters_ptr=arena.ptr + cnt_off)
+        c2.synchronize()
+        assert ('dswx_classify_v8' in c2.last_kernel_info()) == (n >= 8)
+        assert np.array_equal(arena.download(np.uint8, n, where['wtr']), exp['wtr'].ravel())
+        assert arena.download(np.int64, 3, cnt_off).tolist() == exp['counters'].tolist()
+    finally:
+        c2.close()
     arena.free()
 
 
@@ -427,8 +440,8 @@ def test_zero_copy_writes_stay_inside_the_planes(ctx, align):
                     assert np.array_equal(buf[ptr['wtr']:ptr['wtr'] + P].reshape(h, w), exp['wtr'])
                     assert np.array_equal(buf[ptr['diag']:ptr['diag'] + 2 * P].view(np.uint16).reshape(h, w), exp['diag'])
                 del buf
-    # 256 -> table-driven (+ generic for the ragged tails), 16 and 1 -> direct (any address since round 6)
-    want = {256: 'dswx_classify_lut', 16: 'dswx_classify_v8', 1: 'dswx_classify_v8'}[align]
+    # the table-driven kernel whatever the alignment (any address since round 6; + generic for the ragged tails)
+    want = 'dswx_classify_lut'
     assert any(want in k for k in kinds), kinds
 
 
@@ -1132,9 +1145,9 @@ def test_ragged_contiguous_batches_take_the_vector_kernel(ctx, masks):
                     assert cnt[t].tolist() == exp[t]['counters'].tolist(), (n, h, w, t, k)
                 assert (cnt[k:] == -3).all()
         b.free()
-    # 'cover' mode on ragged batches: its bitmaps are indexed by tile-relative 8-pixel groups, which is how the DIRECT kernel
-    # walks a tile -- since round 6 it takes every tile start as it is (unaligned accesses) instead of leaving whole tiles
-    # to the generic kernel; all layers against the numpy oracle's 'cover' chain
+    # 'cover' mode on ragged batches: its bitmaps are indexed by tile-relative 8-pixel groups -- since round 6 the
+    # table-driven kernel walks every tile from its pixel 0 there (unaligned accesses) instead of leaving whole tiles to the
+    # generic kernel; all layers against the numpy oracle's 'cover' chain
     from oracle import dswx_oracle as o
     for (n, h, w) in [(3, 37, 41), (2, 301, 263)]:
         b = _capi.DeviceBatch(ctx, n, h, w, masks=masks, tile_align=1)
@@ -1142,7 +1155,7 @@ def test_ragged_contiguous_batches_take_the_vector_kernel(ctx, masks):
         b.classify(_capi.make_params(mask_adjacent_to_cloud_mode='cover'))
         ctx.synchronize()
         info = ctx.last_kernel_info()
-        assert 'dswx_classify_v8' in info and 'dswx_classify_lut' not in info and 'ragged' not in info, info
+        assert 'dswx_classify_lut' in info and 'dswx_classify_v8' not in info and 'ragged' not in info, info
         cnt = b.read_counters()
         for t in range(n):
             st = synth_tile(400 + t, h, w, with_masks=masks)
