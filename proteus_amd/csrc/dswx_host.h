@@ -71,8 +71,8 @@ struct dswx_ctx {
     int place_force_candidate = -1;   // dswx_batch_place_slide: >= 0 keeps the candidate with that index (packed region at
                                       // offset index * step of the wide range) WHATEVER it measures, without refinement --
                                       // tests only (the kept-placement + trim-while-live case must not hang on a timing)
-    int fused_variant = -1;  // -1 automatic (table-driven kernel when every plane starts on a 256-byte boundary, else the
-                             // direct kernel); 0 / 3 force those two (lab A/B and the variant parity tests)
+    int fused_variant = -1;  // -1 automatic = the table-driven kernel (every layout since round 6); 0 forces the direct
+                             // kernel, 3 the table-driven one (lab A/B and the variant parity tests)
 };
 
 // records a printf-style message for dswx_last_error() and returns `code`
