@@ -46,7 +46,10 @@ def load():
         lib.dswx_codec_set_cpu_budget.argtypes = [ctypes.c_int]
         if lib.dswx_codec_abi_version() != 1:
             raise CodecError(f'{path}: ABI version {lib.dswx_codec_abi_version()}, expected 1')
-        share = int(os.environ.get('DSWX_CPU_SHARE', '0'))           # set by proteus_amd.batch for its worker processes
+        try:
+            share = int(os.environ.get('DSWX_CPU_SHARE', '0') or 0)  # set by proteus_amd.batch for its worker processes
+        except ValueError:
+            share = 0
         if share > 0:
             lib.dswx_codec_set_cpu_budget(share)
         _lib = lib
