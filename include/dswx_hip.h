@@ -491,7 +491,8 @@ int dswx_cog_layout(int64_t height, int64_t width, int32_t elem_bytes, int32_t t
  * hands to DEFLATE.  elem_bytes 1 / 2: integer samples, predictor 1 (none) or 2 (horizontal differencing in the sample's
  * width), overview levels by GDAL's NEAREST rule (src = min(int(0.5 + dst * N / N_ovr), N - 1), restated from
  * GDALResampleChunk_Near: GDAL is not in the reference tree, parity of the rule itself is unpinned).  elem_bytes 4:
- * Float32 with predictor 3 (TIFF Technical Note 3), no overview factors (the reference's are CUBICSPLINE: host). */
+ * Float32 with predictor 3 (TIFF Technical Note 3), one level per call: the reference's overviews of a Float32 layer are
+ * CUBICSPLINE -- build each level with dswx_convolve_axis_device (two passes) and pass it here on its own. */
 int dswx_cog_blocks_device(dswx_ctx_t* ctx, const void* plane, int32_t elem_bytes, int64_t height, int64_t width,
                            int32_t tile, const int32_t* factors, int32_t n_factors, int32_t predictor, void* blocks,
                            void* stream);
@@ -501,6 +502,17 @@ int dswx_cog_blocks_device(dswx_ctx_t* ctx, const void* plane, int32_t elem_byte
  * predictor 3 (Float32, TIFF Technical Note 3: what GDAL writes for a Float32 DEM with PREDICTOR=3).  -> plane [height][width]. */
 int dswx_untile_device(dswx_ctx_t* ctx, const void* blocks, int32_t elem_bytes, int64_t height, int64_t width,
                        int32_t block_width, int32_t block_height, int32_t predictor, void* plane, void* stream);
+/* One separable pass of the CUBICSPLINE overview convolution `save_as_cog` asks GDAL for on non-integer layers
+ * (core.py:41-46; restated from GDAL's GDALResampleChunk_Convolution in proteus_amd/geotiff.py: _convolve_axis -- GDAL is not
+ * in the reference tree, last-ulp agreement of the float results is unpinned): for every line r < n_lines and output
+ * position j < n_out, dst = sum_k src[r, clamp(first[j] + k, 0, n_in - 1)] * weights[j * taps + k], normalised over the taps whose
+ * sample is not NaN; NaN if none is left.  Accumulation in float64 in tap order.  Strides in elements, so that the same entry
+ * does the horizontal pass (lines = rows) and the vertical one (lines = columns); src / dst float32 or float64; `first`
+ * (int32 [n_out]) and `weights` (float64 [n_out][taps]) are DEVICE arrays the host prepares. */
+int dswx_convolve_axis_device(dswx_ctx_t* ctx, const void* src, int32_t src_is_f64, int64_t n_lines, int64_t n_in,
+                              int64_t src_line_stride, int64_t src_elem_stride, int64_t n_out, int32_t taps,
+                              const int32_t* first, const double* weights, void* dst, int32_t dst_is_f64,
+                              int64_t dst_line_stride, int64_t dst_elem_stride, void* stream);
 /* Rows of `width_bytes` bytes from one device raster to another (hipMemcpy2DAsync, device to device): the crop of a DEM
  * with its margin to the product grid (_crop_2d_array_all_sides, dswx_hls.py:4320) without a trip to the host. */
 int dswx_copy_2d_device(dswx_ctx_t* ctx, void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes,

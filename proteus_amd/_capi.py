@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     'dswx_batch_classify', 'dswx_batch_synth', 'dswx_batch_place_search', 'dswx_batch_place_slide',
     'dswx_batch_va_budget', 'dswx_batch_pool_trim',
     'dswx_shadow_layer_batch', 'dswx_landcover_mask_batch',
-    'dswx_cog_layout', 'dswx_cog_blocks_device', 'dswx_untile_device', 'dswx_rgb_planes_device', 'dswx_copy_2d_device',
+    'dswx_cog_layout', 'dswx_cog_blocks_device', 'dswx_untile_device', 'dswx_rgb_planes_device', 'dswx_copy_2d_device', 'dswx_convolve_axis_device',
     'dswx_memcpy_h2d_async', 'dswx_memcpy_d2h_async')
 
 
@@ -254,6 +254,8 @@ def load_library(path=None):
                                               ctypes.c_int32, vp, vp]),
         'dswx_rgb_planes_device': (ctypes.c_int, [vp, vp, vp, vp, vp, i64, ctypes.POINTER(ctypes.c_double * 3),
                                                   ctypes.POINTER(ctypes.c_double * 3), ctypes.c_int32, vp, vp]),
+        'dswx_convolve_axis_device': (ctypes.c_int, [vp, vp, ctypes.c_int32, i64, i64, i64, i64, i64, ctypes.c_int32, vp, vp, vp,
+                                                     ctypes.c_int32, i64, i64, vp]),
         'dswx_copy_2d_device': (ctypes.c_int, [vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]),
         'dswx_memcpy_h2d_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
         'dswx_memcpy_d2h_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
@@ -770,6 +772,14 @@ class Context:
                                                ctypes.c_void_p(blue_ptr), ctypes.c_void_p(diag_ptr) if diag_ptr else None,
                                                int(n_pixels), ctypes.byref(sc), ctypes.byref(of), int(bool(clip)),
                                                ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream) if stream else None))
+
+    def convolve_axis_device(self, src_ptr, src_is_f64, n_lines, n_in, src_line_stride, src_elem_stride, n_out, taps, first_ptr,
+                             weights_ptr, dst_ptr, dst_is_f64, dst_line_stride, dst_elem_stride, stream=None):
+        _check(self.lib.dswx_convolve_axis_device(
+            self.handle, ctypes.c_void_p(src_ptr), int(bool(src_is_f64)), int(n_lines), int(n_in), int(src_line_stride),
+            int(src_elem_stride), int(n_out), int(taps), ctypes.c_void_p(first_ptr), ctypes.c_void_p(weights_ptr),
+            ctypes.c_void_p(dst_ptr), int(bool(dst_is_f64)), int(dst_line_stride), int(dst_elem_stride),
+            ctypes.c_void_p(stream) if stream else None))
 
     def copy_2d_device(self, dst_ptr, dst_pitch, src_ptr, src_pitch, width_bytes, height, stream=None):
         _check(self.lib.dswx_copy_2d_device(self.handle, ctypes.c_void_p(dst_ptr), int(dst_pitch), ctypes.c_void_p(src_ptr),

@@ -204,6 +204,42 @@ __global__ __launch_bounds__(256) void dswx_untile_fp3_gather(const Fp3Args a) {
     a.dst[(size_t)y * (size_t)a.width + (size_t)x] = bits;
 }
 
+// One separable pass of the CUBICSPLINE overview convolution (geotiff._convolve_axis: GDAL's GDALResampleChunk_Convolution
+// restated).  Output element (line r, position j) = sum over taps of src[line r, clamp(first[j] + k)] * w[j][k], normalised over
+// the taps that exist and are not NaN; NaN where nothing is left.  The weights come from the host (the same numpy
+// expression the host writer uses), the accumulation is float64 in tap order.  Strides in ELEMENTS: one kernel for the
+// horizontal pass (lines = rows) and the vertical one (lines = columns).
+struct ConvArgs {
+    const void* src;
+    void* dst;
+    const int* first;
+    const double* w;
+    long long n_lines, n_in, n_out;
+    long long src_line_stride, src_elem_stride, dst_line_stride, dst_elem_stride;
+    int taps, lines_fastest;            // lines_fastest: threadIdx.x walks the lines (vertical pass: coalesced columns)
+};
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void dswx_convolve_axis_v1(const ConvArgs a) {
+    const long long fast = (long long)blockIdx.x * 256 + threadIdx.x, slow = blockIdx.y;
+    const long long r = a.lines_fastest ? fast : slow, j = a.lines_fastest ? slow : fast;
+    if (r >= a.n_lines || j >= a.n_out) return;
+    const TI* __restrict__ line = static_cast<const TI*>(a.src) + r * a.src_line_stride;
+    const double* __restrict__ w = a.w + j * a.taps;
+    const long long f0 = a.first[j];
+    double num = 0.0, den = 0.0;
+    for (int k = 0; k < a.taps; ++k) {
+        long long i = f0 + k;
+        i = i < 0 ? 0 : (i >= a.n_in ? a.n_in - 1 : i);
+        const double g = (double)line[i * a.src_elem_stride];
+        const double ww = (g != g) ? 0.0 : w[k];                // (taps outside the raster carry a zero weight from the host)
+        num += (ww > 0.0 ? g : 0.0) * ww;
+        den += ww;
+    }
+    const double out = den > 0.0 ? num / den : __longlong_as_double(0x7ff8000000000000LL);
+    static_cast<TO*>(a.dst)[r * a.dst_line_stride + j * a.dst_elem_stride] = (TO)out;
+}
+
 struct RgbArgs {
     const short* band[3];
     const unsigned short* diag;
@@ -283,7 +319,7 @@ int dswx_cog_blocks_device(dswx_ctx_t* ctx, const void* plane, int32_t elem_byte
     if (elem_bytes == 4) {
         if (predictor != 3) return dswx_fail(DSWX_ERR_UNSUPPORTED, "4-byte samples: Float32 with PREDICTOR=3 only");
         if (lay.n_levels != 1)
-            return dswx_fail(DSWX_ERR_UNSUPPORTED, "Float32 layers carry CUBICSPLINE overviews in the reference (core.py:41-46): host only");
+            return dswx_fail(DSWX_ERR_UNSUPPORTED, "Float32 layers carry CUBICSPLINE overviews (core.py:41-46): build each level with dswx_convolve_axis_device and pass it alone");
         F32BlockArgs a = {};
         a.src = static_cast<const float*>(plane);
         a.dst = static_cast<unsigned char*>(blocks);
@@ -400,6 +436,33 @@ int dswx_rgb_planes_device(dswx_ctx_t* ctx, const int16_t* red, const int16_t* g
     const unsigned long long groups = ((unsigned long long)n_pixels + 255) / 256;
     if (groups > 0x7fffffffull) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
     hipLaunchKernelGGL(dswx_rgb_planes_v1, dim3((unsigned)groups), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_convolve_axis_device(dswx_ctx_t* ctx, const void* src, int32_t src_is_f64, int64_t n_lines, int64_t n_in,
+                              int64_t src_line_stride, int64_t src_elem_stride, int64_t n_out, int32_t taps, const int32_t* first,
+                              const double* weights, void* dst, int32_t dst_is_f64, int64_t dst_line_stride,
+                              int64_t dst_elem_stride, void* stream) {
+    if (!ctx || !src || !dst || !first || !weights) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (n_lines < 0 || n_in < 1 || n_out < 0 || taps < 1 || taps > 4096) return dswx_fail(DSWX_ERR_ARG, "bad size");
+    if (n_lines == 0 || n_out == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    ConvArgs a = {};
+    a.src = src; a.dst = dst; a.first = first; a.w = weights;
+    a.n_lines = n_lines; a.n_in = n_in; a.n_out = n_out; a.taps = taps;
+    a.src_line_stride = src_line_stride; a.src_elem_stride = src_elem_stride;
+    a.dst_line_stride = dst_line_stride; a.dst_elem_stride = dst_elem_stride;
+    // the thread index walks whichever output index is contiguous in memory
+    a.lines_fastest = dst_line_stride < dst_elem_stride ? 1 : 0;
+    const long long fast = a.lines_fastest ? n_lines : n_out, slow = a.lines_fastest ? n_out : n_lines;
+    if (slow > 65535 || (fast + 255) / 256 > 0x7fffffffLL) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
+    const dim3 grid((unsigned)((fast + 255) / 256), (unsigned)slow), block(256);
+    if (src_is_f64 && dst_is_f64) hipLaunchKernelGGL((dswx_convolve_axis_v1<double, double>), grid, block, 0, s, a);
+    else if (src_is_f64) hipLaunchKernelGGL((dswx_convolve_axis_v1<double, float>), grid, block, 0, s, a);
+    else if (dst_is_f64) hipLaunchKernelGGL((dswx_convolve_axis_v1<float, double>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((dswx_convolve_axis_v1<float, float>), grid, block, 0, s, a);
     HIP_TRY(hipGetLastError());
     return DSWX_OK;
 }

@@ -760,7 +760,8 @@ def _save_output_rgb_file(red, green, blue, output_file, offset_dict, scale_dict
     stages.add('host: RGB scaling', t_rgb, _time.perf_counter())
 
     def job():
-        geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict)
+        geotiff.write_geotiff(output_file, stack, geo_tags=geo_tags, metadata=dswx_metadata_dict,
+                              overviews=geotiff.COG_OVERVIEW_FACTORS)
         logger.info(f'file saved: {output_file}')
     if output_files_list is not None:
         output_files_list.append(output_file)
@@ -774,7 +775,8 @@ def _save_output_rgb_planes(engine, planes, diag, scales, offsets, output_file, 
     _makedirs(output_file)
 
     def job():
-        levels = engine.rgb_levels(planes[0], planes[1], planes[2], diag, scales, offsets, FLAG_CLIP_NEGATIVE_REFLECTANCE)
+        levels = engine.rgb_levels(planes[0], planes[1], planes[2], diag, scales, offsets, FLAG_CLIP_NEGATIVE_REFLECTANCE,
+                                   factors=geotiff.COG_OVERVIEW_FACTORS)
         geotiff.write_geotiff(output_file, None, levels=levels, geo_tags=geo_tags, metadata=dswx_metadata_dict)
         logger.info(f'file saved: {output_file}')
     if output_files_list is not None:
@@ -834,8 +836,8 @@ def _get_confidence_layer_ctable():
 # -----------------------------------------------------------------------------------
 # writers (:2601-2716, :2786-2958) + save_as_cog (core.py:7-91): 512 x 512 tiled DEFLATE
 # GeoTIFF in cloud-optimized layout; integer layers carry NEAREST overviews 4/16/64/128 as
-# the reference builds them; Float32 files (RGB composites, DEM) get none (the reference's
-# CUBICSPLINE resampling for floats is GDAL-internal and not restated)
+# the reference builds them, Float32 files (RGB composites, DEM) cascaded CUBICSPLINE ones
+# (core.py:41-46; GDAL's convolution restated in geotiff.py, on the device since round 6)
 # -----------------------------------------------------------------------------------
 def _makedirs(path):
     d = os.path.dirname(path)
@@ -898,9 +900,9 @@ def _save_array(input_array, output_file, dswx_metadata_dict, geo_tags, descript
 
     def job():
         if resident and (integer or input_array.dtype == np.float32):
-            # the blocks of the image and of its NEAREST overviews, predictor applied, made on the device: the host only
-            # deflates (pipeline.TileEngine.layer_levels; save_as_cog, core.py:7-91)
-            levels = input_array.engine.layer_levels(input_array, geotiff.COG_OVERVIEW_FACTORS if integer else ())
+            # the blocks of the image and of its overviews (NEAREST; Float32: CUBICSPLINE), predictor applied, made on the
+            # device: the host only deflates (pipeline.TileEngine.layer_levels; save_as_cog, core.py:7-91)
+            levels = input_array.engine.layer_levels(input_array, geotiff.COG_OVERVIEW_FACTORS)
             geotiff.write_geotiff(output_file, None, levels=levels, geo_tags=geo_tags, metadata=dswx_metadata_dict,
                                   nodata=no_data_value, descriptions=[description] if description else None,
                                   colormap=ctable)
@@ -909,7 +911,7 @@ def _save_array(input_array, output_file, dswx_metadata_dict, geo_tags, descript
         geotiff.write_geotiff(output_file, input_array.numpy() if resident else input_array, geo_tags=geo_tags,
                               metadata=dswx_metadata_dict, nodata=no_data_value,
                               descriptions=[description] if description else None, colormap=ctable,
-                              overviews=geotiff.COG_OVERVIEW_FACTORS if integer else None)
+                              overviews=geotiff.COG_OVERVIEW_FACTORS)
         logger.info(f'file saved: {output_file}')
     if output_files_list is not None:
         output_files_list.append(output_file)

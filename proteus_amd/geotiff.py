@@ -423,13 +423,12 @@ def _bspline(x):
                     np.where(x < 2.0, (2.0 - x) ** 3 / 6.0, 0.0))
 
 
-def _convolve_axis(a, n_out, axis):
-    """One separable pass of GDAL's overview convolution (GDALResampleChunk_Convolution, overview.cpp) along
-    `axis`: destination pixel i is centred on source coordinate (i + 0.5) * ratio; the kernel is stretched
-    by the decimation ratio (radius 2 * ratio source pixels), evaluated at source pixel centres, and the
-    weights are normalised over the pixels that exist and are not NaN (a destination whose whole support is
-    NaN / outside is NaN).  float64 accumulation."""
-    n_in = a.shape[axis]
+def convolve_weights(n_in, n_out):
+    """(first [n_out] int64, weights [n_out, taps] float64) of one pass of the CUBICSPLINE overview convolution: destination
+    pixel i is centred on source coordinate (i + 0.5) * ratio; the cubic B-spline is stretched by the decimation ratio
+    (radius 2 * ratio source pixels) and evaluated at the source pixel centres first[i] ... first[i] + taps - 1; taps that
+    fall outside the raster carry weight 0.  The host pass below and the device pass (dswx_convolve_axis_device) both
+    take their weights from here."""
     ratio = n_in / n_out
     scale = min(1.0, 1.0 / ratio)                       # < 1 when decimating
     radius = 2.0 / scale
@@ -439,14 +438,27 @@ def _convolve_axis(a, n_out, axis):
     idx = first[:, None] + np.arange(taps)[None, :]                       # [n_out, taps]
     w = _bspline((idx + 0.5 - centre[:, None]) * scale)
     w = np.where((idx >= 0) & (idx < n_in), w, 0.0)
-    idx = np.clip(idx, 0, n_in - 1)
-    a = np.moveaxis(a, axis, -1).astype(np.float64)
-    g = a[..., idx]                                                       # [..., n_out, taps]
-    ok = ~np.isnan(g)
-    ww = np.where(ok, w, 0.0)
-    with np.errstate(invalid='ignore'):
-        num = np.sum(np.where(ww > 0.0, g, 0.0) * ww, axis=-1)          # inf stays inf; zero-weight taps contribute nothing
-    den = np.sum(ww, axis=-1)
+    return first, np.ascontiguousarray(w, dtype=np.float64)
+
+
+def _convolve_axis(a, n_out, axis):
+    """One separable pass of GDAL's overview convolution (GDALResampleChunk_Convolution, overview.cpp) along
+    `axis`: destination pixel i is centred on source coordinate (i + 0.5) * ratio; the kernel is stretched
+    by the decimation ratio (radius 2 * ratio source pixels), evaluated at source pixel centres, and the
+    weights are normalised over the pixels that exist and are not NaN (a destination whose whole support is
+    NaN / outside is NaN).  float64 accumulation."""
+    n_in = a.shape[axis]
+    first, w = convolve_weights(n_in, n_out)
+    a = np.moveaxis(a, axis, -1)
+    num = np.zeros(a.shape[:-1] + (n_out,), dtype=np.float64)
+    den = np.zeros_like(num)
+    # tap by tap, in tap order: the order (and so the last bit) of the device pass, dswx_convolve_axis_v1
+    for k in range(w.shape[1]):
+        g = a[..., np.clip(first + k, 0, n_in - 1)].astype(np.float64)    # [..., n_out]
+        ww = np.where(np.isnan(g), 0.0, w[:, k])
+        with np.errstate(invalid='ignore'):
+            num += np.where(ww > 0.0, g, 0.0) * ww                        # inf stays inf; zero-weight taps contribute nothing
+        den += ww
     with np.errstate(invalid='ignore', divide='ignore'):
         out = np.where(den > 0.0, num / den, np.nan)
     return np.moveaxis(out, -1, axis)

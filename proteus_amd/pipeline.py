@@ -55,6 +55,13 @@ class DevicePlane:
             pass
 
 
+class _PlaneView:
+    """A raster inside another device buffer (no ownership): what the writer-side helpers need of a plane."""
+
+    def __init__(self, ptr, shape, dtype, keep=None):
+        self.ptr, self.shape, self.dtype, self._keep = int(ptr), tuple(shape), np.dtype(dtype), keep
+
+
 class TileEngine:
     POOL_CAP = 6 << 30          # bytes of released device buffers kept for the next tile
 
@@ -63,6 +70,7 @@ class TileEngine:
         self.lock = threading.RLock()
         self._free = {}                     # nbytes -> [DeviceBuffer]
         self._free_bytes = 0
+        self._weights = {}                  # (n_in, n_out) -> (first DeviceBuffer, weights DeviceBuffer, taps): CUBICSPLINE passes
         self._pool_lock = threading.RLock()   # re-entrant: a plane's finalizer (_give) may run -- cyclic GC -- on a thread that is inside _take
 
     # ---- device memory ------------------------------------------------------------------------------------
@@ -91,6 +99,10 @@ class TileEngine:
     def close(self):
         with self._pool_lock:
             spare, self._free, self._free_bytes = self._free, {}, 0
+            weights, self._weights = self._weights, {}
+        for d_first, d_w, _ in weights.values():
+            d_first.free()
+            d_w.free()
         for bufs in spare.values():
             for b in bufs:
                 b.free()
@@ -247,17 +259,63 @@ class TileEngine:
         return out
 
     # ---- writer side ----------------------------------------------------------------------------------------
+    def _conv_weights(self, n_in, n_out):
+        key = (int(n_in), int(n_out))
+        with self._pool_lock:
+            hit = self._weights.get(key)
+        if hit is None:
+            first, w = geotiff.convolve_weights(*key)
+            d_first, d_w = self.ctx.malloc(max(first.size * 4, 16)), self.ctx.malloc(max(w.nbytes, 16))
+            d_first.upload(first.astype(np.int32))
+            d_w.upload(w)
+            hit = (d_first, d_w, w.shape[1])
+            with self._pool_lock:
+                hit = self._weights.setdefault(key, hit)
+        return hit
+
+    def cubicspline_overview(self, plane, factor):
+        """One CUBICSPLINE overview level of a Float32 plane on the device (geotiff.overview_cubicspline: horizontal pass
+        into float64, vertical pass, float32): what `save_as_cog` asks GDAL for on non-integer layers (core.py:41-46)."""
+        H, W = plane.shape
+        oh, ow = -(-H // factor), -(-W // factor)
+        fx, wx, tx = self._conv_weights(W, ow)
+        fy, wy, ty = self._conv_weights(H, oh)
+        tmp = self._take(H * ow * 8)
+        out = self.plane((oh, ow), np.float32)
+        try:
+            with self.lock, stages.span('gpu: CUBICSPLINE overview'):
+                self.ctx.convolve_axis_device(plane.ptr, False, H, W, W, 1, ow, tx, fx.ptr, wx.ptr, tmp.ptr, True, ow, 1)
+                self.ctx.convolve_axis_device(tmp.ptr, True, ow, H, 1, ow, oh, ty, fy.ptr, wy.ptr, out.ptr, False, 1, ow)
+                self.ctx.synchronize()
+        finally:
+            self._give(tmp)
+        return out
+
+    def _float_pyramid(self, plane, factors):
+        """The levels write_geotiff builds for a floating-point layer: cascaded (each from the previous one when the factor
+        divides, GDAL's GDALRegenerateCascadingOverviews), else from the full-resolution raster."""
+        H, W = plane.shape
+        rasters, prev_f = [plane], 1
+        for f in factors:
+            f = int(f)
+            if f > 1 and (H > 1 or W > 1):
+                lv = self.cubicspline_overview(rasters[-1], f // prev_f) if (prev_f > 1 and f % prev_f == 0) \
+                    else self.cubicspline_overview(plane, f)
+                if lv.shape != (-(-H // f), -(-W // f)):            # ceil of a ceil can differ by one: from the full image
+                    lv = self.cubicspline_overview(plane, f)
+                rasters.append(lv)
+                prev_f = f
+        return rasters
+
     def layer_levels(self, plane, factors=(), tile=512):
-        """DevicePlane (u8 / u16 / i16 [H, W], or float32: no factors) -> [geotiff.BlockedLevel]: the blocks of the
-        full-resolution image and of every NEAREST overview, predictor-encoded, in page-locked memory."""
+        """DevicePlane [H, W] -> [geotiff.BlockedLevel]: the blocks of the full-resolution image and of every overview,
+        predictor-encoded, in page-locked memory.  Integer layers (u8 / u16 / i16): NEAREST overviews + PREDICTOR=2, one
+        launch; Float32: CUBICSPLINE overviews (cascaded) + PREDICTOR=3 (core.py:37-46, :66-69)."""
+        if plane.dtype.kind == 'f':
+            return self.float_levels([plane], factors, tile)
         H, W = plane.shape
         dt = plane.dtype
-        if dt.kind == 'f':
-            if dt.itemsize != 4:
-                raise ValueError('float planes: float32 only')
-            factors, predictor = (), 3
-        else:
-            predictor = 2
+        predictor = 2
         lay = _capi.cog_layout(H, W, dt.itemsize, factors, tile)
         total = lay['total_bytes']
         dev_blocks = self._take(total)
@@ -276,28 +334,49 @@ class TileEngine:
                                             host[lv['offset_bytes']: lv['offset_bytes'] + n]))
         return out
 
-    def rgb_levels(self, red, green, blue, diag, scale, offset, clip, tile=512):
-        """The three-band Float32 composite of _save_output_rgb_file (dswx_hls.py:3013-3036) as ONE planar BlockedLevel
-        (bands 3, floating-point predictor): scaling on the device, NaN where `diag` carries the fill code."""
-        H, W = red.shape
-        n = H * W
-        lay = _capi.cog_layout(H, W, 4, (), tile)
-        per_band = lay['total_bytes']
-        rgb = self._take(3 * n * 4)
-        dev_blocks = self._take(3 * per_band)
-        host = self.ctx.pinned_empty((3 * per_band,), np.uint8)
+    def float_levels(self, bands, factors=(), tile=512):
+        """Float32 planes of ONE file (1 band: the DEM layer; 3: an RGB composite) -> [geotiff.BlockedLevel] (planar:
+        band-major inside every level), floating-point predictor, CUBICSPLINE overviews per band."""
+        if any(b.dtype != np.float32 for b in bands):
+            raise ValueError('float planes: float32 only')
+        pyramids = [self._float_pyramid(b, factors) for b in bands]
+        n_levels = len(pyramids[0])
+        sizes = [_capi.cog_layout(pyramids[0][k].shape[0], pyramids[0][k].shape[1], 4, (), tile)['total_bytes'] for k in range(n_levels)]
+        total = len(bands) * sum(sizes)
+        dev_blocks = self._take(total)
+        host = self.ctx.pinned_empty((total,), np.uint8)
+        offs, cur = [], 0
         try:
-            with self.lock, stages.span('gpu: RGB planes -> blocks (+ d2h)'):
-                self.ctx.rgb_planes_device(red.ptr, green.ptr, blue.ptr, diag.ptr if diag is not None else None, n,
-                                           scale, offset, clip, rgb.ptr)
-                for c in range(3):
-                    self.ctx.cog_blocks_device(rgb.ptr + c * n * 4, 4, H, W, dev_blocks.ptr + c * per_band, (), tile, 3)
-                self.ctx.d2h_async(host, dev_blocks.ptr, 3 * per_band)
+            with self.lock, stages.span('gpu: Float32 planes -> blocks (+ d2h)'):
+                for k in range(n_levels):
+                    offs.append(cur)
+                    for c in range(len(bands)):
+                        lv = pyramids[c][k]
+                        self.ctx.cog_blocks_device(lv.ptr, 4, lv.shape[0], lv.shape[1], dev_blocks.ptr + cur, (), tile, 3)
+                        cur += sizes[k]
+                self.ctx.d2h_async(host, dev_blocks.ptr, total)
                 self.ctx.synchronize()
         finally:
-            self._give(rgb)
             self._give(dev_blocks)
-        return [geotiff.BlockedLevel(H, W, 3, np.float32, tile, 3, host)]
+        return [geotiff.BlockedLevel(pyramids[0][k].shape[0], pyramids[0][k].shape[1], len(bands), np.float32, tile, 3,
+                                     host[offs[k]: offs[k] + len(bands) * sizes[k]]) for k in range(n_levels)]
+
+    def rgb_levels(self, red, green, blue, diag, scale, offset, clip, tile=512, factors=()):
+        """The three-band Float32 composite of _save_output_rgb_file (dswx_hls.py:3013-3036) as planar BlockedLevels
+        (floating-point predictor, CUBICSPLINE overviews for `factors`): scaling on the device, NaN where `diag` carries the
+        fill code."""
+        H, W = red.shape
+        n = H * W
+        rgb = self._take(3 * n * 4)
+        try:
+            with self.lock, stages.span('gpu: RGB planes'):
+                self.ctx.rgb_planes_device(red.ptr, green.ptr, blue.ptr, diag.ptr if diag is not None else None, n,
+                                           scale, offset, clip, rgb.ptr)
+                self.ctx.synchronize()
+            views = [_PlaneView(rgb.ptr + c * n * 4, (H, W), np.float32, keep=rgb) for c in range(3)]
+            return self.float_levels(views, factors, tile)
+        finally:
+            self._give(rgb)
 
 
 _engines = {}

@@ -186,7 +186,21 @@ def test_files_from_device_blocks_are_the_host_writers_files(ctx, tmp_path):
             back, info = eng.read_plane(p_dev)
             assert back.shape == shape and back.dtype == dtype and np.array_equal(back.numpy(), arr)
             assert info.nodata == 255.0 and info.metadata['PRODUCT_ID'] == 'x'
-        # RGB composite: host statement vs device planes, files identical
+        # Float32 layer (the DEM layer): CUBICSPLINE overviews, floating-point predictor, NaN nodata
+        for shape in ((3660, 3660), (700, 333), (1, 1)):
+            dem = (rng.normal(size=shape) * 300 + 500).astype(np.float32)
+            dem[rng.random(shape) < 0.02] = np.nan
+            p_host, p_dev = str(tmp_path / 'dem_host.tif'), str(tmp_path / 'dem_dev.tif')
+            geotiff.write_geotiff(p_host, dem, geo_tags=geo, metadata=md, nodata=float('nan'), descriptions=['dem'],
+                                  overviews=FACTORS)
+            geotiff.write_geotiff(p_dev, None, levels=eng.layer_levels(eng.upload(dem), FACTORS), geo_tags=geo, metadata=md,
+                                  nodata=float('nan'), descriptions=['dem'])
+            assert open(p_host, 'rb').read() == open(p_dev, 'rb').read(), shape
+            assert geotiff.validate_cog(p_dev) == []
+            if shape != (1, 1):
+                ovr, _ = geotiff.read_geotiff(p_dev, overview=len(FACTORS) - 1)
+                assert ovr.shape == tuple(-(-n // FACTORS[-1]) for n in shape)
+        # RGB composite: host statement vs device planes, files identical (three bands, CUBICSPLINE overviews of each)
         h, w = 700, 900
         bands = {k: rng.integers(-50, 9000, size=(h, w)).astype(np.int16) for k in ('red', 'green', 'blue')}
         diag = rng.integers(0, 11112, size=(h, w)).astype(np.uint16)
@@ -203,6 +217,9 @@ def test_files_from_device_blocks_are_the_host_writers_files(ctx, tmp_path):
         assert open(p_host, 'rb').read() == open(p_dev, 'rb').read()
         rgb, _ = geotiff.read_geotiff(p_dev)
         assert rgb.shape == (3, h, w) and np.isnan(rgb[:, diag == 65535]).all()
+        assert geotiff.validate_cog(p_dev) == []
+        small, _ = geotiff.read_geotiff(p_dev, overview=0)
+        assert small.shape == (3, -(-h // 4), -(-w // 4)) and np.isfinite(small).any()
     finally:
         eng.close()
 
@@ -343,3 +360,55 @@ def test_device_kernels_against_the_row_by_row_oracle(ctx, shape):
     finally:
         for buf in bufs:
             buf.free()
+
+
+@pytest.mark.parametrize('shape', [(3660, 3660), (1000, 333), (7, 3), (513, 1025), (4, 4), (1, 5), (129, 4097)])
+def test_cubicspline_overview_pyramid_on_the_device(ctx, shape):
+    """save_as_cog's overviews of a non-integer layer (core.py:41-46: CUBICSPLINE, 4 / 16 / 64 / 128, cascaded) from a
+    plane resident on the device (dswx_convolve_axis_device, horizontal pass into float64, vertical pass, float32) against
+    the host writer's statement (geotiff.overview_cubicspline, the same weights, the taps in the same order): every level
+    bit for bit, NaN where the whole support is NaN, infinities kept."""
+    from proteus_amd import pipeline
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    a = (rng.normal(size=shape) * 1000).astype(np.float32)
+    a[rng.random(shape) < 0.03] = np.nan
+    if shape[0] > 200:
+        a[40:140, 60:190] = np.nan                      # a hole larger than the support of every level-1 pixel inside it
+        a[150, 3] = np.inf
+        a[160, 9] = -np.inf
+    eng = pipeline.TileEngine(ctx)
+    try:
+        got = eng._float_pyramid(eng.upload(a), FACTORS)
+        want, prev_f = [a], 1
+        for f in FACTORS:                               # write_geotiff's cascade
+            lv = geotiff.overview_cubicspline(want[-1], f // prev_f) if prev_f > 1 and f % prev_f == 0 \
+                else geotiff.overview_cubicspline(a, f)
+            if lv.shape != tuple(-(-n // f) for n in shape):
+                lv = geotiff.overview_cubicspline(a, f)
+            want.append(lv)
+            prev_f = f
+        if shape == (1, 1):
+            want = want[:1]
+        assert len(got) == len(want)
+        for k, (g, w) in enumerate(zip(got, want)):
+            g = g.numpy()
+            assert g.shape == w.shape and g.dtype == np.float32 == w.dtype, (k, g.shape, w.shape)
+            assert np.array_equal(np.isnan(g), np.isnan(w)), k
+            assert np.array_equal(g, w, equal_nan=True), (k, np.nanmax(np.abs(g.astype(np.float64) - w)))
+        if shape[0] > 200:
+            assert np.isnan(got[1].numpy()).any() and np.isinf(got[1].numpy()).any()
+    finally:
+        eng.close()
+
+
+def test_convolve_axis_refuses_bad_arguments(ctx):
+    d = ctx.malloc(64)
+    try:
+        with pytest.raises(_capi.DswxError):
+            ctx.convolve_axis_device(d.ptr, False, 1, 0, 1, 1, 1, 1, d.ptr, d.ptr, d.ptr, False, 1, 1)        # n_in < 1
+        with pytest.raises(_capi.DswxError):
+            ctx.convolve_axis_device(d.ptr, False, 1, 4, 4, 1, 1, 0, d.ptr, d.ptr, d.ptr, False, 1, 1)        # no taps
+        with pytest.raises(_capi.DswxError):
+            ctx.convolve_axis_device(None, False, 1, 4, 4, 1, 1, 1, d.ptr, d.ptr, d.ptr, False, 1, 1)
+    finally:
+        d.free()
