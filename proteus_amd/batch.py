@@ -78,6 +78,7 @@ def _worker(device, runconfigs, skip_existing=False, in_flight=3, with_stages=Fa
     logging.getLogger('dswx_hls').setLevel(logging.WARNING)
     D.get_context(device)                      # fail loudly before touching any tile
     t_ready = time.perf_counter()
+    cpu0 = os.times()
     if with_stages:
         stages.start()
     out_lock = threading.Lock()
@@ -101,6 +102,8 @@ def _worker(device, runconfigs, skip_existing=False, in_flight=3, with_stages=Fa
         print(json.dumps({'worker_report': {'device': device, 'tiles': len(runconfigs), 'in_flight': n,
                                             'bring_up_s': round(t_ready - t_start, 3),
                                             'tiles_s': round(time.perf_counter() - t_ready, 3),
+                                            # processor time of this process (all its threads, the codec's included)
+                                            'cpu_s': round(sum(os.times()[:2]) - sum(cpu0[:2]), 3),
                                             'stages': stages.stop()}}), flush=True)
     return rc[0]
 

@@ -265,12 +265,17 @@ class TileEngine:
             hit = self._weights.get(key)
         if hit is None:
             first, w = geotiff.convolve_weights(*key)
-            d_first, d_w = self.ctx.malloc(max(first.size * 4, 16)), self.ctx.malloc(max(w.nbytes, 16))
-            d_first.upload(first.astype(np.int32))
-            d_w.upload(w)
+            with self.lock:
+                d_first, d_w = self.ctx.malloc(max(first.size * 4, 16)), self.ctx.malloc(max(w.nbytes, 16))
+                d_first.upload(first.astype(np.int32))
+                d_w.upload(w)
             hit = (d_first, d_w, w.shape[1])
             with self._pool_lock:
-                hit = self._weights.setdefault(key, hit)
+                kept = self._weights.setdefault(key, hit)
+            if kept is not hit:                 # another tile's thread got there first
+                hit[0].free()
+                hit[1].free()
+            hit = kept
         return hit
 
     def cubicspline_overview(self, plane, factor):

@@ -19,10 +19,11 @@ from proteus_amd import stages                  # noqa: E402
 def main():
     size = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3660
     ancillary = '--ancillary' in sys.argv      # BASELINE configs[4]'s product: DEM -> SHAD, CGLS + WorldCover -> LAND, ocean mask; 10 layers
-    out = {'size': size, 'ancillary': ancillary}
+    scene = '--scene' in sys.argv              # spatially coherent scene instead of the per-pixel recipe (make_synthetic_hls.scene_tile)
+    out = {'size': size, 'ancillary': ancillary, 'scene': scene}
     with tempfile.TemporaryDirectory() as d:
         t0 = time.perf_counter()
-        rcfile, files, _, _ = synth_hls.make(d, size=size, ancillary=ancillary, ocean=ancillary)
+        rcfile, files, _, _ = synth_hls.make(d, size=size, ancillary=ancillary, ocean=ancillary, scene=scene)
         out['make_inputs_s'] = round(time.perf_counter() - t0, 2)
         from proteus_amd import batch
         import logging
@@ -45,6 +46,8 @@ def main():
         from proteus_amd import codec
         out['io_threads_default'] = codec.default_threads()
         out['outputs'] = sorted(os.listdir(os.path.join(d, 'output')))
+        out['output_MB'] = round(sum(os.path.getsize(os.path.join(d, 'output', f)) for f in out['outputs']) / 1e6, 2)
+        out['input_MB'] = round(sum(os.path.getsize(f) for f in files) / 1e6, 2)
         out['kernel'] = D.get_context().last_kernel_info()
     print(json.dumps(out, indent=1))
 

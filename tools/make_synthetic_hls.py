@@ -10,6 +10,7 @@ metadata the reference's loader harvests (:2228-2296), OUT_DIR/runconfig.yaml, a
 --masks OUT_DIR/input_masks/{land,shad,ocean}.tif on the same grid.
 """
 import argparse
+import functools
 import os
 import sys
 
@@ -23,11 +24,54 @@ L30 = {'blue': 'B02', 'green': 'B03', 'red': 'B04', 'nir': 'B05', 'swir1': 'B06'
 S30 = {'blue': 'B02', 'green': 'B03', 'red': 'B04', 'nir': 'B8A', 'swir1': 'B11', 'swir2': 'B12'}
 
 
+@functools.lru_cache(maxsize=4)
+def scene_tile(tile, size, patch=60, noise_dn=25):
+    """A spatially COHERENT scene for timing the product run's codecs: the per-pixel recipe of proteus_amd.synth draws a
+    surface type per pixel, so its class maps are noise and DEFLATE works ten times harder on them than on a real product.
+    Here the surface types come in patches (~`patch` pixels across: a smooth random field cut at the same type proportions),
+    the reflectances are the type means plus sensor-like noise (sigma `noise_dn` DN), clouds / cloud shadows / snow are blobs,
+    and a corner is fill.  Same dict as synth_tile (bands, fmask); values within the ranges of that recipe."""
+    import numpy as np
+    from scipy import ndimage
+    from proteus_amd import synth
+    rng = np.random.default_rng(synth.SEED + 7919 * tile)
+
+    def field(cells):
+        g = rng.random((cells + 3, cells + 3))
+        f = ndimage.zoom(g, size / cells, order=1)[:size, :size]
+        return np.clip((f - f.min()) / (f.max() - f.min()), 0.0, 1.0 - 1e-9)
+
+    cells = max(2, size // patch)
+    draw = field(cells)
+    ranks = np.searchsorted(np.sort(draw.ravel())[::max(1, draw.size // 65536)], draw.ravel()).reshape(draw.shape)   # ~uniform 16-bit
+    ranks = np.minimum(ranks, 65535)
+    st = np.searchsorted(np.asarray(synth.TYPE_CUTS[:4]), ranks, side='right')              # 0..4 (fill comes below)
+    mean = np.asarray(synth.TYPE_MEAN, dtype=np.int64)[st]                                   # [H, W, 6]
+    fill = np.zeros((size, size), dtype=bool)
+    k = size // 8
+    yy, xx = np.mgrid[0:size, 0:size]
+    fill[(yy + xx) < k] = True                                                               # the swath edge
+    bands = []
+    for b in range(6):
+        v = mean[..., b] + np.rint(rng.normal(0.0, noise_dn, size=(size, size))).astype(np.int64)
+        v = np.where(fill, synth.BAND_FILL, v)
+        bands.append(v.astype(np.int16))
+    blob = lambda p, c: field(max(2, size // c)) < p                                        # noqa: E731
+    cloud, shadow, snow, water, adjacent = blob(0.12, 200), blob(0.08, 150), blob(0.04, 300), st == 0, blob(0.1, 200)
+    aerosol = (field(max(2, size // 500)) * 4).astype(np.int64)
+    fmask = (aerosol << 6) | (water.astype(np.int64) << 5) | (snow.astype(np.int64) << 4) | (shadow.astype(np.int64) << 3) | \
+        (adjacent.astype(np.int64) << 2) | (cloud.astype(np.int64) << 1)
+    fmask = np.where(fill, synth.FMASK_FILL, fmask).astype(np.uint8)
+    return {'bands': bands, 'fmask': fmask}
+
+
 def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx_hls_synth',
-         ancillary=False, dem_margin=50, ocean=False):
+         ancillary=False, dem_margin=50, ocean=False, scene=False):
     in_dir = os.path.join(out_dir, 'input')
     os.makedirs(in_dir, exist_ok=True)
-    s = synth_tile(tile, size, size, with_masks=masks)
+    if scene and masks:
+        raise ValueError('scene: band files only (no pre-made masks)')
+    s = scene_tile(tile, size) if scene else synth_tile(tile, size, size, with_masks=masks)
     gt = (600000.0, 30.0, 0.0, 4000020.0, 0.0, -30.0)
     geo = geotiff.geo_tags_from_geotransform(gt, epsg=32615)
     stem = f'HLS.{sensor}.T15SYU.2021250T163901.v2.0'
@@ -114,5 +158,6 @@ if __name__ == '__main__':
     ap.add_argument('--size', type=int, default=3660)
     ap.add_argument('--tile', type=int, default=0)
     ap.add_argument('--masks', action='store_true')
+    ap.add_argument('--scene', action='store_true', help='spatially coherent scene (codec timing) instead of the per-pixel recipe')
     a = ap.parse_args()
-    print(make(a.out_dir, a.sensor, a.size, a.tile, a.masks)[0])
+    print(make(a.out_dir, a.sensor, a.size, a.tile, a.masks, scene=a.scene)[0])
