@@ -522,6 +522,11 @@ int dswx_copy_2d_device(dswx_ctx_t* ctx, void* dst, size_t dst_pitch_bytes, cons
 int dswx_rgb_planes_device(dswx_ctx_t* ctx, const int16_t* red, const int16_t* green, const int16_t* blue,
                            const uint16_t* diag, int64_t n_pixels, const double scale[3], const double offset[3],
                            int32_t clip_negative_reflectance, float* out, void* stream);
+/* A plane as GDAL stores it in a Byte band (save_dswx_product creates all ten bands of the multi-band file as GDT_Byte,
+ * dswx_hls.py:2663-2666, so DIAG and DEM saturate there): src_kind 1 uint16 / 2 int16: clamped to 0 .. 255; 3 float32:
+ * NaN -> 0, clamped, rounded half up (GDALCopyWords; GDAL is not in the reference tree: the rule is GDAL's documented
+ * conversion, unpinned by execution). */
+int dswx_to_byte_device(dswx_ctx_t* ctx, const void* src, int32_t src_kind, int64_t n, uint8_t* dst, void* stream);
 
 /* ---- device plumbing for hosts without another HIP binding ------------------- */
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);

@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = (
     'dswx_batch_va_budget', 'dswx_batch_pool_trim',
     'dswx_shadow_layer_batch', 'dswx_landcover_mask_batch',
     'dswx_cog_layout', 'dswx_cog_blocks_device', 'dswx_untile_device', 'dswx_rgb_planes_device', 'dswx_copy_2d_device', 'dswx_convolve_axis_device',
+    'dswx_to_byte_device',
     'dswx_memcpy_h2d_async', 'dswx_memcpy_d2h_async')
 
 
@@ -256,6 +257,7 @@ def load_library(path=None):
                                                   ctypes.POINTER(ctypes.c_double * 3), ctypes.c_int32, vp, vp]),
         'dswx_convolve_axis_device': (ctypes.c_int, [vp, vp, ctypes.c_int32, i64, i64, i64, i64, i64, ctypes.c_int32, vp, vp, vp,
                                                      ctypes.c_int32, i64, i64, vp]),
+        'dswx_to_byte_device': (ctypes.c_int, [vp, vp, ctypes.c_int32, i64, vp, vp]),
         'dswx_copy_2d_device': (ctypes.c_int, [vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]),
         'dswx_memcpy_h2d_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
         'dswx_memcpy_d2h_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
@@ -780,6 +782,13 @@ class Context:
             int(src_elem_stride), int(n_out), int(taps), ctypes.c_void_p(first_ptr), ctypes.c_void_p(weights_ptr),
             ctypes.c_void_p(dst_ptr), int(bool(dst_is_f64)), int(dst_line_stride), int(dst_elem_stride),
             ctypes.c_void_p(stream) if stream else None))
+
+    def to_byte_device(self, src_ptr, src_dtype, n, dst_ptr, stream=None):
+        kind = {'uint16': 1, 'int16': 2, 'float32': 3}.get(np.dtype(src_dtype).name)
+        if kind is None:
+            raise ValueError(f'to_byte_device: {np.dtype(src_dtype)} planes are not taken')
+        _check(self.lib.dswx_to_byte_device(self.handle, ctypes.c_void_p(src_ptr), kind, int(n), ctypes.c_void_p(dst_ptr),
+                                            ctypes.c_void_p(stream) if stream else None))
 
     def copy_2d_device(self, dst_ptr, dst_pitch, src_ptr, src_pitch, width_bytes, height, stream=None):
         _check(self.lib.dswx_copy_2d_device(self.handle, ctypes.c_void_p(dst_ptr), int(dst_pitch), ctypes.c_void_p(src_ptr),

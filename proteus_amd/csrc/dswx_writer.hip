@@ -240,6 +240,23 @@ __global__ __launch_bounds__(256) void dswx_convolve_axis_v1(const ConvArgs a) {
     static_cast<TO*>(a.dst)[r * a.dst_line_stride + j * a.dst_elem_stride] = (TO)out;
 }
 
+// What `gdal_band.WriteArray` stores in a GDT_Byte band (GDALCopyWords; save_dswx_product creates every band of the
+// multi-band file as Byte, dswx_hls.py:2663-2666): integers clamped to 0 .. 255, floating point clamped, rounded half up, NaN -> 0.
+template <typename T>
+__global__ __launch_bounds__(256) void dswx_to_byte_v1(const T* __restrict__ src, unsigned char* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const T v = src[i];
+    if constexpr (sizeof(T) == 4) {
+        double x = (double)v;
+        x = (x != x) ? 0.0 : (x < 0.0 ? 0.0 : (x > 255.0 ? 255.0 : x));
+        x = floor(x + 0.5);
+        dst[i] = (unsigned char)(x > 255.0 ? 255.0 : x);
+    } else {
+        dst[i] = (unsigned char)(v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v));
+    }
+}
+
 struct RgbArgs {
     const short* band[3];
     const unsigned short* diag;
@@ -436,6 +453,22 @@ int dswx_rgb_planes_device(dswx_ctx_t* ctx, const int16_t* red, const int16_t* g
     const unsigned long long groups = ((unsigned long long)n_pixels + 255) / 256;
     if (groups > 0x7fffffffull) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
     hipLaunchKernelGGL(dswx_rgb_planes_v1, dim3((unsigned)groups), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_to_byte_device(dswx_ctx_t* ctx, const void* src, int32_t src_kind, int64_t n, uint8_t* dst, void* stream) {
+    if (!ctx || !src || !dst) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (n < 0 || src_kind < 1 || src_kind > 3) return dswx_fail(DSWX_ERR_ARG, "src_kind: 1 uint16, 2 int16, 3 float32");
+    if (n == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const unsigned long long groups = ((unsigned long long)n + 255) / 256;
+    if (groups > 0x7fffffffull) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
+    const dim3 grid((unsigned)groups), block(256);
+    if (src_kind == 1) hipLaunchKernelGGL(dswx_to_byte_v1<unsigned short>, grid, block, 0, s, static_cast<const unsigned short*>(src), dst, (long long)n);
+    else if (src_kind == 2) hipLaunchKernelGGL(dswx_to_byte_v1<short>, grid, block, 0, s, static_cast<const short*>(src), dst, (long long)n);
+    else hipLaunchKernelGGL(dswx_to_byte_v1<float>, grid, block, 0, s, static_cast<const float*>(src), dst, (long long)n);
     HIP_TRY(hipGetLastError());
     return DSWX_OK;
 }

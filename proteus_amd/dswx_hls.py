@@ -1443,15 +1443,10 @@ def generate_dswx_layers(input_list,
     if output_file and not output_file.endswith('.vrt'):
         # the multi-band file carries the post-aerosol WTR-1 (in-place remap, :5260 -> :5389)
         # CONF is NOT passed (:5383-5397): the loop skips it and the bands after BWTR move up one (see there)
-        host = {n: res[k].numpy() for n, k in (('WTR', 'wtr'), ('BWTR', 'bwtr'), ('DIAG', 'diag'), ('WTR-1', 'wtr1_aerosol'),
-                                               ('WTR-2', 'wtr2'), ('CLOUD', 'cloud'))}
-        def on_host(a):
-            return a.numpy() if isinstance(a, pipeline.DevicePlane) else a
-        save_dswx_product({'WTR': host['WTR'], 'BWTR': host['BWTR'], 'DIAG': host['DIAG'],
-                           'WTR-1': host['WTR-1'], 'WTR-2': host['WTR-2'],
-                           'LAND': on_host(landcover_mask), 'SHAD': on_host(shadow_layer), 'CLOUD': host['CLOUD'],
-                           'DEM': on_host(dem)},
-                          output_file, md, geo_tags, output_files_list=output_files_list)
+        _save_dswx_product_planes(engine, {'WTR': res['wtr'], 'BWTR': res['bwtr'], 'DIAG': res['diag'],
+                                           'WTR-1': res['wtr1_aerosol'], 'WTR-2': res['wtr2'],
+                                           'LAND': landcover_mask, 'SHAD': shadow_layer, 'CLOUD': res['cloud'], 'DEM': dem},
+                                  output_file, md, geo_tags, output_files_list=output_files_list)
     elif output_file:
         logger.warning(f'VRT output "{output_file}" skipped: needs GDAL')
     writes.__exit__(None, None, None)
@@ -1459,6 +1454,38 @@ def generate_dswx_layers(input_list,
     for f in build_list + output_files_list:
         logger.info(f'    {f}')
     return True
+
+
+def _save_dswx_product_planes(engine, layers, output_file, dswx_metadata_dict, geo_tags, output_files_list=None):
+    """save_dswx_product for layers RESIDENT on the device: the Byte conversion of DIAG / DEM (dswx_to_byte_device), the
+    blocks, the NEAREST overviews and the predictor of all ten bands are made in HBM (pipeline.TileEngine.band_stack_levels);
+    the band layout, the descriptions and the nodata planes are save_dswx_product's (see there)."""
+    names = [n for n in band_description_dict if n in layers]
+    first = next((layers[n] for n in names if layers[n] is not None), None)
+    if first is None:
+        raise ValueError('save_dswx_product: no layer to save')
+    shape = tuple(first.shape)
+    nbands = len(band_description_dict)
+    descriptions = [band_description_dict[names[0]]] * len(names) + [''] * (nbands - len(names))
+    _makedirs(output_file)
+
+    def job():
+        bands = []
+        for n in names:
+            a = layers[n]
+            if a is None:
+                bands.append(engine.constant_plane(shape, UINT8_FILL_VALUE))
+            else:
+                bands.append(engine.byte_plane(a if isinstance(a, pipeline.DevicePlane) else engine.upload(np.asarray(a))))
+        if nbands > len(names):
+            bands += [engine.constant_plane(shape, 0)] * (nbands - len(names))    # an unwritten GTiff band reads as zeros
+        levels = engine.band_stack_levels(bands, geotiff.COG_OVERVIEW_FACTORS)
+        geotiff.write_geotiff(output_file, None, levels=levels, geo_tags=geo_tags, metadata=dswx_metadata_dict,
+                              nodata=UINT8_FILL_VALUE, descriptions=descriptions)
+        logger.info(f'file saved: {output_file}')
+    if output_files_list is not None:
+        output_files_list.append(output_file)
+    _run_or_defer(job)
 
 
 # -----------------------------------------------------------------------------------

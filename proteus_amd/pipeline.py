@@ -366,6 +366,48 @@ class TileEngine:
         return [geotiff.BlockedLevel(pyramids[0][k].shape[0], pyramids[0][k].shape[1], len(bands), np.float32, tile, 3,
                                      host[offs[k]: offs[k] + len(bands) * sizes[k]]) for k in range(n_levels)]
 
+    def byte_plane(self, plane):
+        """A layer as GDAL stores it in a Byte band of the multi-band file (dswx_hls._gdal_byte; dswx_to_byte_device)."""
+        if plane.dtype == np.uint8:
+            return plane
+        out = self.plane(plane.shape, np.uint8)
+        with self.lock, stages.span('gpu: layer -> Byte band'):
+            self.ctx.to_byte_device(plane.ptr, plane.dtype, plane.shape[0] * plane.shape[1], out.ptr)
+            self.ctx.synchronize()
+        return out
+
+    def constant_plane(self, shape, value):
+        out = self.plane(shape, np.uint8)
+        with self.lock:
+            _capi._check(self.ctx.lib.dswx_memset_d(self.ctx.handle, out.ptr, int(value) & 0xff, out.nbytes))
+        return out
+
+    def band_stack_levels(self, bands, factors=(), tile=512):
+        """Byte planes of ONE multi-band file (save_dswx_product: ten bands, planar) -> [geotiff.BlockedLevel] (band-major
+        inside every level): blocks + NEAREST overviews + PREDICTOR=2 of every band on the device, each (band, level) piece
+        copied to its place in page-locked memory."""
+        H, W = bands[0].shape
+        if any(b.dtype != np.uint8 or b.shape != (H, W) for b in bands):
+            raise ValueError('band stack: uint8 planes of one shape')
+        lay = _capi.cog_layout(H, W, 1, factors, tile)
+        per_band = lay['total_bytes']
+        sizes = [lv['blocks_down'] * lv['blocks_across'] * tile * tile for lv in lay['levels']]
+        starts = np.concatenate([[0], np.cumsum([len(bands) * n for n in sizes])]).astype(np.int64)
+        dev_blocks = self._take(per_band)
+        host = self.ctx.pinned_empty((len(bands) * per_band,), np.uint8)
+        try:
+            with self.lock, stages.span('gpu: plane -> COG blocks (+ d2h)'):
+                for c, b in enumerate(bands):
+                    self.ctx.cog_blocks_device(b.ptr, 1, H, W, dev_blocks.ptr, factors, tile, 2)
+                    for k, lv in enumerate(lay['levels']):
+                        at = int(starts[k]) + c * sizes[k]
+                        self.ctx.d2h_async(host[at: at + sizes[k]], dev_blocks.ptr + lv['offset_bytes'], sizes[k])
+                self.ctx.synchronize()
+        finally:
+            self._give(dev_blocks)
+        return [geotiff.BlockedLevel(lv['height'], lv['width'], len(bands), np.uint8, tile, 2,
+                                     host[int(starts[k]): int(starts[k + 1])]) for k, lv in enumerate(lay['levels'])]
+
     def rgb_levels(self, red, green, blue, diag, scale, offset, clip, tile=512, factors=()):
         """The three-band Float32 composite of _save_output_rgb_file (dswx_hls.py:3013-3036) as planar BlockedLevels
         (floating-point predictor, CUBICSPLINE overviews for `factors`): scaling on the device, NaN where `diag` carries the

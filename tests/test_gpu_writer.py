@@ -412,3 +412,45 @@ def test_convolve_axis_refuses_bad_arguments(ctx):
             ctx.convolve_axis_device(None, False, 1, 4, 4, 1, 1, 1, d.ptr, d.ptr, d.ptr, False, 1, 1)
     finally:
         d.free()
+
+
+def test_multiband_product_from_resident_layers_is_the_host_writers_file(ctx, tmp_path):
+    """save_dswx_product (dswx_hls.py:2601-2707): ten Byte bands, DIAG and DEM through GDAL's Byte conversion, absent / None
+    layers, descriptions -- from planes resident on the device (dswx_to_byte_device + pipeline.band_stack_levels) the file is
+    byte for byte the one the host mirror writes from the same arrays; the conversion itself against dswx_hls._gdal_byte."""
+    from proteus_amd import dswx_hls as D
+    from proteus_amd import pipeline
+    eng = pipeline.TileEngine(ctx)
+    rng = np.random.default_rng(77)
+    geo = geotiff.geo_tags_from_geotransform((600000.0, 30.0, 0.0, 4000020.0, 0.0, -30.0), epsg=32615)
+    md = {'PRODUCT_ID': 'mb'}
+    try:
+        # the conversion: every uint16 / int16 value; floats around every rounding edge, NaN, infinities
+        u16 = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+        i16 = u16.view(np.int16)
+        f32 = np.concatenate([np.arange(-4, 260, 0.25, dtype=np.float32), np.float32([np.nan, np.inf, -np.inf, 254.5, 255.49, 255.5, 1e30, -1e30,
+                                                                                      0.49999997, 0.5, 1.5, 2.5, 254.49998]),
+                              (rng.normal(size=4000) * 200).astype(np.float32)])
+        f32 = np.resize(f32, (72, 80)).astype(np.float32)
+        for a in (u16, i16, f32):
+            got = eng.byte_plane(eng.upload(a)).numpy()
+            assert got.dtype == np.uint8 and np.array_equal(got, D._gdal_byte(a)), a.dtype
+        for shape in ((1100, 700), (3660, 3660)):
+            u8 = lambda hi: rng.integers(0, hi, size=shape).astype(np.uint8)          # noqa: E731
+            dem = (rng.normal(size=shape) * 150 + 100).astype(np.float32)
+            dem[rng.random(shape) < 0.01] = np.nan
+            layers = {'WTR': u8(3), 'BWTR': u8(2), 'DIAG': rng.integers(0, 11112, size=shape).astype(np.uint16), 'WTR-1': u8(5),
+                      'WTR-2': u8(5), 'LAND': None, 'SHAD': u8(2), 'CLOUD': u8(8), 'DEM': dem}
+            for drop in ((), ('LAND', 'DEM')):
+                use = {k: v for k, v in layers.items() if k not in drop}
+                p_host, p_dev = str(tmp_path / 'mb_host.tif'), str(tmp_path / 'mb_dev.tif')
+                D.save_dswx_product(use, p_host, md, geo)
+                D._save_dswx_product_planes(eng, {k: (None if v is None else eng.upload(v)) for k, v in use.items()}, p_dev, md, geo)
+                assert open(p_host, 'rb').read() == open(p_dev, 'rb').read(), (shape, drop)
+                assert geotiff.validate_cog(p_dev) == []
+            arr, info = geotiff.read_geotiff(p_dev)
+            assert arr.shape == (10,) + shape and np.array_equal(arr[2], np.minimum(layers['DIAG'], 255))
+        with pytest.raises(ValueError):
+            D._save_dswx_product_planes(eng, {'WTR': None}, str(tmp_path / 'x.tif'), md, geo)
+    finally:
+        eng.close()
