@@ -527,6 +527,12 @@ int dswx_rgb_planes_device(dswx_ctx_t* ctx, const int16_t* red, const int16_t* g
  * NaN -> 0, clamped, rounded half up (GDALCopyWords; GDAL is not in the reference tree: the rule is GDAL's documented
  * conversion, unpinned by execution). */
 int dswx_to_byte_device(dswx_ctx_t* ctx, const void* src, int32_t src_kind, int64_t n, uint8_t* dst, void* stream);
+/* dst[i][j] = src[rows[i]][cols[j]] (rows / cols: DEVICE int32 arrays of source indices, which the caller guarantees to lie
+ * inside src_height x src_width): the nearest-neighbour resampling of the browse image (geotiff2png after
+ * _compute_browse_array, dswx_hls.py:5335-5349; GDAL RasterIO's pick src = floor((dst + 0.5) * N_src / N_dst), which the host
+ * evaluates -- proteus_amd/geotiff.py: resample_nearest) on a plane that stays in HBM; only the small image crosses PCIe. */
+int dswx_gather_2d_device(dswx_ctx_t* ctx, const void* src, int32_t elem_bytes, int64_t src_height, int64_t src_width,
+                          const int32_t* rows, int32_t n_rows, const int32_t* cols, int32_t n_cols, void* dst, void* stream);
 
 /* ---- device plumbing for hosts without another HIP binding ------------------- */
 int dswx_device_malloc(dswx_ctx_t* ctx, size_t bytes, void** out);

@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = (
     'dswx_batch_va_budget', 'dswx_batch_pool_trim',
     'dswx_shadow_layer_batch', 'dswx_landcover_mask_batch',
     'dswx_cog_layout', 'dswx_cog_blocks_device', 'dswx_untile_device', 'dswx_rgb_planes_device', 'dswx_copy_2d_device', 'dswx_convolve_axis_device',
-    'dswx_to_byte_device',
+    'dswx_to_byte_device', 'dswx_gather_2d_device',
     'dswx_memcpy_h2d_async', 'dswx_memcpy_d2h_async')
 
 
@@ -258,6 +258,7 @@ def load_library(path=None):
         'dswx_convolve_axis_device': (ctypes.c_int, [vp, vp, ctypes.c_int32, i64, i64, i64, i64, i64, ctypes.c_int32, vp, vp, vp,
                                                      ctypes.c_int32, i64, i64, vp]),
         'dswx_to_byte_device': (ctypes.c_int, [vp, vp, ctypes.c_int32, i64, vp, vp]),
+        'dswx_gather_2d_device': (ctypes.c_int, [vp, vp, ctypes.c_int32, i64, i64, vp, ctypes.c_int32, vp, ctypes.c_int32, vp, vp]),
         'dswx_copy_2d_device': (ctypes.c_int, [vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]),
         'dswx_memcpy_h2d_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
         'dswx_memcpy_d2h_async': (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
@@ -789,6 +790,11 @@ class Context:
             raise ValueError(f'to_byte_device: {np.dtype(src_dtype)} planes are not taken')
         _check(self.lib.dswx_to_byte_device(self.handle, ctypes.c_void_p(src_ptr), kind, int(n), ctypes.c_void_p(dst_ptr),
                                             ctypes.c_void_p(stream) if stream else None))
+
+    def gather_2d_device(self, src_ptr, elem_bytes, src_height, src_width, rows_ptr, n_rows, cols_ptr, n_cols, dst_ptr, stream=None):
+        _check(self.lib.dswx_gather_2d_device(self.handle, ctypes.c_void_p(src_ptr), int(elem_bytes), int(src_height), int(src_width),
+                                              ctypes.c_void_p(rows_ptr), int(n_rows), ctypes.c_void_p(cols_ptr), int(n_cols),
+                                              ctypes.c_void_p(dst_ptr), ctypes.c_void_p(stream) if stream else None))
 
     def copy_2d_device(self, dst_ptr, dst_pitch, src_ptr, src_pitch, width_bytes, height, stream=None):
         _check(self.lib.dswx_copy_2d_device(self.handle, ctypes.c_void_p(dst_ptr), int(dst_pitch), ctypes.c_void_p(src_ptr),

@@ -257,6 +257,16 @@ __global__ __launch_bounds__(256) void dswx_to_byte_v1(const T* __restrict__ src
     }
 }
 
+// dst[i][j] = src[rows[i]][cols[j]]: a nearest-neighbour resampling whose source indices the host computed (the browse PNG of
+// geotiff2png: GDAL RasterIO's pick, restated in geotiff.resample_nearest).
+template <typename T>
+__global__ __launch_bounds__(256) void dswx_gather_2d_v1(const T* __restrict__ src, long long src_width, const int* __restrict__ rows,
+                                                        const int* __restrict__ cols, int n_cols, T* __restrict__ dst) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= n_cols) return;
+    dst[(long long)i * n_cols + j] = src[(long long)rows[i] * src_width + cols[j]];
+}
+
 struct RgbArgs {
     const short* band[3];
     const unsigned short* diag;
@@ -453,6 +463,26 @@ int dswx_rgb_planes_device(dswx_ctx_t* ctx, const int16_t* red, const int16_t* g
     const unsigned long long groups = ((unsigned long long)n_pixels + 255) / 256;
     if (groups > 0x7fffffffull) return dswx_fail(DSWX_ERR_ARG, "raster too large for one launch");
     hipLaunchKernelGGL(dswx_rgb_planes_v1, dim3((unsigned)groups), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return DSWX_OK;
+}
+
+int dswx_gather_2d_device(dswx_ctx_t* ctx, const void* src, int32_t elem_bytes, int64_t src_height, int64_t src_width,
+                          const int32_t* rows, int32_t n_rows, const int32_t* cols, int32_t n_cols, void* dst, void* stream) {
+    if (!ctx || !src || !dst || !rows || !cols) return dswx_fail(DSWX_ERR_ARG, "NULL argument");
+    if (src_height < 1 || src_width < 1 || n_rows < 0 || n_cols < 0 || n_rows > 65535)
+        return dswx_fail(DSWX_ERR_ARG, "bad size (at most 65535 output rows)");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4) return dswx_fail(DSWX_ERR_ARG, "elem_bytes must be 1, 2 or 4");
+    if (n_rows == 0 || n_cols == 0) return DSWX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const dim3 grid((unsigned)((n_cols + 255) / 256), (unsigned)n_rows), block(256);
+    if (elem_bytes == 1)
+        hipLaunchKernelGGL(dswx_gather_2d_v1<unsigned char>, grid, block, 0, s, static_cast<const unsigned char*>(src), (long long)src_width, rows, cols, n_cols, static_cast<unsigned char*>(dst));
+    else if (elem_bytes == 2)
+        hipLaunchKernelGGL(dswx_gather_2d_v1<unsigned short>, grid, block, 0, s, static_cast<const unsigned short*>(src), (long long)src_width, rows, cols, n_cols, static_cast<unsigned short*>(dst));
+    else
+        hipLaunchKernelGGL(dswx_gather_2d_v1<unsigned int>, grid, block, 0, s, static_cast<const unsigned int*>(src), (long long)src_width, rows, cols, n_cols, static_cast<unsigned int*>(dst));
     HIP_TRY(hipGetLastError());
     return DSWX_OK;
 }

@@ -789,11 +789,14 @@ def _browse_png_job(browse, ctable, nodata, dest_png_filename, output_height, ou
     plane itself."""
     def job():
         with stages.span('browse PNG (resample + encode)'):
-            arr = browse.numpy() if isinstance(browse, pipeline.DevicePlane) else np.asarray(browse)
-            h = arr.shape[0] if output_height is None else output_height
-            w = arr.shape[1] if output_width is None else output_width
+            h = browse.shape[0] if output_height is None else output_height
+            w = browse.shape[1] if output_width is None else output_width
+            if isinstance(browse, pipeline.DevicePlane) and 0 < h <= 65535:
+                small = browse.engine.resample_nearest(browse, h, w)            # gathered in HBM
+            else:
+                small = geotiff.resample_nearest(browse.numpy() if isinstance(browse, pipeline.DevicePlane) else np.asarray(browse), h, w)
             _makedirs(dest_png_filename)
-            geotiff.write_png_palette(dest_png_filename, geotiff.resample_nearest(arr, h, w), ctable,
+            geotiff.write_png_palette(dest_png_filename, small, ctable,
                                       transparent_index=None if nodata is None else int(nodata))
         logger.info(f'Browse Image PNG created: {dest_png_filename}')
     return job

@@ -844,7 +844,12 @@ def write_png_palette(path, indices, colormap, transparent_index=None):
 def resample_nearest(arr, out_height, out_width):
     """Nearest-neighbour decimation the way GDAL RasterIO picks source pixels:
     src = floor((dst + 0.5) * src_size / dst_size)."""
-    h, w = arr.shape[-2:]
+    ys, xs = resample_nearest_indices(arr.shape[-2], arr.shape[-1], out_height, out_width)
+    return arr[..., ys[:, None], xs[None, :]]
+
+
+def resample_nearest_indices(h, w, out_height, out_width):
+    """(source rows [out_height], source columns [out_width]) of resample_nearest (the device gather takes them too)."""
     ys = np.minimum(((np.arange(out_height) + 0.5) * h / out_height).astype(np.int64), h - 1)
     xs = np.minimum(((np.arange(out_width) + 0.5) * w / out_width).astype(np.int64), w - 1)
-    return arr[..., ys[:, None], xs[None, :]]
+    return ys, xs

@@ -366,6 +366,30 @@ class TileEngine:
         return [geotiff.BlockedLevel(pyramids[0][k].shape[0], pyramids[0][k].shape[1], len(bands), np.float32, tile, 3,
                                      host[offs[k]: offs[k] + len(bands) * sizes[k]]) for k in range(n_levels)]
 
+    def resample_nearest(self, plane, out_height, out_width):
+        """geotiff.resample_nearest of a resident plane -> numpy [out_height, out_width] (the browse PNG's pixels): the gather
+        runs in HBM, the small image is what crosses PCIe."""
+        H, W = plane.shape
+        ys, xs = geotiff.resample_nearest_indices(H, W, out_height, out_width)
+        idx = np.concatenate([ys, xs]).astype(np.int32)
+        n_out = int(out_height) * int(out_width) * plane.dtype.itemsize
+        d_idx, d_out = self._take(max(idx.nbytes, 16)), self._take(max(n_out, 16))
+        host = self.ctx.pinned_empty((int(out_height), int(out_width)), plane.dtype)
+        pin_idx = self.ctx.pinned_empty(idx.shape, np.int32)
+        np.copyto(pin_idx, idx)
+        try:
+            with self.lock, stages.span('gpu: resample (browse)'):
+                self.ctx.h2d_async(d_idx.ptr, pin_idx)
+                self.ctx.gather_2d_device(plane.ptr, plane.dtype.itemsize, H, W, d_idx.ptr, out_height, d_idx.ptr + 4 * int(out_height),
+                                          out_width, d_out.ptr)
+                if n_out:
+                    self.ctx.d2h_async(host, d_out.ptr, n_out)
+                self.ctx.synchronize()
+        finally:
+            self._give(d_idx)
+            self._give(d_out)
+        return host
+
     def byte_plane(self, plane):
         """A layer as GDAL stores it in a Byte band of the multi-band file (dswx_hls._gdal_byte; dswx_to_byte_device)."""
         if plane.dtype == np.uint8:

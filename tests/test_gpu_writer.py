@@ -454,3 +454,21 @@ def test_multiband_product_from_resident_layers_is_the_host_writers_file(ctx, tm
             D._save_dswx_product_planes(eng, {'WTR': None}, str(tmp_path / 'x.tif'), md, geo)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('dtype', [np.uint8, np.uint16, np.float32])
+def test_browse_resampling_in_hbm(ctx, dtype):
+    """geotiff2png's nearest-neighbour resize (GDAL RasterIO's pick, geotiff.resample_nearest) as a gather on the resident
+    plane: decimation, identity, magnification, one pixel."""
+    from proteus_amd import pipeline
+    eng = pipeline.TileEngine(ctx)
+    rng = np.random.default_rng(5)
+    try:
+        for shape, outs in (((3660, 3660), ((1024, 1024), (3660, 3660), (1, 1), (333, 2048))), ((7, 5), ((14, 9), (3, 5), (1, 2)))):
+            a = rng.integers(0, 250, size=shape).astype(dtype)
+            plane = eng.upload(a)
+            for oh, ow in outs:
+                got = eng.resample_nearest(plane, oh, ow)
+                assert got.dtype == a.dtype and np.array_equal(got, geotiff.resample_nearest(a, oh, ow)), (shape, oh, ow)
+    finally:
+        eng.close()
