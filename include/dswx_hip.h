@@ -505,10 +505,10 @@ int dswx_untile_device(dswx_ctx_t* ctx, const void* blocks, int32_t elem_bytes, 
 /* One separable pass of the CUBICSPLINE overview convolution `save_as_cog` asks GDAL for on non-integer layers
  * (core.py:41-46; restated from GDAL's GDALResampleChunk_Convolution in proteus_amd/geotiff.py: _convolve_axis -- GDAL is not
  * in the reference tree, last-ulp agreement of the float results is unpinned): for every line r < n_lines and output
- * position j < n_out, dst = sum_k src[r, clamp(first[j] + k, 0, n_in - 1)] * weights[j * taps + k], normalised over the taps whose
+ * position j < n_out, dst = sum_k src[r, clamp(first[j] + k, 0, n_in - 1)] * weights[k * n_out + j], normalised over the taps whose
  * sample is not NaN; NaN if none is left.  Accumulation in float64 in tap order.  Strides in elements, so that the same entry
  * does the horizontal pass (lines = rows) and the vertical one (lines = columns); src / dst float32 or float64; `first`
- * (int32 [n_out]) and `weights` (float64 [n_out][taps]) are DEVICE arrays the host prepares. */
+ * (int32 [n_out]) and `weights` (float64 [taps][n_out]) are DEVICE arrays the host prepares. */
 int dswx_convolve_axis_device(dswx_ctx_t* ctx, const void* src, int32_t src_is_f64, int64_t n_lines, int64_t n_in,
                               int64_t src_line_stride, int64_t src_elem_stride, int64_t n_out, int32_t taps,
                               const int32_t* first, const double* weights, void* dst, int32_t dst_is_f64,

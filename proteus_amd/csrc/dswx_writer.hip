@@ -225,14 +225,14 @@ __global__ __launch_bounds__(256) void dswx_convolve_axis_v1(const ConvArgs a) {
     const long long r = a.lines_fastest ? fast : slow, j = a.lines_fastest ? slow : fast;
     if (r >= a.n_lines || j >= a.n_out) return;
     const TI* __restrict__ line = static_cast<const TI*>(a.src) + r * a.src_line_stride;
-    const double* __restrict__ w = a.w + j * a.taps;
+    const double* __restrict__ w = a.w + j;                    // weights [taps][n_out]: neighbouring outputs read neighbouring weights
     const long long f0 = a.first[j];
     double num = 0.0, den = 0.0;
     for (int k = 0; k < a.taps; ++k) {
         long long i = f0 + k;
         i = i < 0 ? 0 : (i >= a.n_in ? a.n_in - 1 : i);
         const double g = (double)line[i * a.src_elem_stride];
-        const double ww = (g != g) ? 0.0 : w[k];                // (taps outside the raster carry a zero weight from the host)
+        const double ww = (g != g) ? 0.0 : w[k * a.n_out];                // (taps outside the raster carry a zero weight from the host)
         num += (ww > 0.0 ? g : 0.0) * ww;
         den += ww;
     }

@@ -268,7 +268,7 @@ class TileEngine:
             with self.lock:
                 d_first, d_w = self.ctx.malloc(max(first.size * 4, 16)), self.ctx.malloc(max(w.nbytes, 16))
                 d_first.upload(first.astype(np.int32))
-                d_w.upload(w)
+                d_w.upload(np.ascontiguousarray(w.T))          # [taps][n_out]: the layout the device pass reads
             hit = (d_first, d_w, w.shape[1])
             with self._pool_lock:
                 kept = self._weights.setdefault(key, hit)

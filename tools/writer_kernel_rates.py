@@ -83,6 +83,30 @@ def main():
     dem = ctx.malloc(side * side * 4)
     ms = timed(ctx, lambda: ctx.copy_2d_device(d_plane.ptr, W * 4, dem.ptr + (50 * side + 50) * 4, side * 4, W * 4, H))
     out['dswx_copy_2d_device (DEM crop, hipMemcpy2DAsync)'] = rec(ms, 2 * H * W * 4)
+    # CUBICSPLINE level 4 of a Float32 layer: horizontal pass (float32 -> float64 [H][ow]) and vertical pass (-> float32 [oh][ow])
+    oh = ow = -(-H // 4)
+    fx, wx = geotiff.convolve_weights(W, ow)
+    d_first, d_w = ctx.malloc(fx.size * 4), ctx.malloc(wx.nbytes)
+    d_first.upload(fx.astype(np.int32))
+    d_w.upload(np.ascontiguousarray(wx.T))
+    tmp, lvl = ctx.malloc(H * ow * 8), ctx.malloc(oh * ow * 4)
+    taps = wx.shape[1]
+    ms = timed(ctx, lambda: ctx.convolve_axis_device(d_plane.ptr, False, H, W, W, 1, ow, taps, d_first.ptr, d_w.ptr, tmp.ptr, True, ow, 1))
+    out['dswx_convolve_axis_v1<float, double> (CUBICSPLINE level 4, horizontal pass, 17 taps)'] = rec(
+        ms, H * W * 4 + H * ow * 8, 'every output reads 17 taps: 4.25 x the plane through the caches, once from memory')
+    ms = timed(ctx, lambda: ctx.convolve_axis_device(tmp.ptr, True, ow, H, 1, ow, oh, taps, d_first.ptr, d_w.ptr, lvl.ptr, False, 1, ow))
+    out['dswx_convolve_axis_v1<double, float> (CUBICSPLINE level 4, vertical pass, 17 taps)'] = rec(ms, H * ow * 8 + oh * ow * 4)
+    # Byte conversion of the multi-band file's DIAG / DEM bands; the browse gather 3660^2 -> 1024^2
+    byte = ctx.malloc(H * W)
+    ms = timed(ctx, lambda: ctx.to_byte_device(d_plane.ptr, np.float32, H * W, byte.ptr))
+    out['dswx_to_byte_v1<float>'] = rec(ms, H * W * 5)
+    ms = timed(ctx, lambda: ctx.to_byte_device(diag.ptr, np.uint16, H * W, byte.ptr))
+    out['dswx_to_byte_v1<uint16>'] = rec(ms, H * W * 3)
+    ys, xs = geotiff.resample_nearest_indices(H, W, 1024, 1024)
+    d_idx = ctx.malloc(2048 * 4)
+    d_idx.upload(np.concatenate([ys, xs]).astype(np.int32))
+    ms = timed(ctx, lambda: ctx.gather_2d_device(byte.ptr, 1, H, W, d_idx.ptr, 1024, d_idx.ptr + 4096, 1024, lvl.ptr))
+    out['dswx_gather_2d_v1<u8> (browse 3660^2 -> 1024^2)'] = rec(ms, 2 * 1024 * 1024, 'bytes: one read and one write per OUTPUT pixel (a latency figure)')
     print(json.dumps(out, indent=1))
     ctx.close()
 
