@@ -42,7 +42,7 @@ def main():
             size = a.size or int(rng.integers(24, 60)) * 8 + int(rng.integers(0, 8))
             anc = t % 5 == 0
             rc, _, _, s = synth_hls.make(os.path.join(d, f't{t}'), sensor=('L30', 'S30')[t % 2], size=size, tile=1000 + t,
-                                         product_id=f'S{t}', ancillary=anc, ocean=anc)
+                                         product_id=f'S{t}', ancillary=anc, ocean=anc, browse=t % 3 == 0)
             rcs.append(rc)
             tiles.append((size, anc, s))
         reports = []
@@ -66,6 +66,21 @@ def main():
                 if not np.array_equal(arr, exp[layer]):
                     print(json.dumps({'ok': False, 'tile': t, 'size': size, 'ancillary': anc, 'layer': layer,
                                       'wrong_pixels': int(np.count_nonzero(arr != exp[layer]))}))
+                    return 1
+                checked += 1
+            if anc:         # the Float32 DEM layer and the first level of its CUBICSPLINE pyramid (made on the device)
+                from proteus_amd.synth import synth_dem
+                dem = synth_dem(1000 + t, size + 100, size + 100)[50:-50, 50:-50]
+                got, _ = geotiff.read_geotiff(os.path.join(out, f'S{t}_v1.0_B10_DEM.tif'))
+                ovr, _ = geotiff.read_geotiff(os.path.join(out, f'S{t}_v1.0_B10_DEM.tif'), overview=0)
+                if not (np.array_equal(got, dem, equal_nan=True) and np.array_equal(ovr, geotiff.overview_cubicspline(dem, 4), equal_nan=True)):
+                    print(json.dumps({'ok': False, 'tile': t, 'size': size, 'layer': 'DEM (image or overview)'}))
+                    return 1
+                checked += 1
+            if t % 3 == 0:
+                png = [f for f in os.listdir(out) if f.endswith('.png')]
+                if len(png) != 1 or os.path.getsize(os.path.join(out, png[0])) < 100:
+                    print(json.dumps({'ok': False, 'tile': t, 'why': 'browse PNG missing', 'files': sorted(os.listdir(out))}))
                     return 1
                 checked += 1
         print(json.dumps({'ok': True, 'tiles': a.tiles, 'in_flight': a.in_flight, 'workers': a.workers, 'layers_checked': checked,

@@ -66,7 +66,7 @@ def scene_tile(tile, size, patch=60, noise_dn=25):
 
 
 def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx_hls_synth',
-         ancillary=False, dem_margin=50, ocean=False, scene=False):
+         ancillary=False, dem_margin=50, ocean=False, scene=False, browse=False):
     in_dir = os.path.join(out_dir, 'input')
     os.makedirs(in_dir, exist_ok=True)
     if scene and masks:
@@ -144,7 +144,7 @@ def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx
         'processing': {'check_ancillary_inputs_coverage': False, 'apply_ocean_masking': bool(ancillary and ocean),
                        'save_land': bool(ancillary),
                        'save_shad': bool(ancillary), 'save_dem': bool(ancillary)},
-        'browse_image_group': {'save_browse': False}}}}
+        'browse_image_group': {'save_browse': bool(browse)}}}}
     rc_path = os.path.join(out_dir, 'runconfig.yaml')
     with open(rc_path, 'w') as fh:
         yaml.safe_dump(rc, fh, sort_keys=False)
