@@ -56,6 +56,12 @@ int dswx_codec_deflate_blocks(const void* const* src, const size_t* src_bytes, v
 int dswx_codec_inflate_blocks(const void* const* src, const size_t* src_bytes, void* const* dst, const size_t* dst_cap,
                               size_t* dst_bytes, int32_t n, int32_t threads);
 
+/* The same for TIFF compression 5 (LZW, TIFF 6.0 section 13, the most-significant-bit-first form libtiff and so GDAL's
+ * COMPRESS=LZW write): ancillary rasters (DEM, land-cover maps) handed over by other GDAL tools are often LZW files.  Like
+ * libtiff's decoder, a stream stops when its block is full; the pre-6.0 "old-style" variant is refused. */
+int dswx_codec_unlzw_blocks(const void* const* src, const size_t* src_bytes, void* const* dst, const size_t* dst_cap,
+                            size_t* dst_bytes, int32_t n, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

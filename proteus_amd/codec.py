@@ -44,6 +44,8 @@ def load():
         lib.dswx_codec_inflate_blocks.restype = ctypes.c_int
         lib.dswx_codec_inflate_blocks.argtypes = [vpp, szp, vpp, szp, szp, ctypes.c_int32, ctypes.c_int32]
         lib.dswx_codec_set_cpu_budget.argtypes = [ctypes.c_int]
+        lib.dswx_codec_unlzw_blocks.restype = ctypes.c_int
+        lib.dswx_codec_unlzw_blocks.argtypes = [vpp, szp, vpp, szp, szp, ctypes.c_int32, ctypes.c_int32]
         if lib.dswx_codec_abi_version() != 1:
             raise CodecError(f'{path}: ABI version {lib.dswx_codec_abi_version()}, expected 1')
         try:
@@ -116,8 +118,8 @@ def deflate_uniform(src, block_bytes, level=6, threads=None):
     return out, offsets.astype(np.int64), sizes.astype(np.int64)
 
 
-def inflate_into(buf, offsets, counts, dst, block_bytes, threads=None):
-    """n zlib streams buf[offsets[i]: offsets[i] + counts[i]] (buf: bytes-like) into dst (uint8-viewable, C-contiguous,
+def inflate_into(buf, offsets, counts, dst, block_bytes, threads=None, scheme='deflate'):
+    """n zlib streams (scheme 'lzw': n TIFF LZW streams) buf[offsets[i]: offsets[i] + counts[i]] (buf: bytes-like) into dst (uint8-viewable, C-contiguous,
     n * block_bytes bytes): block i lands at dst[i * block_bytes].  Returns the produced sizes (int64 [n]); a block that
     inflates to MORE than block_bytes raises."""
     lib = load()
@@ -134,6 +136,6 @@ def inflate_into(buf, offsets, counts, dst, block_bytes, threads=None):
     dst_ptrs = np.uintp(raw.ctypes.data) + np.arange(n, dtype=np.uintp) * np.uintp(block_bytes)
     caps = np.full(n, block_bytes, dtype=np.uintp)
     sizes = np.zeros(n, dtype=np.uintp)
-    _check(lib.dswx_codec_inflate_blocks(_vp(src_ptrs), _sz(counts), _vp(dst_ptrs), _sz(caps), _sz(sizes), n,
-                                         int(threads or default_threads())))
+    entry = {'deflate': lib.dswx_codec_inflate_blocks, 'lzw': lib.dswx_codec_unlzw_blocks}[scheme]
+    _check(entry(_vp(src_ptrs), _sz(counts), _vp(dst_ptrs), _sz(caps), _sz(sizes), n, int(threads or default_threads())))
     return sizes.astype(np.int64)

@@ -129,6 +129,64 @@ int inflate_one(const void* src, size_t n, void* dst, size_t cap, size_t* out) {
     return fail(DSWX_CODEC_ERR_DATA, "corrupt zlib stream (zlib result %d)", rc);
 }
 
+// TIFF compression 5 (LZW, TIFF 6.0 section 13): codes of 9 .. 12 bits packed most significant bit first, 256 = clear the
+// table, 257 = end of information, the code width grows one code EARLY (when entry 2^width - 1 would be assigned next) --
+// what libtiff, hence GDAL's COMPRESS=LZW, writes.  A stream that starts like the pre-6.0 least-significant-bit-first variant
+// (libtiff's "old-style LZW") is refused.  Like libtiff's decoder this stops when the block is full.
+int unlzw_one(const void* src_v, size_t n, void* dst_v, size_t cap, size_t* out) {
+    const unsigned char* src = static_cast<const unsigned char*>(src_v);
+    unsigned char* dst = static_cast<unsigned char*>(dst_v);
+    if (n >= 2 && src[0] == 0 && (src[1] & 1)) return fail(DSWX_CODEC_ERR_DATA, "old-style (LSB-first) LZW is not supported");
+    // every table entry is a string that already stands in the output (entry k = the string of the previous code + the first
+    // byte of the current one, which were written back to back): where it starts and how long it is
+    size_t where[4096];
+    uint16_t length[4096];
+    int nbits = 9, next = 258, old = -1;
+    uint64_t acc = 0;
+    int have = 0;
+    size_t in = 0, pos = 0, pos_old = 0;
+    int len_old = 0;
+    while (pos < cap) {
+        while (have < nbits && in < n) { acc = (acc << 8) | src[in++]; have += 8; }
+        if (have < nbits) break;                                   // ran out of codes without an end code: what there is, is the block
+        const int code = (int)((acc >> (have - nbits)) & ((1u << nbits) - 1));
+        have -= nbits;
+        if (code == 257) break;
+        if (code == 256) { nbits = 9; next = 258; old = -1; continue; }
+        if (old < 0) {
+            if (code > 255) return fail(DSWX_CODEC_ERR_DATA, "corrupt LZW stream (code %d after a clear code)", code);
+            pos_old = pos;
+            len_old = 1;
+            dst[pos++] = (unsigned char)code;
+            old = code;
+            continue;
+        }
+        const bool added = next < 4096;
+        if (added) { where[next] = pos_old; length[next] = (uint16_t)(len_old + 1); }
+        if (code > (added ? next : next - 1))
+            return fail(DSWX_CODEC_ERR_DATA, "corrupt LZW stream (code %d with %d entries)", code, next);
+        const int len = code < 256 ? 1 : length[code];
+        const size_t room = cap - pos, take = (size_t)len < room ? (size_t)len : room;
+        if (code < 256) {
+            dst[pos] = (unsigned char)code;
+        } else {
+            const size_t from = where[code];
+            if (from + take <= pos) memcpy(dst + pos, dst + from, take);
+            else for (size_t i = 0; i < take; ++i) dst[pos + i] = dst[from + i];     // the entry made just now overlaps its own copy
+        }
+        pos_old = pos;
+        len_old = len;
+        pos += take;
+        if (added) {
+            ++next;
+            if (next > (1 << nbits) - 2 && nbits < 12) ++nbits;
+        }
+        old = code;
+    }
+    *out = pos;
+    return DSWX_CODEC_OK;
+}
+
 // The processors this process may really use: the hardware threads, cut down to the container's CPU bandwidth quota
 // (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  More runnable threads than that do not run faster: the quota is spent
 // earlier in every period and the whole group is throttled until the next (measured on the MI355X box of this
@@ -321,6 +379,17 @@ int dswx_codec_inflate_blocks(const void* const* src, const size_t* src_bytes, v
     return run_blocks(n, threads, [&](int i) {
         if (!src[i] || !dst[i]) return fail(DSWX_CODEC_ERR_ARG, "block %d is NULL", i);
         return inflate_one(src[i], src_bytes[i], dst[i], dst_cap[i], &dst_bytes[i]);
+    });
+}
+
+int dswx_codec_unlzw_blocks(const void* const* src, const size_t* src_bytes, void* const* dst, const size_t* dst_cap,
+                            size_t* dst_bytes, int32_t n, int32_t threads) {
+    if (n < 0 || (n > 0 && (!src || !src_bytes || !dst || !dst_cap || !dst_bytes)))
+        return fail(DSWX_CODEC_ERR_ARG, "NULL argument");
+    if (n == 0) return DSWX_CODEC_OK;
+    return run_blocks(n, threads, [&](int i) {
+        if (!src[i] || !dst[i]) return fail(DSWX_CODEC_ERR_ARG, "block %d is NULL", i);
+        return unlzw_one(src[i], src_bytes[i], dst[i], dst_cap[i], &dst_bytes[i]);
     });
 }
 

@@ -6,7 +6,7 @@ src/proteus/dswx_hls.py:2136, `_save_array` :2893, `save_dswx_product` :2601,
 the drop-in carries this small classic-TIFF implementation of exactly what that
 path touches:
 
- read   little/big-endian classic TIFF, strips or tiles, compression none / DEFLATE
+ read   little/big-endian classic TIFF, strips or tiles, compression none / DEFLATE / LZW
         (horizontal predictor 2, floating-point predictor 3), 1..N samples (chunky or
         planar), u8/i8/u16/i16/u32/i32/f32/f64, GDAL_METADATA (42112), GDAL_NODATA (42113),
         colour map and the GeoTIFF tags (33550, 33922, 34264, 34735-34737).
@@ -19,7 +19,7 @@ path touches:
 
 The georeferencing is carried opaquely: the projection of the output product is the
 set of GeoKey tags of the input (the reference copies `GetProjection()` the same
-way, :2256-2258 -> :2668).  BigTIFF and LZW are not supported.
+way, :2256-2258 -> :2668).  BigTIFF is not supported.
 """
 import os
 import struct
@@ -204,7 +204,7 @@ class TiffDirectory:
         fmt = one(TAG_SAMPLE_FORMAT, 1)
         info.dtype = _dtype_of(bits, fmt)
         self.comp = comp = one(TAG_COMPRESSION, 1)
-        if comp not in (1, 8, 32946):
+        if comp not in (1, 5, 8, 32946):
             raise GeoTiffError(f'{path}: compression {comp} is not supported')
         predictor = one(TAG_PREDICTOR, 1)
         self.planar = planar = one(TAG_PLANAR, 1)
@@ -235,7 +235,7 @@ class TiffDirectory:
         # that claims more decoded bytes than that (or, uncompressed, more than the file holds) is not what the file contains
         claimed = self.n_blocks * self.block_bytes
         if info.width < 1 or info.height < 1 or spp < 1 or \
-                claimed > (1100 * len(buf) + (1 << 20) if comp != 1 else len(buf) + self.block_bytes * self.planes * self.across):
+                claimed > ((3000 if comp == 5 else 1100) * len(buf) + (1 << 20) if comp != 1 else len(buf) + self.block_bytes * self.planes * self.across):
             raise GeoTiffError(f'{path}: the directory claims {claimed} bytes of raster, the file has {len(buf)}')
 
         nod = one(TAG_GDAL_NODATA)
@@ -291,9 +291,12 @@ class TiffDirectory:
                     i = p * per_plane + per_plane - 1
                     raw[i * self.block_bytes: (i + 1) * self.block_bytes] = 0
             native = _codec()
+            if self.comp == 5 and native is None:
+                raise GeoTiffError(f'{self.path}: LZW needs the native codec (libdswx_codec.so)')
             if native is not None:
                 try:
-                    native.inflate_into(self.buf, offs, cnts, raw[:need], self.block_bytes)
+                    native.inflate_into(self.buf, offs, cnts, raw[:need], self.block_bytes,
+                                        scheme='lzw' if self.comp == 5 else 'deflate')
                 except native.CodecError as e:
                     raise GeoTiffError(f'{self.path}: {e}')
             else:

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <random>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "dswx_codec.h"
@@ -28,6 +29,93 @@ static std::atomic<long long> g_calls{0}, g_blocks{0}, g_expected_errors{0};
             return;                                                              \
         }                                                                        \
     } while (0)
+
+// An LZW ENCODER of the harness's own (TIFF 6.0 section 13 as libtiff writes it: most significant bit first, clear code at
+// the start and when entry 4094 is due, the width grows when the encoder's next entry passes 2^width - 1), so that the
+// library's decoder is checked against an independent statement of the format, not only against files from Pillow.
+static std::vector<unsigned char> lzw_encode(const std::vector<unsigned char>& in) {
+    std::vector<unsigned char> out;
+    uint64_t acc = 0;
+    int have = 0, nbits = 9, next = 258;
+    auto put = [&](int code) {
+        acc = (acc << nbits) | (uint64_t)code;
+        have += nbits;
+        while (have >= 8) { out.push_back((unsigned char)(acc >> (have - 8))); have -= 8; }
+    };
+    std::unordered_map<uint32_t, int> table;
+    put(256);
+    int w = -1;
+    for (unsigned char c : in) {
+        if (w < 0) { w = c; continue; }
+        const uint32_t key = ((uint32_t)w << 8) | c;
+        auto it = table.find(key);
+        if (it != table.end()) { w = it->second; continue; }
+        put(w);
+        table[key] = next++;
+        if (next == 4094) { put(256); table.clear(); next = 258; nbits = 9; }
+        else if (next > (1 << nbits) - 1) ++nbits;
+        w = c;
+    }
+    if (w >= 0) {
+        put(w);
+        ++next;
+        if (next > (1 << nbits) - 1 && nbits < 12) ++nbits;
+    }
+    put(257);
+    if (have) out.push_back((unsigned char)(acc << (8 - have)));
+    return out;
+}
+
+static void lzw_caller(int id, int rounds) {
+    std::mt19937_64 rng(777 + id);
+    for (int r = 0; r < rounds; ++r) {
+        const int n = 1 + (int)(rng() % 40);
+        const int threads = 1 + (int)(rng() % 12);
+        std::vector<std::vector<unsigned char>> src(n), enc(n), dec(n);
+        std::vector<const void*> ep(n);
+        std::vector<void*> dp(n);
+        std::vector<size_t> es(n), dc(n), ds(n);
+        for (int i = 0; i < n; ++i) {
+            const size_t len = (rng() % 11 == 0) ? 0 : 1 + (size_t)(rng() % 300000);
+            src[i].resize(len);
+            const int kind = (int)(rng() % 4);
+            for (size_t k = 0; k < len; ++k)
+                src[i][k] = kind == 0 ? (unsigned char)(rng() & 0xff) : kind == 1 ? (unsigned char)((k / 97) % 5) : kind == 2 ? 0 : (unsigned char)((k % 7) * (k % 3));
+            enc[i] = lzw_encode(src[i]);
+            dec[i].assign(len + 1, 0xEE);
+            ep[i] = enc[i].data(); es[i] = enc[i].size();
+            dp[i] = dec[i].data(); dc[i] = dec[i].size();
+        }
+        CHECK(dswx_codec_unlzw_blocks(ep.data(), es.data(), dp.data(), dc.data(), ds.data(), n, threads) == DSWX_CODEC_OK, "unlzw");
+        for (int i = 0; i < n; ++i)
+            CHECK(ds[i] == src[i].size() && (ds[i] == 0 || memcmp(dec[i].data(), src[i].data(), ds[i]) == 0) && dec[i][ds[i]] == 0xEE, "LZW round trip");
+        g_calls.fetch_add(1);
+        g_blocks.fetch_add(n);
+        // a destination shorter than the stream: filled, no error, nothing written behind it (libtiff's behaviour)
+        for (int i = 0; i < n; ++i) if (src[i].size() > 10) {
+            dc[i] = src[i].size() / 2;
+            dec[i].assign(src[i].size() + 1, 0xEE);
+            dp[i] = dec[i].data();
+        }
+        CHECK(dswx_codec_unlzw_blocks(ep.data(), es.data(), dp.data(), dc.data(), ds.data(), n, threads) == DSWX_CODEC_OK, "unlzw into short blocks");
+        for (int i = 0; i < n; ++i) if (src[i].size() > 10)
+            CHECK(ds[i] == dc[i] && memcmp(dec[i].data(), src[i].data(), ds[i]) == 0 && dec[i][ds[i]] == 0xEE, "short LZW block");
+        // damaged streams: any outcome but a memory error (the sanitizers watch): OK or a data error
+        for (int i = 0; i < n; ++i) {
+            for (int k = 0; k < 4 && !enc[i].empty(); ++k) enc[i][rng() % enc[i].size()] ^= (unsigned char)(1 + rng() % 255);
+            if (rng() % 3 == 0) enc[i].resize(enc[i].size() / 2);
+            ep[i] = enc[i].data(); es[i] = enc[i].size();
+            if (es[i] == 0) { enc[i].push_back(0x80); ep[i] = enc[i].data(); es[i] = 1; }
+            dc[i] = src[i].size() / 2 + 1;
+            dec[i].assign(dc[i] + 1, 0xEE);
+            dp[i] = dec[i].data();
+        }
+        const int rc = dswx_codec_unlzw_blocks(ep.data(), es.data(), dp.data(), dc.data(), ds.data(), n, threads);
+        CHECK(rc == DSWX_CODEC_OK || rc == DSWX_CODEC_ERR_DATA, "damaged LZW stream");
+        for (int i = 0; i < n; ++i) CHECK(dec[i][dc[i]] == 0xEE, "damaged LZW stream wrote behind its block");
+        g_expected_errors.fetch_add(rc != DSWX_CODEC_OK);
+    }
+}
 
 static void caller(int id, int rounds) {
     std::mt19937_64 rng(1234 + id);
@@ -95,6 +183,7 @@ int main(int argc, char** argv) {
         dswx_codec_force_zlib(engine);
         std::vector<std::thread> ts;
         for (int c = 0; c < callers; ++c) ts.emplace_back(caller, 100 * engine + c, rounds);
+        ts.emplace_back(lzw_caller, engine, rounds / 2 + 1);          // the LZW decoder shares the pool with them
         for (auto& t : ts) t.join();
     }
     dswx_codec_force_zlib(0);

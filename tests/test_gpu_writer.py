@@ -123,6 +123,12 @@ def test_untile_tiles_and_strips(ctx, tmp_path, shape, dtype):
     assert not d.tiled and d.bw == W
     got = _untile(ctx, d.inflate(), dtype, H, W, d.bw, d.bh, d.predictor)
     assert np.array_equal(got, arr)
+    # the same raster as an LZW file (what other GDAL tools often hand over): the native codec's LZW decoder, then the device
+    Image.fromarray(arr).save(q, compression='tiff_lzw', tiffinfo={317: 2})
+    d = geotiff.open_geotiff(q)
+    assert d.comp == 5 and d.predictor == 2
+    got = _untile(ctx, d.inflate(), dtype, H, W, d.bw, d.bh, d.predictor)
+    assert np.array_equal(got, arr)
 
 
 def test_rgb_planes(ctx):

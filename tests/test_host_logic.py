@@ -745,3 +745,50 @@ def test_every_tool_and_helper_script_parses():
     assert len(paths) > 20
     for p in paths:
         ast.parse(open(p).read(), filename=p)
+
+
+def test_lzw_files_read_like_deflate_files(tmp_path):
+    """TIFF compression 5 (LZW): ancillary rasters from other GDAL tools are often LZW files, and `gdal.Open` reads them like
+    any other.  libtiff (through Pillow) writes them -- strips, predictor 1 / 2 / 3, one- to four-byte samples, rasters that
+    compress 150 : 1 and rasters that do not compress -- and the reader (native decoder, proteus_amd/csrc/dswx_codec.cpp)
+    returns the arrays; a damaged file is an unreadable file, not a crash.  (The decoder is also checked against an
+    encoder of the sanitizer harness's own: tests/native/codec_stress.cpp.)"""
+    from PIL import Image, features
+    if not features.check('libtiff'):
+        pytest.skip('Pillow without libtiff')
+    rng = np.random.default_rng(55)
+    cases = (('classes', rng.integers(0, 5, size=(700, 513)).astype(np.uint8), 1),
+             ('bytes_p2', rng.integers(0, 255, size=(300, 1000)).astype(np.uint8), 2),
+             ('flat', np.full((2000, 1500), 7, np.uint8), 1),
+             ('u16_p2', rng.integers(0, 9000, size=(333, 1000)).astype(np.uint16), 2),
+             ('i32', rng.integers(-10 ** 6, 10 ** 6, size=(100, 77)).astype(np.int32), 1),
+             ('f32', rng.normal(size=(300, 257)).astype(np.float32), 1),
+             ('f32_p3', (rng.normal(size=(300, 257)) * 100).astype(np.float32), 3),
+             ('noise', rng.integers(0, 256, size=(1024, 1024)).astype(np.uint8), 1),
+             ('one', np.array([[9]], np.uint8), 1))
+    for name, arr, pred in cases:
+        p = str(tmp_path / f'{name}.tif')
+        Image.fromarray(arr).save(p, compression='tiff_lzw', tiffinfo={317: pred} if pred > 1 else {})
+        d = geotiff.open_geotiff(p)
+        assert d.comp == 5 and d.predictor == pred, name
+        got, info = geotiff.read_geotiff(p)
+        assert got.dtype == arr.dtype and np.array_equal(got, arr), name
+    # damage: flipped bytes inside the strips, a truncated file
+    p = str(tmp_path / 'classes.tif')
+    raw = bytearray(open(p, 'rb').read())
+    d = geotiff.open_geotiff(p)
+    for trial in range(40):
+        bad = bytearray(raw)
+        for _ in range(6):
+            i = int(rng.integers(0, d.n_blocks))
+            bad[d.offs[i] + int(rng.integers(0, d.cnts[i]))] ^= int(rng.integers(1, 256))
+        q = str(tmp_path / 'bad.tif')
+        open(q, 'wb').write(bytes(bad))
+        try:
+            got, _ = geotiff.read_geotiff(q)
+            assert got.shape == (700, 513)
+        except geotiff.GeoTiffError:
+            pass
+    open(q, 'wb').write(bytes(raw[:len(raw) // 2]))
+    with pytest.raises(geotiff.GeoTiffError):
+        geotiff.read_geotiff(q)
