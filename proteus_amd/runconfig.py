@@ -28,9 +28,12 @@ def deep_update(main, update):
     return main
 
 
+_SAFE_LOADER = getattr(yaml, 'CSafeLoader', yaml.SafeLoader)     # libyaml when PyYAML was built with it: the same documents, ~10 x faster
+
+
 def load_yaml(path):
     with open(path) as fh:
-        return yaml.safe_load(fh)
+        return yaml.load(fh, Loader=_SAFE_LOADER)
 
 
 # ---- schema ------------------------------------------------------------------------
