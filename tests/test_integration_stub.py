@@ -115,16 +115,16 @@ def test_batch_stub_runs_and_matches_the_oracle():
     lib.dswx_ctx_destroy(ctx)
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name='resident_batch'):
     import shutil
     import subprocess
     if shutil.which('gcc') is None:
         pytest.skip('no gcc')
-    exe = str(tmp_path / 'resident_batch')
+    exe = str(tmp_path / name)
     lib_dir = os.path.dirname(_capi.library_path())
     _capi.load_library()                      # builds the library when missing or stale
     subprocess.run(['gcc', '-std=c11', '-O2', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'),
-                    os.path.join(ROOT, 'examples', 'resident_batch.c'), '-L', lib_dir, '-ldswx_hip',
+                    os.path.join(ROOT, 'examples', f'{name}.c'), '-L', lib_dir, '-ldswx_hip',
                     f'-Wl,-rpath,{lib_dir}', '-o', exe], check=True)
     return exe
 
@@ -170,6 +170,44 @@ def test_c_example_runs_and_matches_the_oracle(tmp_path):
         return h
     for key in ('diag', 'wtr1', 'wtr2', 'wtr', 'bwtr', 'conf', 'cloud'):
         assert f'checksum {key} {fnv([e[key] for e in exp]):016x}' in lines, key
+
+
+def test_writer_side_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    import subprocess
+    exe = _build_c_example(tmp_path, 'product_layers')
+    if _capi.device_count() > 0:
+        pytest.skip('a GPU is present (the GPU test runs the program)')
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and 'no CPU fallback' in r.stderr
+
+
+@pytest.mark.gpu
+def test_writer_side_c_example_matches_the_row_by_row_oracle(tmp_path):
+    """examples/product_layers.c: the ABI v6 entries (dswx_cog_layout, dswx_cog_blocks_device, dswx_untile_device) from C
+    alone -- the level geometry and an FNV-1a checksum of every level's block bytes of the WTR layer against
+    oracle/cog_oracle.py (NEAREST pick, tiling, horizontal differencing, row by row) on the oracle's own WTR."""
+    import subprocess
+    from oracle import c_oracle, cog_oracle
+    from proteus_amd.synth import synth_tile
+    exe = _build_c_example(tmp_path, 'product_layers')
+    size, tile = 700, 128
+    r = subprocess.run([exe, str(size), str(tile)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    s = synth_tile(0, size, size, with_masks=True)
+    wtr = c_oracle.classify(_capi.default_params(), s['bands'], s['fmask'], land=s['land'], shad=s['shad'], ocean=s['ocean'])['wtr']
+
+    def fnv(data):
+        h = 1469598103934665603
+        for byte in bytes(data):
+            h = ((h ^ byte) * 1099511628211) & 0xffffffffffffffff
+        return h
+    levels = cog_oracle.cog_levels(wtr, (4, 16, 64, 128), tile, 2)
+    assert lines[0] == f'levels {len(levels)}, {sum(len(b) for _, _, b in levels)} bytes'
+    for k, ((h, w, data), f) in enumerate(zip(levels, (1, 4, 16, 64, 128))):
+        assert lines[1 + k] == (f'level {k}: factor {f}, {h} x {w}, {-(-h // tile)} x {-(-w // tile)} blocks, '
+                                f'checksum {fnv(data):016x}'), (k, lines[1 + k])
+    assert lines[1 + len(levels)] == f'layer checksum {fnv(wtr.tobytes()):016x}, round trip ok'
 
 
 def cog_stub_source():
