@@ -295,10 +295,13 @@ class TiffDirectory:
                 raise GeoTiffError(f'{self.path}: LZW needs the native codec (libdswx_codec.so)')
             if native is not None:
                 try:
-                    native.inflate_into(self.buf, offs, cnts, raw[:need], self.block_bytes,
-                                        scheme='lzw' if self.comp == 5 else 'deflate')
+                    sizes = native.inflate_into(self.buf, offs, cnts, raw[:need], self.block_bytes,
+                                                scheme='lzw' if self.comp == 5 else 'deflate')
                 except native.CodecError as e:
                     raise GeoTiffError(f'{self.path}: {e}')
+                # a stream that ends early leaves the rest of its block as zeros (the staging buffer is recycled memory)
+                for i in np.flatnonzero(sizes < self.block_bytes):
+                    raw[i * self.block_bytes + int(sizes[i]): (i + 1) * self.block_bytes] = 0
             else:
                 def one_block(i):
                     data = zlib.decompress(self.buf[offs[i]: offs[i] + cnts[i]])[:self.block_bytes]
