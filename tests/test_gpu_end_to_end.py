@@ -345,7 +345,8 @@ def test_batch_driver_single_gpu(tmp_path):
 def test_product_from_band_files_written_by_another_library(tmp_path):
     """The reader side of the pipeline on FOREIGN layouts: the seven band files rewritten by Pillow / libtiff -- DEFLATE
     STRIPS with the horizontal predictor (the short last strip; the device's untile kernel with block width = raster
-    width, not a multiple of 8), one of them uncompressed with a stray PREDICTOR tag (libtiff ignores it there) -- carrying
+    width, not a multiple of 8), one of them uncompressed with a stray PREDICTOR tag (libtiff ignores it there), two of them
+    LZW files (the native codec's LZW decoder) -- carrying
     the GDAL metadata and nodata tags of the originals.  The product's layers are what the oracle computes from the
     arrays."""
     from PIL import Image, TiffImagePlugin, features
@@ -370,9 +371,10 @@ def test_product_from_band_files_written_by_another_library(tmp_path):
             ifd[339] = 2                                        # SampleFormat: two's complement
         dst = str(foreign / os.path.basename(path))
         img = Image.fromarray(arr.view(np.uint16) if arr.dtype == np.int16 else arr)
-        img.save(dst, compression=None if k == 2 else 'tiff_adobe_deflate', tiffinfo=ifd)
+        img.save(dst, compression=None if k == 2 else ('tiff_lzw' if k in (4, 6) else 'tiff_adobe_deflate'), tiffinfo=ifd)
         d = geotiff.open_geotiff(dst)
         assert not d.tiled and d.bw == size and d.info.dtype == arr.dtype and d.predictor == (1 if k == 2 else 2)
+        assert d.comp == (1 if k == 2 else (5 if k in (4, 6) else 8))
         assert k == 2 or (d.down > 1 and size % d.bh)           # DEFLATE: several strips, the last one short
         new_files.append(dst)
     out = {n: str(tmp_path / f'{n}.tif') for n in ('wtr', 'conf', 'diag', 'cloud')}
