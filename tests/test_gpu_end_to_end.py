@@ -508,3 +508,19 @@ def test_ancillary_files_off_grid_are_refused(tmp_path):
     with pytest.raises(NotImplementedError, match='shoreline'):
         D.generate_dswx_layers(files, shoreline_shapefile='coast.shp', apply_ocean_masking=True,
                                scratch_dir=str(tmp_path))
+
+
+def test_product_option_fuzz_and_inflight_soak():
+    """Short runs of the two product-path soaks in child processes (their long runs: profiles/r06_product_fuzz.json,
+    r06_inflight_soak.json): random option sets through generate_dswx_layers with four runs side by side in one process, and
+    the node-level driver with six tiles in flight -- every output file checked against the oracles inside the helpers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for argv in (['product_fuzz.py', '--cases', '48', '--threads', '4', '--seed', '9'],
+                 ['inflight_soak.py', '--tiles', '24', '--in-flight', '6']):
+        res = subprocess.run([sys.executable, os.path.join(root, 'tests', 'helpers', argv[0])] + argv[1:], capture_output=True,
+                             text=True, timeout=600)
+        assert res.returncode == 0, (argv, res.stdout[-800:], res.stderr[-800:])
+        assert json.loads(res.stdout.strip().splitlines()[-1])['ok'] is True
