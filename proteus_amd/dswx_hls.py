@@ -1479,7 +1479,12 @@ def _save_dswx_product_planes(engine, layers, output_file, dswx_metadata_dict, g
             if a is None:
                 bands.append(engine.constant_plane(shape, UINT8_FILL_VALUE))
             else:
-                bands.append(engine.byte_plane(a if isinstance(a, pipeline.DevicePlane) else engine.upload(np.asarray(a))))
+                if not isinstance(a, pipeline.DevicePlane):
+                    a = np.asarray(a)
+                    if a.dtype.name not in ('uint8', 'bool', 'uint16', 'int16', 'float32'):
+                        a = _gdal_byte(a)                           # a type the device conversion does not take
+                    a = engine.upload(a)
+                bands.append(engine.byte_plane(a))
         if nbands > len(names):
             bands += [engine.constant_plane(shape, 0)] * (nbands - len(names))    # an unwritten GTiff band reads as zeros
         levels = engine.band_stack_levels(bands, geotiff.COG_OVERVIEW_FACTORS)
