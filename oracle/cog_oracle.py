@@ -16,12 +16,23 @@ What it restates, and from where:
       planes, most significant byte first, then the whole row of bytes differenced byte-wise.
   The inverses (horAcc / fpAcc) are what `ReadAsArray` applies when a band file is read (dswx_hls.py:2136-2302).
 * `_save_output_rgb_file` (dswx_hls.py:3013-3036): scale * (float32(band) - offset), NaN at the invalid pixels.
+* CUBICSPLINE overviews of the non-integer layers (core.py:41-46): GDAL's GDALResampleChunk_Convolution with the cubic
+  B-spline (GWKBSpline; published algorithm, gcore/overview.cpp + alg/gdalwarpkernel.cpp): a destination pixel is centred on
+  source coordinate (i + 0.5) * ratio, the kernel is stretched by the decimation ratio (support 2 * ratio source pixels
+  either side), evaluated at the source pixel centres, normalised over the pixels that exist and are not NaN; horizontal
+  pass, then vertical pass, in double; levels in cascade (GDALRegenerateCascadingOverviews).
+* the Byte bands of `save_dswx_product` (dswx_hls.py:2663-2666: every band GDT_Byte): GDALCopyWords clamps integers to
+  0 .. 255 and rounds floating point half up after clamping, NaN -> 0.
+* the browse PNG's resize (`geotiff2png`, dswx_hls.py:5335-5349): GDAL RasterIO's nearest pick, src = floor((dst + 0.5) *
+  N_src / N_dst).
 
-PINNING.  No GDAL exists in this image, so the NEAREST rule is unpinned by execution ("parity unpinned" for the
-overview pick: DESIGN.md section 8 says so).  The two predictors ARE pinned against an independent implementation: libtiff,
+PINNING.  No GDAL exists in this image, so the NEAREST rule, the CUBICSPLINE convolution, the Byte conversion and the
+RasterIO pick are unpinned by execution ("parity unpinned" for them: DESIGN.md section 8 says so).  The two predictors ARE pinned against an independent implementation: libtiff,
 through Pillow, decodes files whose blocks were made by these functions' product-side counterparts
 (tests/test_host_logic.py) and encodes files these inverses decode (tests/test_cog_oracle.py).
 """
+import math
+
 import numpy as np
 
 
@@ -141,3 +152,101 @@ def rgb_planes(bands, diag, scales, offsets, clip=True):
             v[diag == 65535] = np.nan
         out.append(v)
     return np.stack(out)
+
+
+def _bspline(x):
+    """The cubic B-spline, support |x| < 2."""
+    x = abs(x)
+    if x <= 1.0:
+        return 2.0 / 3.0 + x * x * (0.5 * x - 1.0)
+    if x < 2.0:
+        return (2.0 - x) ** 3 / 6.0
+    return 0.0
+
+
+def _convolve_line(line, n_out):
+    """One line (Python floats) -> n_out values (Python floats): the stretched B-spline over the existing, non-NaN taps."""
+    n_in = len(line)
+    ratio = n_in / n_out
+    scale = min(1.0, 1.0 / ratio)
+    radius = 2.0 / scale
+    taps = int(math.ceil(2 * radius)) + 1
+    out = []
+    for i in range(n_out):
+        centre = (i + 0.5) * ratio
+        first = int(math.floor(centre - radius + 0.5))
+        num = den = 0.0
+        for j in range(first, first + taps):
+            if j < 0 or j >= n_in:
+                continue
+            v = line[j]
+            if v != v:
+                continue
+            w = _bspline((j + 0.5 - centre) * scale)
+            if w > 0.0:
+                num += v * w
+            den += w
+        out.append(num / den if den > 0.0 else float('nan'))
+    return out
+
+
+def cubicspline_overview(arr, factor):
+    """One CUBICSPLINE overview level of a 2-D float32 raster, line by line: rows first (kept in double), then columns."""
+    h, w = arr.shape
+    oh, ow = -(-h // factor), -(-w // factor)
+    rows = [_convolve_line([float(v) for v in arr[y]], ow) for y in range(h)]
+    out = np.empty((oh, ow), np.float32)
+    with np.errstate(over='ignore'):
+        for x in range(ow):
+            col = _convolve_line([rows[y][x] for y in range(h)], oh)
+            for y in range(oh):
+                out[y, x] = np.float32(col[y])
+    return out
+
+
+def cubicspline_pyramid(arr, factors):
+    """[arr, level f1, level f2, ...]: each level from the previous one when its factor divides (and the sizes agree), else
+    from the full-resolution raster."""
+    h, w = arr.shape
+    levels, prev_f = [arr], 1
+    for f in factors:
+        if f <= 1 or (h, w) == (1, 1):
+            continue
+        want = (-(-h // f), -(-w // f))
+        lv = None
+        if prev_f > 1 and f % prev_f == 0:
+            lv = cubicspline_overview(levels[-1], f // prev_f)
+            if lv.shape != want:
+                lv = None
+        if lv is None:
+            lv = cubicspline_overview(arr, f)
+        levels.append(lv)
+        prev_f = f
+    return levels
+
+
+def gdal_byte(arr):
+    """A raster as GDAL stores it in a Byte band, element by element."""
+    flat = arr.ravel()
+    out = np.empty(flat.size, np.uint8)
+    for i, v in enumerate(flat):
+        if arr.dtype.kind == 'f':
+            x = float(v)
+            if x != x:
+                x = 0.0
+            x = min(max(x, 0.0), 255.0)
+            out[i] = int(min(math.floor(x + 0.5), 255.0))
+        else:
+            out[i] = min(max(int(v), 0), 255)
+    return out.reshape(arr.shape)
+
+
+def resample_nearest(arr, out_height, out_width):
+    """RasterIO's nearest-neighbour resize, element by element."""
+    h, w = arr.shape
+    out = np.empty((out_height, out_width), arr.dtype)
+    for i in range(out_height):
+        y = min(int((i + 0.5) * h / out_height), h - 1)
+        for j in range(out_width):
+            out[i, j] = arr[y, min(int((j + 0.5) * w / out_width), w - 1)]
+    return out

@@ -108,3 +108,46 @@ def test_rgb_oracle_statement():
     assert out.dtype == np.float32 and out.shape == (3, 40, 50)
     assert np.isnan(out[:, diag == 65535]).all() and not np.isnan(out[:, diag != 65535]).any()
     assert out[1, 1, 1] == np.float32(2e-4) * (np.float32(max(int(bands[1][1, 1]), 1)) - np.float32(-3.0))
+
+
+@pytest.mark.parametrize('shape', [(37, 53), (64, 64), (5, 3), (1, 7), (130, 90), (2, 2)])
+def test_cubicspline_byte_and_resize_statements_against_the_oracle(shape):
+    """The host writer's whole-array statements of the three GDAL rules round 6 moved onto the device -- CUBICSPLINE
+    overview pyramid of a Float32 layer (core.py:41-46), the Byte bands of the multi-band file (dswx_hls.py:2663-2666), the
+    browse image's resize (:5335-5349) -- against oracle/cog_oracle.py's element-by-element restatements: bit for bit, NaN
+    holes, infinities and rounding edges included; plus the properties that define the convolution (a constant raster
+    stays constant, weights renormalised around NaN, all-NaN support -> NaN)."""
+    from oracle import cog_oracle as co
+    from proteus_amd import dswx_hls as D
+    rng = np.random.default_rng(shape[0] * 31 + shape[1])
+    a = (rng.normal(size=shape) * 1000).astype(np.float32)
+    a[rng.random(shape) < 0.05] = np.nan
+    if shape[0] > 30:
+        a[3:22, 4:30] = np.nan
+        a[25, 7], a[27, 9] = np.inf, -np.inf
+    want = co.cubicspline_pyramid(a, geotiff.COG_OVERVIEW_FACTORS)
+    got, prev = [a], 1
+    for f in geotiff.COG_OVERVIEW_FACTORS:                     # write_geotiff's cascade
+        lv = geotiff.overview_cubicspline(got[-1], f // prev) if prev > 1 and f % prev == 0 else geotiff.overview_cubicspline(a, f)
+        if lv.shape != tuple(-(-n // f) for n in shape):
+            lv = geotiff.overview_cubicspline(a, f)
+        got.append(lv)
+        prev = f
+    assert len(got) == len(want) == 5
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g.dtype == np.float32 and g.shape == w.shape and np.array_equal(g, w, equal_nan=True), k
+    if shape[0] > 30:
+        assert np.isnan(want[1]).any() and np.isinf(want[1]).any()
+    flat = np.full(shape, 3.25, np.float32)
+    flat[0, 0] = np.nan                                         # renormalised: the constant survives a missing tap
+    lv = co.cubicspline_overview(flat, 4)
+    assert np.allclose(lv[np.isfinite(lv)], 3.25, rtol=1e-6, atol=0) and np.isfinite(lv).sum() >= lv.size - 1
+    # Byte conversion
+    f = np.concatenate([np.arange(-3, 260, 0.25), [np.nan, np.inf, -np.inf, 1e30, 254.5, 255.49, 0.49999997]]).astype(np.float32)
+    for arr in (f.reshape(1, -1), np.arange(-300, 700, dtype=np.int16).reshape(10, 100), np.arange(0, 65536, 257, dtype=np.uint16).reshape(1, -1),
+                rng.integers(0, 256, size=shape).astype(np.uint8)):
+        assert np.array_equal(D._gdal_byte(arr), co.gdal_byte(arr)), arr.dtype
+    # resize
+    u = rng.integers(0, 255, size=shape).astype(np.uint8)
+    for oh, ow in ((10, 10), shape, (70, 90), (1, 1), (5, 100)):
+        assert np.array_equal(geotiff.resample_nearest(u, oh, ow), co.resample_nearest(u, oh, ow)), (oh, ow)

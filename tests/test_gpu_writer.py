@@ -478,3 +478,33 @@ def test_browse_resampling_in_hbm(ctx, dtype):
                 assert got.dtype == a.dtype and np.array_equal(got, geotiff.resample_nearest(a, oh, ow)), (shape, oh, ow)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('shape', [(37, 53), (5, 3), (1, 7), (130, 90), (259, 77)])
+def test_round6_writer_kernels_against_the_element_by_element_oracle(ctx, shape):
+    """dswx_convolve_axis_device (the CUBICSPLINE pyramid), dswx_to_byte_device, dswx_gather_2d_device against
+    oracle/cog_oracle.py's restatements of the three GDAL rules (element by element, no code shared with the product)."""
+    from oracle import cog_oracle as co
+    from proteus_amd import pipeline
+    rng = np.random.default_rng(shape[0] * 17 + shape[1])
+    a = (rng.normal(size=shape) * 1000).astype(np.float32)
+    a[rng.random(shape) < 0.05] = np.nan
+    if shape[0] > 30:
+        a[3:22, 4:30] = np.nan
+        a[25, 7], a[27, 9] = np.inf, -np.inf
+    eng = pipeline.TileEngine(ctx)
+    try:
+        got = eng._float_pyramid(eng.upload(a), FACTORS)
+        want = co.cubicspline_pyramid(a, FACTORS)
+        assert len(got) == len(want)
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert np.array_equal(g.numpy(), w, equal_nan=True), k
+        f = np.resize(np.concatenate([np.arange(-3, 260, 0.25), [np.nan, np.inf, -np.inf, 1e30, 254.5, 255.49]]).astype(np.float32), shape)
+        for arr in (f, rng.integers(-300, 700, size=shape).astype(np.int16), rng.integers(0, 65536, size=shape).astype(np.uint16)):
+            assert np.array_equal(eng.byte_plane(eng.upload(arr)).numpy(), co.gdal_byte(arr)), arr.dtype
+        u = rng.integers(0, 255, size=shape).astype(np.uint8)
+        plane = eng.upload(u)
+        for oh, ow in ((10, 10), shape, (70, 90), (1, 1), (5, 100)):
+            assert np.array_equal(eng.resample_nearest(plane, oh, ow), co.resample_nearest(u, oh, ow)), (oh, ow)
+    finally:
+        eng.close()
