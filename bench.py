@@ -102,6 +102,9 @@ def parse_args():
                     help='measure the `strong` sub-record (BASELINE configs[3]) after the first record whatever N is: at N = 1 '
                          'the one rank walks all 4096 tiles in 512-tile chunks (the weak batch is freed first: the same '
                          'sequence an N > 1 rank goes through, at its real sizes)')
+    ap.add_argument('--no-product-run', action='store_true',
+                    help='skip the product-run leg of the plain N = 1 command (one full GeoTIFF-in / COG-out product of a '
+                         '3660 x 3660 tile in a child process, after the timed regions)')
     ap.add_argument('--no-single-tile', action='store_true',
                     help='skip the configs[1] leg (profiling runs: keeps the kernel statistics to the batch launches)')
     ap.add_argument('--cpu-parallel-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -263,6 +266,33 @@ def cpu_baseline_parallel():
         return json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:      # the baseline is a report, never a reason to lose the bench line
         return {'error': str(e)[:200]}
+
+
+def product_run_leg(timeout_s=240):
+    """The number a user of `dswx_hls.py <runconfig>` sees, beside the kernel's: ONE full product run of a 3660 x 3660
+    tile -- seven DEFLATE GeoTIFFs in, seven cloud-optimized layers out, through proteus_amd.dswx_hls.generate_dswx_layers
+    (inflate on host threads, untile / classify / COG blocks + overviews on the device, deflate on host threads) -- in a
+    CHILD process with its own HIP context (tools/e2e_time.py: best of three), on the bench's synthetic recipe (a surface
+    type per pixel: noise-like class maps, DEFLATE at its slowest) and on a spatially coherent scene.  After the timed
+    regions; never `value`; a failure is a record."""
+    import subprocess
+    out = {}
+    for key, extra in (('synthetic_recipe_tile', []), ('coherent_scene_tile', ['--scene'])):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'e2e_time.py'),
+                                str(TILE)] + extra, capture_output=True, text=True, timeout=timeout_s)
+            d = json.loads(r.stdout[r.stdout.index('{'):])
+            out[key] = {'seconds_per_product': d['generate_dswx_layers_s_io_threads_default'],
+                        'Mpixels_per_s': round(TILE * TILE / d['generate_dswx_layers_s_io_threads_default'] / 1e6, 1),
+                        'codec_threads': d['io_threads_default'],
+                        'seconds_on_one_codec_thread': d['generate_dswx_layers_s_io_threads_1'],
+                        'input_MB': d.get('input_MB'), 'output_MB': d.get('output_MB'),
+                        'stages_wall_s': {n: v['wall_s'] for n, v in d['stages_io_threads_default']['stages'].items()}}
+        except Exception as e:      # noqa: BLE001  (a reported figure must never cost the bench line)
+            out[key] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    out['note'] = ('one fresh child process per input kind, warm product runs inside it (best of three); host codec = '
+                   'libdswx_codec.so on the container\'s CPU quota; DESIGN.md section 6, profiles/r06_product_run.json')
+    return out
 
 
 def single_tile_leg(ctx, params, masks, reps=50):
@@ -1305,6 +1335,8 @@ def _main():
                 out['single_tile'] = single_tile_leg(ctx, env.params, args.masks)
             except Exception as e:
                 out['single_tile'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+        if solo and args.plain_command and not args.plain_tiles and not args.no_product_run:
+            out['product_run'] = product_run_leg()
         if world == 1 and not args.no_cpu_baseline and not failed_any:
             try:
                 out['cpu_baseline'] = cpu_baseline_sample()

@@ -524,3 +524,21 @@ def test_product_option_fuzz_and_inflight_soak():
                              text=True, timeout=600)
         assert res.returncode == 0, (argv, res.stdout[-800:], res.stderr[-800:])
         assert json.loads(res.stdout.strip().splitlines()[-1])['ok'] is True
+
+
+def test_bench_product_run_leg(monkeypatch):
+    """bench.py's `product_run` record (the plain N = 1 command, after the timed regions): one product of the synthetic
+    recipe and one of a coherent scene in child processes -- at a small tile size here."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    monkeypatch.setattr(bench, 'TILE', 300)
+    rec = bench.product_run_leg(timeout_s=200)
+    for key in ('synthetic_recipe_tile', 'coherent_scene_tile'):
+        assert 'error' not in rec[key], rec[key]
+        assert rec[key]['seconds_per_product'] > 0 and rec[key]['stages_wall_s']['gpu: classify (resident planes)'] >= 0
+        assert rec[key]['output_MB'] > 0
+    # a child that cannot run is a record, not an exception
+    monkeypatch.setattr(bench, 'TILE', 0)
+    assert 'error' in bench.product_run_leg(timeout_s=60)['synthetic_recipe_tile']
