@@ -276,6 +276,8 @@ def product_run_leg(timeout_s=240):
     type per pixel: noise-like class maps, DEFLATE at its slowest) and on a spatially coherent scene.  After the timed
     regions; never `value`; a failure is a record."""
     import subprocess
+    if 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCPROFILER')) for k in os.environ):
+        return {'skipped': 'running under a profiler: its trace stays the bench kernels\' (run `python tools/e2e_time.py` on its own)'}
     out = {}
     for key, extra in (('synthetic_recipe_tile', []), ('coherent_scene_tile', ['--scene'])):
         try:
