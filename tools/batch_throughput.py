@@ -19,7 +19,7 @@ from proteus_amd import batch                   # noqa: E402
 
 def main():
     scene = '--scene' in sys.argv
-    pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+    pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith('--') and sys.argv[i - 1] != '--grid']
     n = int(pos[0]) if len(pos) > 0 else 8
     size = int(pos[1]) if len(pos) > 1 else 3660
     out = {'tiles': n, 'size': size, 'inputs': 'coherent scenes (4 distinct)' if scene else 'per-pixel recipe (noise-like class maps)'}
@@ -27,7 +27,10 @@ def main():
         rcs = [synth_hls.make(os.path.join(d, f't{i}'), sensor=('L30', 'S30')[i % 2], size=size, tile=i % 4 if scene else i,
                               product_id=f'P{i}', scene=scene)[0] for i in range(n)]
         import shutil
-        for wpg, in_flight in ((1, 1), (1, 3), (2, 2)) if scene else ((1, 1), (1, 3), (2, 2), (4, 1), (8, 1)):
+        grid = ((1, 1), (1, 3), (2, 2)) if scene else ((1, 1), (1, 3), (2, 2), (4, 1), (8, 1))
+        if '--grid' in sys.argv:            # workers per GPU x tiles in flight, e.g. --grid 1x3,2x2,2x3
+            grid = tuple(tuple(int(v) for v in g.split('x')) for g in sys.argv[sys.argv.index('--grid') + 1].split(','))
+        for wpg, in_flight in grid:
             for i in range(n):
                 shutil.rmtree(os.path.join(d, f't{i}', 'output'), ignore_errors=True)
             reports = []
