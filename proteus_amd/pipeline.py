@@ -259,23 +259,18 @@ class TileEngine:
         return out
 
     # ---- writer side ----------------------------------------------------------------------------------------
+    WEIGHTS_CAP = 64            # (n_in, n_out) pairs kept: a worker sees one tile size, i.e. about ten pairs
+
     def _conv_weights(self, n_in, n_out):
+        """Device copies of geotiff.convolve_weights(n_in, n_out), cached.  Called with the engine's lock HELD."""
         key = (int(n_in), int(n_out))
-        with self._pool_lock:
-            hit = self._weights.get(key)
+        hit = self._weights.get(key)
         if hit is None:
             first, w = geotiff.convolve_weights(*key)
-            with self.lock:
-                d_first, d_w = self.ctx.malloc(max(first.size * 4, 16)), self.ctx.malloc(max(w.nbytes, 16))
-                d_first.upload(first.astype(np.int32))
-                d_w.upload(np.ascontiguousarray(w.T))          # [taps][n_out]: the layout the device pass reads
-            hit = (d_first, d_w, w.shape[1])
-            with self._pool_lock:
-                kept = self._weights.setdefault(key, hit)
-            if kept is not hit:                 # another tile's thread got there first
-                hit[0].free()
-                hit[1].free()
-            hit = kept
+            d_first, d_w = self.ctx.malloc(max(first.size * 4, 16)), self.ctx.malloc(max(w.nbytes, 16))
+            d_first.upload(first.astype(np.int32))
+            d_w.upload(np.ascontiguousarray(w.T))               # [taps][n_out]: the layout the device pass reads
+            hit = self._weights[key] = (d_first, d_w, w.shape[1])
         return hit
 
     def cubicspline_overview(self, plane, factor):
@@ -283,12 +278,17 @@ class TileEngine:
         into float64, vertical pass, float32): what `save_as_cog` asks GDAL for on non-integer layers (core.py:41-46)."""
         H, W = plane.shape
         oh, ow = -(-H // factor), -(-W // factor)
-        fx, wx, tx = self._conv_weights(W, ow)
-        fy, wy, ty = self._conv_weights(H, oh)
         tmp = self._take(H * ow * 8)
         out = self.plane((oh, ow), np.float32)
         try:
             with self.lock, stages.span('gpu: CUBICSPLINE overview'):
+                if len(self._weights) + 2 > self.WEIGHTS_CAP:   # rasters of ever-changing sizes: start over -- here, under the
+                    for d_first, d_w, _ in self._weights.values():      # lock and before this call's own lookups, so that no
+                        d_first.free()                                  # launch ever reads a freed entry
+                        d_w.free()
+                    self._weights.clear()
+                fx, wx, tx = self._conv_weights(W, ow)
+                fy, wy, ty = self._conv_weights(H, oh)
                 self.ctx.convolve_axis_device(plane.ptr, False, H, W, W, 1, ow, tx, fx.ptr, wx.ptr, tmp.ptr, True, ow, 1)
                 self.ctx.convolve_axis_device(tmp.ptr, True, ow, H, 1, ow, oh, ty, fy.ptr, wy.ptr, out.ptr, False, 1, ow)
                 self.ctx.synchronize()

@@ -508,3 +508,29 @@ def test_round6_writer_kernels_against_the_element_by_element_oracle(ctx, shape)
             assert np.array_equal(eng.resample_nearest(plane, oh, ow), co.resample_nearest(u, oh, ow)), (oh, ow)
     finally:
         eng.close()
+
+
+def test_cubicspline_weight_cache_starts_over_without_losing_a_launch(ctx):
+    """The device copies of the convolution weights are cached per (n_in, n_out) and the cache is emptied when it outgrows
+    its cap: with a cap of four pairs, pyramids of many different sizes in a row -- each level still bit for bit the host's."""
+    from proteus_amd import pipeline
+    eng = pipeline.TileEngine(ctx)
+    eng.WEIGHTS_CAP = 4
+    rng = np.random.default_rng(99)
+    try:
+        for k in range(12):
+            shape = (int(rng.integers(5, 90)), int(rng.integers(5, 90)))
+            a = rng.normal(size=shape).astype(np.float32)
+            got = eng._float_pyramid(eng.upload(a), FACTORS)
+            want, prev = [a], 1
+            for f in FACTORS:
+                lv = geotiff.overview_cubicspline(want[-1], f // prev) if prev > 1 and f % prev == 0 else geotiff.overview_cubicspline(a, f)
+                if lv.shape != tuple(-(-n // f) for n in shape):
+                    lv = geotiff.overview_cubicspline(a, f)
+                want.append(lv)
+                prev = f
+            assert len(eng._weights) <= 4
+            for g, w in zip(got, want):
+                assert np.array_equal(g.numpy(), w, equal_nan=True), (k, shape)
+    finally:
+        eng.close()
