@@ -43,8 +43,12 @@ def one_case(case, root):
     d = os.path.join(root, f'c{case}')
     h = int(rng.integers(1, 70)) * 8 + int(rng.integers(0, 8)) if rng.random() < 0.8 else int(rng.integers(1, 9))
     size = max(h, 2)
-    _, files, _, s = synth_hls.make(d, sensor=('L30', 'S30')[case % 2], size=size, tile=5000 + case, masks=True)
-    kw, okw, desc = {}, {}, {'case': case, 'size': size}
+    # two cases in five: a nodata wedge at the top of the tile (a granule at a swath edge; up to the whole tile); band files in small tiles
+    fill_rows = float(rng.choice([0.0, 0.0, 0.3, 0.7, 1.0])) if size >= 16 else 0.0
+    file_tile = int(rng.choice([16, 64, 128, 512]))
+    _, files, _, s = synth_hls.make(d, sensor=('L30', 'S30')[case % 2], size=size, tile=5000 + case, masks=True,
+                                    fill_rows=fill_rows, file_tile=file_tile)
+    kw, okw, desc = {}, {}, {'case': case, 'size': size, 'fill_rows': fill_rows, 'file_tile': file_tile}
     if rng.random() < 0.5:
         kw['landcover_mask'], okw['landcover'] = s['land'], s['land']
     if rng.random() < 0.5:
@@ -99,7 +103,8 @@ def one_case(case, root):
         if key in outs:
             got, _ = geotiff.read_geotiff(outs[key])
             want = cog_oracle.rgb_planes([s['bands'][i] for i in idx], exp['DIAG'], [0.0001] * 3, [0.0] * 3)
-            if got.shape != want.shape or not np.array_equal(got, want, equal_nan=True) or np.isnan(got[:, valid]).any():
+            if got.shape != want.shape or not np.array_equal(got, want, equal_nan=True) or np.isnan(got[:, valid]).any() or \
+                    not np.isnan(got[:, ~valid]).all():
                 raise Mismatch(f'{desc}: composite {key}')
             if geotiff.validate_cog(outs[key]):
                 raise Mismatch(f'{desc}: composite {key}: {geotiff.validate_cog(outs[key])}')
@@ -136,7 +141,7 @@ def main():
     logging.getLogger('dswx_hls').setLevel(logging.ERROR)
     D.get_context(0)
     t0 = time.perf_counter()
-    seen = {'mode': {}, 'outputs': {}, 'scaled': 0, 'multiband': 0}
+    seen = {'mode': {}, 'outputs': {}, 'scaled': 0, 'multiband': 0, 'with_nodata_rows': 0}
     with tempfile.TemporaryDirectory() as root:
         try:
             with ThreadPoolExecutor(a.threads) as ex:
@@ -150,6 +155,7 @@ def main():
             seen['outputs'][k] = seen['outputs'].get(k, 0) + 1
         seen['scaled'] += desc['scaled']
         seen['multiband'] += desc['multiband']
+        seen['with_nodata_rows'] += desc['fill_rows'] > 0
     print(json.dumps({'ok': True, 'cases': a.cases, 'threads': a.threads, 'seed': a.seed, 'files_checked': sum(n for n, _ in results),
                       'seen': seen, 'seconds': round(time.perf_counter() - t0, 1)}))
     return 0

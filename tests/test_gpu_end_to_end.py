@@ -542,3 +542,39 @@ def test_bench_product_run_leg(monkeypatch):
     # a child that cannot run is a record, not an exception
     monkeypatch.setattr(bench, 'TILE', 0)
     assert 'error' in bench.product_run_leg(timeout_s=60)['synthetic_recipe_tile']
+
+
+def test_nodata_wedge_and_fmask_fill_over_valid_reflectances(tmp_path):
+    """A granule at a swath edge: the top 45 % of the tile is nodata (Fmask 255, bands -9999), and a rectangle further down
+    carries Fmask fill over VALID reflectances (the reference calls such pixels invalid all the same: its cumulative fill
+    test includes Fmask, dswx_hls.py:2195-2209); band files in 128 x 128 tiles.  Every layer, the composite and the coverage
+    metadata are what the oracle computes from the arrays that were written; without a usable Fmask fill value (no nodata
+    tag, no _FillValue) the Fmask plane invalidates nothing, as in the reference."""
+    from proteus_amd import dswx_hls as D
+    size = 700
+    rcfile, files, _, s = synth_hls.make(str(tmp_path / 'in'), size=size, tile=88, fill_rows=0.45, file_tile=128)
+    fm = np.array(s['fmask'])
+    fm[400:660, 130:520] = 255
+    geo, meta = geotiff.read_geotiff(files[0])[1].geo_tags, geotiff.read_geotiff(files[-1])[1].metadata
+    geotiff.write_geotiff(files[-1], fm, geo_tags=geo, metadata=meta, nodata=255, tile=128)
+    outs = {n: str(tmp_path / f'{n}.tif') for n in ('wtr', 'conf', 'diag', 'cloud', 'rgb', 'wtr1', 'wtr2', 'bwtr')}
+    assert D.generate_dswx_layers(files, output_interpreted_band=outs['wtr'], output_confidence_layer=outs['conf'],
+                                  output_diagnostic_layer=outs['diag'], output_cloud_layer=outs['cloud'],
+                                  output_rgb_file=outs['rgb'], output_non_masked_dswx=outs['wtr1'],
+                                  output_shadow_masked_dswx=outs['wtr2'], output_binary_water=outs['bwtr'],
+                                  scratch_dir=str(tmp_path / 'scratch'))
+    exp = o.classify_tile(s['bands'], fm)
+    for n, layer in (('wtr', 'WTR'), ('conf', 'CONF'), ('diag', 'DIAG'), ('cloud', 'CLOUD'), ('wtr1', 'WTR-1'), ('wtr2', 'WTR-2'),
+                     ('bwtr', 'BWTR')):
+        arr, info = geotiff.read_geotiff(outs[n])
+        assert np.array_equal(arr, exp[layer]), layer
+    assert info.metadata['SPATIAL_COVERAGE'] == str(exp['counters']['SPATIAL_COVERAGE'])
+    rgb, _ = geotiff.read_geotiff(outs['rgb'])
+    valid = exp['DIAG'] != 65535
+    want = np.float32(0.0001) * (np.clip(s['bands'][2], 1, None).astype(np.float32) - np.float32(0.0))
+    assert np.isnan(rgb[:, ~valid]).all() and np.array_equal(rgb[0][valid], want[valid]) and not valid[:300].any()
+    assert not valid[400:660, 130:520].any() and (s['bands'][2][400:660, 130:520] != -9999).any()
+    geotiff.write_geotiff(files[-1], fm, geo_tags=geo, metadata={k: v for k, v in meta.items() if k != '_FillValue'}, tile=128)
+    assert D.generate_dswx_layers(files, output_interpreted_band=outs['wtr'], scratch_dir=str(tmp_path / 'scratch'))
+    arr, _ = geotiff.read_geotiff(outs['wtr'])
+    assert np.array_equal(arr, o.classify_tile(s['bands'], fm, fmask_fill=-9999.)['WTR'])

@@ -19,13 +19,14 @@ from proteus_amd import batch                   # noqa: E402
 
 def main():
     scene = '--scene' in sys.argv
-    pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith('--') and sys.argv[i - 1] != '--grid']
+    fill = float(sys.argv[sys.argv.index('--fill-rows') + 1]) if '--fill-rows' in sys.argv else 0.0      # nodata rows at the top of every tile
+    pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith('--') and sys.argv[i - 1] not in ('--grid', '--fill-rows')]
     n = int(pos[0]) if len(pos) > 0 else 8
     size = int(pos[1]) if len(pos) > 1 else 3660
-    out = {'tiles': n, 'size': size, 'inputs': 'coherent scenes (4 distinct)' if scene else 'per-pixel recipe (noise-like class maps)'}
+    out = {'tiles': n, 'size': size, 'nodata_rows': fill, 'inputs': 'coherent scenes (4 distinct)' if scene else 'per-pixel recipe (noise-like class maps)'}
     with tempfile.TemporaryDirectory() as d:
         rcs = [synth_hls.make(os.path.join(d, f't{i}'), sensor=('L30', 'S30')[i % 2], size=size, tile=i % 4 if scene else i,
-                              product_id=f'P{i}', scene=scene)[0] for i in range(n)]
+                              product_id=f'P{i}', scene=scene, fill_rows=fill)[0] for i in range(n)]
         import shutil
         grid = ((1, 1), (1, 3), (2, 2)) if scene else ((1, 1), (1, 3), (2, 2), (4, 1), (8, 1))
         if '--grid' in sys.argv:            # workers per GPU x tiles in flight, e.g. --grid 1x3,2x2,2x3

@@ -66,12 +66,20 @@ def scene_tile(tile, size, patch=60, noise_dn=25):
 
 
 def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx_hls_synth',
-         ancillary=False, dem_margin=50, ocean=False, scene=False, browse=False):
+         ancillary=False, dem_margin=50, ocean=False, scene=False, browse=False, fill_rows=0.0, file_tile=512):
     in_dir = os.path.join(out_dir, 'input')
     os.makedirs(in_dir, exist_ok=True)
     if scene and masks:
         raise ValueError('scene: band files only (no pre-made masks)')
     s = scene_tile(tile, size) if scene else synth_tile(tile, size, size, with_masks=masks)
+    if fill_rows > 0:
+        # a granule at a swath edge: the top of the tile is nodata in every file (bands at their fill value, Fmask at 255)
+        import numpy as np
+        n = int(round(size * fill_rows))
+        s = dict(s, bands=[np.array(b) for b in s['bands']], fmask=np.array(s['fmask']))
+        for b in s['bands']:
+            b[:n] = -9999
+        s['fmask'][:n] = 255
     gt = (600000.0, 30.0, 0.0, 4000020.0, 0.0, -30.0)
     geo = geotiff.geo_tags_from_geotransform(gt, epsg=32615)
     stem = f'HLS.{sensor}.T15SYU.2021250T163901.v2.0'
@@ -91,10 +99,10 @@ def make(out_dir, sensor='L30', size=3660, tile=0, masks=False, product_id='dswx
     files = []
     for band, arr in zip(('blue', 'green', 'red', 'nir', 'swir1', 'swir2'), s['bands']):
         path = os.path.join(in_dir, f'{stem}.{names[band]}.tif')
-        geotiff.write_geotiff(path, arr, geo_tags=geo, metadata=meta, nodata=-9999)
+        geotiff.write_geotiff(path, arr, geo_tags=geo, metadata=meta, nodata=-9999, tile=file_tile)
         files.append(path)
     path = os.path.join(in_dir, f'{stem}.Fmask.tif')
-    geotiff.write_geotiff(path, s['fmask'], geo_tags=geo, metadata=meta, nodata=255)
+    geotiff.write_geotiff(path, s['fmask'], geo_tags=geo, metadata=meta, nodata=255, tile=file_tile)
     files.append(path)
     mask_files = {}
     if masks:
